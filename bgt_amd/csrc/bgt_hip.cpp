@@ -1,0 +1,653 @@
+// libbgt_hip.so -- C ABI (include/bgt_hip.h) over the gfx950 kernels of scan_kernels.hip.
+// Host side only: .pbf parsing/packing, HBM residency, selection tables, launches, result staging.
+// There is deliberately no CPU decode path in this file: every genotype comes out of the HIP kernels.
+#include "../../include/bgt_hip.h"
+#include "scan_kernels.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace bgth;
+
+// ----------------------------------------------------------------------------------------------------
+// errors
+// ----------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static void set_err(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+#define HIP_TRY(expr, onfail)                                                            \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            set_err("[E::%s] %s: %s", __func__, #expr, hipGetErrorString(e_));           \
+            onfail;                                                                      \
+        }                                                                                \
+    } while (0)
+
+extern "C" const char *bgth_last_error(void) { return g_err; }
+extern "C" const char *bgth_version(void) { return "bgt-hip 0.1 (gfx950)"; }
+
+extern "C" int bgth_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { set_err("[E::bgth_device_count] %s", hipGetErrorString(e)); return -1; }
+    return n;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// objects
+// ----------------------------------------------------------------------------------------------------
+struct Selection {
+    int width = 0, n_chunks = 0, G = 1;
+    std::vector<int32_t> slot_col, slot_of_out, group_haps;
+    std::vector<uint32_t> chunk_desc;
+    int32_t *d_slot_col = nullptr, *d_slot_of_out = nullptr, *d_group_haps = nullptr;
+    uint32_t *d_chunk_desc = nullptr;
+    void release()
+    {
+        if (d_slot_col) hipFree(d_slot_col);
+        if (d_slot_of_out) hipFree(d_slot_of_out);
+        if (d_group_haps) hipFree(d_group_haps);
+        if (d_chunk_desc) hipFree(d_chunk_desc);
+        d_slot_col = d_slot_of_out = d_group_haps = nullptr;
+        d_chunk_desc = nullptr;
+    }
+};
+
+struct bgth_pbf_s {
+    int device = 0;
+    int32_t m = 0, g = 0, shift = 0;
+    int64_t n = 0, n_blk = 0;
+    int64_t rle_bytes = 0;
+    uint8_t  *d_rle = nullptr;
+    uint64_t *d_rowdesc = nullptr;
+    int32_t  *d_rank0 = nullptr;      // [n_blk][2][m] ranks by column at every checkpoint
+};
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    bool reserve(size_t n)
+    {
+        if (n <= cap) return true;
+        if (p) hipFree(p);
+        p = nullptr; cap = 0;
+        if (hipMalloc(&p, n) != hipSuccess) return false;
+        cap = n;
+        return true;
+    }
+    void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct HostBuf {   // pinned
+    void *p = nullptr;
+    size_t cap = 0;
+    bool reserve(size_t n)
+    {
+        if (n <= cap) return true;
+        if (p) hipHostFree(p);
+        p = nullptr; cap = 0;
+        if (hipHostMalloc(&p, n, hipHostMallocDefault) != hipSuccess) return false;
+        cap = n;
+        return true;
+    }
+    void release() { if (p) hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+struct bgth_reader_s {
+    bgth_pbf_t *pbf = nullptr;
+    Selection sel;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    DevBuf raw, fin, h0, h1, gt, planes;
+    HostBuf h_counts, h_planes;
+    float t_ms[3] = {0, 0, 0};
+    Geometry geom = {0, 0, 0, 0, 0, 0};
+    int tune_threads = 0, tune_cpt = 0, tune_K = 0;
+    // pull interface
+    int64_t next = 0, ring0 = 0, ring1 = 0;
+    bool ring_planes = false;
+    const uint8_t *ret[2] = {nullptr, nullptr};
+    const int32_t *last_counts = nullptr;
+};
+
+static bool use_device(int device)
+{
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) { set_err("[E::bgth] hipSetDevice(%d): %s", device, hipGetErrorString(e)); return false; }
+    return true;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// selection tables
+// ----------------------------------------------------------------------------------------------------
+// Output columns are regrouped into SLOTS: all columns of group 0, padded to a multiple of 64, then
+// group 1, ...; inside a group the output order is kept.  (ref bgt.c:239-242: the subset list is
+// {2*sample, 2*sample+1} in ascending sample order; ref bgt.c:154,612-621: one group id per sample.)
+static bool build_selection(Selection &s, int m, int n_sub, const int32_t *sub, const uint32_t *group, int G)
+{
+    s.release();
+    if (n_sub <= 0 || n_sub >= m || sub == nullptr) { n_sub = m; sub = nullptr; }   // ref pbwt.c:377
+    if (G < 1 || G > 32) { set_err("[E::bgth_reader_select] n_groups %d out of 1..32", G); return false; }
+    if (group == nullptr) G = 1;
+    s.width = n_sub; s.G = G;
+    std::vector<std::vector<int32_t>> by_group(G);
+    for (int i = 0; i < n_sub; ++i) {
+        const int col = sub ? sub[i] : i;
+        if (col < 0 || col >= m) { set_err("[E::bgth_reader_select] column %d out of range", col); return false; }
+        int g = 0;
+        if (group) {
+            const uint32_t gi = group[i >> 1];
+            if (gi < 1 || gi > (uint32_t)G) { set_err("[E::bgth_reader_select] group id %u out of 1..%d", gi, G); return false; }
+            g = (int)gi - 1;
+        }
+        by_group[g].push_back(i);
+    }
+    s.slot_of_out.assign(n_sub, -1);
+    s.group_haps.assign(G, 0);
+    s.slot_col.clear(); s.chunk_desc.clear();
+    for (int g = 0; g < G; ++g) {
+        const std::vector<int32_t> &v = by_group[g];
+        s.group_haps[g] = (int32_t)v.size();
+        for (size_t k = 0; k < v.size(); k += 64) {
+            const int nv = (int)std::min<size_t>(64, v.size() - k);
+            for (int l = 0; l < 64; ++l) {
+                if (l < nv) {
+                    const int out = v[k + l];
+                    s.slot_of_out[out] = (int32_t)s.slot_col.size();
+                    s.slot_col.push_back(sub ? sub[out] : out);
+                } else s.slot_col.push_back(-1);
+            }
+            s.chunk_desc.push_back((uint32_t)g | (uint32_t)nv << 8);
+        }
+    }
+    s.n_chunks = (int)s.chunk_desc.size();
+    if (s.n_chunks == 0) { set_err("[E::bgth_reader_select] empty selection"); return false; }
+    const size_t nslot = s.slot_col.size();
+    HIP_TRY(hipMalloc((void**)&s.d_slot_col, nslot * 4), return false);
+    HIP_TRY(hipMalloc((void**)&s.d_slot_of_out, (size_t)n_sub * 4), return false);
+    HIP_TRY(hipMalloc((void**)&s.d_group_haps, (size_t)G * 4), return false);
+    HIP_TRY(hipMalloc((void**)&s.d_chunk_desc, (size_t)s.n_chunks * 4), return false);
+    HIP_TRY(hipMemcpy(s.d_slot_col, s.slot_col.data(), nslot * 4, hipMemcpyHostToDevice), return false);
+    HIP_TRY(hipMemcpy(s.d_slot_of_out, s.slot_of_out.data(), (size_t)n_sub * 4, hipMemcpyHostToDevice), return false);
+    HIP_TRY(hipMemcpy(s.d_group_haps, s.group_haps.data(), (size_t)G * 4, hipMemcpyHostToDevice), return false);
+    HIP_TRY(hipMemcpy(s.d_chunk_desc, s.chunk_desc.data(), (size_t)s.n_chunks * 4, hipMemcpyHostToDevice), return false);
+    return true;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// .pbf image -> HBM
+// ----------------------------------------------------------------------------------------------------
+static bgth_pbf_t *pbf_alloc(int device, int m, int g, int shift, int64_t n)
+{
+    if (g != 2) { set_err("[E::bgth_pbf] only g=2 bit planes are supported (BGT writes 2, import.c:68); got %d", g); return nullptr; }
+    if (m <= 0 || shift < 0 || shift > 30) { set_err("[E::bgth_pbf] bad header m=%d shift=%d", m, shift); return nullptr; }
+    Geometry geo;
+    if (!choose_geometry(m, (m + 63) / 64, 1, 1, 0, 0, 0, &geo)) {
+        set_err("[E::bgth_pbf] m=%d columns: one row's two bit-vectors do not fit the 160 KiB LDS", m);
+        return nullptr;
+    }
+    bgth_pbf_t *p = new bgth_pbf_s();
+    p->device = device; p->m = m; p->g = g; p->shift = shift; p->n = n;
+    p->n_blk = (n + ((int64_t)1 << shift) - 1) >> shift;
+    return p;
+}
+
+extern "C" void bgth_pbf_close(bgth_pbf_t *p)
+{
+    if (!p) return;
+    hipSetDevice(p->device);
+    if (p->d_rle) hipFree(p->d_rle);
+    if (p->d_rowdesc) hipFree(p->d_rowdesc);
+    if (p->d_rank0) hipFree(p->d_rank0);
+    delete p;
+}
+
+// Walks the record stream of an image (format: SURVEY.md App. A; ref pbwt.c:288-311 writer,
+// :313-337 reader) and splits it into packed RLE bytes, row descriptors and checkpoint permutations.
+extern "C" bgth_pbf_t *bgth_pbf_open_mem(const void *image, size_t len, int device)
+{
+    const uint8_t *buf = (const uint8_t*)image;
+    if (len < 16 || memcmp(buf, "PBF\1", 4) != 0) { set_err("[E::bgth_pbf_open] not a PBF image"); return nullptr; }
+    int32_t hdr[3];
+    memcpy(hdr, buf + 4, 12);
+    const int m = hdr[0], g = hdr[1], shift = hdr[2];
+    int64_t n_footer = -1;
+    size_t end = len;
+    if (len >= 16 + 21) {
+        uint64_t off;
+        memcpy(&off, buf + len - 8, 8);
+        if (off >= 16 && off + 13 <= len && buf[off] == 'I') { memcpy(&n_footer, buf + off + 1, 8); end = (size_t)off; }
+    }
+    if (!use_device(device)) return nullptr;
+    bgth_pbf_t *p = pbf_alloc(device, m, g, shift, 0);
+    if (!p) return nullptr;
+
+    std::vector<uint8_t> rle;
+    std::vector<uint64_t> desc;
+    std::vector<int32_t> perms;
+    rle.reserve(end);
+    size_t pos = 16;
+    int64_t row = 0;
+    const int64_t blk_rows = (int64_t)1 << shift;
+    while (pos < end && buf[pos] != 'I') {
+        if (buf[pos] == 'S') {
+            if (row % blk_rows != 0) { set_err("[E::bgth_pbf_open] 'S' record at row %lld is not on a block boundary", (long long)row); goto fail; }
+            if (pos + 1 + (size_t)g * m * 4 > end) { set_err("[E::bgth_pbf_open] truncated 'S' record"); goto fail; }
+            const size_t at = perms.size();
+            perms.resize(at + (size_t)g * m);
+            memcpy(perms.data() + at, buf + pos + 1, (size_t)g * m * 4);
+            pos += 1 + (size_t)g * m * 4;
+        } else if (row % blk_rows == 0) { set_err("[E::bgth_pbf_open] missing 'S' record at row %lld", (long long)row); goto fail; }
+        if (pos >= end || buf[pos] != 'B') { set_err("[E::bgth_pbf_open] bad record tag at offset %zu", pos); goto fail; }
+        ++pos;
+        for (int k = 0; k < g; ++k) {
+            int32_t l;
+            if (pos + 4 > end) { set_err("[E::bgth_pbf_open] truncated 'B' record"); goto fail; }
+            memcpy(&l, buf + pos, 4);
+            pos += 4;
+            if (l < 0 || l >= (1 << 24) || pos + (size_t)l > end) { set_err("[E::bgth_pbf_open] bad RLE length %d at row %lld", l, (long long)row); goto fail; }
+            desc.push_back((uint64_t)rle.size() | (uint64_t)l << kDescLenShift);
+            rle.insert(rle.end(), buf + pos, buf + pos + l);
+            pos += (size_t)l;
+        }
+        ++row;
+    }
+    if (n_footer >= 0 && n_footer != row) { set_err("[E::bgth_pbf_open] footer says %lld rows, stream has %lld", (long long)n_footer, (long long)row); goto fail; }
+    if (rle.size() >= ((size_t)1 << kDescLenShift)) { set_err("[E::bgth_pbf_open] RLE payload too large"); goto fail; }
+    p->n = row;
+    p->n_blk = (row + blk_rows - 1) >> shift;
+    p->rle_bytes = (int64_t)rle.size();
+    {
+        const size_t pad = 256;    // kernels may read whole dwords past the last string
+        HIP_TRY(hipMalloc((void**)&p->d_rle, rle.size() + pad), goto fail);
+        HIP_TRY(hipMemset(p->d_rle + rle.size(), 0, pad), goto fail);
+        if (!rle.empty()) HIP_TRY(hipMemcpy(p->d_rle, rle.data(), rle.size(), hipMemcpyHostToDevice), goto fail);
+        HIP_TRY(hipMalloc((void**)&p->d_rowdesc, std::max<size_t>(desc.size(), 1) * 8), goto fail);
+        if (!desc.empty()) HIP_TRY(hipMemcpy(p->d_rowdesc, desc.data(), desc.size() * 8, hipMemcpyHostToDevice), goto fail);
+        // checkpoints: permutation (rank -> column) to rank form (column -> rank), on the device
+        const size_t np = perms.size();
+        if (np) {
+            int32_t *d_perm = nullptr;
+            HIP_TRY(hipMalloc((void**)&d_perm, np * 4), goto fail);
+            HIP_TRY(hipMalloc((void**)&p->d_rank0, np * 4), { hipFree(d_perm); goto fail; });
+            HIP_TRY(hipMemcpy(d_perm, perms.data(), np * 4, hipMemcpyHostToDevice), { hipFree(d_perm); goto fail; });
+            HIP_TRY(launch_invert(d_perm, p->d_rank0, m, (int64_t)(np / m), nullptr), { hipFree(d_perm); goto fail; });
+            HIP_TRY(hipDeviceSynchronize(), { hipFree(d_perm); goto fail; });
+            hipFree(d_perm);
+        }
+    }
+    return p;
+fail:
+    bgth_pbf_close(p);
+    return nullptr;
+}
+
+extern "C" bgth_pbf_t *bgth_pbf_open(const char *path, int device)
+{
+    FILE *fp = fopen(path, "rb");
+    if (!fp) { set_err("[E::bgth_pbf_open] cannot open '%s'", path); return nullptr; }
+    fseek(fp, 0, SEEK_END);
+    const long sz = ftell(fp);
+    fseek(fp, 0, SEEK_SET);
+    std::vector<uint8_t> buf((size_t)sz);
+    if (sz > 0 && fread(buf.data(), 1, (size_t)sz, fp) != (size_t)sz) { fclose(fp); set_err("[E::bgth_pbf_open] short read on '%s'", path); return nullptr; }
+    fclose(fp);
+    return bgth_pbf_open_mem(buf.data(), buf.size(), device);
+}
+
+static bool run_block_pass(bgth_pbf_t *p, Selection &all, int64_t blk, int32_t *d_final, hipStream_t s)
+{
+    Geometry geo;
+    if (!choose_geometry(p->m, all.n_chunks, 1, 1, 0, 0, 0, &geo)) { set_err("[E::bgth] geometry"); return false; }
+    ScanArgs a;
+    memset(&a, 0, sizeof(a));
+    a.rle = p->d_rle; a.rowdesc = p->d_rowdesc;
+    a.rank0 = p->d_rank0; a.rank0_blk_stride = (int64_t)2 * p->m;
+    a.slot_col = all.d_slot_col; a.chunk_desc = all.d_chunk_desc;
+    a.raw_counts = nullptr; a.h0 = a.h1 = nullptr; a.final_rank = d_final;
+    a.m = p->m; a.nw = (p->m + 31) / 32; a.shift = p->shift; a.n_chunks = all.n_chunks; a.G = 1; a.K = geo.K;
+    a.blk0 = (int32_t)blk; a.n_blk = 1; a.n_slices = geo.slices;
+    a.row1 = std::min<int64_t>(p->n, (blk + 1) << p->shift);
+    a.row0 = a.row1;                      // nothing emitted: only the final ranks are wanted
+    HIP_TRY(launch_scan(a, geo, s), return false);
+    return true;
+}
+
+extern "C" bgth_pbf_t *bgth_pbf_from_rle(int m, int g, int shift, int64_t n_rows, const uint8_t *rle,
+                                         const uint32_t *len, int device)
+{
+    if (!use_device(device)) return nullptr;
+    bgth_pbf_t *p = pbf_alloc(device, m, g, shift, n_rows);
+    if (!p) return nullptr;
+    std::vector<uint64_t> desc((size_t)n_rows * g);
+    uint64_t off = 0;
+    for (size_t i = 0; i < desc.size(); ++i) {
+        if (len[i] >= (1u << 24)) { set_err("[E::bgth_pbf_from_rle] string %zu too long", i); bgth_pbf_close(p); return nullptr; }
+        desc[i] = off | (uint64_t)len[i] << kDescLenShift;
+        off += len[i];
+    }
+    p->rle_bytes = (int64_t)off;
+    Selection all;
+    {
+        const size_t pad = 256;
+        HIP_TRY(hipMalloc((void**)&p->d_rle, off + pad), goto fail);
+        HIP_TRY(hipMemset(p->d_rle + off, 0, pad), goto fail);
+        if (off) HIP_TRY(hipMemcpy(p->d_rle, rle, off, hipMemcpyHostToDevice), goto fail);
+        HIP_TRY(hipMalloc((void**)&p->d_rowdesc, std::max<size_t>(desc.size(), 1) * 8), goto fail);
+        if (!desc.empty()) HIP_TRY(hipMemcpy(p->d_rowdesc, desc.data(), desc.size() * 8, hipMemcpyHostToDevice), goto fail);
+        const size_t per = (size_t)2 * m;
+        HIP_TRY(hipMalloc((void**)&p->d_rank0, std::max<int64_t>(p->n_blk, 1) * per * 4), goto fail);
+        std::vector<int32_t> ident(per);
+        for (int k = 0; k < 2; ++k) for (int j = 0; j < m; ++j) ident[(size_t)k * m + j] = j;   // ref pbwt.c:103
+        HIP_TRY(hipMemcpy(p->d_rank0, ident.data(), per * 4, hipMemcpyHostToDevice), goto fail);
+        if (!build_selection(all, m, 0, nullptr, nullptr, 1)) goto fail;
+        // block b's final ranks are block b+1's checkpoint: strictly sequential, one launch per block
+        for (int64_t b = 0; b + 1 < p->n_blk; ++b)
+            if (!run_block_pass(p, all, b, p->d_rank0 + (size_t)(b + 1) * per, nullptr)) goto fail;
+        HIP_TRY(hipDeviceSynchronize(), goto fail);
+    }
+    all.release();
+    return p;
+fail:
+    all.release();
+    bgth_pbf_close(p);
+    return nullptr;
+}
+
+extern "C" int64_t bgth_pbf_save(const bgth_pbf_t *p, const char *path)
+{
+    if (!p) return -1;
+    if (!use_device(p->device)) return -1;
+    const int m = p->m;
+    const size_t per = (size_t)2 * m;
+    std::vector<uint8_t> rle((size_t)p->rle_bytes);
+    std::vector<uint64_t> desc((size_t)p->n * 2);
+    std::vector<int32_t> perm(per);
+    int32_t *d_perm = nullptr;
+    FILE *fp = fopen(path, "wb");
+    if (!fp) { set_err("[E::bgth_pbf_save] cannot create '%s'", path); return -1; }
+    std::vector<uint64_t> idx;
+    int64_t written = -1;
+    {
+        if (!rle.empty()) HIP_TRY(hipMemcpy(rle.data(), p->d_rle, rle.size(), hipMemcpyDeviceToHost), goto done);
+        if (!desc.empty()) HIP_TRY(hipMemcpy(desc.data(), p->d_rowdesc, desc.size() * 8, hipMemcpyDeviceToHost), goto done);
+        HIP_TRY(hipMalloc((void**)&d_perm, per * 4), goto done);
+        int32_t hdr[3] = {p->m, p->g, p->shift};
+        fwrite("PBF\1", 1, 4, fp); fwrite(hdr, 4, 3, fp);
+        for (int64_t r = 0; r < p->n; ++r) {
+            if ((r & (((int64_t)1 << p->shift) - 1)) == 0) {
+                const int64_t b = r >> p->shift;
+                HIP_TRY(launch_invert(p->d_rank0 + (size_t)b * per, d_perm, m, 2, nullptr), goto done);
+                HIP_TRY(hipMemcpy(perm.data(), d_perm, per * 4, hipMemcpyDeviceToHost), goto done);
+                idx.push_back((uint64_t)ftell(fp));
+                fputc('S', fp);
+                fwrite(perm.data(), 4, per, fp);
+            }
+            fputc('B', fp);
+            for (int k = 0; k < 2; ++k) {
+                const uint64_t d = desc[(size_t)r * 2 + k];
+                const int32_t l = (int32_t)(d >> kDescLenShift);
+                fwrite(&l, 4, 1, fp);
+                fwrite(rle.data() + (d & kDescOffMask), 1, (size_t)l, fp);
+            }
+        }
+        const uint64_t off = (uint64_t)ftell(fp);
+        const int32_t n_idx = (int32_t)idx.size();
+        fputc('I', fp);
+        fwrite(&p->n, 8, 1, fp); fwrite(&n_idx, 4, 1, fp);
+        fwrite(idx.data(), 8, idx.size(), fp); fwrite(&off, 8, 1, fp);
+        written = ftell(fp);
+    }
+done:
+    if (d_perm) hipFree(d_perm);
+    fclose(fp);
+    return written;
+}
+
+extern "C" int bgth_pbf_get_m(const bgth_pbf_t *p) { return p->m; }
+extern "C" int bgth_pbf_get_g(const bgth_pbf_t *p) { return p->g; }
+extern "C" int bgth_pbf_get_shift(const bgth_pbf_t *p) { return p->shift; }
+extern "C" int64_t bgth_pbf_get_n(const bgth_pbf_t *p) { return p->n; }
+extern "C" int64_t bgth_pbf_rle_bytes(const bgth_pbf_t *p) { return p->rle_bytes; }
+extern "C" int64_t bgth_pbf_hbm_bytes(const bgth_pbf_t *p)
+{
+    return p->rle_bytes + 256 + p->n * 2 * 8 + p->n_blk * 2 * (int64_t)p->m * 4;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// reader
+// ----------------------------------------------------------------------------------------------------
+extern "C" bgth_reader_t *bgth_reader_create(bgth_pbf_t *p)
+{
+    if (!p) { set_err("[E::bgth_reader_create] NULL image"); return nullptr; }
+    if (!use_device(p->device)) return nullptr;
+    bgth_reader_t *r = new bgth_reader_s();
+    r->pbf = p;
+    HIP_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking), { delete r; return nullptr; });
+    for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&r->ev[i]), { delete r; return nullptr; });
+    if (!build_selection(r->sel, p->m, 0, nullptr, nullptr, 1)) { bgth_reader_destroy(r); return nullptr; }
+    return r;
+}
+
+extern "C" void bgth_reader_destroy(bgth_reader_t *r)
+{
+    if (!r) return;
+    hipSetDevice(r->pbf->device);
+    if (r->stream) hipStreamSynchronize(r->stream);
+    r->sel.release();
+    r->raw.release(); r->fin.release(); r->h0.release(); r->h1.release(); r->gt.release(); r->planes.release();
+    r->h_counts.release(); r->h_planes.release();
+    for (int i = 0; i < 4; ++i) if (r->ev[i]) hipEventDestroy(r->ev[i]);
+    if (r->stream) hipStreamDestroy(r->stream);
+    delete r;
+}
+
+extern "C" int bgth_reader_select(bgth_reader_t *r, int n_sub, const int32_t *sub, const uint32_t *group,
+                                  int n_groups)
+{
+    if (!r) return -1;
+    if (!use_device(r->pbf->device)) return -1;
+    hipStreamSynchronize(r->stream);
+    if (!build_selection(r->sel, r->pbf->m, n_sub, sub, group, n_groups)) return -1;
+    r->ring0 = r->ring1 = 0;          // invalidate the pull ring
+    return 0;
+}
+
+extern "C" int bgth_reader_width(const bgth_reader_t *r) { return r->sel.width; }
+extern "C" int bgth_reader_slot_words(const bgth_reader_t *r) { return r->sel.n_chunks; }
+extern "C" int bgth_reader_slot_map(const bgth_reader_t *r, int32_t *out)
+{
+    memcpy(out, r->sel.slot_of_out.data(), (size_t)r->sel.width * 4);
+    return r->sel.width;
+}
+
+extern "C" int bgth_reader_tune(bgth_reader_t *r, int threads, int cpt, int K)
+{
+    r->tune_threads = threads; r->tune_cpt = cpt; r->tune_K = K;
+    return 0;
+}
+
+static int gx_of(int G) { return G > 1 ? G : 0; }
+
+// enqueue decode+reduce of [row0,row1) on stream s; results in d_fin (+ optional planes)
+static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_t *d_fin, uint64_t *d_h0,
+                            uint64_t *d_h1, hipStream_t s, bool timed)
+{
+    bgth_pbf_t *p = r->pbf;
+    if (row0 < 0 || row1 > p->n || row0 > row1) { set_err("[E::bgth_reader_scan] rows [%lld,%lld) outside 0..%lld", (long long)row0, (long long)row1, (long long)p->n); return -1; }
+    const int64_t rows = row1 - row0;
+    if (rows == 0) return 0;
+    const int G = r->sel.G;
+    const int64_t blk0 = row0 >> p->shift, blk1 = (row1 - 1) >> p->shift;
+    Geometry geo;
+    if (!choose_geometry(p->m, r->sel.n_chunks, G, (int)(blk1 - blk0 + 1), r->tune_threads, r->tune_cpt, r->tune_K, &geo)) {
+        set_err("[E::bgth_reader_scan] no launch geometry for m=%d (threads=%d cpt=%d)", p->m, r->tune_threads, r->tune_cpt);
+        return -1;
+    }
+    r->geom = geo;
+    if (!r->raw.reserve((size_t)rows * G * 3 * 4)) { set_err("[E::bgth_reader_scan] out of HBM"); return -1; }
+    ScanArgs a;
+    memset(&a, 0, sizeof(a));
+    a.rle = p->d_rle; a.rowdesc = p->d_rowdesc;
+    a.rank0 = p->d_rank0; a.rank0_blk_stride = (int64_t)2 * p->m;
+    a.slot_col = r->sel.d_slot_col; a.chunk_desc = r->sel.d_chunk_desc;
+    a.raw_counts = (int32_t*)r->raw.p; a.h0 = d_h0; a.h1 = d_h1; a.final_rank = nullptr;
+    a.m = p->m; a.nw = (p->m + 31) / 32; a.shift = p->shift; a.n_chunks = r->sel.n_chunks; a.G = G; a.K = geo.K;
+    a.blk0 = (int32_t)blk0; a.n_blk = (int32_t)(blk1 - blk0 + 1); a.n_slices = geo.slices;
+    a.row0 = row0; a.row1 = row1;
+    if (timed) HIP_TRY(hipEventRecord(r->ev[0], s), return -1);
+    HIP_TRY(hipMemsetAsync(r->raw.p, 0, (size_t)rows * G * 3 * 4, s), return -1);
+    if (timed) HIP_TRY(hipEventRecord(r->ev[1], s), return -1);
+    HIP_TRY(launch_scan(a, geo, s), return -1);
+    if (timed) HIP_TRY(hipEventRecord(r->ev[2], s), return -1);
+    HIP_TRY(launch_finalize((const int32_t*)r->raw.p, d_fin, r->sel.d_group_haps, rows, G, s), return -1);
+    if (timed) HIP_TRY(hipEventRecord(r->ev[3], s), return -1);
+    return rows;
+}
+
+static void collect_timing(bgth_reader_t *r)
+{
+    hipEventElapsedTime(&r->t_ms[0], r->ev[1], r->ev[2]);
+    hipEventElapsedTime(&r->t_ms[1], r->ev[2], r->ev[3]);
+    hipEventElapsedTime(&r->t_ms[2], r->ev[0], r->ev[3]);
+}
+
+extern "C" int64_t bgth_reader_scan_device(bgth_reader_t *r, int64_t row0, int64_t row1, void *d_counts,
+                                           void *d_h0, void *d_h1, void *stream)
+{
+    if (!r || !d_counts) { set_err("[E::bgth_reader_scan_device] NULL argument"); return -1; }
+    if (!use_device(r->pbf->device)) return -1;
+    hipStream_t s = stream ? (hipStream_t)stream : r->stream;
+    const int64_t n = enqueue_scan(r, row0, row1, (int32_t*)d_counts, (uint64_t*)d_h0, (uint64_t*)d_h1, s, true);
+    if (n < 0) return n;
+    if (!stream) { HIP_TRY(hipStreamSynchronize(s), return -1); collect_timing(r); }
+    return n;
+}
+
+extern "C" int64_t bgth_reader_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_t *counts, uint8_t *gt)
+{
+    if (!r) return -1;
+    bgth_pbf_t *p = r->pbf;
+    if (!use_device(p->device)) return -1;
+    if (row0 < 0 || row1 > p->n || row0 > row1) { set_err("[E::bgth_reader_scan] rows [%lld,%lld) outside 0..%lld", (long long)row0, (long long)row1, (long long)p->n); return -1; }
+    const int G = r->sel.G, gx = gx_of(G);
+    const size_t cstride = (size_t)(1 + gx) * 3;
+    const int nb = (r->sel.width + 3) / 4;
+    // with genotypes the planes are large: walk the range in pieces of whole blocks
+    int64_t piece = row1 - row0;
+    if (gt) {
+        const int64_t per_row = (int64_t)r->sel.n_chunks * 16 + nb;
+        int64_t max_rows = ((int64_t)1 << 30) / std::max<int64_t>(per_row, 1);
+        const int64_t blk_rows = (int64_t)1 << p->shift;
+        max_rows = std::max<int64_t>(blk_rows, max_rows / blk_rows * blk_rows);
+        piece = std::min(piece, max_rows);
+    }
+    for (int64_t a0 = row0; a0 < row1;) {
+        // pieces end on block boundaries so that no block is decoded twice
+        int64_t a1 = std::min(row1, a0 + piece);
+        if (a1 < row1) a1 = std::max<int64_t>(a0 + 1, (a1 >> p->shift) << p->shift);
+        const int64_t rows = a1 - a0;
+        if (!r->fin.reserve((size_t)rows * cstride * 4)) { set_err("[E::bgth_reader_scan] out of HBM"); return -1; }
+        uint64_t *d_h0 = nullptr, *d_h1 = nullptr;
+        if (gt) {
+            const size_t pl = (size_t)rows * r->sel.n_chunks * 8;
+            if (!r->h0.reserve(pl) || !r->h1.reserve(pl) || !r->gt.reserve((size_t)rows * nb)) { set_err("[E::bgth_reader_scan] out of HBM"); return -1; }
+            d_h0 = (uint64_t*)r->h0.p; d_h1 = (uint64_t*)r->h1.p;
+        }
+        if (enqueue_scan(r, a0, a1, (int32_t*)r->fin.p, d_h0, d_h1, r->stream, true) < 0) return -1;
+        if (gt) HIP_TRY(launch_pack2(d_h0, d_h1, r->sel.d_slot_of_out, (uint8_t*)r->gt.p, rows, r->sel.n_chunks, r->sel.width, r->stream), return -1);
+        if (counts) HIP_TRY(hipMemcpyAsync(counts + (size_t)(a0 - row0) * cstride, r->fin.p, (size_t)rows * cstride * 4, hipMemcpyDeviceToHost, r->stream), return -1);
+        if (gt) HIP_TRY(hipMemcpyAsync(gt + (size_t)(a0 - row0) * nb, r->gt.p, (size_t)rows * nb, hipMemcpyDeviceToHost, r->stream), return -1);
+        HIP_TRY(hipStreamSynchronize(r->stream), return -1);
+        collect_timing(r);
+        a0 = a1;
+    }
+    return row1 - row0;
+}
+
+extern "C" int bgth_reader_last_timing(const bgth_reader_t *r, float out[3])
+{
+    out[0] = r->t_ms[0]; out[1] = r->t_ms[1]; out[2] = r->t_ms[2];
+    return 0;
+}
+
+extern "C" int bgth_reader_last_geometry(const bgth_reader_t *r, int out[6])
+{
+    out[0] = r->geom.threads; out[1] = r->geom.cpt; out[2] = r->geom.slices;
+    out[3] = r->geom.K; out[4] = r->geom.lds_bytes; out[5] = r->geom.workgroups;
+    return 0;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// pull interface: pbf_seek / pbf_read semantics served from batches decoded on the device
+// ----------------------------------------------------------------------------------------------------
+extern "C" int bgth_reader_seek(bgth_reader_t *r, int64_t row)
+{
+    if (!r) return -1;
+    if (row < 0 || row >= r->pbf->n) { set_err("[E::bgth_reader_seek] row %lld out of range", (long long)row); return -1; }   // ref pbwt.c:359
+    r->next = row;
+    return 0;
+}
+
+static bool refill(bgth_reader_t *r)
+{
+    bgth_pbf_t *p = r->pbf;
+    const int64_t blk_rows = (int64_t)1 << p->shift;
+    const int width = r->sel.width;
+    const int gx = gx_of(r->sel.G);
+    const size_t cstride = (size_t)(1 + gx) * 3;
+    // decode to the end of a block; several blocks per refill while the byte planes stay under 256 MiB
+    int64_t max_rows = ((int64_t)256 << 20) / std::max(1, 2 * width);
+    max_rows = std::max<int64_t>(blk_rows, max_rows / blk_rows * blk_rows);
+    const int64_t row0 = r->next;
+    int64_t row1 = std::min<int64_t>(p->n, ((row0 >> p->shift) << p->shift) + max_rows);
+    const int64_t rows = row1 - row0;
+    const size_t pl = (size_t)rows * r->sel.n_chunks * 8, by = (size_t)rows * width;
+    if (!r->fin.reserve((size_t)rows * cstride * 4) || !r->h0.reserve(pl) || !r->h1.reserve(pl) ||
+        !r->planes.reserve(2 * by) || !r->h_counts.reserve((size_t)rows * cstride * 4) || !r->h_planes.reserve(2 * by)) {
+        set_err("[E::bgth_reader_read] out of memory for a %lld-row batch", (long long)rows);
+        return false;
+    }
+    if (enqueue_scan(r, row0, row1, (int32_t*)r->fin.p, (uint64_t*)r->h0.p, (uint64_t*)r->h1.p, r->stream, true) < 0) return false;
+    uint8_t *d_a0 = (uint8_t*)r->planes.p, *d_a1 = d_a0 + by;
+    HIP_TRY(launch_unpack_bytes((uint64_t*)r->h0.p, (uint64_t*)r->h1.p, r->sel.d_slot_of_out, d_a0, d_a1, rows, r->sel.n_chunks, width, r->stream), return false);
+    HIP_TRY(hipMemcpyAsync(r->h_counts.p, r->fin.p, (size_t)rows * cstride * 4, hipMemcpyDeviceToHost, r->stream), return false);
+    HIP_TRY(hipMemcpyAsync(r->h_planes.p, r->planes.p, 2 * by, hipMemcpyDeviceToHost, r->stream), return false);
+    HIP_TRY(hipStreamSynchronize(r->stream), return false);
+    collect_timing(r);
+    r->ring0 = row0; r->ring1 = row1;
+    return true;
+}
+
+extern "C" const uint8_t **bgth_reader_read(bgth_reader_t *r)
+{
+    if (!r) return nullptr;
+    bgth_pbf_t *p = r->pbf;
+    if (r->next >= p->n) return nullptr;                         // ref pbwt.c:336: no more 'B' records
+    if (!use_device(p->device)) return nullptr;
+    if (r->next < r->ring0 || r->next >= r->ring1) if (!refill(r)) return nullptr;
+    const int width = r->sel.width;
+    const size_t by = (size_t)(r->ring1 - r->ring0) * width;
+    const size_t k = (size_t)(r->next - r->ring0);
+    r->ret[0] = (const uint8_t*)r->h_planes.p + k * width;
+    r->ret[1] = (const uint8_t*)r->h_planes.p + by + k * width;
+    r->last_counts = (const int32_t*)r->h_counts.p + k * (size_t)(1 + gx_of(r->sel.G)) * 3;
+    ++r->next;
+    return r->ret;
+}
+
+extern "C" const int32_t *bgth_reader_last_counts(const bgth_reader_t *r) { return r->last_counts; }

@@ -1,0 +1,52 @@
+// Internal interface between the C-ABI host code (bgt_hip.cpp) and the gfx950 kernels (scan_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bgth {
+
+// Row descriptor: byte offset of the RLE string in the packed stream (low 40 bits) | length (high 24).
+constexpr int      kDescLenShift = 40;
+constexpr uint64_t kDescOffMask  = (1ull << kDescLenShift) - 1;
+
+// Chunk descriptor (one per 64 tracked slots): group id (bits 0..7, 0-based) | valid slots (bits 8..14).
+// Slots are laid out group by group, each group padded to a multiple of 64, so a 64-slot chunk never
+// mixes groups and the per-chunk ballot/popcount reduction needs no per-lane group lookup.
+
+struct ScanArgs {
+    const uint8_t  *rle;         // packed RLE strings of the whole file
+    const uint64_t *rowdesc;     // [2*n_rows]
+    const int32_t  *rank0;       // initial ranks by column: [blk][2][m] (blk_stride = 2*m) or one [2][m]
+    int64_t         rank0_blk_stride;
+    const int32_t  *slot_col;    // [n_chunks*64] column of each tracked slot, -1 = padding
+    const uint32_t *chunk_desc;  // [n_chunks]
+    int32_t        *raw_counts;  // [(row1-row0)][G][3] += {n(code1), n(code2), n(code3)}
+    uint64_t       *h0, *h1;     // optional [(row1-row0)][n_chunks] bit planes in slot order
+    int32_t        *final_rank;  // optional [2][m]: ranks by column after the last row of the launch
+    int32_t  m, nw, shift, n_chunks, G, K;
+    int32_t  blk0, n_blk, n_slices;
+    int64_t  row0, row1;         // rows whose results are emitted; decoding starts at blk0<<shift
+};
+
+struct Geometry { int threads, cpt, slices, K, lds_bytes, workgroups; };
+
+// Picks threads/columns-per-thread/slices/K for a selection of n_chunks*64 slots over n_blk blocks.
+// Returns false if the row bit-vectors of this m cannot fit in LDS.
+bool choose_geometry(int m, int n_chunks, int G, int n_blk, int want_threads, int want_cpt, int want_K,
+                     Geometry *g);
+hipError_t launch_scan(const ScanArgs &a, const Geometry &g, hipStream_t s);
+
+// raw {c1,c2,c3} per group -> {AN,AC,AC<M>} for total (+ per group when G>1)
+hipError_t launch_finalize(const int32_t *raw, int32_t *out, const int32_t *group_haps, int64_t n_rows,
+                           int G, hipStream_t s);
+// inv[perm[j]] = j for n_perm permutations of m entries each
+hipError_t launch_invert(const int32_t *perm, int32_t *inv, int m, int64_t n_perm, hipStream_t s);
+// slot-ordered bit planes -> 2-bit codes in output-column order (4 per byte)
+hipError_t launch_pack2(const uint64_t *h0, const uint64_t *h1, const int32_t *slot_of_out, uint8_t *gt,
+                        int64_t n_rows, int n_chunks, int width, hipStream_t s);
+// slot-ordered bit planes -> byte-per-column planes a0/a1 in output order (what pbf_read returns)
+hipError_t launch_unpack_bytes(const uint64_t *h0, const uint64_t *h1, const int32_t *slot_of_out,
+                               uint8_t *a0, uint8_t *a1, int64_t n_rows, int n_chunks, int width,
+                               hipStream_t s);
+
+}  // namespace bgth

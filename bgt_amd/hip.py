@@ -1,0 +1,250 @@
+"""ctypes mirror of include/bgt_hip.h.  No fallback: a missing library or device raises."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "lib", "libbgt_hip.so")
+
+i32p = C.POINTER(C.c_int32)
+u32p = C.POINTER(C.c_uint32)
+u8p = C.POINTER(C.c_uint8)
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def build_library(force=False):
+    """Compile the gfx950 library in-tree (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(_HERE, "csrc")
+    if force and os.path.exists(_LIB_PATH):
+        os.remove(_LIB_PATH)
+    subprocess.check_call(["make", "-s", "-C", src])
+    return _LIB_PATH
+
+
+def _load():
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError("bgt_amd: %s is missing -- build it with `make -C bgt_amd/csrc` "
+                           "(there is no CPU fallback)" % _LIB_PATH)
+    L = C.CDLL(_LIB_PATH)
+    L.bgth_last_error.restype = C.c_char_p
+    L.bgth_version.restype = C.c_char_p
+    L.bgth_device_count.restype = C.c_int
+    L.bgth_pbf_open.restype = C.c_void_p
+    L.bgth_pbf_open.argtypes = [C.c_char_p, C.c_int]
+    L.bgth_pbf_open_mem.restype = C.c_void_p
+    L.bgth_pbf_open_mem.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    L.bgth_pbf_from_rle.restype = C.c_void_p
+    L.bgth_pbf_from_rle.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
+    L.bgth_pbf_save.restype = C.c_int64
+    L.bgth_pbf_save.argtypes = [C.c_void_p, C.c_char_p]
+    L.bgth_pbf_close.argtypes = [C.c_void_p]
+    for f in ("bgth_pbf_get_m", "bgth_pbf_get_g", "bgth_pbf_get_shift"):
+        getattr(L, f).restype = C.c_int
+        getattr(L, f).argtypes = [C.c_void_p]
+    for f in ("bgth_pbf_get_n", "bgth_pbf_hbm_bytes", "bgth_pbf_rle_bytes"):
+        getattr(L, f).restype = C.c_int64
+        getattr(L, f).argtypes = [C.c_void_p]
+    L.bgth_reader_create.restype = C.c_void_p
+    L.bgth_reader_create.argtypes = [C.c_void_p]
+    L.bgth_reader_destroy.argtypes = [C.c_void_p]
+    L.bgth_reader_select.restype = C.c_int
+    L.bgth_reader_select.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    L.bgth_reader_width.restype = C.c_int
+    L.bgth_reader_width.argtypes = [C.c_void_p]
+    L.bgth_reader_scan.restype = C.c_int64
+    L.bgth_reader_scan.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+    L.bgth_reader_scan_device.restype = C.c_int64
+    L.bgth_reader_scan_device.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]
+    L.bgth_reader_slot_words.restype = C.c_int
+    L.bgth_reader_slot_words.argtypes = [C.c_void_p]
+    L.bgth_reader_slot_map.restype = C.c_int
+    L.bgth_reader_slot_map.argtypes = [C.c_void_p, C.c_void_p]
+    L.bgth_reader_seek.restype = C.c_int
+    L.bgth_reader_seek.argtypes = [C.c_void_p, C.c_int64]
+    L.bgth_reader_read.restype = C.POINTER(u8p)
+    L.bgth_reader_read.argtypes = [C.c_void_p]
+    L.bgth_reader_last_counts.restype = i32p
+    L.bgth_reader_last_counts.argtypes = [C.c_void_p]
+    L.bgth_reader_last_timing.restype = C.c_int
+    L.bgth_reader_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    L.bgth_reader_last_geometry.restype = C.c_int
+    L.bgth_reader_last_geometry.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    L.bgth_reader_tune.restype = C.c_int
+    L.bgth_reader_tune.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    return L
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _load()
+    return _lib
+
+
+def last_error():
+    return lib().bgth_last_error().decode()
+
+
+def device_count():
+    return lib().bgth_device_count()
+
+
+class HipPbf:
+    """A .pbf image resident in HBM (bgth_pbf_t)."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise RuntimeError(last_error() or "bgth_pbf_open failed")
+        self.h = handle
+        L = lib()
+        self.m = L.bgth_pbf_get_m(handle)
+        self.g = L.bgth_pbf_get_g(handle)
+        self.shift = L.bgth_pbf_get_shift(handle)
+        self.n = L.bgth_pbf_get_n(handle)
+
+    @classmethod
+    def open(cls, path, device=0):
+        return cls(lib().bgth_pbf_open(os.fsencode(path), device))
+
+    @classmethod
+    def from_bytes(cls, data, device=0):
+        buf = np.frombuffer(data, np.uint8)
+        return cls(lib().bgth_pbf_open_mem(buf.ctypes.data, buf.size, device))
+
+    @classmethod
+    def from_rle(cls, m, shift, rle, lens, device=0):
+        """rle: uint8 array of concatenated strings (row-major, plane-minor); lens: uint32 per string."""
+        rle = np.ascontiguousarray(rle, np.uint8)
+        lens = np.ascontiguousarray(lens, np.uint32)
+        assert lens.size % 2 == 0 and int(lens.sum(dtype=np.int64)) == rle.size
+        return cls(lib().bgth_pbf_from_rle(m, 2, shift, lens.size // 2, rle.ctypes.data, lens.ctypes.data, device))
+
+    def save(self, path):
+        n = lib().bgth_pbf_save(self.h, os.fsencode(path))
+        if n < 0:
+            raise RuntimeError(last_error())
+        return n
+
+    @property
+    def hbm_bytes(self):
+        return lib().bgth_pbf_hbm_bytes(self.h)
+
+    @property
+    def rle_bytes(self):
+        return lib().bgth_pbf_rle_bytes(self.h)
+
+    def close(self):
+        if self.h:
+            lib().bgth_pbf_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HipReader:
+    """Per-reader device state (bgth_reader_t)."""
+
+    def __init__(self, pbf):
+        self.pbf = pbf
+        self.h = lib().bgth_reader_create(pbf.h)
+        if not self.h:
+            raise RuntimeError(last_error())
+        self.n_groups = 1
+
+    def close(self):
+        if self.h:
+            lib().bgth_reader_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def select(self, cols=None, group=None, n_groups=1):
+        c = g = None
+        n = 0
+        if cols is not None:
+            c = np.ascontiguousarray(cols, np.int32)
+            n = c.size
+        if group is not None:
+            g = np.ascontiguousarray(group, np.uint32)
+        rc = lib().bgth_reader_select(self.h, n, c.ctypes.data if c is not None else None,
+                                      g.ctypes.data if g is not None else None, n_groups)
+        if rc < 0:
+            raise RuntimeError(last_error())
+        self.n_groups = n_groups if group is not None else 1
+
+    @property
+    def width(self):
+        return lib().bgth_reader_width(self.h)
+
+    @property
+    def count_entries(self):
+        return 1 + (self.n_groups if self.n_groups > 1 else 0)
+
+    def tune(self, threads=0, cols_per_thread=0, rows_per_batch=0):
+        lib().bgth_reader_tune(self.h, threads, cols_per_thread, rows_per_batch)
+
+    def scan(self, row0, row1, want_gt=False):
+        rows = row1 - row0
+        counts = np.zeros((rows, self.count_entries, 3), np.int32)
+        gt = np.zeros((rows, (self.width + 3) // 4), np.uint8) if want_gt else None
+        n = lib().bgth_reader_scan(self.h, row0, row1, counts.ctypes.data, gt.ctypes.data if want_gt else None)
+        if n < 0:
+            raise RuntimeError(last_error())
+        return (counts, gt) if want_gt else counts
+
+    def scan_device(self, row0, row1, d_counts_ptr, d_h0_ptr=None, d_h1_ptr=None, stream=None):
+        n = lib().bgth_reader_scan_device(self.h, row0, row1, d_counts_ptr, d_h0_ptr, d_h1_ptr, stream)
+        if n < 0:
+            raise RuntimeError(last_error())
+        return n
+
+    @property
+    def slot_words(self):
+        return lib().bgth_reader_slot_words(self.h)
+
+    def slot_map(self):
+        out = np.zeros(self.width, np.int32)
+        lib().bgth_reader_slot_map(self.h, out.ctypes.data)
+        return out
+
+    def seek(self, row):
+        if lib().bgth_reader_seek(self.h, row) < 0:
+            raise RuntimeError(last_error())
+
+    def read(self):
+        r = lib().bgth_reader_read(self.h)
+        if not r:
+            return None
+        w = self.width
+        return np.stack([np.ctypeslib.as_array(r[k], (w,)).copy() for k in range(2)])
+
+    def last_counts(self):
+        p = lib().bgth_reader_last_counts(self.h)
+        return np.ctypeslib.as_array(p, (self.count_entries, 3)).copy()
+
+    def timing(self):
+        t = (C.c_float * 3)()
+        lib().bgth_reader_last_timing(self.h, t)
+        return {"scan_ms": t[0], "finalize_ms": t[1], "total_ms": t[2]}
+
+    def geometry(self):
+        g = (C.c_int * 6)()
+        lib().bgth_reader_last_geometry(self.h, g)
+        return dict(zip(("threads", "cols_per_thread", "slices", "rows_per_batch", "lds_bytes", "workgroups"), g))

@@ -1,0 +1,115 @@
+/*
+ * bgt_hip.h -- C ABI of the MI355X-native BGT genotype-matrix read path (libbgt_hip.so).
+ *
+ * This is the drop-in boundary one level below the reader API of the reference: the "codec seam"
+ * of pbwt.h (pbf_open_r / pbf_subset / pbf_seek / pbf_read / pbf_close, reference pbwt.h:35-88,
+ * pbwt.c:221-388) fused with the per-site reduction the reader runs on the decoded planes
+ * (bgtm_cal_info, reference bgt.c:735-757) and the 2-bit genotype packing that feeds bgt_gen_gt
+ * (reference bgt.c:290-313).  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Objects
+ *   bgth_pbf_t     a .pbf image resident in HBM: RLE row strings, row directory and the rank form of
+ *                  every 'S' checkpoint.  Read-only after open; may be shared by many readers
+ *                  (the way one bgt_file_t is shared by many bgt_t, reference bgt.h:27,92).
+ *   bgth_reader_t  per-reader state: column selection, group table, HIP stream, result buffers
+ *                  (the reader half of pbf_t + bgt_t::out/group, reference pbwt.c:189-196, bgt.h:33-34).
+ *
+ * Error convention mirrors the reference: NULL / negative int on failure, message retrievable with
+ * bgth_last_error() (the reference prints "[E::func]" from the caller, view.c:103-137).
+ * Nothing in this library falls back to the CPU: without a usable HIP device every entry point that
+ * touches genotypes fails.
+ */
+#ifndef BGT_HIP_H
+#define BGT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bgth_pbf_s bgth_pbf_t;
+typedef struct bgth_reader_s bgth_reader_t;
+
+/* ---- library ---- */
+const char *bgth_last_error(void);               /* thread-local, never NULL                       */
+int         bgth_device_count(void);             /* HIP devices visible; <0 on runtime failure     */
+const char *bgth_version(void);
+
+/* ---- .pbf image in HBM  (replaces pbf_open_r / pbf_close / pbf_get_*, pbwt.c:221-286,390-393) ---- */
+bgth_pbf_t *bgth_pbf_open(const char *path, int device);
+bgth_pbf_t *bgth_pbf_open_mem(const void *image, size_t len, int device);
+/* Build an image from bare RLE strings (row-major, plane-minor: row0/plane0,row0/plane1,row1/plane0..)
+ * and derive every checkpoint on the device by one sequential decode pass: the device-side
+ * equivalent of what pbf_write records while encoding (pbwt.c:292-301).  len[i] is the byte length
+ * of string i; strings are concatenated in `rle`.  g must be 2. */
+bgth_pbf_t *bgth_pbf_from_rle(int m, int g, int shift, int64_t n_rows, const uint8_t *rle,
+                              const uint32_t *len, int device);
+/* Serialise an image back to the on-disk format (header, 'S'/'B' records, 'I' footer; pbwt.c:199-311).
+ * Returns bytes written or <0. */
+int64_t     bgth_pbf_save(const bgth_pbf_t *p, const char *path);
+void        bgth_pbf_close(bgth_pbf_t *p);
+int         bgth_pbf_get_m(const bgth_pbf_t *p);       /* columns = 2 * samples                     */
+int         bgth_pbf_get_g(const bgth_pbf_t *p);       /* bit planes (2 for BGT)                    */
+int         bgth_pbf_get_shift(const bgth_pbf_t *p);   /* checkpoint every 1<<shift rows            */
+int64_t     bgth_pbf_get_n(const bgth_pbf_t *p);       /* rows                                      */
+int64_t     bgth_pbf_hbm_bytes(const bgth_pbf_t *p);   /* device footprint                          */
+int64_t     bgth_pbf_rle_bytes(const bgth_pbf_t *p);   /* total RLE payload                         */
+
+/* ---- reader ---- */
+bgth_reader_t *bgth_reader_create(bgth_pbf_t *p);
+void           bgth_reader_destroy(bgth_reader_t *r);
+
+/* Column selection (replaces pbf_subset, pbwt.c:374-388, as called by bgt_prepare, bgt.c:239-243) and
+ * group table (bgt_t::group / bgtm_t::group, bgt.c:612-621).
+ *   n_sub / sub   columns to decode in output order; n_sub<=0 or sub==NULL selects all m columns.
+ *   group         optional, one 1-based group id per PAIR of output columns (= per sample), n_sub/2
+ *                 entries, as bgtm_t::group; NULL = one group.
+ *   n_groups      number of groups (1..32, BGT_MAX_GROUPS bgt.h:13).
+ * Returns 0 or <0. */
+int bgth_reader_select(bgth_reader_t *r, int n_sub, const int32_t *sub, const uint32_t *group,
+                       int n_groups);
+int bgth_reader_width(const bgth_reader_t *r);         /* output columns per row (n_sub or m)       */
+
+/* Decode rows [row0,row1) of the selection and reduce each to allele counts.
+ *   counts  host buffer int32[(row1-row0)][1+Gx][3] with Gx = n_groups>1 ? n_groups : 0; per entry
+ *           {AN, AC, AC<M>} exactly as bgt_info_t an/ac[0]/ac[1] and gan/gac (bgt.h:44-47): entry 0 is
+ *           the total, entries 1..G the groups.  May be NULL.
+ *   gt      optional host buffer uint8[(row1-row0)][(width+3)/4]: 2-bit codes a1<<1|a0 of output
+ *           column i at bits 2*(i&3) of byte i>>2 (the pair bgt_gen_gt reads, bgt.c:306-311).
+ * Returns rows decoded or <0. */
+int64_t bgth_reader_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_t *counts, uint8_t *gt);
+
+/* Same, results left in HBM (for callers that own device memory, e.g. a collective over xGMI):
+ *   d_counts  device int32[(row1-row0)][1+Gx][3]
+ *   d_h0/d_h1 optional device uint64[(row1-row0)][slot_words]: bit planes in SLOT order
+ *             (see bgth_reader_slot_map); pass NULL to skip.
+ *   stream    hipStream_t to enqueue on (NULL = the reader's own stream); the call is asynchronous
+ *             with respect to the host when a stream is given. */
+int64_t bgth_reader_scan_device(bgth_reader_t *r, int64_t row0, int64_t row1, void *d_counts,
+                                void *d_h0, void *d_h1, void *stream);
+int     bgth_reader_slot_words(const bgth_reader_t *r);           /* uint64 words per row and plane  */
+int     bgth_reader_slot_map(const bgth_reader_t *r, int32_t *slot_of_output); /* width entries      */
+
+/* Pull interface with the semantics of pbf_seek + pbf_read (pbwt.c:349-372, 313-337): one row per
+ * call, byte-per-column planes valid until the next call; rows are decoded on the device in batches
+ * and served from a host ring.  NULL at end of file. */
+int             bgth_reader_seek(bgth_reader_t *r, int64_t row);
+const uint8_t **bgth_reader_read(bgth_reader_t *r);
+/* counts of the row returned by the last bgth_reader_read: int32[1+Gx][3] */
+const int32_t  *bgth_reader_last_counts(const bgth_reader_t *r);
+
+/* Timing of the last scan on the device (HIP events on the launch stream), milliseconds:
+ * out[0] = decode kernel, out[1] = finalize kernel, out[2] = whole enqueue..done. */
+int bgth_reader_last_timing(const bgth_reader_t *r, float out[3]);
+/* Launch geometry of the last scan: out = {threads, cols_per_thread, slices, rows_per_batch,
+ * lds_bytes, workgroups}. */
+int bgth_reader_last_geometry(const bgth_reader_t *r, int out[6]);
+/* Override the automatic launch geometry (0 = automatic). For tuning and tests. */
+int bgth_reader_tune(bgth_reader_t *r, int threads, int cols_per_thread, int rows_per_batch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

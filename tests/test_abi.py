@@ -1,0 +1,61 @@
+"""CPU-side checks of the drop-in boundary: the library loads and exports exactly the entry points the
+header declares (no compute calls here: there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    import bgt_amd
+    if not os.path.exists(bgt_amd.library_path()):
+        bgt_amd.build_library()
+    return bgt_amd.library_path()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "bgt_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bgth_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_all_exported(libpath):
+    names = declared_symbols()
+    assert len(names) >= 25
+    lib = ctypes.CDLL(libpath)
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_no_undeclared_exports(libpath):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", libpath]).decode()
+    exported = sorted(set(re.findall(r" T (bgth_[a-z0-9_]+)", out)))
+    assert exported == declared_symbols()
+
+
+def test_library_does_not_link_the_oracle(libpath):
+    out = subprocess.check_output(["ldd", libpath]).decode()
+    assert "liborc" not in out and "libbgt_ref" not in out
+    syms = subprocess.check_output(["nm", "-D", libpath]).decode()
+    assert "orc_" not in syms
+
+
+def test_fails_loudly_without_a_device(libpath):
+    import bgt_amd
+    if bgt_amd.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(RuntimeError):
+        bgt_amd.HipPbf.from_bytes(open(os.path.join(ROOT, "tests", "golden", "ex1.pbf"), "rb").read())
+
+
+def test_product_sources_never_touch_the_oracle():
+    for base, _, files in os.walk(os.path.join(ROOT, "bgt_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".c")):
+                text = open(os.path.join(base, f)).read()
+                assert "liborc" not in text and "import orc" not in text and "oracle/" not in text, f

@@ -1,0 +1,225 @@
+"""GPU parity: the HIP path (through the C ABI of libbgt_hip.so) against the CPU oracle and against the
+golden fixtures the compiled reference produced.  Bit-exact: genotype bytes and AC/AN integers."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import orc
+import scenarios
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = np.load(os.path.join(HERE, "golden", "codec.npz"))
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import bgt_amd
+    assert os.path.exists(bgt_amd.library_path()), "libbgt_hip.so must be built in-tree"
+    assert bgt_amd.device_count() > 0, bgt_amd.last_error()
+    return bgt_amd
+
+
+def unpack_gt(gt, width):
+    codes = np.stack([(gt >> (2 * k)) & 3 for k in range(4)], -1).reshape(gt.shape[0], -1)
+    return codes[:, :width]
+
+
+def oracle_scan(data, row0, row1, cols=None, group=None, n_groups=1):
+    p = orc.Pbf(data)
+    if cols is not None:
+        p.subset(cols)
+    counts, gt = p.scan(row0, row1, group=group, n_groups=n_groups, want_gt=True)
+    return counts.reshape(row1 - row0, -1, 3), gt
+
+
+def replay_hip(rd, ops):
+    out = []
+    for op in ops:
+        if op[0] == "subset":
+            rd.select(op[1])
+        elif op[0] == "seek":
+            rd.seek(op[1])
+        else:
+            for _ in range(op[1]):
+                a = rd.read()
+                if a is None:
+                    break
+                out.append(a)
+    return np.stack(out) if out else np.zeros((0, 2, rd.width), np.uint8)
+
+
+@pytest.mark.parametrize("name", list(scenarios.cases().keys()))
+def test_golden_scenarios_pull_interface(hip, name):
+    """pbf_subset / pbf_seek / pbf_read semantics, expected planes produced by the compiled reference."""
+    mat, shift = scenarios.cases()[name]
+    rows, m = mat.shape
+    data = bytes(GOLD[name + "/pbf"])
+    pbf = hip.HipPbf.from_bytes(data)
+    assert (pbf.m, pbf.g, pbf.shift, pbf.n) == (m, 2, shift, rows)
+    for i, ops in enumerate(scenarios.scenarios(name, rows, m, shift)):
+        rd = hip.HipReader(pbf)
+        got = replay_hip(rd, ops)
+        exp = GOLD["%s/s%d" % (name, i)]
+        if name == "longrun":
+            exp = np.unpackbits(exp, axis=-1)[..., :int(GOLD["%s/s%d_w" % (name, i)])]
+        assert got.shape == exp.shape, (name, i)
+        assert np.array_equal(got, exp), (name, i)
+        rd.close()
+    pbf.close()
+
+
+@pytest.mark.parametrize("name", list(scenarios.cases().keys()))
+def test_golden_scan_counts_and_genotypes(hip, name):
+    mat, shift = scenarios.cases()[name]
+    rows, m = mat.shape
+    data = bytes(GOLD[name + "/pbf"])
+    pbf = hip.HipPbf.from_bytes(data)
+    rd = hip.HipReader(pbf)
+    counts, gt = rd.scan(0, rows, want_gt=True)
+    assert np.array_equal(unpack_gt(gt, m), mat)
+    assert np.array_equal(counts[:, 0, 0], (mat != 2).sum(1))
+    assert np.array_equal(counts[:, 0, 1], (mat == 1).sum(1))
+    assert np.array_equal(counts[:, 0, 2], (mat == 3).sum(1))
+    oc, ogt = oracle_scan(data, 0, rows)
+    assert np.array_equal(counts, oc) and np.array_equal(gt, ogt)
+
+
+def make_case(seed, m, rows, shift, **kw):
+    rng = np.random.default_rng(seed)
+    mat = scenarios.ld_matrix(rng, rows, m, **kw)
+    return mat, orc.encode_pbf(mat, 2, shift), rng
+
+
+@pytest.mark.parametrize("seed,m,rows,shift", [(11, 64, 50, 3), (12, 63, 70, 4), (13, 65, 40, 13), (14, 1, 20, 2),
+                                               (15, 2, 33, 3), (16, 1000, 300, 6), (17, 5008, 200, 5),
+                                               (18, 4097, 100, 13), (19, 20000, 64, 4)])
+def test_random_cohorts_full(hip, seed, m, rows, shift):
+    mat, data, rng = make_case(seed, m, rows, shift, n_founders=8, switch=0.02)
+    pbf = hip.HipPbf.from_bytes(data)
+    rd = hip.HipReader(pbf)
+    counts, gt = rd.scan(0, rows, want_gt=True)
+    assert np.array_equal(unpack_gt(gt, m), mat)
+    oc, ogt = oracle_scan(data, 0, rows)
+    assert np.array_equal(counts, oc)
+    assert np.array_equal(gt, ogt)
+    # counts-only path (no genotype planes) must agree with the genotype path
+    assert np.array_equal(rd.scan(0, rows), oc)
+    # a range that starts and ends inside blocks
+    a, b = rows // 3, rows - rows // 4
+    c2, g2 = rd.scan(a, b, want_gt=True)
+    assert np.array_equal(c2, oc[a:b]) and np.array_equal(g2, ogt[a:b])
+    assert rd.scan(5 if rows > 5 else 0, 5 if rows > 5 else 0).shape[0] == 0      # empty range
+
+
+@pytest.mark.parametrize("seed,m,rows,shift,frac", [(21, 200, 120, 4, 0.05), (22, 5008, 150, 5, 0.2),
+                                                    (23, 5008, 90, 13, 0.5), (24, 20000, 40, 3, 0.05),
+                                                    (25, 130, 64, 3, 0.9)])
+def test_sample_subset(hip, seed, m, rows, shift, frac):
+    """-s sample subset: columns {2s, 2s+1} of the chosen samples in ascending order (ref bgt.c:239-242)."""
+    mat, data, rng = make_case(seed, m, rows, shift, n_founders=5, switch=0.05)
+    ns = m // 2
+    samples = np.sort(rng.choice(ns, size=max(1, int(ns * frac)), replace=False))
+    cols = np.stack([2 * samples, 2 * samples + 1], 1).reshape(-1)
+    pbf = hip.HipPbf.from_bytes(data)
+    rd = hip.HipReader(pbf)
+    rd.select(cols)
+    assert rd.width == cols.size
+    counts, gt = rd.scan(0, rows, want_gt=True)
+    assert np.array_equal(unpack_gt(gt, cols.size), mat[:, cols])
+    oc, ogt = oracle_scan(data, 0, rows, cols=cols)
+    assert np.array_equal(counts, oc) and np.array_equal(gt, ogt)
+
+
+@pytest.mark.parametrize("seed,m,rows,shift,G", [(31, 120, 80, 4, 2), (32, 5008, 100, 5, 3), (33, 2000, 60, 13, 32),
+                                                 (34, 20000, 30, 3, 2), (35, 300, 50, 4, 5)])
+def test_sample_groups(hip, seed, m, rows, shift, G):
+    """several -s groups: per-group AN/AC (ref bgt.c:740-750); samples outside every group are not decoded."""
+    mat, data, rng = make_case(seed, m, rows, shift, n_founders=6, switch=0.03)
+    ns = m // 2
+    tag = rng.integers(0, G + 1, ns)             # 0 = not selected
+    samples = np.nonzero(tag)[0]
+    cols = np.stack([2 * samples, 2 * samples + 1], 1).reshape(-1)
+    group = tag[samples].astype(np.uint32)
+    pbf = hip.HipPbf.from_bytes(data)
+    rd = hip.HipReader(pbf)
+    rd.select(cols, group=group, n_groups=G)
+    counts, gt = rd.scan(0, rows, want_gt=True)
+    assert counts.shape == (rows, 1 + G, 3)
+    oc, ogt = oracle_scan(data, 0, rows, cols=cols if cols.size < m else None, group=group, n_groups=G)
+    assert np.array_equal(counts, oc)
+    assert np.array_equal(gt, ogt)
+    sub = mat[:, cols]
+    for g in range(1, G + 1):
+        sel = np.repeat(group == g, 2)
+        assert np.array_equal(counts[:, g, 1], (sub[:, sel] == 1).sum(1))
+        assert np.array_equal(counts[:, g, 0], (sub[:, sel] != 2).sum(1))
+
+
+@pytest.mark.parametrize("threads,cpt,K", [(256, 2, 1), (256, 4, 3), (256, 8, 16), (256, 16, 2), (512, 8, 4),
+                                           (512, 16, 5), (1024, 8, 2), (1024, 16, 7), (1024, 24, 1)])
+def test_every_launch_geometry(hip, threads, cpt, K):
+    """Force each kernel instantiation (and multi-slice launches) on one cohort."""
+    mat, data, rng = make_case(41, 5008, 130, 5, n_founders=7, switch=0.04)
+    oc, ogt = oracle_scan(data, 0, 130)
+    pbf = hip.HipPbf.from_bytes(data)
+    rd = hip.HipReader(pbf)
+    rd.tune(threads, cpt, K)
+    counts, gt = rd.scan(0, 130, want_gt=True)
+    geo = rd.geometry()
+    assert (geo["threads"], geo["cols_per_thread"]) == (threads, cpt)
+    assert np.array_equal(counts, oc) and np.array_equal(gt, ogt), geo
+    assert np.array_equal(rd.scan(3, 127), oc[3:127])
+    # the same with two groups (the MULTI kernels)
+    ns = 5008 // 2
+    group = (1 + (np.arange(ns) % 2)).astype(np.uint32)
+    rd.select(np.arange(5008), group=group, n_groups=2)
+    c2 = rd.scan(0, 130)
+    o2, _ = oracle_scan(data, 0, 130, group=group, n_groups=2)
+    assert np.array_equal(c2, o2)
+
+
+def split_rle(data):
+    m, g, shift = struct.unpack("<iii", data[4:16])
+    pos, strings = 16, []
+    while data[pos:pos + 1] != b"I":
+        if data[pos:pos + 1] == b"S":
+            pos += 1 + 4 * g * m
+        pos += 1
+        for _ in range(g):
+            (l,) = struct.unpack("<i", data[pos:pos + 4])
+            strings.append(data[pos + 4:pos + 4 + l])
+            pos += 4 + l
+    return m, shift, strings
+
+
+@pytest.mark.parametrize("seed,m,rows,shift", [(51, 300, 200, 4), (52, 5008, 100, 5), (53, 70, 33, 3)])
+def test_checkpoints_rebuilt_on_device(hip, tmp_path, seed, m, rows, shift):
+    """bgth_pbf_from_rle derives every 'S' record on the GPU; saved file == the encoder's file, byte for byte."""
+    mat, data, rng = make_case(seed, m, rows, shift)
+    m_, shift_, strings = split_rle(data)
+    rle = np.frombuffer(b"".join(strings), np.uint8)
+    lens = np.array([len(s) for s in strings], np.uint32)
+    pbf = hip.HipPbf.from_rle(m, shift, rle, lens)
+    out = str(tmp_path / "re.pbf")
+    pbf.save(out)
+    assert open(out, "rb").read() == data
+
+
+def test_bad_inputs_fail_loudly(hip):
+    with pytest.raises(RuntimeError):
+        hip.HipPbf.from_bytes(b"not a pbf image at all")
+    mat, data, rng = make_case(61, 64, 10, 3)
+    pbf = hip.HipPbf.from_bytes(data)
+    rd = hip.HipReader(pbf)
+    with pytest.raises(RuntimeError):
+        rd.scan(0, 11)
+    with pytest.raises(RuntimeError):
+        rd.select([0, 64])
+    with pytest.raises(RuntimeError):
+        rd.select([0, 1], group=[3], n_groups=2)
+    with pytest.raises(RuntimeError):
+        rd.seek(10)
