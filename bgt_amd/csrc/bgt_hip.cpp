@@ -115,6 +115,7 @@ struct bgth_reader_s {
     DevBuf raw, fin, h0, h1, gt, planes;
     HostBuf h_counts, h_planes;
     float t_ms[3] = {0, 0, 0};
+    bool t_pending = false;           // events recorded on a caller stream, not yet read back
     Geometry geom = {0, 0, 0, 0, 0, 0};
     int tune_threads = 0, tune_cpt = 0, tune_K = 0;
     // pull interface
@@ -521,9 +522,12 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
 
 static void collect_timing(bgth_reader_t *r)
 {
-    hipEventElapsedTime(&r->t_ms[0], r->ev[1], r->ev[2]);
-    hipEventElapsedTime(&r->t_ms[1], r->ev[2], r->ev[3]);
-    hipEventElapsedTime(&r->t_ms[2], r->ev[0], r->ev[3]);
+    float t[3];
+    if (hipEventElapsedTime(&t[0], r->ev[1], r->ev[2]) != hipSuccess) return;   // not finished yet
+    if (hipEventElapsedTime(&t[1], r->ev[2], r->ev[3]) != hipSuccess) return;
+    if (hipEventElapsedTime(&t[2], r->ev[0], r->ev[3]) != hipSuccess) return;
+    r->t_ms[0] = t[0]; r->t_ms[1] = t[1]; r->t_ms[2] = t[2];
+    r->t_pending = false;
 }
 
 extern "C" int64_t bgth_reader_scan_device(bgth_reader_t *r, int64_t row0, int64_t row1, void *d_counts,
@@ -534,6 +538,7 @@ extern "C" int64_t bgth_reader_scan_device(bgth_reader_t *r, int64_t row0, int64
     hipStream_t s = stream ? (hipStream_t)stream : r->stream;
     const int64_t n = enqueue_scan(r, row0, row1, (int32_t*)d_counts, (uint64_t*)d_h0, (uint64_t*)d_h1, s, true);
     if (n < 0) return n;
+    r->t_pending = true;
     if (!stream) { HIP_TRY(hipStreamSynchronize(s), return -1); collect_timing(r); }
     return n;
 }
@@ -579,8 +584,10 @@ extern "C" int64_t bgth_reader_scan(bgth_reader_t *r, int64_t row0, int64_t row1
     return row1 - row0;
 }
 
-extern "C" int bgth_reader_last_timing(const bgth_reader_t *r, float out[3])
+extern "C" int bgth_reader_last_timing(const bgth_reader_t *rc, float out[3])
 {
+    bgth_reader_t *r = const_cast<bgth_reader_t*>(rc);
+    if (r->t_pending) { hipSetDevice(r->pbf->device); collect_timing(r); }
     out[0] = r->t_ms[0]; out[1] = r->t_ms[1]; out[2] = r->t_ms[2];
     return 0;
 }

@@ -248,3 +248,30 @@ class HipReader:
         g = (C.c_int * 6)()
         lib().bgth_reader_last_geometry(self.h, g)
         return dict(zip(("threads", "cols_per_thread", "slices", "rows_per_batch", "lds_bytes", "workgroups"), g))
+
+
+# ---------------------------------------------------------------------------------------------------
+# synthetic cohorts (include/bgt_synth.h)
+# ---------------------------------------------------------------------------------------------------
+def synth_rows(m, row0, n_rows, seed, n_threads=0):
+    """Draw rows [row0,row0+n_rows) of cohort (seed, m) in the PBWT domain. Returns (rle uint8[], len uint32[2n])."""
+    L = lib()
+    L.bgth_synth_rows.restype = C.c_void_p
+    L.bgth_synth_rows.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_uint64, C.c_int]
+    L.bgth_synth_rle.restype = C.c_void_p
+    L.bgth_synth_rle.argtypes = [C.c_void_p]
+    L.bgth_synth_len.restype = C.c_void_p
+    L.bgth_synth_len.argtypes = [C.c_void_p]
+    L.bgth_synth_bytes.restype = C.c_int64
+    L.bgth_synth_bytes.argtypes = [C.c_void_p]
+    L.bgth_synth_free.argtypes = [C.c_void_p]
+    h = L.bgth_synth_rows(m, row0, n_rows, seed, n_threads)
+    if not h:
+        raise RuntimeError("bgth_synth_rows failed")
+    try:
+        nb = L.bgth_synth_bytes(h)
+        rle = np.ctypeslib.as_array(C.cast(L.bgth_synth_rle(h), u8p), (max(nb, 1),))[:nb].copy()
+        lens = np.ctypeslib.as_array(C.cast(L.bgth_synth_len(h), u32p), (2 * n_rows,)).copy()
+    finally:
+        L.bgth_synth_free(h)
+    return rle, lens
