@@ -71,7 +71,8 @@ struct bgth_pbf_s {
     int device = 0;
     int32_t m = 0, g = 0, shift = 0;
     int64_t n = 0, n_blk = 0;
-    int64_t rle_bytes = 0;
+    int64_t rle_bytes = 0;            // RLE payload as in the file
+    int64_t packed_bytes = 0;         // payload + padding of every string to 4 bytes
     uint8_t  *d_rle = nullptr;
     uint64_t *d_rowdesc = nullptr;
     int32_t  *d_rank0 = nullptr;      // [n_blk][2][m] ranks by column at every checkpoint
@@ -240,6 +241,7 @@ extern "C" bgth_pbf_t *bgth_pbf_open_mem(const void *image, size_t len, int devi
     std::vector<uint8_t> rle;
     std::vector<uint64_t> desc;
     std::vector<int32_t> perms;
+    int64_t payload = 0;
     rle.reserve(end);
     size_t pos = 16;
     int64_t row = 0;
@@ -261,8 +263,10 @@ extern "C" bgth_pbf_t *bgth_pbf_open_mem(const void *image, size_t len, int devi
             memcpy(&l, buf + pos, 4);
             pos += 4;
             if (l < 0 || l >= (1 << 24) || pos + (size_t)l > end) { set_err("[E::bgth_pbf_open] bad RLE length %d at row %lld", l, (long long)row); goto fail; }
+            while (rle.size() & 3) rle.push_back(0);          // kernels read whole aligned dwords
             desc.push_back((uint64_t)rle.size() | (uint64_t)l << kDescLenShift);
             rle.insert(rle.end(), buf + pos, buf + pos + l);
+            payload += l;
             pos += (size_t)l;
         }
         ++row;
@@ -271,7 +275,8 @@ extern "C" bgth_pbf_t *bgth_pbf_open_mem(const void *image, size_t len, int devi
     if (rle.size() >= ((size_t)1 << kDescLenShift)) { set_err("[E::bgth_pbf_open] RLE payload too large"); goto fail; }
     p->n = row;
     p->n_blk = (row + blk_rows - 1) >> shift;
-    p->rle_bytes = (int64_t)rle.size();
+    p->rle_bytes = payload;
+    p->packed_bytes = (int64_t)rle.size();
     {
         const size_t pad = 256;    // kernels may read whole dwords past the last string
         HIP_TRY(hipMalloc((void**)&p->d_rle, rle.size() + pad), goto fail);
@@ -335,13 +340,23 @@ extern "C" bgth_pbf_t *bgth_pbf_from_rle(int m, int g, int shift, int64_t n_rows
     bgth_pbf_t *p = pbf_alloc(device, m, g, shift, n_rows);
     if (!p) return nullptr;
     std::vector<uint64_t> desc((size_t)n_rows * g);
-    uint64_t off = 0;
+    std::vector<uint8_t> packed;
+    uint64_t off = 0, src = 0;
+    {
+        uint64_t total = 0;
+        for (size_t i = 0; i < desc.size(); ++i) total += ((uint64_t)len[i] + 3) & ~(uint64_t)3;
+        packed.resize(total);
+    }
     for (size_t i = 0; i < desc.size(); ++i) {
         if (len[i] >= (1u << 24)) { set_err("[E::bgth_pbf_from_rle] string %zu too long", i); bgth_pbf_close(p); return nullptr; }
         desc[i] = off | (uint64_t)len[i] << kDescLenShift;
-        off += len[i];
+        memcpy(packed.data() + off, rle + src, len[i]);
+        src += len[i];
+        off += ((uint64_t)len[i] + 3) & ~(uint64_t)3;           // kernels read whole aligned dwords
     }
-    p->rle_bytes = (int64_t)off;
+    p->rle_bytes = (int64_t)src;
+    p->packed_bytes = (int64_t)off;
+    rle = packed.data();
     Selection all;
     {
         const size_t pad = 256;
@@ -375,7 +390,7 @@ extern "C" int64_t bgth_pbf_save(const bgth_pbf_t *p, const char *path)
     if (!use_device(p->device)) return -1;
     const int m = p->m;
     const size_t per = (size_t)2 * m;
-    std::vector<uint8_t> rle((size_t)p->rle_bytes);
+    std::vector<uint8_t> rle((size_t)p->packed_bytes);
     std::vector<uint64_t> desc((size_t)p->n * 2);
     std::vector<int32_t> perm(per);
     int32_t *d_perm = nullptr;
@@ -426,7 +441,7 @@ extern "C" int64_t bgth_pbf_get_n(const bgth_pbf_t *p) { return p->n; }
 extern "C" int64_t bgth_pbf_rle_bytes(const bgth_pbf_t *p) { return p->rle_bytes; }
 extern "C" int64_t bgth_pbf_hbm_bytes(const bgth_pbf_t *p)
 {
-    return p->rle_bytes + 256 + p->n * 2 * 8 + p->n_blk * 2 * (int64_t)p->m * 4;
+    return p->packed_bytes + 256 + p->n * 2 * 8 + p->n_blk * 2 * (int64_t)p->m * 4;
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -510,6 +525,7 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
     a.m = p->m; a.nw = (p->m + 31) / 32; a.shift = p->shift; a.n_chunks = r->sel.n_chunks; a.G = G; a.K = geo.K;
     a.blk0 = (int32_t)blk0; a.n_blk = (int32_t)(blk1 - blk0 + 1); a.n_slices = geo.slices;
     a.row0 = row0; a.row1 = row1;
+    { const char *dbg = getenv("BGTH_DEBUG_SKIP"); a.debug_skip = dbg ? atoi(dbg) : 0; }
     if (timed) HIP_TRY(hipEventRecord(r->ev[0], s), return -1);
     HIP_TRY(hipMemsetAsync(r->raw.p, 0, (size_t)rows * G * 3 * 4, s), return -1);
     if (timed) HIP_TRY(hipEventRecord(r->ev[1], s), return -1);

@@ -26,6 +26,7 @@ struct ScanArgs {
     int32_t  m, nw, shift, n_chunks, G, K;
     int32_t  blk0, n_blk, n_slices;
     int64_t  row0, row1;         // rows whose results are emitted; decoding starts at blk0<<shift
+    int32_t  debug_skip;         // profiling aid (env BGTH_DEBUG_SKIP): 1 = no phase B, 2 = no RLE read, 4 = no directory build
 };
 
 struct Geometry { int threads, cpt, slices, K, lds_bytes, workgroups; };

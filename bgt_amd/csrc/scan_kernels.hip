@@ -33,15 +33,25 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t mask)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-__device__ __forceinline__ uint32_t wave_incl_add(uint32_t v, int lane)
+// inclusive prefix sum over the 64 lanes, all in the VALU (DPP row shifts + the two row broadcasts)
+__device__ __forceinline__ uint32_t wave_incl_add(uint32_t v)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d);
-        if (lane >= d) v += t;
-    }
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
     return v;
 }
+
+// value of the lane below (lane 0 receives `first`)
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v, uint32_t first)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138, 0xf, 0xf, false);   // wave_shr:1
+}
+
+__device__ __forceinline__ uint32_t lane63(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
 
 __device__ __forceinline__ uint32_t rle_len(uint32_t byte)
 {   // reference pbwt.c:12-21 as arithmetic: code = byte>>1, len = (code&15) << 4*(code>>4)
@@ -64,48 +74,210 @@ __device__ __forceinline__ uint32_t rle_len(uint32_t byte)
 // named (v112..v123) and declared as clobbers; every ds_read is waited for inside the statement.
 // ----------------------------------------------------------------------------------------------------
 #define BGTH_TAIL(R, ELO, EHI, T, MASK, N0)            \
-    "v_and_b32 " T ", " T ", " ELO "\n\t"              \
+    "v_bfe_u32 " T ", " ELO ", 0, " R "\n\t"           \
     "v_bcnt_u32_b32 " T ", " T ", " EHI "\n\t"         \
     "v_bfe_u32 " ELO ", " ELO ", " R ", 1\n\t"         \
     "v_cmp_ne_u32_e64 " MASK ", 0, " ELO "\n\t"        \
     "v_sub_u32 " EHI ", " R ", " T "\n\t"              \
     "v_add_u32 " T ", " N0 ", " T "\n\t"               \
     "v_cndmask_b32_e64 " R ", " EHI ", " T ", " MASK "\n\t"
+#define BGTH_ADDR(T, R, BASE)                          \
+    "v_lshrrev_b32 " T ", 5, " R "\n\t"                \
+    "v_lshl_add_u32 " T ", " T ", 3, " BASE "\n\t"
 
+// per column, on the scalar unit (keeps the VALU for the lookups): ones of plane 0, ones of plane 1,
+// ones in both.  M0/M1 are the ballots the v_cmp of the two lookups produced.
+#define BGTH_COUNT(M0, M1, CA, CB, CC)                 \
+    "s_bcnt1_i32_b64 vcc_lo, " M0 "\n\t"               \
+    "s_add_u32 " CA ", " CA ", vcc_lo\n\t"             \
+    "s_bcnt1_i32_b64 vcc_lo, " M1 "\n\t"               \
+    "s_add_u32 " CB ", " CB ", vcc_lo\n\t"             \
+    "s_and_b64 vcc, " M0 ", " M1 "\n\t"                \
+    "s_bcnt1_i32_b64 vcc_lo, vcc\n\t"                  \
+    "s_add_u32 " CC ", " CC ", vcc_lo\n\t"
+
+// two columns x two planes: 4 LDS reads in flight
 __device__ __forceinline__ void step2(uint32_t &ra0, uint32_t &ra1, uint32_t &rb0, uint32_t &rb1,
                                       uint64_t &ma0, uint64_t &ma1, uint64_t &mb0, uint64_t &mb1,
+                                      uint32_t &ca, uint32_t &cb, uint32_t &cc,
                                       uint32_t base0, uint32_t base1, uint32_t n00, uint32_t n01)
 {
     asm volatile(
         "s_waitcnt lgkmcnt(0)\n\t"
-        "v_lshrrev_b32 v120, 5, %0\n\t"
-        "v_lshrrev_b32 v121, 5, %1\n\t"
-        "v_lshrrev_b32 v122, 5, %2\n\t"
-        "v_lshrrev_b32 v123, 5, %3\n\t"
-        "v_lshl_add_u32 v120, v120, 3, %8\n\t"
-        "v_lshl_add_u32 v121, v121, 3, %9\n\t"
-        "v_lshl_add_u32 v122, v122, 3, %8\n\t"
-        "v_lshl_add_u32 v123, v123, 3, %9\n\t"
-        "ds_read_b64 v[112:113], v120\n\t"
-        "ds_read_b64 v[114:115], v121\n\t"
-        "ds_read_b64 v[116:117], v122\n\t"
-        "ds_read_b64 v[118:119], v123\n\t"
-        "v_bfm_b32 v120, %0, 0\n\t"
-        "v_bfm_b32 v121, %1, 0\n\t"
-        "v_bfm_b32 v122, %2, 0\n\t"
-        "v_bfm_b32 v123, %3, 0\n\t"
+        BGTH_ADDR("v120", "%0", "%11") BGTH_ADDR("v121", "%1", "%12")
+        BGTH_ADDR("v122", "%2", "%11") BGTH_ADDR("v123", "%3", "%12")
+        "ds_read_b64 v[104:105], v120\n\t"
+        "ds_read_b64 v[106:107], v121\n\t"
+        "ds_read_b64 v[108:109], v122\n\t"
+        "ds_read_b64 v[110:111], v123\n\t"
         "s_waitcnt lgkmcnt(3)\n\t"
-        BGTH_TAIL("%0", "v112", "v113", "v120", "%4", "%10")
+        BGTH_TAIL("%0", "v104", "v105", "v120", "%4", "%13")
         "s_waitcnt lgkmcnt(2)\n\t"
-        BGTH_TAIL("%1", "v114", "v115", "v121", "%5", "%11")
+        BGTH_TAIL("%1", "v106", "v107", "v121", "%5", "%14")
+        BGTH_COUNT("%4", "%5", "%8", "%9", "%10")
         "s_waitcnt lgkmcnt(1)\n\t"
-        BGTH_TAIL("%2", "v116", "v117", "v122", "%6", "%10")
+        BGTH_TAIL("%2", "v108", "v109", "v122", "%6", "%13")
         "s_waitcnt lgkmcnt(0)\n\t"
-        BGTH_TAIL("%3", "v118", "v119", "v123", "%7", "%11")
-        : "+v"(ra0), "+v"(ra1), "+v"(rb0), "+v"(rb1), "=&s"(ma0), "=&s"(ma1), "=&s"(mb0), "=&s"(mb1)
+        BGTH_TAIL("%3", "v110", "v111", "v123", "%7", "%14")
+        BGTH_COUNT("%6", "%7", "%8", "%9", "%10")
+        : "+v"(ra0), "+v"(ra1), "+v"(rb0), "+v"(rb1), "=&s"(ma0), "=&s"(ma1), "=&s"(mb0), "=&s"(mb1),
+          "+s"(ca), "+s"(cb), "+s"(cc)
         : "s"(base0), "s"(base1), "s"(n00), "s"(n01)
-        : "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123",
-          "memory");
+        : "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v120", "v121", "v122", "v123",
+          "vcc", "scc", "memory");
+}
+
+// four columns x two planes: 8 LDS reads in flight
+__device__ __forceinline__ void step4(uint32_t (&r0)[4], uint32_t (&r1)[4], uint64_t (&m0)[4], uint64_t (&m1)[4],
+                                      uint32_t &ca, uint32_t &cb, uint32_t &cc,
+                                      uint32_t base0, uint32_t base1, uint32_t n00, uint32_t n01)
+{
+    asm volatile(
+        "s_waitcnt lgkmcnt(0)\n\t"
+        BGTH_ADDR("v120", "%0", "%19") BGTH_ADDR("v121", "%1", "%20")
+        BGTH_ADDR("v122", "%2", "%19") BGTH_ADDR("v123", "%3", "%20")
+        BGTH_ADDR("v124", "%4", "%19") BGTH_ADDR("v125", "%5", "%20")
+        BGTH_ADDR("v126", "%6", "%19") BGTH_ADDR("v127", "%7", "%20")
+        "ds_read_b64 v[104:105], v120\n\t"
+        "ds_read_b64 v[106:107], v121\n\t"
+        "ds_read_b64 v[108:109], v122\n\t"
+        "ds_read_b64 v[110:111], v123\n\t"
+        "ds_read_b64 v[112:113], v124\n\t"
+        "ds_read_b64 v[114:115], v125\n\t"
+        "ds_read_b64 v[116:117], v126\n\t"
+        "ds_read_b64 v[118:119], v127\n\t"
+        "s_waitcnt lgkmcnt(7)\n\t"
+        BGTH_TAIL("%0", "v104", "v105", "v120", "%8", "%21")
+        "s_waitcnt lgkmcnt(6)\n\t"
+        BGTH_TAIL("%1", "v106", "v107", "v121", "%9", "%22")
+        BGTH_COUNT("%8", "%9", "%16", "%17", "%18")
+        "s_waitcnt lgkmcnt(5)\n\t"
+        BGTH_TAIL("%2", "v108", "v109", "v122", "%10", "%21")
+        "s_waitcnt lgkmcnt(4)\n\t"
+        BGTH_TAIL("%3", "v110", "v111", "v123", "%11", "%22")
+        BGTH_COUNT("%10", "%11", "%16", "%17", "%18")
+        "s_waitcnt lgkmcnt(3)\n\t"
+        BGTH_TAIL("%4", "v112", "v113", "v124", "%12", "%21")
+        "s_waitcnt lgkmcnt(2)\n\t"
+        BGTH_TAIL("%5", "v114", "v115", "v125", "%13", "%22")
+        BGTH_COUNT("%12", "%13", "%16", "%17", "%18")
+        "s_waitcnt lgkmcnt(1)\n\t"
+        BGTH_TAIL("%6", "v116", "v117", "v126", "%14", "%21")
+        "s_waitcnt lgkmcnt(0)\n\t"
+        BGTH_TAIL("%7", "v118", "v119", "v127", "%15", "%22")
+        BGTH_COUNT("%14", "%15", "%16", "%17", "%18")
+        : "+v"(r0[0]), "+v"(r1[0]), "+v"(r0[1]), "+v"(r1[1]), "+v"(r0[2]), "+v"(r1[2]), "+v"(r0[3]), "+v"(r1[3]),
+          "=&s"(m0[0]), "=&s"(m1[0]), "=&s"(m0[1]), "=&s"(m1[1]), "=&s"(m0[2]), "=&s"(m1[2]), "=&s"(m0[3]), "=&s"(m1[3]),
+          "+s"(ca), "+s"(cb), "+s"(cc)
+        : "s"(base0), "s"(base1), "s"(n00), "s"(n01)
+        : "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115",
+          "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127",
+          "vcc", "scc", "memory");
+}
+
+// ----------------------------------------------------------------------------------------------------
+// Phase A for one plane-row, executed by ONE wave: RLE string -> bit-vector + rank directory in LDS.
+//   1. clear the row's entries
+//   2. every lane decodes 4 code bytes (strings are packed 4-byte aligned), a wave prefix sum of the
+//      run lengths gives every run's start, and wherever the bit differs from the previous byte's bit
+//      the row "toggles" at the run start: the lane xors the mask ~0 << (start & 31) into the word of
+//      the start (LDS atomic; bytes of zero length cancel out).  After all toggles a word holds the
+//      prefix parity of its own toggles, and its bit 31 their total parity.
+//   3. the row bits are that word, inverted when the parity of the toggles in all earlier words is
+//      odd (ballot of bit 31 + mbcnt); a wave prefix sum of the word popcounts is the rank
+//      directory.  The number of ones falls out as the final carry.
+// LDS operations of one wave complete in order, so no workgroup barrier is needed between the steps;
+// the wavefront fences only pin the compiler's ordering.
+// ----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void build_plane_row(const ScanArgs &a, uint2 *bd, uint32_t *n0_out, uint64_t desc,
+                                                uint32_t pre0, uint32_t pre1, int lane, uint32_t tail_mask)
+{
+    const int m = a.m, nw = a.nw;
+    for (int i = lane; i < nw; i += 64) bd[i] = make_uint2(0u, 0u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (!(a.debug_skip & 2)) {
+        const uint32_t *q4 = reinterpret_cast<const uint32_t*>(a.rle + (desc & kDescOffMask));
+        const uint32_t len = (uint32_t)(desc >> kDescLenShift);
+        uint32_t pos = 0, prevbit = 0;
+        bool stop = false;
+        for (uint32_t base = 0; base < len && !stop; base += 256) {
+            const uint32_t k0 = base + 4u * (uint32_t)lane;
+            // the first 512 bytes were fetched one batch ahead (pre0/pre1); longer strings read on
+            const uint32_t w = base == 0 ? pre0 : base == 256 ? pre1 : (k0 < len ? q4[(base >> 2) + lane] : 0u);
+            uint32_t byte[4], l[4];
+            bool valid[4];
+            bool anyz = false;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                byte[i] = (w >> (8 * i)) & 255u;
+                valid[i] = k0 + i < len;
+                anyz = anyz || (valid[i] && byte[i] == 0u);
+            }
+            const uint64_t z = __ballot(anyz);                  // a zero byte ends the row (ref pbwt.c:73)
+            if (z) {
+                const int first = __ffsll((unsigned long long)z) - 1;
+                bool dead = lane > first;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (lane == first && byte[i] == 0u) dead = true;
+                    valid[i] = valid[i] && !dead;
+                }
+                stop = true;
+            }
+            uint32_t run = 0, before[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { l[i] = valid[i] ? rle_len(byte[i]) : 0u; before[i] = run; run += l[i]; }
+            const uint32_t incl = wave_incl_add(run);
+            const uint32_t lane_start = pos + incl - run;
+            uint32_t pb = wave_shr1(byte[3] & 1u, prevbit);      // bit of the byte before this lane's first
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t b = byte[i] & 1u, start = lane_start + before[i];
+                if (valid[i] && b != pb && start < (uint32_t)m) atomicXor(&bd[start >> 5].x, 0xffffffffu << (start & 31));
+                pb = b;
+            }
+            prevbit = lane63(byte[3] & 1u);
+            pos += lane63(incl);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // Four 64-word groups per trip: their LDS reads, in-word prefix xors and popcount scans are
+    // independent, only two scalars (toggle parity, ones so far) are carried from group to group.
+    uint32_t carry_x = 0, carry_c = 0;
+    if (!(a.debug_skip & 4))
+    for (int base = 0; base < nw; base += 256) {
+        uint32_t t[4], w[4], c[4], incl[4];
+        uint64_t par[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int i = base + g * 64 + lane;
+            t[g] = i < nw ? bd[i].x : 0u;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            w[g] = t[g];                                  // already the in-word prefix parity (see step 2)
+            par[g] = __ballot(t[g] >> 31);                // bit 31 = parity of the toggles in the word
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int i = base + g * 64 + lane;
+            const uint32_t cin = (lanes_below(par[g]) ^ carry_x) & 1u;   // parity of the toggles before this word
+            uint32_t v = cin ? ~w[g] : w[g];
+            if (i == nw - 1) v &= tail_mask;
+            if (i >= nw) v = 0u;
+            w[g] = v;
+            c[g] = (uint32_t)__popc(v);
+            incl[g] = wave_incl_add(c[g]);
+            carry_x ^= (uint32_t)__popcll(par[g]) & 1u;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int i = base + g * 64 + lane;
+            if (i < nw) bd[i] = make_uint2(w[g], carry_c + incl[g] - c[g]);
+            carry_c += lane63(incl[g]);
+        }
+    }
+    if (lane == 0) *n0_out = (uint32_t)m - carry_c;
 }
 
 // Template switches:  MULTI = more than one sample group (per-chunk LDS atomics instead of per-wave
@@ -153,7 +325,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a)
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
             const int c = chunk0 + j;
-            const int col = c < a.n_chunks ? a.slot_col[c * 64 + lane] : -1;
+            const int col = (c < a.n_chunks && !(a.debug_skip & 8)) ? a.slot_col[c * 64 + lane] : -1;
             r0[j] = col >= 0 ? (uint32_t)rk[col] : pad_rank;
             r1[j] = col >= 0 ? (uint32_t)rk[m + col] : pad_rank;
         }
@@ -163,68 +335,53 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a)
 
     const uint32_t tail_mask = (m & 31) ? ((1u << (m & 31)) - 1u) : 0xffffffffu;
 
+    // ---- software prefetch of the RLE strings: the row descriptors run two batches ahead of phase A,
+    // the first 512 bytes of every string one batch ahead, so that their HBM latency hides under
+    // phase B of the batch before.
+    uint64_t dsc[2], dsc_next[2];
+    uint32_t pre[2][2];
+    auto fetch_desc = [&](int64_t rb_, int i) -> uint64_t {
+        const int p = wave + i * NWAVE;
+        const int64_t left = blk_end - rb_;
+        const int kc = (int)(left < K ? left : K);
+        return (rb_ < blk_end && p < 2 * kc) ? a.rowdesc[2 * rb_ + p] : 0ull;
+    };
+    auto fetch_data = [&](uint64_t d, int c) -> uint32_t {
+        const uint32_t len = (uint32_t)(d >> kDescLenShift);
+        const uint32_t k0 = (uint32_t)c * 256u + 4u * (uint32_t)lane;
+        return k0 < len ? reinterpret_cast<const uint32_t*>(a.rle + (d & kDescOffMask))[c * 64 + lane] : 0u;
+    };
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        dsc[i] = fetch_desc(blk_beg, i);
+        dsc_next[i] = fetch_desc(blk_beg + K, i);
+        pre[i][0] = fetch_data(dsc[i], 0);
+        pre[i][1] = fetch_data(dsc[i], 1);
+    }
+
     for (int64_t rb = blk_beg; rb < blk_end; rb += K) {
         const int Kc = (int)((blk_end - rb) < K ? (blk_end - rb) : K);
 
         // ================= phase A: build the bit-vectors of Kc rows x 2 planes =================
-        for (int p = wave; p < 2 * Kc; p += NWAVE) {
-            uint2 *bd = BD + (size_t)p * nwp;
-            for (int i = lane; i < nw; i += 64) bd[i] = make_uint2(0u, 0u);
+        // K <= NWAVE (host guarantees): a wave builds at most two plane-rows per batch, on its own.
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int p = wave + i * NWAVE;
+            if (p < 2 * Kc)
+                build_plane_row(a, BD + (size_t)p * nwp, n0s + p, dsc[i], pre[i][0], pre[i][1], lane, tail_mask);
         }
-        __syncthreads();
-        for (int p = wave; p < 2 * Kc; p += NWAVE) {
-            uint2 *bd = BD + (size_t)p * nwp;
-            const uint64_t d   = a.rowdesc[2 * rb + p];
-            const uint8_t *q   = a.rle + (d & kDescOffMask);
-            const uint32_t len = (uint32_t)(d >> kDescLenShift);
-            uint32_t pos = 0, prevbit = 0, ones = 0;
-            bool stop = false;
-            for (uint32_t base = 0; base < len && !stop; base += 64) {
-                const uint32_t k = base + lane;
-                bool valid = k < len;
-                const uint32_t byte = valid ? (uint32_t)q[k] : 0xffu;
-                const uint64_t z = __ballot(valid && byte == 0u);   // a zero byte ends the row (pbwt.c:73)
-                if (z) { valid = valid && lane < (__ffsll((unsigned long long)z) - 1); stop = true; }
-                const uint32_t l = valid ? rle_len(byte) : 0u;
-                const uint32_t b = byte & 1u;
-                const uint32_t incl  = wave_incl_add(l, lane);
-                const uint32_t start = pos + incl - l;
-                uint32_t pb = __shfl_up(b, 1);
-                if (lane == 0) pb = prevbit;
-                if (valid && b != pb && start < (uint32_t)m)
-                    atomicXor(&bd[start >> 5].x, 1u << (start & 31));
-                const uint32_t incl1 = wave_incl_add(b ? l : 0u, lane);
-                ones += __shfl(incl1, 63);
-                const int nvalid = __popcll(__ballot(valid));
-                if (nvalid) prevbit = __shfl(b, nvalid - 1);
-                pos += __shfl(incl, 63);
-            }
-            if (lane == 0) n0s[p] = (uint32_t)m - ones;
-        }
-        __syncthreads();
-        for (int p = wave; p < 2 * Kc; p += NWAVE) {
-            uint2 *bd = BD + (size_t)p * nwp;
-            uint32_t carry_x = 0, carry_c = 0;
-            for (int base = 0; base < nw; base += 64) {
-                const int i = base + lane;
-                const bool valid = i < nw;
-                const uint32_t t = valid ? bd[i].x : 0u;
-                uint32_t x = t;                       // prefix xor inside the word
-                x ^= x << 1; x ^= x << 2; x ^= x << 4; x ^= x << 8; x ^= x << 16;
-                const uint64_t par = __ballot(__popc(t) & 1);
-                const uint32_t cin = (lanes_below(par) ^ carry_x) & 1u;   // parity of toggles before word
-                uint32_t w = cin ? ~x : x;
-                if (i == nw - 1) w &= tail_mask;
-                if (!valid) w = 0u;
-                const uint32_t incl = wave_incl_add((uint32_t)__popc(w), lane);
-                if (valid) bd[i] = make_uint2(w, carry_c + incl - (uint32_t)__popc(w));
-                carry_x ^= (uint32_t)__popcll(par) & 1u;
-                carry_c += __shfl(incl, 63);
-            }
+        // issue the loads of the next batch (data) and of the one after (descriptors) before phase B
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            dsc[i] = dsc_next[i];
+            pre[i][0] = fetch_data(dsc[i], 0);
+            pre[i][1] = fetch_data(dsc[i], 1);
+            dsc_next[i] = fetch_desc(rb + 2 * K, i);
         }
         __syncthreads();
 
         // ================= phase B: walk the rows, ranks stay in registers =================
+        if (!(a.debug_skip & 1))
         for (int k = 0; k < Kc; ++k) {
             const uint32_t base0 = lds0 + (uint32_t)(2 * k) * (uint32_t)nwp * 8u;    // LDS byte addresses
             const uint32_t base1 = base0 + (uint32_t)nwp * 8u;
@@ -232,40 +389,38 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a)
             const uint32_t n01 = __builtin_amdgcn_readfirstlane(n0s[2 * k + 1]);
             const bool emit = (rb + k) >= a.row0;
             // ones of plane 0, ones of plane 1, ones in both:  n(code1) = ca - cc, n(code2) = cb - cc
-            int32_t ca = 0, cb = 0, cc = 0;
+            uint32_t ca = 0, cb = 0, cc = 0;
             uint64_t keep0 = 0, keep1 = 0;
 #pragma unroll
-            for (int j = 0; j < CPT; j += 2) {
-                uint64_t mA0, mA1, mB0, mB1;
-                step2(r0[j], r1[j], r0[j + 1], r1[j + 1], mA0, mA1, mB0, mB1, base0, base1, n00, n01);
-                if (GT) {
-                    if (lane == j) { keep0 = mA0; keep1 = mA1; }
-                    if (lane == j + 1) { keep0 = mB0; keep1 = mB1; }
+            for (int j = 0; j < CPT; j += 4) {
+                uint64_t m0[4] = {0, 0, 0, 0}, m1[4] = {0, 0, 0, 0};
+                const int NC = (CPT - j) >= 4 ? 4 : 2;                // CPT is even: the tail is one pair
+                if (NC == 4) {
+                    uint32_t q0[4] = {r0[j], r0[j + 1], r0[j + 2], r0[j + 3]};
+                    uint32_t q1[4] = {r1[j], r1[j + 1], r1[j + 2], r1[j + 3]};
+                    step4(q0, q1, m0, m1, ca, cb, cc, base0, base1, n00, n01);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { r0[j + u] = q0[u]; r1[j + u] = q1[u]; }
+                } else {
+                    step2(r0[j], r1[j], r0[j + 1], r1[j + 1], m0[0], m1[0], m0[1], m1[1], ca, cb, cc, base0, base1, n00, n01);
                 }
-                if (MULTI) {
-                    const int c = chunk0 + j;                                // wave-uniform
-                    if (emit && lane == 0) {
-                        if (c < a.n_chunks) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (u >= NC) break;
+                    if (GT && lane == j + u) { keep0 = m0[u]; keep1 = m1[u]; }
+                    if (MULTI) {
+                        const int c = chunk0 + j + u;                        // wave-uniform
+                        if (emit && lane == 0 && c < a.n_chunks) {
                             int32_t *dst = lcnt + ((size_t)k * G + (a.chunk_desc[c] & 255u)) * 3;
-                            atomicAdd(dst + 0, __builtin_amdgcn_readfirstlane(__popcll(mA0 & ~mA1)));
-                            atomicAdd(dst + 1, __builtin_amdgcn_readfirstlane(__popcll(~mA0 & mA1)));
-                            atomicAdd(dst + 2, __builtin_amdgcn_readfirstlane(__popcll(mA0 & mA1)));
-                        }
-                        if (c + 1 < a.n_chunks) {
-                            int32_t *dst = lcnt + ((size_t)k * G + (a.chunk_desc[c + 1] & 255u)) * 3;
-                            atomicAdd(dst + 0, __builtin_amdgcn_readfirstlane(__popcll(mB0 & ~mB1)));
-                            atomicAdd(dst + 1, __builtin_amdgcn_readfirstlane(__popcll(~mB0 & mB1)));
-                            atomicAdd(dst + 2, __builtin_amdgcn_readfirstlane(__popcll(mB0 & mB1)));
+                            atomicAdd(dst + 0, __builtin_amdgcn_readfirstlane(__popcll(m0[u] & ~m1[u])));
+                            atomicAdd(dst + 1, __builtin_amdgcn_readfirstlane(__popcll(~m0[u] & m1[u])));
+                            atomicAdd(dst + 2, __builtin_amdgcn_readfirstlane(__popcll(m0[u] & m1[u])));
                         }
                     }
-                } else {
-                    ca += __popcll(mA0) + __popcll(mB0);
-                    cb += __popcll(mA1) + __popcll(mB1);
-                    cc += __popcll(mA0 & mA1) + __popcll(mB0 & mB1);
                 }
             }
             if (!MULTI && lane == 0)
-                reinterpret_cast<int4*>(lcnt)[k * NWAVE + wave] = make_int4(ca - cc, cb - cc, cc, 0);
+                reinterpret_cast<int4*>(lcnt)[k * NWAVE + wave] = make_int4((int)(ca - cc), (int)(cb - cc), (int)cc, 0);
             if (GT && emit && lane < CPT && chunk0 + lane < a.n_chunks) {
                 const size_t at = (size_t)(rb + k - a.row0) * a.n_chunks + chunk0 + lane;
                 a.h0[at] = keep0;
@@ -326,9 +481,9 @@ static hipError_t launch_one(const ScanArgs &a, const Geometry &g, hipStream_t s
 }
 
 #define BGTH_GEOMS(X) \
-    X(256, 2) X(256, 4) X(256, 8) X(256, 16) \
-    X(512, 8) X(512, 16) \
-    X(1024, 8) X(1024, 16) X(1024, 24)
+    X(256, 2) X(256, 4) X(256, 8) X(256, 12) X(256, 16) X(256, 20) \
+    X(512, 4) X(512, 8) X(512, 10) X(512, 12) X(512, 16) X(512, 20) \
+    X(1024, 4) X(1024, 8) X(1024, 10) X(1024, 12) X(1024, 16) X(1024, 20) X(1024, 24)
 
 struct GeomEntry { int nt, cpt; };
 static const GeomEntry kGeoms[] = {
@@ -373,6 +528,7 @@ bool choose_geometry(int m, int n_chunks, int G, int n_blk, int want_threads, in
     // LDS budget: leave room for 1024/threads workgroups per CU, but at least one row
     int budget = (int)((long)kLdsBytes * g->threads / 1024);
     int K = want_K > 0 ? want_K : 16;
+    if (K > g->threads / 64) K = g->threads / 64;          // a wave builds at most two plane-rows per batch
     while (K > 1 && lds_need(nw, K, G, g->threads) > budget) --K;
     while (K > 1 && lds_need(nw, K, G, g->threads) > kLdsBytes) --K;
     g->K = K;
