@@ -189,83 +189,87 @@ __device__ __forceinline__ void step4(uint32_t (&r0)[4], uint32_t (&r1)[4], uint
 // LDS operations of one wave complete in order, so no workgroup barrier is needed between the steps;
 // the wavefront fences only pin the compiler's ordering.
 // ----------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void build_plane_row(const ScanArgs &a, uint2 *bd, uint32_t *n0_out, uint64_t desc,
-                                                uint32_t pre0, uint32_t pre1, int lane, uint32_t tail_mask)
+// step 2: RLE string -> toggles (one wave)
+__device__ __forceinline__ void rle_toggles(const ScanArgs &a, uint2 *bd, uint64_t desc, uint32_t pre0, uint32_t pre1,
+                                            uint32_t pre2, uint32_t pre3, int npre, int lane)
 {
-    const int m = a.m, nw = a.nw;
-    for (int i = lane; i < nw; i += 64) bd[i] = make_uint2(0u, 0u);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    if (!(a.debug_skip & 2)) {
-        const uint32_t *q4 = reinterpret_cast<const uint32_t*>(a.rle + (desc & kDescOffMask));
-        const uint32_t len = (uint32_t)(desc >> kDescLenShift);
-        uint32_t pos = 0, prevbit = 0;
-        bool stop = false;
-        for (uint32_t base = 0; base < len && !stop; base += 256) {
-            const uint32_t k0 = base + 4u * (uint32_t)lane;
-            // the first 512 bytes were fetched one batch ahead (pre0/pre1); longer strings read on
-            const uint32_t w = base == 0 ? pre0 : base == 256 ? pre1 : (k0 < len ? q4[(base >> 2) + lane] : 0u);
-            uint32_t byte[4], l[4];
-            bool valid[4];
-            bool anyz = false;
+    const int m = a.m;
+    const uint32_t *q4 = reinterpret_cast<const uint32_t*>(a.rle + (desc & kDescOffMask));
+    const uint32_t len = (uint32_t)(desc >> kDescLenShift);
+    uint32_t pos = 0, prevbit = 0;
+    bool stop = false;
+    for (uint32_t base = 0; base < len && !stop; base += 256) {
+        const uint32_t k0 = base + 4u * (uint32_t)lane;
+        // the first 256*npre bytes were fetched one batch ahead; longer strings read on
+        uint32_t w;
+        if (base == 0) w = pre0;
+        else if (base == 256) w = pre1;
+        else if (base == 512 && npre > 2) w = pre2;
+        else if (base == 768 && npre > 2) w = pre3;
+        else w = k0 < len ? q4[(base >> 2) + lane] : 0u;
+        uint32_t byte[4], l[4];
+        bool valid[4];
+        bool anyz = false;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                byte[i] = (w >> (8 * i)) & 255u;
-                valid[i] = k0 + i < len;
-                anyz = anyz || (valid[i] && byte[i] == 0u);
-            }
-            const uint64_t z = __ballot(anyz);                  // a zero byte ends the row (ref pbwt.c:73)
-            if (z) {
-                const int first = __ffsll((unsigned long long)z) - 1;
-                bool dead = lane > first;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (lane == first && byte[i] == 0u) dead = true;
-                    valid[i] = valid[i] && !dead;
-                }
-                stop = true;
-            }
-            uint32_t run = 0, before[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { l[i] = valid[i] ? rle_len(byte[i]) : 0u; before[i] = run; run += l[i]; }
-            const uint32_t incl = wave_incl_add(run);
-            const uint32_t lane_start = pos + incl - run;
-            uint32_t pb = wave_shr1(byte[3] & 1u, prevbit);      // bit of the byte before this lane's first
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t b = byte[i] & 1u, start = lane_start + before[i];
-                if (valid[i] && b != pb && start < (uint32_t)m) atomicXor(&bd[start >> 5].x, 0xffffffffu << (start & 31));
-                pb = b;
-            }
-            prevbit = lane63(byte[3] & 1u);
-            pos += lane63(incl);
+        for (int i = 0; i < 4; ++i) {
+            byte[i] = (w >> (8 * i)) & 255u;
+            valid[i] = k0 + i < len;
+            anyz = anyz || (valid[i] && byte[i] == 0u);
         }
+        const uint64_t z = __ballot(anyz);                  // a zero byte ends the row (ref pbwt.c:73)
+        if (z) {
+            const int first = __ffsll((unsigned long long)z) - 1;
+            bool dead = lane > first;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (lane == first && byte[i] == 0u) dead = true;
+                valid[i] = valid[i] && !dead;
+            }
+            stop = true;
+        }
+        uint32_t run = 0, before[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { l[i] = valid[i] ? rle_len(byte[i]) : 0u; before[i] = run; run += l[i]; }
+        const uint32_t incl = wave_incl_add(run);
+        const uint32_t lane_start = pos + incl - run;
+        uint32_t pb = wave_shr1(byte[3] & 1u, prevbit);      // bit of the byte before this lane's first
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t b = byte[i] & 1u, start = lane_start + before[i];
+            if (valid[i] && b != pb && start < (uint32_t)m) atomicXor(&bd[start >> 5].x, 0xffffffffu << (start & 31));
+            pb = b;
+        }
+        prevbit = lane63(byte[3] & 1u);
+        pos += lane63(incl);
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    // Four 64-word groups per trip: their LDS reads, in-word prefix xors and popcount scans are
-    // independent, only two scalars (toggle parity, ones so far) are carried from group to group.
-    uint32_t carry_x = 0, carry_c = 0;
-    if (!(a.debug_skip & 4))
-    for (int base = 0; base < nw; base += 256) {
-        uint32_t t[4], w[4], c[4], incl[4];
+}
+
+// step 3 over the words [w0,w1) of a row (one wave).  WRITE=false only measures the segment: the parity of
+// its toggles and its ones if it were entered with carry parity 0 (a team of waves needs that first).
+// Four 64-word groups per trip: their LDS reads and popcount scans are independent, only two scalars
+// (toggle parity, ones so far) are carried from group to group.
+template <bool WRITE>
+__device__ __forceinline__ void directory_pass(uint2 *bd, int w0, int w1, int nw, uint32_t tail_mask,
+                                               uint32_t &carry_x, uint32_t &carry_c, int lane)
+{
+    for (int base = w0; base < w1; base += 256) {
+        uint32_t t[4], c[4], incl[4];
         uint64_t par[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int i = base + g * 64 + lane;
-            t[g] = i < nw ? bd[i].x : 0u;
+            t[g] = i < w1 ? bd[i].x : 0u;
         }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            w[g] = t[g];                                  // already the in-word prefix parity (see step 2)
-            par[g] = __ballot(t[g] >> 31);                // bit 31 = parity of the toggles in the word
-        }
+        for (int g = 0; g < 4; ++g) par[g] = __ballot(t[g] >> 31);      // bit 31 = parity of the word's toggles
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int i = base + g * 64 + lane;
             const uint32_t cin = (lanes_below(par[g]) ^ carry_x) & 1u;   // parity of the toggles before this word
-            uint32_t v = cin ? ~w[g] : w[g];
+            uint32_t v = cin ? ~t[g] : t[g];
             if (i == nw - 1) v &= tail_mask;
-            if (i >= nw) v = 0u;
-            w[g] = v;
+            if (i >= w1) v = 0u;
+            t[g] = v;
             c[g] = (uint32_t)__popc(v);
             incl[g] = wave_incl_add(c[g]);
             carry_x ^= (uint32_t)__popcll(par[g]) & 1u;
@@ -273,11 +277,24 @@ __device__ __forceinline__ void build_plane_row(const ScanArgs &a, uint2 *bd, ui
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int i = base + g * 64 + lane;
-            if (i < nw) bd[i] = make_uint2(w[g], carry_c + incl[g] - c[g]);
+            if (WRITE && i < w1) bd[i] = make_uint2(t[g], carry_c + incl[g] - c[g]);
             carry_c += lane63(incl[g]);
         }
     }
-    if (lane == 0) *n0_out = (uint32_t)m - carry_c;
+}
+
+// whole plane-row by one wave
+__device__ __forceinline__ void build_plane_row(const ScanArgs &a, uint2 *bd, uint32_t *n0_out, uint64_t desc,
+                                                uint32_t pre0, uint32_t pre1, int lane, uint32_t tail_mask)
+{
+    const int nw = a.nw;
+    for (int i = lane; i < nw; i += 64) bd[i] = make_uint2(0u, 0u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (!(a.debug_skip & 2)) rle_toggles(a, bd, desc, pre0, pre1, 0u, 0u, 2, lane);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    uint32_t carry_x = 0, carry_c = 0;
+    if (!(a.debug_skip & 4)) directory_pass<true>(bd, 0, nw, nw, tail_mask, carry_x, carry_c, lane);
+    if (lane == 0) *n0_out = (uint32_t)a.m - carry_c;
 }
 
 // Template switches:  MULTI = more than one sample group (per-chunk LDS atomics instead of per-wave
@@ -335,13 +352,20 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a)
 
     const uint32_t tail_mask = (m & 31) ? ((1u << (m & 31)) - 1u) : 0xffffffffu;
 
+    // ---- who builds which plane-row of a batch.  wpp == 1: wave w builds plane-rows w and w + NWAVE
+    // on its own (K <= NWAVE).  wpp > 1 (wide cohorts: few rows fit the LDS): a team of wpp waves builds
+    // plane-row (wave / wpp) together, synchronised by workgroup barriers.
+    const int wpp = a.wpp;
+    const int team = wave / wpp, tw = wave - team * wpp;
+    uint32_t *seginfo = n0s + 2 * K;                                     // [NWAVE][2] {toggle parity, ones}
+
     // ---- software prefetch of the RLE strings: the row descriptors run two batches ahead of phase A,
     // the first 512 bytes of every string one batch ahead, so that their HBM latency hides under
     // phase B of the batch before.
     uint64_t dsc[2], dsc_next[2];
     uint32_t pre[2][2];
     auto fetch_desc = [&](int64_t rb_, int i) -> uint64_t {
-        const int p = wave + i * NWAVE;
+        const int p = wpp == 1 ? wave + i * NWAVE : (tw == 0 ? team : 1 << 30);   // team mode: both slots = the team's string
         const int64_t left = blk_end - rb_;
         const int kc = (int)(left < K ? left : K);
         return (rb_ < blk_end && p < 2 * kc) ? a.rowdesc[2 * rb_ + p] : 0ull;
@@ -351,31 +375,67 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a)
         const uint32_t k0 = (uint32_t)c * 256u + 4u * (uint32_t)lane;
         return k0 < len ? reinterpret_cast<const uint32_t*>(a.rle + (d & kDescOffMask))[c * 64 + lane] : 0u;
     };
+    const int c1 = wpp == 1 ? 0 : 2;                  // team mode: slot 1 holds chunks 2,3 of the same string
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         dsc[i] = fetch_desc(blk_beg, i);
         dsc_next[i] = fetch_desc(blk_beg + K, i);
-        pre[i][0] = fetch_data(dsc[i], 0);
-        pre[i][1] = fetch_data(dsc[i], 1);
+        pre[i][0] = fetch_data(dsc[i], i * c1);
+        pre[i][1] = fetch_data(dsc[i], i * c1 + 1);
     }
 
     for (int64_t rb = blk_beg; rb < blk_end; rb += K) {
         const int Kc = (int)((blk_end - rb) < K ? (blk_end - rb) : K);
 
         // ================= phase A: build the bit-vectors of Kc rows x 2 planes =================
-        // K <= NWAVE (host guarantees): a wave builds at most two plane-rows per batch, on its own.
+        if (wpp == 1) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int p = wave + i * NWAVE;
-            if (p < 2 * Kc)
-                build_plane_row(a, BD + (size_t)p * nwp, n0s + p, dsc[i], pre[i][0], pre[i][1], lane, tail_mask);
+            for (int i = 0; i < 2; ++i) {
+                const int p = wave + i * NWAVE;
+                if (p < 2 * Kc)
+                    build_plane_row(a, BD + (size_t)p * nwp, n0s + p, dsc[i], pre[i][0], pre[i][1], lane, tail_mask);
+            }
+        } else {
+            const bool active = team < 2 * Kc;
+            uint2 *bd = BD + (size_t)team * nwp;
+            if (active) for (int i = tw * 64 + lane; i < nw; i += wpp * 64) bd[i] = make_uint2(0u, 0u);
+            __syncthreads();
+            if (active && tw == 0 && !(a.debug_skip & 2))
+                rle_toggles(a, bd, dsc[0], pre[0][0], pre[0][1], pre[1][0], pre[1][1], 4, lane);
+            __syncthreads();
+            // every wave of the team owns a contiguous segment of the row's words
+            const int seg = (((nw + wpp - 1) / wpp) + 63) & ~63;
+            const int w0 = tw * seg < nw ? tw * seg : nw;
+            const int w1 = w0 + seg < nw ? w0 + seg : nw;
+            if (active) {
+                uint32_t px = 0, pc = 0;
+                directory_pass<false>(bd, w0, w1, nw, tail_mask, px, pc, lane);
+                if (lane == 0) { seginfo[2 * wave] = px; seginfo[2 * wave + 1] = pc; }
+            }
+            __syncthreads();
+            if (active) {
+                // carries into this segment: an earlier segment entered with odd parity is inverted, so it
+                // holds (its valid positions - its measured ones)
+                uint32_t cx = 0, cnt = 0;
+                for (int s2 = 0; s2 < tw; ++s2) {
+                    const int a0 = s2 * seg < nw ? s2 * seg : nw, a1 = a0 + seg < nw ? a0 + seg : nw;
+                    const uint32_t hi = (uint32_t)a1 * 32u < (uint32_t)m ? (uint32_t)a1 * 32u : (uint32_t)m;
+                    const uint32_t lo = (uint32_t)a0 * 32u < (uint32_t)m ? (uint32_t)a0 * 32u : (uint32_t)m;
+                    const uint32_t spx = seginfo[2 * (team * wpp + s2)], spc = seginfo[2 * (team * wpp + s2) + 1];
+                    cnt += cx ? (hi - lo) - spc : spc;
+                    cx ^= spx;
+                }
+                cx = __builtin_amdgcn_readfirstlane(cx); cnt = __builtin_amdgcn_readfirstlane(cnt);
+                directory_pass<true>(bd, w0, w1, nw, tail_mask, cx, cnt, lane);
+                if (tw == wpp - 1 && lane == 0) n0s[team] = (uint32_t)m - cnt;
+            }
         }
         // issue the loads of the next batch (data) and of the one after (descriptors) before phase B
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             dsc[i] = dsc_next[i];
-            pre[i][0] = fetch_data(dsc[i], 0);
-            pre[i][1] = fetch_data(dsc[i], 1);
+            pre[i][0] = fetch_data(dsc[i], i * c1);
+            pre[i][1] = fetch_data(dsc[i], i * c1 + 1);
             dsc_next[i] = fetch_desc(rb + 2 * K, i);
         }
         __syncthreads();
@@ -482,7 +542,7 @@ static hipError_t launch_one(const ScanArgs &a, const Geometry &g, hipStream_t s
 
 #define BGTH_GEOMS(X) \
     X(256, 2) X(256, 4) X(256, 8) X(256, 12) X(256, 16) X(256, 20) \
-    X(512, 4) X(512, 8) X(512, 10) X(512, 12) X(512, 16) X(512, 20) \
+    X(512, 4) X(512, 8) X(512, 10) X(512, 12) X(512, 16) X(512, 20) X(512, 24) X(512, 32) X(512, 40) X(512, 48) \
     X(1024, 4) X(1024, 8) X(1024, 10) X(1024, 12) X(1024, 16) X(1024, 20) X(1024, 24)
 
 struct GeomEntry { int nt, cpt; };
@@ -495,7 +555,40 @@ static const GeomEntry kGeoms[] = {
 static int lds_need(int nw, int K, int G, int threads)
 {
     const int cnt = G > 1 ? K * G * 3 * 4 : K * (threads / 64) * 16;
-    return ((16 * K * (nw + 1) + 15) & ~15) + cnt + 2 * K * 4;
+    return ((16 * K * (nw + 1) + 15) & ~15) + cnt + 2 * K * 4 + (threads / 64) * 8;
+}
+
+// Cost model (cycles per decoded row on one CU; the kernel is VALU-bound at one wave-instruction per
+// 4 cycles and SIMD, measured on MI355X):
+//   phase B   9 VALU per lookup -> cpt * 2 planes * 9 * 4 cycles * (threads/256 waves per SIMD)
+//   phase A   ~(120 + 0.4 * nw) wave-instructions per plane-row, two plane-rows per row, built by
+//             (threads/64) waves over a batch of K rows
+// Workgroups (blocks x slices) are spread over the 256 CUs; a CU's workgroups share its VALUs.
+static int wpp_for(int nt, int K)
+{
+    int wpp = 1;
+    while (wpp * 2 * 2 * K <= nt / 64 && wpp < 8) wpp *= 2;         // waves per plane-row
+    return wpp;
+}
+
+static long model_cost(int nw, int n_chunks, int n_blk, int nt, int cpt, int K, int *slices_out)
+{
+    const int nwave = nt / 64, cap = nwave * cpt;
+    const int slices = (n_chunks + cap - 1) / cap;
+    const long tB = (long)cpt * 72 * (nt / 256);
+    const long lat = 8 + 5 * (nt / 256);                 // cycles per dependent instruction of a building wave
+    const int wpp = wpp_for(nt, K);
+    long tA;
+    if (wpp == 1) {
+        const int rounds = (2 * K + nwave - 1) / nwave;  // plane-rows per wave and batch
+        tA = (long)rounds * (120 + (long)(nw * 4) / 10) * lat / K;
+    } else {
+        tA = (320 + (long)(nw * 56) / (100 * wpp)) * lat / K;   // serial RLE decode + two directory passes / wpp
+    }
+    const long wgs = (long)n_blk * slices;
+    const long per_cu = (wgs + 255) / 256;
+    *slices_out = slices;
+    return per_cu * (tA + tB);
 }
 
 bool choose_geometry(int m, int n_chunks, int G, int n_blk, int want_threads, int want_cpt, int want_K,
@@ -503,36 +596,31 @@ bool choose_geometry(int m, int n_chunks, int G, int n_blk, int want_threads, in
 {
     const int nw = (m + 31) / 32;
     if (lds_need(nw, 1, G, 1024) > kLdsBytes) return false;
-    int best = -1;
+    int best = -1, best_K = 1;
     long best_cost = 0;
-    // enough workgroups to cover the 256 CUs when the file has few blocks
-    int want_slices = n_blk >= 256 ? 1 : (256 + n_blk - 1) / n_blk;
-    if (want_slices > 8) want_slices = 8;
     for (int i = 0; i < (int)(sizeof(kGeoms) / sizeof(kGeoms[0])); ++i) {
         const int nt = kGeoms[i].nt, cpt = kGeoms[i].cpt;
         if (want_threads && nt != want_threads) continue;
         if (want_cpt && cpt != want_cpt) continue;
-        const int cap = nt / 64 * cpt;                       // chunks per workgroup
-        const int slices = (n_chunks + cap - 1) / cap;
-        const long waste = (long)slices * cap - n_chunks;    // idle chunk slots
-        // cost: wasted lanes + distance from the wanted slice count + a bias to mid-size cpt
-        long cost = waste * 4 + labs((long)slices - want_slices) * (long)n_chunks / 2;
-        if (cpt > 24) cost += n_chunks / 8;
-        if (best < 0 || cost < best_cost) best = i, best_cost = cost;
+        // rows per batch: as many as fit the LDS, at most one per wave (a wave builds <= 2 plane-rows)
+        int K = want_K > 0 ? want_K : nt / 64;
+        if (K > nt / 64) K = nt / 64;
+        while (K > 1 && lds_need(nw, K, G, nt) > kLdsBytes) --K;
+        int slices;
+        const long cost = model_cost(nw, n_chunks, n_blk, nt, cpt, K, &slices);
+        // ties: fewer idle slots, then more threads (more waves to hide LDS latency)
+        const long waste = (long)slices * (nt / 64) * cpt - n_chunks;
+        const long key = cost * 4096 + (waste < 4095 ? waste : 4095);
+        if (best < 0 || key < best_cost || (key == best_cost && nt > kGeoms[best].nt)) best = i, best_cost = key, best_K = K;
     }
     if (best < 0) return false;
     g->threads = kGeoms[best].nt;
     g->cpt     = kGeoms[best].cpt;
     const int cap = g->threads / 64 * g->cpt;
     g->slices  = (n_chunks + cap - 1) / cap;
-    // LDS budget: leave room for 1024/threads workgroups per CU, but at least one row
-    int budget = (int)((long)kLdsBytes * g->threads / 1024);
-    int K = want_K > 0 ? want_K : 16;
-    if (K > g->threads / 64) K = g->threads / 64;          // a wave builds at most two plane-rows per batch
-    while (K > 1 && lds_need(nw, K, G, g->threads) > budget) --K;
-    while (K > 1 && lds_need(nw, K, G, g->threads) > kLdsBytes) --K;
-    g->K = K;
-    g->lds_bytes = (lds_need(nw, K, G, g->threads) + 15) & ~15;
+    g->K = best_K;
+    g->lds_bytes = (lds_need(nw, best_K, G, g->threads) + 15) & ~15;
+    g->wpp = wpp_for(g->threads, best_K);
     g->workgroups = ((n_blk + 7) / 8) * 8 * g->slices;
     return true;
 }

@@ -162,7 +162,8 @@ def test_sample_groups(hip, seed, m, rows, shift, G):
 @pytest.mark.parametrize("threads,cpt,K", [(256, 2, 1), (256, 4, 3), (256, 8, 16), (256, 12, 4), (256, 16, 2),
                                            (256, 20, 1), (512, 4, 8), (512, 8, 4), (512, 10, 3), (512, 12, 2),
                                            (512, 16, 5), (512, 20, 8), (1024, 4, 16), (1024, 8, 2), (1024, 10, 9),
-                                           (1024, 12, 3), (1024, 16, 7), (1024, 20, 5), (1024, 24, 1)])
+                                           (1024, 12, 3), (1024, 16, 7), (1024, 20, 5), (1024, 24, 1), (512, 24, 1),
+                                           (512, 32, 2), (512, 40, 4), (512, 48, 1), (256, 2, 2), (1024, 8, 4)])
 def test_every_launch_geometry(hip, threads, cpt, K):
     """Force each kernel instantiation (and multi-slice launches) on one cohort."""
     mat, data, rng = make_case(41, 5008, 130, 5, n_founders=7, switch=0.04)
