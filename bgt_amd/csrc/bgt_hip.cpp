@@ -674,3 +674,19 @@ extern "C" const uint8_t **bgth_reader_read(bgth_reader_t *r)
 }
 
 extern "C" const int32_t *bgth_reader_last_counts(const bgth_reader_t *r) { return r->last_counts; }
+
+// ----------------------------------------------------------------------------------------------------
+// diagnostics
+// ----------------------------------------------------------------------------------------------------
+extern "C" int bgth_debug_stream_read(int device, size_t bytes, int width, int repeats)
+{
+    if (!use_device(device)) return -1;
+    void *buf = nullptr; uint32_t *sink = nullptr;
+    HIP_TRY(hipMalloc(&buf, bytes), return -1);
+    HIP_TRY(hipMalloc((void**)&sink, 4), { hipFree(buf); return -1; });
+    HIP_TRY(hipMemset(buf, 1, bytes), { hipFree(buf); hipFree(sink); return -1; });
+    for (int i = 0; i < repeats; ++i) HIP_TRY(launch_stream_read(buf, bytes, width, sink, nullptr), break);
+    hipDeviceSynchronize();
+    hipFree(buf); hipFree(sink);
+    return 0;
+}

@@ -50,4 +50,6 @@ hipError_t launch_unpack_bytes(const uint64_t *h0, const uint64_t *h1, const int
                                uint8_t *a0, uint8_t *a1, int64_t n_rows, int n_chunks, int width,
                                hipStream_t s);
 
+hipError_t launch_stream_read(const void *src, size_t bytes, int width, uint32_t *sink, hipStream_t s);
+
 }  // namespace bgth

@@ -739,4 +739,29 @@ hipError_t launch_unpack_bytes(const uint64_t *h0, const uint64_t *h1, const int
     return hipGetLastError();
 }
 
+
+// ----------------------------------------------------------------------------------------------------
+// PMC calibration aid: stream a buffer of known size with the access width of the scan kernel (one
+// dword per lane) or with 16-byte loads, so that rocprofv3's FETCH_SIZE can be scaled to real bytes
+// (MI355X_MICROARCH.md, HBM: "calibrate on a known byte count in your own access pattern").
+// ----------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void stream_read_kernel(const T *src, size_t n, uint32_t *sink)
+{
+    uint32_t acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const T v = src[i];
+        const uint32_t *w = reinterpret_cast<const uint32_t*>(&v);
+        for (unsigned k = 0; k < sizeof(T) / 4; ++k) acc ^= w[k];
+    }
+    if (acc == 0x9e3779b9u) *sink = acc;          // keeps the loads alive
+}
+
+hipError_t launch_stream_read(const void *src, size_t bytes, int width, uint32_t *sink, hipStream_t s)
+{
+    if (width == 16) hipLaunchKernelGGL(stream_read_kernel<uint4>, dim3(2048), dim3(256), 0, s, (const uint4*)src, bytes / 16, sink);
+    else hipLaunchKernelGGL(stream_read_kernel<uint32_t>, dim3(2048), dim3(256), 0, s, (const uint32_t*)src, bytes / 4, sink);
+    return hipGetLastError();
+}
+
 }  // namespace bgth

@@ -109,6 +109,10 @@ int bgth_reader_last_geometry(const bgth_reader_t *r, int out[6]);
 /* Override the automatic launch geometry (0 = automatic). For tuning and tests. */
 int bgth_reader_tune(bgth_reader_t *r, int threads, int cols_per_thread, int rows_per_batch);
 
+/* Diagnostics: stream `bytes` of HBM `repeats` times with `width`-byte loads per lane (4 or 16); used under
+ * rocprofv3 to calibrate the FETCH_SIZE counter against a known byte count. */
+int bgth_debug_stream_read(int device, size_t bytes, int width, int repeats);
+
 #ifdef __cplusplus
 }
 #endif

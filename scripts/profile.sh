@@ -16,3 +16,7 @@ for PASS in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_I
   rocprofv3 --pmc $PASS --output-format csv -d $OUT/pmc_$N -- $BENCH > $OUT/pmc_$N.log 2>&1
 done
 find $OUT -name "*.csv" | head -50
+# FETCH_SIZE calibration on 1 GiB streamed with 4-byte and 16-byte loads
+for W in 4 16; do
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/calib_w$W -- python $R/scripts/calib_fetch.py $W > $OUT/calib_w$W.log 2>&1
+done

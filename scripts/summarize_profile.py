@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Condense a scripts/profile.sh run (gpurun_out/prof_<tag>) into profiles/<tag>/ (committed evidence):
+kernel_stats.csv (rocprofv3 --kernel-trace --stats), pmc_summary.json (mean per launch of the bench-size
+scan kernel for every PMC pass), fetch_calibration.json and profiles/traffic_latest.json (HBM bytes per
+launch = FETCH_SIZE scaled by the calibration + WRITE_SIZE)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", "prof_" + tag)
+dst = os.path.join(root, "profiles", tag)
+os.makedirs(dst, exist_ok=True)
+for f in glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")):
+    shutil.copy(f, os.path.join(dst, "kernel_stats.csv"))
+stats = list(csv.DictReader(open(os.path.join(dst, "kernel_stats.csv"))))
+# the bench-size launches: the scan kernel instance with the fewest calls and the largest average
+scan = [r for r in stats if "scan_kernel" in r["Name"]]
+main = max(scan, key=lambda r: float(r["AverageNs"]))
+kname = main["Name"]
+out = {"kernel": kname, "calls": int(main["Calls"]), "avg_ms": float(main["AverageNs"]) / 1e6, "counters": {}}
+for f in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv"))):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Kernel_Name"] == kname:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for c, v in agg.items():
+        out["counters"][c] = {"launches": len(v), "mean_per_launch": sum(v) / len(v)}
+calib = {}
+for w in (4, 16):
+    fs = glob.glob(os.path.join(src, "calib_w%d" % w, "*", "*counter_collection.csv"))
+    vals = [float(r["Counter_Value"]) for f in fs for r in csv.DictReader(open(f))
+            if "stream_read" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE"]
+    if vals:
+        mean = sum(vals) / len(vals)
+        calib["width%d" % w] = {"bytes_streamed": 1 << 30, "FETCH_SIZE_KiB": mean,
+                                "bytes_per_counted_byte": (1 << 30) / (mean * 1024.0)}
+json.dump(calib, open(os.path.join(dst, "fetch_calibration.json"), "w"), indent=1)
+c = out["counters"]
+if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+    k = calib.get("width4", {}).get("bytes_per_counted_byte", 1.0)
+    fetch = c["FETCH_SIZE"]["mean_per_launch"] * 1024.0 * k
+    write = c["WRITE_SIZE"]["mean_per_launch"] * 1024.0
+    out["hbm_bytes_per_launch"] = {"fetch_corrected": fetch, "write": write, "total": fetch + write,
+                                   "fetch_scale_from_calibration": k}
+    meta = json.load(open(os.path.join(root, "gpurun_out", "bench_for_%s.json" % tag))) if os.path.exists(
+        os.path.join(root, "gpurun_out", "bench_for_%s.json" % tag)) else {}
+    json.dump({"tag": tag, "workload": "c2", "sites": 1000000, "hbm_bytes_per_launch": fetch + write,
+               "fetch_bytes": fetch, "write_bytes": write, "fetch_scale": k, "kernel": kname},
+              open(os.path.join(root, "profiles", "traffic_latest.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
+print(json.dumps(out, indent=1)[:3000])

@@ -19,9 +19,12 @@ def libpath():
 
 
 def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "bgt_hip.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(bgth_[a-z0-9_]+)\s*\(", text)))
+    names = set()
+    for h in ("bgt_hip.h", "bgt_synth.h"):
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names.update(re.findall(r"\b(bgth_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
 
 
 def test_header_symbols_all_exported(libpath):
