@@ -121,7 +121,9 @@ struct bgth_reader_s {
     int tune_threads = 0, tune_cpt = 0, tune_K = 0;
     // pull interface
     int64_t next = 0, ring0 = 0, ring1 = 0;
-    bool ring_planes = false;
+    bool ring_has_planes = false;
+    bool want_planes = true;          // pull interface: also deliver byte planes (else counts only)
+    int64_t max_ahead = 0;            // rows per refill (0 = automatic)
     const uint8_t *ret[2] = {nullptr, nullptr};
     const int32_t *last_counts = nullptr;
 };
@@ -633,26 +635,34 @@ static bool refill(bgth_reader_t *r)
     const int width = r->sel.width;
     const int gx = gx_of(r->sel.G);
     const size_t cstride = (size_t)(1 + gx) * 3;
-    // decode to the end of a block; several blocks per refill while the byte planes stay under 256 MiB
-    int64_t max_rows = ((int64_t)256 << 20) / std::max(1, 2 * width);
+    // Decode to the end of a block, several blocks per refill: with byte planes while they stay under
+    // 256 MiB, with counts only a wide window (the whole point of the device: one launch, many sites).
+    int64_t max_rows = r->want_planes ? ((int64_t)256 << 20) / std::max(1, 2 * width) : (int64_t)1 << 22;
+    if (r->max_ahead > 0) max_rows = std::min(max_rows, r->max_ahead);
     max_rows = std::max<int64_t>(blk_rows, max_rows / blk_rows * blk_rows);
     const int64_t row0 = r->next;
     int64_t row1 = std::min<int64_t>(p->n, ((row0 >> p->shift) << p->shift) + max_rows);
     const int64_t rows = row1 - row0;
     const size_t pl = (size_t)rows * r->sel.n_chunks * 8, by = (size_t)rows * width;
-    if (!r->fin.reserve((size_t)rows * cstride * 4) || !r->h0.reserve(pl) || !r->h1.reserve(pl) ||
-        !r->planes.reserve(2 * by) || !r->h_counts.reserve((size_t)rows * cstride * 4) || !r->h_planes.reserve(2 * by)) {
+    if (!r->fin.reserve((size_t)rows * cstride * 4) || !r->h_counts.reserve((size_t)rows * cstride * 4)) {
         set_err("[E::bgth_reader_read] out of memory for a %lld-row batch", (long long)rows);
         return false;
     }
-    if (enqueue_scan(r, row0, row1, (int32_t*)r->fin.p, (uint64_t*)r->h0.p, (uint64_t*)r->h1.p, r->stream, true) < 0) return false;
-    uint8_t *d_a0 = (uint8_t*)r->planes.p, *d_a1 = d_a0 + by;
-    HIP_TRY(launch_unpack_bytes((uint64_t*)r->h0.p, (uint64_t*)r->h1.p, r->sel.d_slot_of_out, d_a0, d_a1, rows, r->sel.n_chunks, width, r->stream), return false);
+    if (r->want_planes && (!r->h0.reserve(pl) || !r->h1.reserve(pl) || !r->planes.reserve(2 * by) || !r->h_planes.reserve(2 * by))) {
+        set_err("[E::bgth_reader_read] out of memory for a %lld-row batch", (long long)rows);
+        return false;
+    }
+    uint64_t *d_h0 = r->want_planes ? (uint64_t*)r->h0.p : nullptr, *d_h1 = r->want_planes ? (uint64_t*)r->h1.p : nullptr;
+    if (enqueue_scan(r, row0, row1, (int32_t*)r->fin.p, d_h0, d_h1, r->stream, true) < 0) return false;
+    if (r->want_planes) {
+        uint8_t *d_a0 = (uint8_t*)r->planes.p, *d_a1 = d_a0 + by;
+        HIP_TRY(launch_unpack_bytes(d_h0, d_h1, r->sel.d_slot_of_out, d_a0, d_a1, rows, r->sel.n_chunks, width, r->stream), return false);
+        HIP_TRY(hipMemcpyAsync(r->h_planes.p, r->planes.p, 2 * by, hipMemcpyDeviceToHost, r->stream), return false);
+    }
     HIP_TRY(hipMemcpyAsync(r->h_counts.p, r->fin.p, (size_t)rows * cstride * 4, hipMemcpyDeviceToHost, r->stream), return false);
-    HIP_TRY(hipMemcpyAsync(r->h_planes.p, r->planes.p, 2 * by, hipMemcpyDeviceToHost, r->stream), return false);
     HIP_TRY(hipStreamSynchronize(r->stream), return false);
     collect_timing(r);
-    r->ring0 = row0; r->ring1 = row1;
+    r->ring0 = row0; r->ring1 = row1; r->ring_has_planes = r->want_planes;
     return true;
 }
 
@@ -662,15 +672,25 @@ extern "C" const uint8_t **bgth_reader_read(bgth_reader_t *r)
     bgth_pbf_t *p = r->pbf;
     if (r->next >= p->n) return nullptr;                         // ref pbwt.c:336: no more 'B' records
     if (!use_device(p->device)) return nullptr;
-    if (r->next < r->ring0 || r->next >= r->ring1) if (!refill(r)) return nullptr;
+    if (r->next < r->ring0 || r->next >= r->ring1 || (r->want_planes && !r->ring_has_planes)) if (!refill(r)) return nullptr;
     const int width = r->sel.width;
     const size_t by = (size_t)(r->ring1 - r->ring0) * width;
     const size_t k = (size_t)(r->next - r->ring0);
-    r->ret[0] = (const uint8_t*)r->h_planes.p + k * width;
-    r->ret[1] = (const uint8_t*)r->h_planes.p + by + k * width;
+    if (r->want_planes) {
+        r->ret[0] = (const uint8_t*)r->h_planes.p + k * width;
+        r->ret[1] = (const uint8_t*)r->h_planes.p + by + k * width;
+    } else r->ret[0] = r->ret[1] = nullptr;
     r->last_counts = (const int32_t*)r->h_counts.p + k * (size_t)(1 + gx_of(r->sel.G)) * 3;
     ++r->next;
     return r->ret;
+}
+
+extern "C" int bgth_reader_config(bgth_reader_t *r, int want_planes, int64_t max_rows_ahead)
+{
+    if (!r) return -1;
+    r->want_planes = want_planes != 0;
+    r->max_ahead = max_rows_ahead;
+    return 0;
 }
 
 extern "C" const int32_t *bgth_reader_last_counts(const bgth_reader_t *r) { return r->last_counts; }

@@ -1,0 +1,160 @@
+/* bgzf_io.c -- BGZF = a series of gzip members of at most 64 KiB, each carrying its own compressed size in
+ * a "BC" extra field (SAM/BAM spec 4.1; the reference's bgzf.c implements the same container). */
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+#include "bgzf_io.h"
+
+#define BLOCK_DATA 0xff00          /* uncompressed bytes per block, as the reference writer uses */
+#define BLOCK_MAX  0x10000
+
+struct bgzr_s {
+    FILE *fp;
+    uint8_t *in, *out;
+    size_t out_len, out_pos;
+    int eof;
+};
+
+bgzr_t *bgzr_open(const char *path)
+{
+    FILE *fp = fopen(path, "rb");
+    bgzr_t *r;
+    int c0, c1;
+    if (!fp) return NULL;
+    c0 = fgetc(fp); c1 = fgetc(fp);
+    if (c0 != 0x1f || c1 != 0x8b) { fclose(fp); return NULL; }
+    rewind(fp);
+    r = (bgzr_t*)calloc(1, sizeof(*r));
+    r->fp = fp;
+    r->in = (uint8_t*)malloc(BLOCK_MAX);
+    r->out = (uint8_t*)malloc(BLOCK_MAX);
+    return r;
+}
+
+static int next_block(bgzr_t *r)
+{
+    uint8_t hdr[12], *p;
+    unsigned xlen, bsize = 0, i;
+    size_t rest;
+    z_stream zs;
+    if (fread(hdr, 1, 12, r->fp) != 12) { r->eof = 1; return 0; }
+    if (hdr[0] != 0x1f || hdr[1] != 0x8b || !(hdr[3] & 4)) return -1;
+    xlen = hdr[10] | hdr[11] << 8;
+    if (fread(r->in, 1, xlen, r->fp) != xlen) return -1;
+    for (i = 0; i + 4 <= xlen;) {                       /* find the BC subfield */
+        unsigned slen = r->in[i + 2] | r->in[i + 3] << 8;
+        if (r->in[i] == 'B' && r->in[i + 1] == 'C' && slen == 2) bsize = (r->in[i + 4] | r->in[i + 5] << 8) + 1u;
+        i += 4 + slen;
+    }
+    if (bsize < 12 + xlen + 8) return -1;
+    rest = bsize - 12 - xlen;                           /* deflate data + crc32 + isize */
+    if (fread(r->in, 1, rest, r->fp) != rest) return -1;
+    p = r->in;
+    memset(&zs, 0, sizeof(zs));
+    zs.next_in = p; zs.avail_in = (uInt)(rest - 8);
+    zs.next_out = r->out; zs.avail_out = BLOCK_MAX;
+    if (inflateInit2(&zs, -15) != Z_OK) return -1;
+    if (inflate(&zs, Z_FINISH) != Z_STREAM_END) { inflateEnd(&zs); return -1; }
+    inflateEnd(&zs);
+    r->out_len = zs.total_out;
+    r->out_pos = 0;
+    return 1;
+}
+
+long bgzr_read(bgzr_t *r, void *dst, size_t n)
+{
+    size_t got = 0;
+    while (got < n) {
+        size_t k;
+        if (r->out_pos == r->out_len) {
+            int s;
+            if (r->eof) break;
+            s = next_block(r);
+            if (s < 0) return -1;
+            if (s == 0) break;
+            continue;
+        }
+        k = r->out_len - r->out_pos;
+        if (k > n - got) k = n - got;
+        memcpy((uint8_t*)dst + got, r->out + r->out_pos, k);
+        r->out_pos += k; got += k;
+    }
+    return (long)got;
+}
+
+void bgzr_close(bgzr_t *r)
+{
+    if (!r) return;
+    fclose(r->fp); free(r->in); free(r->out); free(r);
+}
+
+/* ---------------- writer ---------------- */
+struct bgzw_s {
+    FILE *fp;
+    int level;
+    uint8_t *buf, *cbuf;
+    size_t fill;
+    uint64_t coff;
+};
+
+bgzw_t *bgzw_open(FILE *fp, int level)
+{
+    bgzw_t *w = (bgzw_t*)calloc(1, sizeof(*w));
+    w->fp = fp;
+    w->level = (level < 0 || level > 9) ? Z_DEFAULT_COMPRESSION : level;
+    w->buf = (uint8_t*)malloc(BLOCK_MAX);
+    w->cbuf = (uint8_t*)malloc(BLOCK_MAX);
+    return w;
+}
+
+static int flush_block(bgzw_t *w)
+{
+    static const uint8_t head[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+    z_stream zs;
+    uint32_t crc, n = (uint32_t)w->fill, total;
+    memset(&zs, 0, sizeof(zs));
+    zs.next_in = w->buf; zs.avail_in = n;
+    zs.next_out = w->cbuf + 18; zs.avail_out = BLOCK_MAX - 18 - 8;
+    if (deflateInit2(&zs, w->level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return -1;
+    if (deflate(&zs, Z_FINISH) != Z_STREAM_END) { deflateEnd(&zs); return -1; }
+    deflateEnd(&zs);
+    total = (uint32_t)zs.total_out + 18 + 8;
+    memcpy(w->cbuf, head, 16);
+    w->cbuf[16] = (uint8_t)((total - 1) & 0xff); w->cbuf[17] = (uint8_t)((total - 1) >> 8);
+    crc = (uint32_t)crc32(crc32(0L, NULL, 0), w->buf, n);
+    memcpy(w->cbuf + total - 8, &crc, 4);
+    memcpy(w->cbuf + total - 4, &n, 4);
+    if (fwrite(w->cbuf, 1, total, w->fp) != total) return -1;
+    w->coff += total;
+    w->fill = 0;
+    return 0;
+}
+
+int bgzw_write(bgzw_t *w, const void *src, size_t n)
+{
+    const uint8_t *p = (const uint8_t*)src;
+    while (n) {
+        size_t k = BLOCK_DATA - w->fill;
+        if (k > n) k = n;
+        memcpy(w->buf + w->fill, p, k);
+        w->fill += k; p += k; n -= k;
+        if (w->fill == BLOCK_DATA && flush_block(w) < 0) return -1;
+    }
+    return 0;
+}
+
+uint64_t bgzw_tell(const bgzw_t *w) { return w->coff << 16 | (uint64_t)w->fill; }
+
+int bgzw_close(bgzw_t *w)
+{
+    int rc = 0;
+    if (!w) return 0;
+    /* the BGZF end-of-file marker is one fixed empty member (SAM spec 4.1.2), whatever the level */
+    static const uint8_t eof_marker[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0,
+                                           0, 0, 0, 0, 0, 0, 0, 0};
+    if (w->fill && flush_block(w) < 0) rc = -1;
+    if (fwrite(eof_marker, 1, 28, w->fp) != 28) rc = -1;
+    fflush(w->fp);
+    free(w->buf); free(w->cbuf); free(w);
+    return rc;
+}

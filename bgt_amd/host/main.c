@@ -1,0 +1,17 @@
+/* main.c -- the `bgt` executable of this build: dispatches `view` (alias `mview`) to the MI355X reader. */
+#include <stdio.h>
+#include <string.h>
+#include "../../include/bgt_reader.h"
+#include "../../include/bgt_hip.h"
+
+int main(int argc, char *argv[])
+{
+    if (argc < 2) {
+        fprintf(stderr, "Usage: bgt <command> <arguments>\nCommands:\n  view     extract from BGT (genotype-matrix read path on MI355X)\n  version  show version\n");
+        return 1;
+    }
+    if (strcmp(argv[1], "view") == 0 || strcmp(argv[1], "mview") == 0) return main_view(argc - 1, argv + 1);
+    if (strcmp(argv[1], "version") == 0) { puts(bgth_version()); return 0; }
+    fprintf(stderr, "[E::%s] unrecognized command '%s' (this build provides the read path: view)\n", __func__, argv[1]);
+    return 1;
+}

@@ -1,0 +1,802 @@
+/* reader.c -- the BGT reader API (include/bgt_reader.h) on top of the MI355X codec (include/bgt_hip.h).
+ *
+ * Host logic only: which site comes next, which samples are selected, how the per-database results are
+ * merged, which INFO fields are written, whether the site passes the filter.  Every genotype and every
+ * allele count comes from the device through bgth_reader_read(); there is no CPU decoder here.
+ * Reference behaviour restated: bgt.c:40-81 (open), :89-246 (single reader), :272-356 (site pull),
+ * :364-676 (multi reader set-up), :692-757 (INFO and filter), :797-888 (merge loop).
+ */
+#include <assert.h>
+#include <limits.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+#include "../../include/bgt_reader.h"
+#include "../../include/bgt_hip.h"
+
+int bgt_no_file = 0;
+
+/* ------------------------------------------------------------------------------------------------
+ * site table: prefix.bcf held column-wise in memory
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int64_t n;
+    int32_t *rid, *pos, *rlen, *row, *n_allele;
+    uint32_t *ref_off, *alt_off;
+    uint16_t *ref_len, *alt_len;
+    char *pool; size_t pool_len, pool_cap;
+    int32_t max_rlen;
+} sitetab_t;
+
+static void st_free(sitetab_t *t)
+{
+    if (!t) return;
+    free(t->rid); free(t->pos); free(t->rlen); free(t->row); free(t->n_allele);
+    free(t->ref_off); free(t->alt_off); free(t->ref_len); free(t->alt_len); free(t->pool); free(t);
+}
+
+static uint32_t st_intern(sitetab_t *t, const uint8_t *s, int n)
+{
+    uint32_t at = (uint32_t)t->pool_len;
+    if (t->pool_len + (size_t)n + 1 > t->pool_cap) {
+        t->pool_cap = t->pool_cap ? t->pool_cap * 2 : 1 << 16;
+        while (t->pool_len + (size_t)n + 1 > t->pool_cap) t->pool_cap *= 2;
+        t->pool = (char*)realloc(t->pool, t->pool_cap);
+    }
+    memcpy(t->pool + at, s, (size_t)n);
+    t->pool[at + (uint32_t)n] = 0;
+    t->pool_len += (size_t)n + 1;
+    return at;
+}
+
+static int tv_bytes(int type) { return type == 1 || type == 7 ? 1 : type == 2 ? 2 : (type == 3 || type == 5) ? 4 : 0; }
+static int32_t tv_int(const uint8_t *p, int type)
+{
+    if (type == 1) return *(const int8_t*)p;
+    if (type == 2) { int16_t v; memcpy(&v, p, 2); return v; }
+    { int32_t v; memcpy(&v, p, 4); return v; }
+}
+static int tv_size(const uint8_t *p, const uint8_t **q, int *type)
+{
+    *type = *p & 15;
+    if (*p >> 4 != 15) { *q = p + 1; return *p >> 4; }
+    { int t = p[1] & 15; *q = p + 2 + tv_bytes(t); return tv_int(p + 2, t); }
+}
+
+/* every record of the site-only BCF: rid/pos/rlen, REF, first ALT, number of alleles and INFO/_row
+ * (the row of the genotype matrix; ref bgt.c:272-288 asserts it is present and that there are no samples) */
+static sitetab_t *st_load(bgzr_t *fp, const bcf_hdr_t *h)
+{
+    const int row_key = bcf_id2int(h, BCF_DT_ID, "_row");
+    sitetab_t *t = (sitetab_t*)calloc(1, sizeof(*t));
+    bcf1_t *b = bcf_init1();
+    int64_t cap = 0;
+    int ret;
+    if (row_key < 0) { bcf_destroy1(b); st_free(t); return NULL; }
+    while ((ret = bcf_read1_stream(fp, b)) == 0) {
+        const uint8_t *p = (const uint8_t*)b->shared.s, *q;
+        int n, type, i, row = -1;
+        if (t->n == cap) {
+            cap = cap ? cap * 2 : 1 << 16;
+            t->rid = (int32_t*)realloc(t->rid, (size_t)cap * 4); t->pos = (int32_t*)realloc(t->pos, (size_t)cap * 4);
+            t->rlen = (int32_t*)realloc(t->rlen, (size_t)cap * 4); t->row = (int32_t*)realloc(t->row, (size_t)cap * 4);
+            t->n_allele = (int32_t*)realloc(t->n_allele, (size_t)cap * 4);
+            t->ref_off = (uint32_t*)realloc(t->ref_off, (size_t)cap * 4); t->alt_off = (uint32_t*)realloc(t->alt_off, (size_t)cap * 4);
+            t->ref_len = (uint16_t*)realloc(t->ref_len, (size_t)cap * 2); t->alt_len = (uint16_t*)realloc(t->alt_len, (size_t)cap * 2);
+        }
+        if (b->n_sample != 0 || b->n_allele < 2) { ret = -3; break; }
+        n = tv_size(p, &q, &type); p = q + n;                                   /* ID */
+        n = tv_size(p, &q, &type);                                              /* REF */
+        t->ref_off[t->n] = st_intern(t, q, n); t->ref_len[t->n] = (uint16_t)n; p = q + n;
+        n = tv_size(p, &q, &type);                                              /* first ALT */
+        t->alt_off[t->n] = st_intern(t, q, n); t->alt_len[t->n] = (uint16_t)n; p = q + n;
+        for (i = 2; i < (int)b->n_allele; ++i) { n = tv_size(p, &q, &type); p = q + n; }
+        n = tv_size(p, &q, &type); p = q + (size_t)n * tv_bytes(type);          /* FILTER */
+        for (i = 0; i < (int)b->n_info; ++i) {
+            int kt, key;
+            tv_size(p, &q, &kt); key = tv_int(q, kt); p = q + tv_bytes(kt);
+            n = tv_size(p, &q, &type);
+            if (key == row_key && n >= 1) row = tv_int(q, type);
+            p = q + (size_t)n * tv_bytes(type);
+        }
+        if (row < 0) { ret = -3; break; }
+        t->rid[t->n] = b->rid; t->pos[t->n] = b->pos; t->rlen[t->n] = b->rlen;
+        t->row[t->n] = row; t->n_allele[t->n] = b->n_allele;
+        if (b->rlen > t->max_rlen) t->max_rlen = b->rlen;
+        ++t->n;
+    }
+    bcf_destroy1(b);
+    if (ret < -1) { st_free(t); return NULL; }
+    return t;
+}
+
+/* order of sites across databases: contig, position, reference length, then the first ALT as bytes with
+ * the shorter one first on a tie (ref vcf.c:1152-1164) */
+static int st_cmp(const sitetab_t *a, int64_t i, const sitetab_t *b, int64_t j)
+{
+    int la, lb, r;
+    if (a->rid[i] != b->rid[j]) return a->rid[i] - b->rid[j];
+    if (a->pos[i] != b->pos[j]) return a->pos[i] - b->pos[j];
+    if (a->rlen[i] != b->rlen[j]) return a->rlen[i] - b->rlen[j];
+    la = a->alt_len[i]; lb = b->alt_len[j];
+    r = strncmp(a->pool + a->alt_off[i], b->pool + b->alt_off[j], (size_t)(la < lb ? la : lb));
+    return r ? r : la - lb;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * private state behind the opaque pointers of bgt_t
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct { int64_t next; } cursor_t;                   /* bgt_t::bcf */
+typedef struct { int tid, beg, end; int64_t at; int done; } region_t;   /* bgt_t::itr */
+typedef struct { bgth_reader_t *rd; int64_t site; const int32_t *counts; int skip_device; } devrd_t;   /* bgt_t::pb */
+
+/* ------------------------------------------------------------------------------------------------
+ * files
+ * ------------------------------------------------------------------------------------------------ */
+static void set_mgs(bgt_file_t *bf)                           /* ref bgt.c:24-38: optional _mgs:i: tag */
+{
+    int i, j, key = -1;
+    for (i = 0; i < bf->f->n_rows; ++i) bf->mgs[i] = -1;
+    for (i = 0; i < bf->f->n_keys; ++i) if (strcmp(bf->f->keys[i], "_mgs") == 0) key = i;
+    if (key < 0) return;
+    for (i = 0; i < bf->f->n_rows; ++i) {
+        const fmf1_t *r = &bf->f->rows[i];
+        for (j = 0; j < r->n_meta; ++j)
+            if ((int)r->meta[j].key == key && r->meta[j].type == FMF_INT && r->meta[j].v.i >= 0) bf->mgs[i] = r->meta[j].v.i;
+    }
+}
+
+bgt_file_t *bgt_open(const char *prefix)
+{
+    char *fn = (char*)malloc(strlen(prefix) + 16);
+    bgt_file_t *bf = NULL;
+    bgzr_t *fp;
+    FILE *t;
+    sprintf(fn, "%s.bcf", prefix);
+    if ((fp = bgzr_open(fn)) == NULL) goto fail;
+    bf = (bgt_file_t*)calloc(1, sizeof(*bf));
+    if ((bf->h0 = bcf_hdr_read_stream(fp)) == NULL) goto fail;
+    sprintf(fn, "%s.bcf.csi", prefix);                       /* the reference refuses a BGT without its index */
+    if ((t = fopen(fn, "rb")) == NULL) goto fail;
+    fclose(t);
+    if ((bf->idx = st_load(fp, bf->h0)) == NULL) goto fail;
+    sprintf(fn, "%s.spl", prefix);
+    if ((bf->f = fmf_read(fn)) == NULL) goto fail;
+    bf->prefix = strdup(prefix);
+    bf->mgs = (int32_t*)calloc((size_t)(bf->f->n_rows ? bf->f->n_rows : 1), 4);
+    set_mgs(bf);
+    bgzr_close(fp);
+    free(fn);
+    return bf;
+fail:
+    free(fn);
+    if (fp) bgzr_close(fp);
+    if (bf) bgt_close(bf);
+    return NULL;
+}
+
+void bgt_close(bgt_file_t *bf)
+{
+    if (!bf) return;
+    if (bf->gpu) bgth_pbf_close((bgth_pbf_t*)bf->gpu);
+    free(bf->mgs);
+    st_free((sitetab_t*)bf->idx);
+    if (bf->h0) bcf_hdr_destroy(bf->h0);
+    if (bf->f) fmf_destroy(bf->f);
+    free(bf->prefix); free(bf);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * single-database reader
+ * ------------------------------------------------------------------------------------------------ */
+bgt_t *bgt_reader_init(const bgt_file_t *bf)
+{
+    bgt_t *bgt = (bgt_t*)calloc(1, sizeof(*bgt));
+    devrd_t *dv = (devrd_t*)calloc(1, sizeof(*dv));
+    bgt->f = bf;
+    bgt->pb = dv;
+    bgt->bcf = calloc(1, sizeof(cursor_t));
+    bgt->b0 = bcf_init1();
+    bgt->gtag = (uint32_t*)calloc((size_t)(bf->f->n_rows ? bf->f->n_rows : 1), 4);
+    return bgt;
+}
+
+void bgt_reader_destroy(bgt_t *bgt)
+{
+    devrd_t *dv;
+    if (!bgt) return;
+    dv = (devrd_t*)bgt->pb;
+    if (dv) { if (dv->rd) bgth_reader_destroy(dv->rd); free(dv); }
+    bcf_destroy1(bgt->b0);
+    free(bgt->gtag); free(bgt->group); free(bgt->out); free(bgt->bcf); free(bgt->itr);
+    if (bgt->h_out) bcf_hdr_destroy(bgt->h_out);
+    free(bgt);
+}
+
+/* names after ':' or ',' separated by commas, or the first column of a file (ref hts.c hts_readlines) */
+static char **read_names(const char *arg, int *n_out)
+{
+    char **s = NULL;
+    int n = 0, m = 0;
+    gzFile fp = gzopen(arg, "r");
+    *n_out = 0;
+    if (fp) {
+        char line[65536];
+        while (gzgets(fp, line, sizeof(line))) {
+            size_t l = strcspn(line, "\t\n");
+            if (line[0] == '\n' || line[0] == 0) continue;
+            line[l] = 0;
+            if (n == m) { m = m ? m * 2 : 16; s = (char**)realloc(s, (size_t)m * sizeof(char*)); }
+            s[n++] = strdup(line);
+        }
+        gzclose(fp);
+    } else if (*arg == ':' || *arg == ',') {
+        const char *p, *q;
+        for (q = p = arg + 1;; ++p)
+            if (*p == ',' || *p == 0) {
+                if (n == m) { m = m ? m * 2 : 16; s = (char**)realloc(s, (size_t)m * sizeof(char*)); }
+                s[n] = (char*)calloc((size_t)(p - q) + 1, 1);
+                memcpy(s[n++], q, (size_t)(p - q));
+                q = p + 1;
+                if (*p == 0) break;
+            }
+    } else return NULL;
+    *n_out = n;
+    return s;
+}
+
+static int cmp_str(const void *a, const void *b) { return strcmp(*(char* const*)a, *(char* const*)b); }
+
+/* tag the samples of one more group; returns its size or <0 (ref bgt.c:121-161) */
+static int add_group_core(bgt_t *bgt, int n, char **samples, const char *expr)
+{
+    const fmf_t *f = bgt->f->f;
+    int i, size = 0;
+    if (n == BGT_SET_ALL_SAMPLES) {
+        for (i = 0; i < f->n_rows; ++i) bgt->gtag[i] = 1;
+        bgt->n_groups = 1;
+        return f->n_rows;
+    }
+    if (n > 0 || expr != NULL) {
+        kexpr_t *ke = NULL;
+        int err;
+        if (expr && (ke = ke_parse(expr, &err)) == NULL) return -1;
+        if (n > 0) qsort(samples, (size_t)n, sizeof(char*), cmp_str);
+        for (i = 0; i < f->n_rows; ++i) {
+            int add = 0;
+            if (ke && fmf_test(f, i, ke)) add = 1;
+            if (n > 0 && bsearch(&f->rows[i].name, samples, (size_t)n, sizeof(char*), cmp_str)) {
+                const int mgs = bgt->f->mgs[i] >= 0 ? bgt->f->mgs[i] : bgt->mgs_def;
+                if (mgs == 1 || mgs == 0) add = 1;           /* a sample may be named only if its mgs allows it */
+            }
+            if (add) { ++size; bgt->gtag[i] = (uint32_t)bgt->n_groups + 1; }   /* a later group overrides */
+        }
+        ke_destroy(ke);
+        ++bgt->n_groups;
+        return size;
+    }
+    return -1;
+}
+
+static int is_file(const char *fn)
+{
+    FILE *fp;
+    if (bgt_no_file) return 0;
+    if ((fp = fopen(fn, "r")) == NULL) return 0;
+    fclose(fp);
+    return 1;
+}
+
+static int add_group(bgt_t *bgt, const char *expr)            /* ref bgt.c:174-188 */
+{
+    if (*expr == ':' || *expr == ',' || (*expr != '?' && is_file(expr))) {
+        int n, i, ret;
+        char **s = read_names(expr, &n);
+        ret = add_group_core(bgt, n, s, NULL);
+        for (i = 0; i < n; ++i) free(s[i]);
+        free(s);
+        return ret;
+    }
+    return add_group_core(bgt, 0, NULL, expr);
+}
+
+/* "chr", "chr:beg-end", "chr:beg" with 1-based inclusive coordinates and optional thousands commas
+ * (ref hts.c:821-850); returns the length of the contig name */
+static int parse_region(const char *s, int *beg, int *end)
+{
+    int l = (int)strlen(s), name_end = l, i, k;
+    *beg = 0; *end = 1 << 29;
+    for (i = l - 1; i >= 0; --i) if (s[i] == ':') break;
+    if (i >= 0) name_end = i;
+    if (name_end < l) {
+        int hyphens = 0;
+        for (i = name_end + 1; i < l; ++i) {
+            if (s[i] == '-') ++hyphens;
+            else if (!(s[i] >= '0' && s[i] <= '9') && s[i] != ',') break;
+        }
+        if (i < l || hyphens > 1) name_end = l;
+    }
+    if (name_end < l) {
+        char *tmp = (char*)malloc((size_t)(l - name_end) + 1), *p;
+        for (i = name_end + 1, k = 0; i < l; ++i) if (s[i] != ',') tmp[k++] = s[i];
+        tmp[k] = 0;
+        if ((*beg = (int)strtol(tmp, &p, 10) - 1) < 0) *beg = 0;
+        *end = *p ? (int)strtol(p + 1, &p, 10) : 1 << 29;
+        free(tmp);
+        if (*beg > *end) { name_end = l; *beg = 0; *end = 1 << 29; }
+    }
+    return name_end;
+}
+
+int bgt_set_region(bgt_t *bgt, const char *reg)               /* ref bgt.c:190-196, hts.c:852-866 */
+{
+    const sitetab_t *t = (const sitetab_t*)bgt->f->idx;
+    region_t *r;
+    int beg, end, tid, nl;
+    char *name;
+    int64_t lo, hi;
+    free(bgt->itr); bgt->itr = NULL;
+    nl = parse_region(reg, &beg, &end);
+    name = (char*)calloc((size_t)nl + 1, 1);
+    memcpy(name, reg, (size_t)nl);
+    if ((tid = bcf_id2int(bgt->f->h0, BCF_DT_CTG, name)) < 0) tid = bcf_id2int(bgt->f->h0, BCF_DT_CTG, reg);
+    free(name);
+    if (tid < 0) return -1;
+    r = (region_t*)calloc(1, sizeof(*r));
+    r->tid = tid; r->beg = beg; r->end = end;
+    /* first site that can overlap: sites are sorted by (contig, position); a site starting up to
+     * max_rlen before `beg` may still reach into the region */
+    lo = 0; hi = t->n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (t->rid[mid] < tid || (t->rid[mid] == tid && t->pos[mid] + t->max_rlen <= beg)) lo = mid + 1; else hi = mid;
+    }
+    r->at = lo;
+    bgt->itr = r;
+    bgt->b0->shared.l = 0;
+    return 0;
+}
+
+int bgt_set_start(bgt_t *bgt, int64_t i)                      /* ref bgt.c:198-201, vcf.c:1195-1209 */
+{
+    const sitetab_t *t = (const sitetab_t*)bgt->f->idx;
+    if (i < 0 || i >= t->n) return -1;                        /* the reference does not move the file then */
+    ((cursor_t*)bgt->bcf)->next = i;
+    return 0;
+}
+
+void bgt_set_bed(bgt_t *bgt, const void *bed, int excl) { bgt->bed = bed; bgt->bed_excl = excl; }
+
+/* selected samples in .spl order and their groups; install the column selection on the device
+ * (ref bgt.c:207-246; the subset list is {2s, 2s+1} for every selected sample s) */
+/* the HBM image of prefix.pbf is opened on first need and cached on the file handle, shared by every
+ * reader of that file; each reader owns its own device reader (stream, selection, result buffers) */
+static int ensure_device(bgt_t *bgt)
+{
+    bgt_file_t *wf = (bgt_file_t*)bgt->f;
+    devrd_t *dv = (devrd_t*)bgt->pb;
+    if (dv->rd) return 0;
+    if (wf->gpu == NULL) {
+        char *fn = (char*)malloc(strlen(wf->prefix) + 8);
+        sprintf(fn, "%s.pbf", wf->prefix);
+        wf->gpu = bgth_pbf_open(fn, 0);
+        free(fn);
+    }
+    if (wf->gpu) dv->rd = bgth_reader_create((bgth_pbf_t*)wf->gpu);
+    if (dv->rd == NULL) { fprintf(stderr, "[E::%s] %s\n", __func__, bgth_last_error()); return -1; }
+    return 0;
+}
+
+static int prepare_one(bgt_t *bgt, int n_groups_total, int need_device)
+{
+    const fmf_t *f = bgt->f->f;
+    devrd_t *dv = (devrd_t*)bgt->pb;
+    int i, rc = 0;
+    int32_t *cols;
+    dv->skip_device = !need_device;
+    if (need_device && ensure_device(bgt) < 0) rc = -1;
+    if (bgt->n_groups == 0) add_group_core(bgt, BGT_SET_ALL_SAMPLES, NULL, NULL);
+    for (i = 0, bgt->n_out = 0; i < f->n_rows; ++i) if (bgt->gtag[i] > 0) ++bgt->n_out;
+    bgt->out = (int*)realloc(bgt->out, (size_t)(bgt->n_out ? bgt->n_out : 1) * sizeof(int));
+    bgt->group = (uint32_t*)realloc(bgt->group, (size_t)(bgt->n_out ? bgt->n_out : 1) * 4);
+    for (i = 0, bgt->n_out = 0; i < f->n_rows; ++i)
+        if (bgt->gtag[i] > 0) { bgt->group[bgt->n_out] = bgt->gtag[i]; bgt->out[bgt->n_out++] = i; }
+    if (bgt->n_out > 0 && dv->rd) {
+        cols = (int32_t*)malloc((size_t)bgt->n_out * 2 * 4);
+        for (i = 0; i < bgt->n_out; ++i) { cols[2 * i] = bgt->out[i] * 2; cols[2 * i + 1] = bgt->out[i] * 2 + 1; }
+        rc = bgth_reader_select(dv->rd, bgt->n_out * 2, cols, n_groups_total > 1 ? bgt->group : NULL,
+                                n_groups_total > 1 ? n_groups_total : 1);
+        if (rc < 0) fprintf(stderr, "[E::%s] %s\n", __func__, bgth_last_error());
+        free(cols);
+    }
+    dv->site = -1;
+    bgt->b0->shared.l = 0;
+    return rc;
+}
+
+/* next site of this database: a region walks the overlapping sites in file order, otherwise the cursor
+ * advances (ref bgt.c:272-288, :315-331; hts.c:868-900) */
+static int64_t next_site(bgt_t *bgt)
+{
+    const sitetab_t *t = (const sitetab_t*)bgt->f->idx;
+    region_t *r = (region_t*)bgt->itr;
+    if (r) {
+        while (!r->done && r->at < t->n) {
+            const int64_t i = r->at++;
+            if (t->rid[i] != r->tid || t->pos[i] >= r->end) { r->done = 1; break; }
+            if (t->pos[i] + t->rlen[i] > r->beg) return i;
+        }
+        r->done = 1;
+        return -1;
+    } else {
+        cursor_t *c = (cursor_t*)bgt->bcf;
+        return c->next < t->n ? c->next++ : -1;
+    }
+}
+
+static void fill_b0(bgt_t *bgt, int64_t i)
+{
+    const sitetab_t *t = (const sitetab_t*)bgt->f->idx;
+    bcf_set_site(bgt->b0, t->rid[i], t->pos[i], t->rlen[i], t->pool + t->ref_off[i], t->ref_len[i],
+                 t->pool + t->alt_off[i], t->alt_len[i], NULL);
+    bgt->b0->n_allele = (uint32_t)t->n_allele[i];
+}
+
+/* pull one site and its genotype row (ref bgt.c:333-345) */
+static int read_rec(bgt_t *bgt, bgt_rec_t *r)
+{
+    const sitetab_t *t = (const sitetab_t*)bgt->f->idx;
+    devrd_t *dv = (devrd_t*)bgt->pb;
+    const uint8_t **a;
+    int64_t i;
+    r->b0 = NULL; r->a[0] = r->a[1] = NULL;
+    if (bgt->n_out == 0) return -1;
+    if ((i = next_site(bgt)) < 0) return -1;
+    fill_b0(bgt, i);
+    dv->site = i;
+    if (dv->skip_device) {                                    /* `view -G` without -C/-f/-s groups: the output does */
+        static const int32_t zero[3 * 33];                    /* not depend on a single genotype */
+        dv->counts = zero; r->b0 = bgt->b0;
+        return t->row[i];
+    }
+    if (dv->rd == NULL) return -2;
+    if (bgth_reader_seek(dv->rd, t->row[i]) < 0 || (a = bgth_reader_read(dv->rd)) == NULL) {
+        fprintf(stderr, "[E::%s] %s\n", __func__, bgth_last_error());
+        return -2;
+    }
+    dv->counts = bgth_reader_last_counts(dv->rd);
+    r->b0 = bgt->b0; r->a[0] = a[0]; r->a[1] = a[1];
+    return t->row[i];
+}
+
+static const int8_t bits2gt[4] = {2, 4, 0, 6};              /* (allele+1)<<1 for REF, ALT, missing, <M> (ref bgt.c:250) */
+
+static void gen_gt(const bcf_hdr_t *h, bcf1_t *b, int m, const uint8_t *const *a, const int32_t *mgs)
+{                                                             /* ref bgt.c:290-313 */
+    int i, m2 = m;
+    b->indiv.l = 0;
+    if (mgs) { for (i = m2 = 0; i < m; ++i) m2 += mgs[i] <= 1; if (m2 == 0) return; }
+    b->n_fmt = 1; b->n_sample = (uint32_t)m2;
+    bcf_enc_int1(&b->indiv, bcf_id2int(h, BCF_DT_ID, "GT"));
+    bcf_enc_size(&b->indiv, 2, BCF_BT_INT8);
+    ks_need(&b->indiv, (size_t)m2 * 2 + 1);
+    for (i = 0; i < m << 1; ++i)
+        if (!mgs || mgs[i >> 1] <= 1) b->indiv.s[b->indiv.l++] = (char)bits2gt[a[1][i] << 1 | a[0][i]];
+    b->indiv.s[b->indiv.l] = 0;
+}
+
+int bgt_read(bgt_t *bgt, bcf1_t *b)                           /* ref bgt.c:347-356 */
+{
+    bgt_rec_t r;
+    int ret;
+    if (bgt->h_out == NULL) {
+        devrd_t *dv = (devrd_t*)bgt->pb;
+        kstring_t s = {0, 0, 0};
+        int i;
+        prepare_one(bgt, 1, 1);
+        if (dv->rd) bgth_reader_config(dv->rd, 1, 0);
+        bgt->h_out = bcf_hdr_init();                          /* input header + FORMAT + the selected samples */
+        ks_putn(&s, bgt->f->h0->text, (size_t)bgt->f->h0->l_text);
+        while (s.l && s.s[s.l - 1] == 0) --s.l;
+        if (bgt->n_out > 0) {
+            ks_puts(&s, "\tFORMAT");
+            for (i = 0; i < bgt->n_out; ++i) { ks_putc(&s, '\t'); ks_puts(&s, bgt->f->f->rows[bgt->out[i]].name); }
+        }
+        bgt->h_out->text = s.s; bgt->h_out->l_text = (int32_t)s.l + 1;
+        bcf_hdr_parse(bgt->h_out);
+    }
+    if ((ret = read_rec(bgt, &r)) < 0) return ret;
+    b->rid = r.b0->rid; b->pos = r.b0->pos; b->rlen = r.b0->rlen; b->qual = r.b0->qual;
+    b->n_info = 0; b->n_allele = r.b0->n_allele; b->n_fmt = 0; b->n_sample = 0;
+    b->shared.l = 0; ks_putn(&b->shared, r.b0->shared.s, r.b0->shared.l);
+    gen_gt(bgt->h_out, b, bgt->n_out, r.a, NULL);
+    return ret;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * multi-database reader
+ * ------------------------------------------------------------------------------------------------ */
+bgtm_t *bgtm_reader_init(int n_files, bgt_file_t *const *bf)
+{
+    bgtm_t *bm = (bgtm_t*)calloc(1, sizeof(*bm));
+    int i;
+    bm->n_bgt = n_files;
+    bm->bgt = (bgt_t**)calloc((size_t)n_files, sizeof(void*));
+    for (i = 0; i < n_files; ++i) bm->bgt[i] = bgt_reader_init(bf[i]);
+    bm->r = (bgt_rec_t*)calloc((size_t)n_files, sizeof(bgt_rec_t));
+    return bm;
+}
+
+void bgtm_reader_destroy(bgtm_t *bm)
+{
+    int i;
+    if (!bm) return;
+    free(bm->hap); free(bm->alcnt);
+    if (bm->site_flt) ke_destroy(bm->site_flt);
+    free(bm->mgs); free(bm->group); free(bm->sample_idx);
+    if (bm->h_out) bcf_hdr_destroy(bm->h_out);
+    free(bm->a[0]); free(bm->a[1]);
+    for (i = 0; i < bm->n_fields; ++i) ke_destroy(bm->fields[i]);
+    free(bm->fields); free(bm->tbl_line.s);
+    for (i = 0; i < bm->n_bgt; ++i) bgt_reader_destroy(bm->bgt[i]);
+    free(bm->r); free(bm->bgt); free(bm);
+}
+
+int bgtm_add_group(bgtm_t *bm, const char *expr)              /* ref bgt.c:408-416 */
+{
+    int i, ret = 0, size = 0;
+    for (i = 0; i < bm->n_bgt; ++i) {
+        if ((ret = add_group(bm->bgt[i], expr)) < 0) break;
+        size += ret;
+    }
+    if (i == bm->n_bgt) ++bm->n_groups;
+    return i == bm->n_bgt ? size : ret;
+}
+
+int bgtm_set_region(bgtm_t *bm, const char *reg)
+{
+    int i, ret = 0;
+    for (i = 0; i < bm->n_bgt; ++i) if ((ret = bgt_set_region(bm->bgt[i], reg)) < 0) break;
+    return ret;
+}
+
+int bgtm_set_start(bgtm_t *bm, int64_t n) { int i; for (i = 0; i < bm->n_bgt; ++i) bgt_set_start(bm->bgt[i], n); return 0; }
+void bgtm_set_bed(bgtm_t *bm, const void *bed, int excl) { int i; for (i = 0; i < bm->n_bgt; ++i) bgt_set_bed(bm->bgt[i], bed, excl); }
+void bgtm_set_flag(bgtm_t *bm, int flag) { bm->flag = flag; }
+
+int bgtm_set_flt_site(bgtm_t *bm, const char *expr)           /* ref bgt.c:444-455: non-zero = parse error bits */
+{
+    int err;
+    if (bm->site_flt) ke_destroy(bm->site_flt);
+    bm->site_flt = ke_parse(expr, &err);
+    if (err != 0) { bm->site_flt = NULL; return err; }
+    return 0;
+}
+
+int bgtm_set_mgs(bgtm_t *bm, int mgs_def)
+{
+    int i;
+    for (i = 0; i < bm->n_bgt; ++i) bm->bgt[i]->mgs_def = mgs_def;
+    bm->mgs_def = mgs_def;
+    return 0;
+}
+
+static int not_built(const char *what)
+{
+    fprintf(stderr, "[E::bgt] %s is not part of this build (genotype-matrix read path only; SURVEY.md 8f)\n", what);
+    return -1;
+}
+int bgtm_set_table(bgtm_t *bm, const char *fmt) { (void)bm; (void)fmt; return not_built("tabular output (-t)"); }
+int bgtm_set_alleles(bgtm_t *bm, const char *expr, const fmf_t *f, const char *fn)
+{ (void)bm; (void)expr; (void)f; (void)fn; return not_built("allele-set queries (-a/-S/-H)"); }
+bgt_hapcnt_t *bgtm_hapcnt(const bgtm_t *bm, int *n_hap) { (void)bm; *n_hap = 0; not_built("haplotype counting (-H)"); return NULL; }
+char *bgtm_hapcnt_print_destroy(const bgtm_t *bm, int n_hap, bgt_hapcnt_t *hc) { (void)bm; (void)n_hap; (void)hc; return NULL; }
+char *bgtm_alcnt_print(const bgtm_t *bm) { (void)bm; return NULL; }
+int bgt_al_parse(const char *al, bgt_allele_t *a) { (void)al; (void)a; return not_built("allele parsing"); }
+void bgt_al_format(const bgt_allele_t *a, kstring_t *s)
+{
+    s->l = 0;
+    ks_putn(s, a->chr.s, (size_t)(a->al - a->chr.s - 1)); ks_putc(s, ':');
+    ks_puti(s, a->pos); ks_putc(s, ':'); ks_puti(s, a->rlen); ks_putc(s, ':');
+    ks_putn(s, a->al, (size_t)(a->chr.s + a->chr.l - a->al));
+}
+void bgt_al_from_bcf(const bcf_hdr_t *h, const bcf1_t *b, bgt_allele_t *a, bgt_allele_t *r)
+{ (void)h; (void)b; (void)a; (void)r; not_built("allele extraction"); }
+
+/* merged sample list, groups, output header, device selections (ref bgt.c:597-676) */
+int bgtm_prepare(bgtm_t *bm)
+{
+    kstring_t h = {0, 0, 0};
+    const bcf_hdr_t *h0;
+    int i, j, m, need_counts, rc = 0;
+    if (bm->n_bgt == 0) return 0;
+    /* does any output depend on a genotype?  not for `-G` without -C / -f / several groups (ref bgt.c:850) */
+    need_counts = (bm->flag & BGT_F_SET_AC) || bm->site_flt || bm->n_fields > 0 || bm->n_groups > 1;
+    for (i = bm->n_out = 0; i < bm->n_bgt; ++i) {
+        if (prepare_one(bm->bgt[i], bm->n_groups, !(bm->flag & BGT_F_NO_GT) || need_counts) < 0) rc = -1;
+        bm->n_out += bm->bgt[i]->n_out;
+    }
+    bm->mgs = (int32_t*)realloc(bm->mgs, (size_t)(bm->n_out ? bm->n_out : 1) * 4);
+    bm->group = (uint32_t*)realloc(bm->group, (size_t)(bm->n_out ? bm->n_out : 1) * 4);
+    bm->sample_idx = (uint64_t*)realloc(bm->sample_idx, (size_t)(bm->n_out ? bm->n_out : 1) * 8);
+    for (i = m = 0; i < bm->n_bgt; ++i) {
+        const bgt_t *bgt = bm->bgt[i];
+        for (j = 0; j < bgt->n_out; ++j) {
+            bm->sample_idx[m] = (uint64_t)i << 32 | (uint32_t)bgt->out[j];
+            bm->group[m] = bm->n_groups ? bgt->group[j] : 1;
+            bm->mgs[m++] = bgt->f->mgs[bgt->out[j]] >= 0 ? bgt->f->mgs[bgt->out[j]] : bm->mgs_def;
+        }
+    }
+    if (bm->n_groups == 0) bm->n_groups = 1;
+    for (i = m = 0; i < bm->n_out; ++i) if (bm->mgs[i] <= 1) ++m;
+    if (m == 0) bm->flag |= BGT_F_NO_GT;
+
+    h0 = bm->bgt[0]->f->h0;
+    ks_puts(&h, "##fileformat=VCFv4.1\n");
+    ks_puts(&h, "##INFO=<ID=AC,Number=A,Type=String,Description=\"Count of alternate alleles\">\n");
+    ks_puts(&h, "##INFO=<ID=AN,Number=A,Type=String,Description=\"Count of total alleles\">\n");
+    for (i = 1; i <= bm->n_groups; ++i) {
+        ks_printf(&h, "##INFO=<ID=AC%d,Number=A,Type=String,Description=\"Count of alternate alleles for sample group %d\">\n", i, i);
+        ks_printf(&h, "##INFO=<ID=AN%d,Number=A,Type=String,Description=\"Count of total alleles for sample group %d\">\n", i, i);
+    }
+    ks_puts(&h, "##INFO=<ID=END,Number=1,Type=Integer,Description=\"Ending position\">\n");
+    ks_puts(&h, "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n");
+    ks_puts(&h, "##ALT=<ID=M,Description=\"Multi-allele\">\n");
+    ks_puts(&h, "##ALT=<ID=DEL,Description=\"Deletion\">\n");
+    ks_puts(&h, "##ALT=<ID=DUP,Description=\"Duplication\">\n");
+    ks_puts(&h, "##ALT=<ID=INS,Description=\"Insertion\">\n");
+    ks_puts(&h, "##ALT=<ID=INV,Description=\"Inversion\">\n");
+    ks_puts(&h, "##ALT=<ID=DUP:TANDEM,Description=\"Tandem duplication\">\n");
+    ks_puts(&h, "##ALT=<ID=DEL:ME,Description=\"Deletion of mobile element\">\n");
+    ks_puts(&h, "##ALT=<ID=INS:ME,Description=\"Insertion of mobile element\">\n");
+    for (i = 0; i < h0->n[BCF_DT_CTG]; ++i)
+        ks_printf(&h, "##contig=<ID=%s,length=%d>\n", h0->id[BCF_DT_CTG][i].key, h0->id[BCF_DT_CTG][i].val->info[0]);
+    ks_puts(&h, "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO");
+    if (!(bm->flag & BGT_F_NO_GT)) {
+        ks_puts(&h, "\tFORMAT");
+        for (i = m = 0; i < bm->n_bgt; ++i) {
+            const bgt_t *bgt = bm->bgt[i];
+            for (j = 0; j < bgt->n_out; ++j) {
+                if (bm->mgs[m++] > 1) continue;
+                ks_putc(&h, '\t');
+                ks_puts(&h, bgt->f->f->rows[bgt->out[j]].name);
+            }
+        }
+    }
+    if (bm->h_out) bcf_hdr_destroy(bm->h_out);
+    bm->h_out = bcf_hdr_init();
+    bm->h_out->l_text = (int32_t)h.l + 1; bm->h_out->m_text = (int32_t)h.m; bm->h_out->text = h.s;
+    bcf_hdr_parse(bm->h_out);
+
+    bm->a[0] = (uint8_t*)realloc(bm->a[0], (size_t)(bm->n_out ? bm->n_out : 1) << 1);
+    bm->a[1] = (uint8_t*)realloc(bm->a[1], (size_t)(bm->n_out ? bm->n_out : 1) << 1);
+
+    /* what the device has to deliver per site: byte planes only if genotypes are printed */
+    for (i = 0; i < bm->n_bgt; ++i) {
+        devrd_t *dv = (devrd_t*)bm->bgt[i]->pb;
+        if (dv->rd) bgth_reader_config(dv->rd, !(bm->flag & BGT_F_NO_GT), 0);
+    }
+    return rc;
+}
+
+int bgtm_test_mgs(const bgtm_t *bm)                           /* ref bgt.c:678-688 */
+{
+    int i, cnt[BGT_MAX_GROUPS];
+    memset(cnt, 0, sizeof(cnt));
+    for (i = 0; i < bm->n_out; ++i) ++cnt[bm->group[i] - 1];
+    for (i = 0; i < bm->n_out; ++i) if (bm->mgs[i] > cnt[bm->group[i] - 1]) return 0;
+    return 1;
+}
+
+static char *group_key(char key[5], char nc, int g)           /* AN1..AN32 / AC1..AC32 (ref bgt.c:692-698) */
+{
+    key[0] = 'A'; key[1] = nc;
+    if (g < 9) { key[2] = (char)('0' + g + 1); key[3] = 0; }
+    else { key[2] = (char)('0' + (g + 1) / 10); key[3] = (char)('0' + (g + 1) % 10); key[4] = 0; }
+    return key;
+}
+
+static int pass_site_flt(const bgt_info_t *ss, kexpr_t *flt)  /* ref bgt.c:700-719 */
+{
+    int i, err, yes;
+    char key[5];
+    if (flt == NULL) return 1;
+    ke_set_int(flt, "AN", ss->an);
+    ke_set_int(flt, "AC", ss->ac[0]);
+    for (i = 0; i < ss->n_groups; ++i) {
+        ke_set_int(flt, group_key(key, 'N', i), ss->gan[i]);
+        ke_set_int(flt, group_key(key, 'C', i), ss->gac[i][0]);
+    }
+    yes = !!ke_eval_int(flt, &err);
+    return err ? 0 : yes;
+}
+
+static void fill_info(const bcf_hdr_t *h, const bgt_info_t *ss, bcf1_t *b)   /* ref bgt.c:721-733 */
+{
+    bcf_append_info_ints(h, b, "AN", 1, &ss->an);
+    bcf_append_info_ints(h, b, "AC", (int)b->n_allele - 1, ss->ac);
+    if (ss->n_groups > 1) {
+        int i;
+        char key[5];
+        for (i = 0; i < ss->n_groups; ++i) {
+            bcf_append_info_ints(h, b, group_key(key, 'N', i), 1, &ss->gan[i]);
+            bcf_append_info_ints(h, b, group_key(key, 'C', i), (int)b->n_allele - 1, ss->gac[i]);
+        }
+    }
+}
+
+/* one merged site.  Returns 0 = emitted, 1 = filtered out, -1 = no more sites (ref bgt.c:797-878).
+ * AC/AN of the merged site = sum over the databases that carry the site of the counts the device
+ * reduced for that database's row (ref bgt.c:735-757 over the concatenated planes; a database
+ * without the site contributes code 2 = missing, which adds to no count, ref :837-840,755-756). */
+static int read_core(bgtm_t *bm, bcf1_t *b)
+{
+    int i, off = 0, n_rest = 0, max_allele = 0, best = -1, l_ref;
+    const sitetab_t *bt = NULL;
+    int64_t bs = -1;
+    bgt_info_t ss;
+    for (i = 0; i < bm->n_bgt; ++i) {
+        if (bm->r[i].b0 == NULL) read_rec(bm->bgt[i], &bm->r[i]);
+        n_rest += bm->r[i].b0 != NULL;
+        if (bm->r[i].b0) bm->n_gt_read += (uint64_t)bm->bgt[i]->n_out;
+    }
+    if (n_rest == 0) return -1;
+    for (i = 0; i < bm->n_bgt; ++i) {                         /* the smallest look-ahead site */
+        const sitetab_t *t = (const sitetab_t*)bm->bgt[i]->f->idx;
+        const int64_t s = ((devrd_t*)bm->bgt[i]->pb)->site;
+        if (bm->r[i].b0 == NULL) continue;
+        if (best >= 0) {
+            const int c = st_cmp(bt, bs, t, s);
+            if (c > 0) { best = i; bt = t; bs = s; max_allele = t->n_allele[s]; }
+            else if (c == 0 && t->n_allele[s] > max_allele) max_allele = t->n_allele[s];
+        } else { best = i; bt = t; bs = s; max_allele = t->n_allele[s]; }
+    }
+    assert(best >= 0 && max_allele >= 2);
+    bcf_set_site(b, bt->rid[bs], bt->pos[bs], bt->rlen[bs], bt->pool + bt->ref_off[bs], bt->ref_len[bs],
+                 bt->pool + bt->alt_off[bs], bt->alt_len[bs], max_allele > 2 ? "<M>" : NULL);
+    l_ref = bt->ref_len[bs];
+    if (l_ref != b->rlen) { int32_t val = b->pos + b->rlen; bcf_append_info_ints(bm->h_out, b, "END", 1, &val); }
+
+    memset(&ss, 0, sizeof(ss));
+    ss.n_groups = bm->n_groups;
+    for (i = 0; i < bm->n_bgt; ++i) {                         /* consume the databases that have this site */
+        bgt_t *bgt = bm->bgt[i];
+        const sitetab_t *t = (const sitetab_t*)bgt->f->idx;
+        devrd_t *dv = (devrd_t*)bgt->pb;
+        if (bgt->n_out == 0) continue;
+        if (bm->r[i].b0 && st_cmp(bt, bs, t, dv->site) == 0) {
+            const int32_t *c = dv->counts;
+            int g;
+            bm->r[i].b0 = NULL;
+            if (bm->r[i].a[0]) {
+                memcpy(bm->a[0] + off, bm->r[i].a[0], (size_t)bgt->n_out << 1);
+                memcpy(bm->a[1] + off, bm->r[i].a[1], (size_t)bgt->n_out << 1);
+            }
+            ss.an += c[0]; ss.ac[0] += c[1]; ss.ac[1] += c[2];
+            if (bm->n_groups > 1)
+                for (g = 0; g < bm->n_groups; ++g) {
+                    ss.gan[g] += c[3 * (1 + g)]; ss.gac[g][0] += c[3 * (1 + g) + 1]; ss.gac[g][1] += c[3 * (1 + g) + 2];
+                }
+        } else if (!(bm->flag & BGT_F_NO_GT)) {               /* this database lacks the site: all missing */
+            memset(bm->a[0] + off, 0, (size_t)bgt->n_out << 1);
+            memset(bm->a[1] + off, 1, (size_t)bgt->n_out << 1);
+        }
+        off += bgt->n_out << 1;
+    }
+    if ((bm->flag & BGT_F_SET_AC) || bm->site_flt || bm->n_fields > 0 || bm->n_groups > 1) {
+        fill_info(bm->h_out, &ss, b);
+        if (!pass_site_flt(&ss, bm->site_flt)) return 1;
+    }
+    return 0;
+}
+
+int bgtm_read(bgtm_t *bm, bcf1_t *b)                          /* ref bgt.c:880-888 */
+{
+    int ret;
+    if (bm->h_out == NULL) bgtm_prepare(bm);
+    while ((ret = read_core(bm, b)) > 0) {}
+    if (ret >= 0 && (bm->flag & BGT_F_NO_GT) == 0)
+        gen_gt(bm->h_out, b, bm->n_out, (const uint8_t *const*)bm->a, bm->mgs);
+    return ret;
+}

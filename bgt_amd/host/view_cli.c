@@ -1,0 +1,104 @@
+/* view_cli.c -- `bgt view`: option handling and the pull loop of reference view.c:14-183, on the MI355X
+ * reader.  Options outside the genotype-matrix read path (-B/-e BED, -a/-d/-M/-S/-H allele queries,
+ * -t tables) are recognised and refused. */
+#include <limits.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+#include "../../include/bgt_reader.h"
+
+static int usage(const char *cmd)
+{
+    fprintf(stderr, "Usage: bgt %s [options] <bgt-prefix> [...]\n", cmd);
+    fprintf(stderr, "Options:\n");
+    fprintf(stderr, "  -s EXPR   sample group: ,name1,name2 | file | expression on .spl metadata (repeatable)\n");
+    fprintf(stderr, "  -r STR    region chr[:beg-end]\n");
+    fprintf(stderr, "  -i INT    start from the INT-th site (1-based)      -n INT   emit at most INT sites\n");
+    fprintf(stderr, "  -f STR    site filter on AC, AN, AC#, AN# (e.g. 'AC>0', 'AC1/AN1>=0.1&&AC2==0')\n");
+    fprintf(stderr, "  -G        no sample genotypes     -C   write AC/AN (implied by -f or several -s)\n");
+    fprintf(stderr, "  -b        BCF output   -l INT   compression level   -u   uncompressed BCF\n");
+    return 1;
+}
+
+int main_view(int argc, char *argv[])
+{
+    int i, c, n_files, out_bcf = 0, clevel = -1, flag = 0, u_set = 0, n_groups = 0;
+    long seekn = -1, n_rec = LONG_MAX, n_read = 0;
+    char *reg = NULL, *site_flt = NULL, *gexpr[BGT_MAX_GROUPS];
+    bgt_file_t **files;
+    bgtm_t *bm;
+    bcf1_t *b;
+    bgzw_t *bz = NULL;
+    kstring_t line = {0, 0, 0};
+
+    optind = 1;
+    while ((c = getopt(argc, argv, "ubs:r:l:CMGB:ef:g:a:i:n:SHt:d:")) >= 0) {
+        switch (c) {
+        case 'b': out_bcf = 1; break;
+        case 'r': reg = optarg; break;
+        case 'l': clevel = atoi(optarg); break;
+        case 'u': u_set = 1; break;
+        case 'C': flag |= BGT_F_SET_AC; break;
+        case 'G': flag |= BGT_F_NO_GT; break;
+        case 'i': seekn = atol(optarg) - 1; break;
+        case 'n': n_rec = atol(optarg); break;
+        case 'f': site_flt = optarg; break;
+        case 's': if (n_groups < BGT_MAX_GROUPS) gexpr[n_groups++] = optarg; break;
+        case 'B': case 'e': case 'a': case 'd': case 'M': case 'S': case 'H': case 't':
+            fprintf(stderr, "[E::%s] option -%c is outside the genotype-matrix read path and not part of this build.\n", __func__, c);
+            return 1;
+        default: break;
+        }
+    }
+    if (n_rec < 0) { fprintf(stderr, "[E::%s] option -n must be at least 0.\n", __func__); return 1; }
+    if (clevel > 9) clevel = 9;
+    if (u_set) { clevel = 0; out_bcf = 1; }
+    if (n_groups > 1) flag |= BGT_F_SET_AC;
+    if (argc - optind < 1) return usage(argv[0]);
+
+    n_files = argc - optind;
+    files = (bgt_file_t**)calloc((size_t)n_files, sizeof(bgt_file_t*));
+    for (i = 0; i < n_files; ++i)
+        if ((files[i] = bgt_open(argv[optind + i])) == NULL) {
+            fprintf(stderr, "[E::%s] failed to open BGT with prefix '%s'\n", __func__, argv[optind + i]);
+            return 1;
+        }
+    bm = bgtm_reader_init(n_files, files);
+    bgtm_set_flag(bm, flag);
+    if (site_flt && bgtm_set_flt_site(bm, site_flt) != 0) {
+        fprintf(stderr, "[E::%s] failed to set frequency filters. Syntax error?\n", __func__);
+        return 1;
+    }
+    if (reg && bgtm_set_region(bm, reg) < 0) {
+        fprintf(stderr, "[E::%s] failed to set region. Region format error?\n", __func__);
+        return 1;
+    }
+    if (seekn > 0) bgtm_set_start(bm, seekn);
+    for (i = 0; i < n_groups; ++i)
+        if (bgtm_add_group(bm, gexpr[i]) < 0) {
+            fprintf(stderr, "[E::%s] failed to add sample group '%s'.\n", __func__, gexpr[i]);
+            return 1;
+        }
+    if (bgtm_prepare(bm) < 0) { fprintf(stderr, "[E::%s] failed to prepare the readers.\n", __func__); return 1; }
+
+    /* the reference builds the mode string "wb%d" and takes its first digit as the level, so the default
+     * -1 compresses at level 1 (view.c:144-146, bgzf.c:138-146) */
+    if (out_bcf) { bz = bgzw_open(stdout, clevel < 0 ? 1 : clevel); bcf_hdr_write_stream(bz, bm->h_out); }
+    else vcf_hdr_write_text(stdout, bm->h_out);
+
+    b = bcf_init1();
+    while (bgtm_read(bm, b) >= 0 && n_read < n_rec) {
+        if (bz) bcf_write1_stream(bz, b);
+        else { vcf_format1(bm->h_out, b, &line); fwrite(line.s, 1, line.l, stdout); fputc('\n', stdout); }
+        ++n_read;
+    }
+    bcf_destroy1(b);
+    if (bz) bgzw_close(bz);
+    fflush(stdout);
+    free(line.s);
+    bgtm_reader_destroy(bm);
+    for (i = 0; i < n_files; ++i) bgt_close(files[i]);
+    free(files);
+    return 0;
+}

@@ -97,6 +97,10 @@ int     bgth_reader_slot_map(const bgth_reader_t *r, int32_t *slot_of_output); /
  * and served from a host ring.  NULL at end of file. */
 int             bgth_reader_seek(bgth_reader_t *r, int64_t row);
 const uint8_t **bgth_reader_read(bgth_reader_t *r);
+/* What the pull interface delivers: want_planes = 0 keeps only the counts (the `-G` path: the returned
+ * array then holds two NULL plane pointers) and lets one refill cover millions of rows;
+ * max_rows_ahead bounds a refill (0 = automatic). */
+int             bgth_reader_config(bgth_reader_t *r, int want_planes, int64_t max_rows_ahead);
 /* counts of the row returned by the last bgth_reader_read: int32[1+Gx][3] */
 const int32_t  *bgth_reader_last_counts(const bgth_reader_t *r);
 

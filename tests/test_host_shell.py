@@ -1,0 +1,132 @@
+"""The host shell of the read path (libbgt.so + `bgt view`): struct ABI, expression language, metadata
+parsing and the CLI against outputs of the compiled reference.  CPU tests cover everything that does not
+depend on a genotype; the GPU tests replay every golden `bgt view` command byte for byte."""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden", "bgt")
+BGT = os.path.join(ROOT, "bgt_amd", "bin", "bgt")
+LIB = os.path.join(ROOT, "bgt_amd", "lib", "libbgt.so")
+REF_BGT = os.path.join(ROOT, "oracle", "_ref", "bgt")
+MANIFEST = json.load(open(os.path.join(GOLD, "manifest.json")))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    import bgt_amd
+    bgt_amd.build_library()
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bgt_amd", "host")])
+    assert os.path.exists(BGT) and os.path.exists(LIB)
+
+
+def run_view(args, prefixes, exe=BGT):
+    return subprocess.run([exe, "view"] + args + prefixes, cwd=GOLD, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+
+
+def test_struct_layouts_are_the_reference_abi(tmp_path):
+    """sizes/offsets bgt-server.go relies on (x86-64)."""
+    src = tmp_path / "abi.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "bgt.h"\n'
+                   'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+                   'sizeof(bgtm_t),offsetof(bgtm_t,n_gt_read),offsetof(bgtm_t,h_out),offsetof(bgtm_t,a),'
+                   'offsetof(bgtm_t,n_fields),offsetof(bgtm_t,tbl_line),offsetof(bgtm_t,n_aal),sizeof(bgt_t),'
+                   'sizeof(bgt_info_t),sizeof(bcf1_t),offsetof(bcf1_t,shared),offsetof(bcf1_t,indiv),'
+                   'sizeof(bcf_hdr_t),offsetof(bcf_hdr_t,text));printf("%zu\\n",sizeof(fmf_t));return 0;}\n')
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    assert out == ["184", "16", "80", "88", "104", "120", "144", "104", "400", "152", "24", "48", "104", "72", "48"]
+
+
+def test_api_symbols_exported():
+    lib = C.CDLL(LIB)
+    for name in ("bgt_open bgt_close bgt_reader_init bgt_reader_destroy bgt_set_bed bgt_set_region bgt_set_start "
+                 "bgt_read bgtm_reader_init bgtm_reader_destroy bgtm_set_flag bgtm_set_flt_site bgtm_set_bed "
+                 "bgtm_set_region bgtm_set_start bgtm_set_table bgtm_set_alleles bgtm_set_mgs bgtm_add_group "
+                 "bgtm_prepare bgtm_test_mgs bgtm_read bgtm_hapcnt bgtm_hapcnt_print_destroy bgtm_alcnt_print "
+                 "bgt_al_parse bgt_al_format bgt_al_from_bcf bgt_no_file vcf_format1 bcf_init1 bcf_destroy1 fmf_read "
+                 "main_view").split():
+        assert hasattr(lib, name), name          # ref bgt.h:83-123 + what bgt-server.go links directly
+
+
+def test_expression_language_matches_reference_vectors():
+    lib = C.CDLL(LIB)
+    lib.ke_parse.restype = C.c_void_p
+    lib.ke_parse.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
+    lib.ke_set_int.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    lib.ke_eval.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_char_p), C.POINTER(C.c_int)]
+    lib.ke_destroy.argtypes = [C.c_void_p]
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "expr.json")))
+    for case in gold["cases"]:
+        err = C.c_int(0)
+        ke = lib.ke_parse(case["expr"].encode(), C.byref(err))
+        assert err.value == case["parse_err"], case["expr"]
+        assert bool(ke) == (case["parse_err"] == 0), case["expr"]
+        if not ke:
+            continue
+        for v, exp in zip(gold["vars"], case["eval"]):
+            for k, x in v.items():
+                lib.ke_set_int(ke, k.encode(), x)
+            i, r, s, t = C.c_int64(0), C.c_double(0), C.c_char_p(), C.c_int(0)
+            ee = lib.ke_eval(ke, C.byref(i), C.byref(r), C.byref(s), C.byref(t))
+            assert (ee, t.value, i.value, repr(r.value)) == (exp["err"], exp["type"], exp["i"], exp["r"]), (case["expr"], v)
+        lib.ke_destroy(ke)
+
+
+CPU_VIEWS = ["synA_G"]          # `-G` without -C/-f/groups: no output byte depends on a genotype
+
+
+@pytest.mark.parametrize("name", CPU_VIEWS)
+def test_cli_genotype_independent_goldens(name):
+    v = MANIFEST["views"][name]
+    res = run_view(v["args"], v["prefixes"])
+    assert res.returncode == v["rc"]
+    assert res.stdout == open(os.path.join(GOLD, "expected", name + ".out"), "rb").read()
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BGT), reason="oracle/_ref not built")
+@pytest.mark.parametrize("args,prefixes", [(["-G"], ["synA", "synB"]), (["-G", "-r", "11:1000-1100"], ["synA"]),
+                                           (["-G", "-r", "11:1,035-1,120"], ["synB", "synA"]), (["-G", "-r", "12"], ["synA"]),
+                                           (["-G", "-r", "11:1101"], ["synA"]), (["-G", "-i", "5", "-n", "7"], ["synA"]),
+                                           (["-G", "-i", "29"], ["synA", "synB"]), (["-G", "-n", "0"], ["synA"]),
+                                           (["-G", "-i", "1000"], ["synA"]), (["-G", "-s", "pop==\"X\""], ["synA"]),
+                                           (["-G"], ["ex3"]), (["-G", "-r", "13"], ["synA"]), (["-bG"], ["synA"]),
+                                           (["-uG"], ["synB", "synA"]), (["-G", "-l", "1", "-b"], ["synA"])])
+def test_cli_live_against_reference_without_genotypes(args, prefixes):
+    mine, ref = run_view(args, prefixes), run_view(args, prefixes, exe=REF_BGT)
+    assert mine.returncode == ref.returncode
+    assert mine.stdout == ref.stdout, (args, prefixes)
+
+
+def test_metadata_selection_matches_reference_counts():
+    """-s expressions / lists / files resolve to the same samples (checked through the VCF header)."""
+    if not os.path.exists(REF_BGT):
+        pytest.skip("oracle/_ref not built")
+    for sel in (["-s", "idx%5==0"], ["-s", ",A003,A010,A011,A049"], ["-s", ":A001"], ["-s", "pop==\"X\"||idx>45"],
+                ["-s", "pop!=\"Y\"&&idx<30"], ["-s", "nosuchkey==1"], ["-s", "_ROW_==\"A007\""]):
+        mine, ref = run_view(["-G"] + sel, ["synA"]), run_view(["-G"] + sel, ["synA"], exe=REF_BGT)
+        assert mine.stdout == ref.stdout, sel
+
+
+def test_refused_options_fail_loudly():
+    for opt in (["-S", "-a", "x"], ["-t", "AC"], ["-B", "x.bed"]):
+        res = run_view(opt, ["synA"])
+        assert res.returncode != 0 and b"not part of this build" in res.stderr
+    assert run_view(["-G"], ["nosuchprefix"]).returncode != 0
+    assert run_view(["-G", "-f", "AC>"], ["synA"]).returncode != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(MANIFEST["views"].keys()))
+def test_cli_every_golden_view_on_gpu(name):
+    """25 `bgt view` commands whose expected stdout was produced by the compiled reference."""
+    v = MANIFEST["views"][name]
+    res = run_view(v["args"], v["prefixes"])
+    assert res.returncode == v["rc"], res.stderr.decode()
+    exp = open(os.path.join(GOLD, "expected", name + ".out"), "rb").read()
+    assert res.stdout == exp, res.stderr.decode()[-400:]
