@@ -108,16 +108,29 @@ void draw_plane(Rng &g, int64_t m, int64_t ones, int64_t clusters, std::vector<u
     put_run(out, (uint32_t)zero_runs[clusters], 0);
 }
 
+// what is decided per site before any genotype is drawn: stream 2 of (seed, row)
+struct SiteDraw { double f; bool mono, multi; int ref, alt; };
+
+SiteDraw draw_site(uint64_t seed, int64_t row)
+{
+    Rng g(seed, (uint64_t)row, 2);
+    SiteDraw s;
+    if (g.uniform() < 0.5) s.f = 0.5 / (double)(2 + g.below(200));          // rare half of the spectrum
+    else s.f = g.uniform() * 0.5;
+    s.mono = g.uniform() < 0.02;                    // a few monomorphic sites so that -f'AC>0' filters
+    s.multi = g.uniform() < 0.05;                   // carries <M> (a third allele) in plane 1
+    s.ref = (int)g.below(4);
+    s.alt = (s.ref + 1 + (int)g.below(3)) & 3;      // a different nucleotide
+    return s;
+}
+
 void draw_row(int m, uint64_t seed, int64_t row, std::vector<uint8_t> &out, uint32_t len[2])
 {
+    const SiteDraw sd = draw_site(seed, row);
     {   // plane 0: ALT / <M>
         Rng g(seed, (uint64_t)row, 0);
         const size_t at = out.size();
-        double f;
-        if (g.uniform() < 0.5) f = 0.5 / (double)(2 + g.below(200));
-        else f = g.uniform() * 0.5;
-        int64_t ones = (int64_t)std::llround(f * m);
-        if (g.uniform() < 0.02) ones = 0;           // a few monomorphic sites so that -f'AC>0' filters
+        const int64_t ones = sd.mono ? 0 : (int64_t)std::llround(sd.f * m);
         const int64_t clusters = 1 + (int64_t)(std::sqrt((double)ones) * (1.0 + g.uniform()));
         draw_plane(g, m, ones, clusters, out);
         len[0] = (uint32_t)(out.size() - at);
@@ -126,7 +139,7 @@ void draw_row(int m, uint64_t seed, int64_t row, std::vector<uint8_t> &out, uint
         Rng g(seed, (uint64_t)row, 1);
         const size_t at = out.size();
         int64_t ones = g.binomial(m, 1e-3);
-        if (g.uniform() < 0.05) ones += g.binomial(m, 2e-2);
+        if (sd.multi) ones += g.binomial(m, 2e-2);
         const int64_t clusters = std::max<int64_t>(1, ones - (int64_t)g.below((uint64_t)(ones / 4 + 1)));
         draw_plane(g, m, ones, clusters, out);
         len[1] = (uint32_t)(out.size() - at);
@@ -170,3 +183,13 @@ extern "C" const uint8_t *bgth_synth_rle(const bgth_synth_t *s) { return s->rle.
 extern "C" const uint32_t *bgth_synth_len(const bgth_synth_t *s) { return s->len.data(); }
 extern "C" int64_t bgth_synth_bytes(const bgth_synth_t *s) { return (int64_t)s->rle.size(); }
 extern "C" void bgth_synth_free(bgth_synth_t *s) { delete s; }
+
+// Site description of a synthetic row (contig 11, POS = 1000 + 10*row, random distinct
+// REF/ALT nucleotides, a third allele on the 5 % multi-allelic sites).
+extern "C" void bgth_synth_site(uint64_t seed, int64_t row, int32_t *pos1, char *ref, char *alt, int32_t *n_allele)
+{
+    const SiteDraw sd = draw_site(seed, row);
+    *pos1 = (int32_t)(1000 + 10 * row);
+    *ref = "ACGT"[sd.ref]; *alt = "ACGT"[sd.alt];
+    *n_allele = sd.multi ? 3 : 2;
+}

@@ -1,6 +1,8 @@
 /* main.c -- the `bgt` executable of this build: dispatches `view` (alias `mview`) to the MI355X reader. */
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include "../../include/bgt_synth.h"
 #include "../../include/bgt_reader.h"
 #include "../../include/bgt_hip.h"
 
@@ -11,6 +13,10 @@ int main(int argc, char *argv[])
         return 1;
     }
     if (strcmp(argv[1], "view") == 0 || strcmp(argv[1], "mview") == 0) return main_view(argc - 1, argv + 1);
+    if (strcmp(argv[1], "synth") == 0) {                       /* bgt synth <prefix> <samples> <sites> [seed] */
+        if (argc < 5) { fprintf(stderr, "Usage: bgt synth <out-prefix> <n-samples> <n-sites> [seed]\n"); return 1; }
+        return bgt_synth_trio(argv[2], atoi(argv[3]), atoll(argv[4]), argc > 5 ? strtoull(argv[5], 0, 10) : 1, 0) ? 1 : 0;
+    }
     if (strcmp(argv[1], "version") == 0) { puts(bgth_version()); return 0; }
     fprintf(stderr, "[E::%s] unrecognized command '%s' (this build provides the read path: view)\n", __func__, argv[1]);
     return 1;

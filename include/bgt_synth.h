@@ -33,6 +33,13 @@ const uint8_t *bgth_synth_rle(const bgth_synth_t *s);     /* concatenated string
 const uint32_t *bgth_synth_len(const bgth_synth_t *s);    /* 2*n_rows lengths                            */
 int64_t        bgth_synth_bytes(const bgth_synth_t *s);
 void           bgth_synth_free(bgth_synth_t *s);
+/* site line of row `row`: 1-based position on contig 11, REF and ALT nucleotide, 2 or 3 alleles */
+void           bgth_synth_site(uint64_t seed, int64_t row, int32_t *pos1, char *ref, char *alt, int32_t *n_allele);
+
+
+/* Exported by libbgt.so (host shell): write a complete synthetic BGT database prefix.{pbf,bcf,bcf.csi,spl}
+ * of n_samples x n_sites (needs the device for the checkpoints). 0 on success. */
+int bgt_synth_trio(const char *prefix, int n_samples, int64_t n_sites, uint64_t seed, int device);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,62 @@
+"""End-to-end drop-in check at the shape of BASELINE.json configs[0] (2,504 samples x 50,000 sites): the
+synthetic database written by this repo's generator is read by BOTH the compiled reference
+(oracle/_ref/bgt, CPU) and this repo's `bgt view` (MI355X); stdout must be byte-identical."""
+import hashlib
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BGT = os.path.join(ROOT, "bgt_amd", "bin", "bgt")
+REF = os.path.join(ROOT, "oracle", "_ref", "bgt")
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c1(tmp_path_factory):
+    import bgt_amd
+    bgt_amd.build_library()
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bgt_amd", "host")])
+    d = tmp_path_factory.mktemp("c1")
+    prefix = str(d / "c1")
+    subprocess.check_call([BGT, "synth", prefix, "2504", "50000", "1"])
+    for ext in ("pbf", "bcf", "bcf.csi", "spl"):
+        assert os.path.getsize(prefix + "." + ext) > 0
+    return prefix
+
+
+def md5_of(cmd):
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    return p.returncode, hashlib.md5(p.stdout).hexdigest(), len(p.stdout), p.stderr.decode()[-300:]
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref not present")
+@pytest.mark.parametrize("args", [["-C", "-G"], ["-G", "-f", "AC>0"], ["-G", "-f", "AC>0", "-r", "11:20000-300000"],
+                                  ["-C", "-G", "-i", "40000", "-n", "5000"],
+                                  ["-G", "-s", "pop==\"A\"", "-s", "pop==\"B\"", "-f", "AC1>0&&AC2==0"],
+                                  ["-C", "-G", "-s", "idx%20==0"], ["-C", "-r", "11:100000-101000", "-s", "idx<40"],
+                                  ["-G", "-s", "pop==\"A\"", "-s", "pop==\"C\"", "-f", "AC1/AN1>=0.1&&AC2<5"],
+                                  ["-C", "-r", "11:1000-1500"], ["-bCG", "-n", "3000"]])
+def test_same_bytes_as_reference_binary(c1, args):
+    mine = md5_of([BGT, "view"] + args + [c1])
+    ref = md5_of([REF, "view"] + args + [c1])
+    assert mine[0] == ref[0] == 0, (mine, ref)
+    assert mine[2] > 0 and mine[1:3] == ref[1:3], (args, mine, ref)
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref not present")
+def test_generated_pbf_is_what_the_reference_encoder_writes(c1, tmp_path):
+    """decode the synthetic .pbf with the reference (pbfview) and re-encode it with the reference: same bytes,
+    i.e. the PBWT-domain generator + GPU checkpoints produce a canonical file."""
+    pbfview = os.path.join(ROOT, "oracle", "_ref", "pbfview")
+    small = str(tmp_path / "small")
+    subprocess.check_call([BGT, "synth", small, "300", "20000", "7"])
+    pim = tmp_path / "x.pim"
+    with open(pim, "wb") as f:
+        subprocess.check_call([pbfview, small + ".pbf"], stdout=f)
+    re = tmp_path / "re.pbf"
+    with open(re, "wb") as f:
+        subprocess.check_call([pbfview, "-Sb", str(pim)], stdout=f)
+    assert open(re, "rb").read() == open(small + ".pbf", "rb").read()
