@@ -159,8 +159,14 @@ def main():
                       "hbm_resident_bytes": pbf.hbm_bytes},
         }
 
-    # ---- CPU baseline + on-box parity check (rank 0, N=1 only): the oracle on a bounded sample
+    # ---- CPU baseline + on-box parity check (rank 0, N=1 only) on a bounded sample of the same cohort:
+    # the first `cpu_sample` sites.  Preferred: the COMPILED REFERENCE (oracle/_ref/bgt, built from
+    # /root/reference in the build container and shipped with the repo) running the metric's own command
+    # line on a database this repo writes; its stdout is also compared with this repo's `bgt view`.
+    # Always: the CPU oracle (port) on the same rows, compared with the counts the GPU delivered.
     if rank == 0 and world == 1 and args.cpu_sample > 0:
+        import hashlib
+        import subprocess
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import orc                                            # CPU oracle: checker / baseline only
         ns = min(sites, args.cpu_sample)
@@ -171,19 +177,47 @@ def main():
             path = os.path.join(tmp, "sample.pbf")
             sample.save(path)
             data = open(path, "rb").read()
-        sample.close()
-        p = orc.Pbf(data)
-        t0 = time.perf_counter()
-        oc = p.scan(0, ns)
-        n_pass_cpu = int((oc[:, 1] > 0).sum())
-        t_cpu = time.perf_counter() - t0
-        same = bool(np.array_equal(oc.reshape(ns, 1, 3), host.numpy()[:ns]))
-        out["cpu_baseline"] = {"value": ns / t_cpu, "unit": "sites/s", "cores": 1, "kind": "port",
-                               "sample": "first %d sites of the same cohort (oracle/liborc.so: decode both "
-                                         "planes + AC/AN + AC>0, one thread, %.1f s)" % (ns, t_cpu),
-                               "gpu_matches_cpu_on_sample": same, "sites_passing_filter": n_pass_cpu}
-        if not same:
-            out["parity_error"] = "GPU counts differ from the CPU oracle on the sample"
+            sample.close()
+            p = orc.Pbf(data)
+            t0 = time.perf_counter()
+            oc = p.scan(0, ns)
+            n_pass_cpu = int((oc[:, 1] > 0).sum())
+            t_cpu = time.perf_counter() - t0
+            same = bool(np.array_equal(oc.reshape(ns, 1, 3), host.numpy()[:ns]))
+            port = {"value": ns / t_cpu, "unit": "sites/s", "cores": 1, "kind": "port",
+                    "sample": "first %d sites of the same cohort (oracle/liborc.so: decode both planes + AC/AN + "
+                              "AC>0, one thread, %.1f s)" % (ns, t_cpu),
+                    "gpu_matches_cpu_on_sample": same, "sites_passing_filter": n_pass_cpu}
+            out["cpu_baseline"] = port
+            if not same:
+                out["parity_error"] = "GPU counts differ from the CPU oracle on the sample"
+            ref_bin = os.path.join(ROOT, "oracle", "_ref", "bgt")
+            my_bin = os.path.join(ROOT, "bgt_amd", "bin", "bgt")
+            if os.path.exists(ref_bin) and args.workload == "c2":
+                try:
+                    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bgt_amd", "host")])
+                    prefix = os.path.join(tmp, "db")
+                    subprocess.check_call([my_bin, "synth", prefix, str(n_samples), str(ns), str(args.seed)])
+                    cmd = ["view", "-G", "-f", "AC>0", prefix]
+                    t0 = time.perf_counter()
+                    ref_out = subprocess.run([ref_bin] + cmd, stdout=subprocess.PIPE, check=True).stdout
+                    t_ref = time.perf_counter() - t0
+                    t0 = time.perf_counter()
+                    my_out = subprocess.run([my_bin] + cmd, stdout=subprocess.PIPE, check=True).stdout
+                    t_mine = time.perf_counter() - t0
+                    cli_same = hashlib.md5(ref_out).hexdigest() == hashlib.md5(my_out).hexdigest()
+                    out["cpu_baseline"] = {
+                        "value": ns / t_ref, "unit": "sites/s", "cores": 1, "kind": "reference",
+                        "sample": "reference `bgt view -G -f'AC>0'` (oracle/_ref/bgt, gcc -O2, one thread, %.1f s wall incl. "
+                                  "open) on a %d-sample x %d-site database = first sites of the same cohort"
+                                  % (t_ref, n_samples, ns),
+                        "cli_stdout_identical_to_reference": cli_same, "cli_stdout_bytes": len(ref_out),
+                        "this_repo_cli_same_command_s": round(t_mine, 2),
+                        "gpu_matches_cpu_on_sample": same, "port": port}
+                    if not cli_same:
+                        out["parity_error"] = "`bgt view` stdout differs from the reference binary"
+                except Exception as e:                        # keep the port numbers, say why
+                    out["cpu_baseline"]["reference_leg_error"] = repr(e)[:200]
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
