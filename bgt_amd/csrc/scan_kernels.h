@@ -23,7 +23,7 @@ struct ScanArgs {
     int32_t        *raw_counts;  // [(row1-row0)][G][3] += {n(code1), n(code2), n(code3)}
     uint64_t       *h0, *h1;     // optional [(row1-row0)][n_chunks] bit planes in slot order
     int32_t        *final_rank;  // optional [2][m]: ranks by column after the last row of the launch
-    int32_t  m, nw, shift, n_chunks, G, K, wpp;
+    int32_t  m, nw, shift, n_chunks, G, K, wpp, seg_shift;   // seg_shift: log2 positions per team segment
     int32_t  blk0, n_blk, n_slices;
     int64_t  row0, row1;         // rows whose results are emitted; decoding starts at blk0<<shift
     int32_t  debug_skip;         // profiling aid (env BGTH_DEBUG_SKIP): 1 = no phase B, 2 = no RLE read, 4 = no directory build

@@ -51,6 +51,14 @@ __device__ __forceinline__ uint32_t wave_shr1(uint32_t v, uint32_t first)
     return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138, 0xf, 0xf, false);   // wave_shr:1
 }
 
+// Workgroup barrier for data exchanged through LDS only.  __syncthreads() also drains vmcnt (its
+// workgroup-scope release covers global memory), which would turn every software-prefetched global load
+// into a stall at the next barrier; LDS traffic only needs lgkmcnt(0).
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ uint32_t lane63(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
 
 __device__ __forceinline__ uint32_t rle_len(uint32_t byte)
@@ -189,12 +197,16 @@ __device__ __forceinline__ void step4(uint32_t (&r0)[4], uint32_t (&r1)[4], uint
 // LDS operations of one wave complete in order, so no workgroup barrier is needed between the steps;
 // the wavefront fences only pin the compiler's ordering.
 // ----------------------------------------------------------------------------------------------------
-// step 2: RLE string -> toggles (one wave)
-__device__ __forceinline__ void rle_toggles(const ScanArgs &a, uint2 *bd, uint64_t desc, uint32_t pre0, uint32_t pre1,
-                                            uint32_t pre2, uint32_t pre3, int npre, int lane)
+// step 2: RLE string -> toggles (one wave).  SEG: the row is finished by a team of waves, each owning a
+// segment of 1 << seg_shift positions; record per segment the parity of its toggles and its number of
+// ones (known here from the run lengths), so that every wave can start its segment with the right carries.
+template <bool SEG>
+__device__ __forceinline__ void rle_toggles(const ScanArgs &a, const uint8_t *__restrict__ rle, uint2 *bd, uint64_t desc,
+                                            uint32_t pre0, uint32_t pre1, uint32_t pre2, uint32_t pre3, int npre, int lane,
+                                            int seg_shift, uint32_t *segtab)
 {
     const int m = a.m;
-    const uint32_t *q4 = reinterpret_cast<const uint32_t*>(a.rle + (desc & kDescOffMask));
+    const uint32_t *q4 = reinterpret_cast<const uint32_t*>(rle + (desc & kDescOffMask));
     const uint32_t len = (uint32_t)(desc >> kDescLenShift);
     uint32_t pos = 0, prevbit = 0;
     bool stop = false;
@@ -202,8 +214,8 @@ __device__ __forceinline__ void rle_toggles(const ScanArgs &a, uint2 *bd, uint64
         const uint32_t k0 = base + 4u * (uint32_t)lane;
         // the first 256*npre bytes were fetched one batch ahead; longer strings read on
         uint32_t w;
-        if (base == 0) w = pre0;
-        else if (base == 256) w = pre1;
+        if (base == 0 && npre > 0) w = pre0;
+        else if (base == 256 && npre > 0) w = pre1;
         else if (base == 512 && npre > 2) w = pre2;
         else if (base == 768 && npre > 2) w = pre3;
         else w = k0 < len ? q4[(base >> 2) + lane] : 0u;
@@ -236,7 +248,20 @@ __device__ __forceinline__ void rle_toggles(const ScanArgs &a, uint2 *bd, uint64
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t b = byte[i] & 1u, start = lane_start + before[i];
-            if (valid[i] && b != pb && start < (uint32_t)m) atomicXor(&bd[start >> 5].x, 0xffffffffu << (start & 31));
+            if (valid[i] && b != pb && start < (uint32_t)m) {
+                atomicXor(&bd[start >> 5].x, 0xffffffffu << (start & 31));
+                if (SEG) atomicXor(&segtab[2 * (start >> seg_shift)], 1u);
+            }
+            if (SEG && b && l[i] && start < (uint32_t)m) {   // ones of this run piece, split at segment borders
+                uint32_t at = start;
+                const uint32_t end = start + l[i] < (uint32_t)m ? start + l[i] : (uint32_t)m;
+                while (at < end) {
+                    const uint32_t sg = at >> seg_shift, lim = (sg + 1u) << seg_shift;
+                    const uint32_t upto = end < lim ? end : lim;
+                    atomicAdd(&segtab[2 * sg + 1], upto - at);
+                    at = upto;
+                }
+            }
             pb = b;
         }
         prevbit = lane63(byte[3] & 1u);
@@ -244,64 +269,165 @@ __device__ __forceinline__ void rle_toggles(const ScanArgs &a, uint2 *bd, uint64
     }
 }
 
-// step 3 over the words [w0,w1) of a row (one wave).  WRITE=false only measures the segment: the parity of
-// its toggles and its ones if it were entered with carry parity 0 (a team of waves needs that first).
-// Four 64-word groups per trip: their LDS reads and popcount scans are independent, only two scalars
-// (toggle parity, ones so far) are carried from group to group.
-template <bool WRITE>
+// step 3 over the words [w0,w1) of a row (one wave; w0 a multiple of 4).  A lane owns 4 consecutive words
+// per trip (256 words per trip): one ballot/mbcnt for the toggle parity entering the lane and one DPP
+// prefix sum of the lane's ones serve four words, the chain across the four is local arithmetic.
 __device__ __forceinline__ void directory_pass(uint2 *bd, int w0, int w1, int nw, uint32_t tail_mask,
                                                uint32_t &carry_x, uint32_t &carry_c, int lane)
 {
     for (int base = w0; base < w1; base += 256) {
-        uint32_t t[4], c[4], incl[4];
-        uint64_t par[4];
+        const int i0 = base + 4 * lane;
+        const uint4 *src = reinterpret_cast<const uint4*>(bd + i0);      // rows are 16-byte aligned
+        uint32_t t[4] = {0u, 0u, 0u, 0u};
+        if (i0 + 3 < w1) { const uint4 lo = src[0], hi = src[1]; t[0] = lo.x; t[1] = lo.z; t[2] = hi.x; t[3] = hi.z; }
+        else {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int i = base + g * 64 + lane;
-            t[g] = i < w1 ? bd[i].x : 0u;
+            for (int k = 0; k < 4; ++k) if (i0 + k < w1) t[k] = bd[i0 + k].x;
         }
+        const uint32_t p0 = t[0] >> 31, p1 = t[1] >> 31, p2 = t[2] >> 31, p3 = t[3] >> 31;   // toggle parity per word
+        const uint64_t par = __ballot((p0 ^ p1 ^ p2 ^ p3) != 0u);
+        uint32_t cin = (lanes_below(par) ^ carry_x) & 1u;                // parity of all toggles before word i0
+        uint32_t v[4], pre[4], ones = 0;
+        const uint32_t pk[4] = {p0, p1, p2, p3};
 #pragma unroll
-        for (int g = 0; g < 4; ++g) par[g] = __ballot(t[g] >> 31);      // bit 31 = parity of the word's toggles
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int i = base + g * 64 + lane;
-            const uint32_t cin = (lanes_below(par[g]) ^ carry_x) & 1u;   // parity of the toggles before this word
-            uint32_t v = cin ? ~t[g] : t[g];
-            if (i == nw - 1) v &= tail_mask;
-            if (i >= w1) v = 0u;
-            t[g] = v;
-            c[g] = (uint32_t)__popc(v);
-            incl[g] = wave_incl_add(c[g]);
-            carry_x ^= (uint32_t)__popcll(par[g]) & 1u;
+        for (int k = 0; k < 4; ++k) {
+            uint32_t x = t[k] ^ (0u - cin);                              // inverted when the carry parity is odd
+            if (i0 + k == nw - 1) x &= tail_mask;
+            if (i0 + k >= w1) x = 0u;
+            v[k] = x; pre[k] = ones; ones += (uint32_t)__popc(x);
+            cin ^= pk[k];
         }
+        const uint32_t incl = wave_incl_add(ones);
+        const uint32_t b = carry_c + incl - ones;
+        if (i0 + 3 < w1) {
+            uint4 *dst = reinterpret_cast<uint4*>(bd + i0);
+            dst[0] = make_uint4(v[0], b, v[1], b + pre[1]);
+            dst[1] = make_uint4(v[2], b + pre[2], v[3], b + pre[3]);
+        } else {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int i = base + g * 64 + lane;
-            if (WRITE && i < w1) bd[i] = make_uint2(t[g], carry_c + incl[g] - c[g]);
-            carry_c += lane63(incl[g]);
+            for (int k = 0; k < 4; ++k) if (i0 + k < w1) bd[i0 + k] = make_uint2(v[k], b + pre[k]);
+        }
+        carry_x ^= (uint32_t)__popcll(par) & 1u;
+        carry_c += lane63(incl);
+    }
+}
+
+// ---- team-parallel RLE decode: wave tw of a team owns the 256-byte chunks tw and tw + wpp of the string.
+// Pass 1 measures a chunk (symbols covered, bit of its last byte, whether a terminating zero byte was
+// seen); after a barrier pass 2 turns the chunk into toggles, knowing where it starts.
+struct ChunkDecode { uint32_t l[4], before[4], bit[4], run; bool valid[4]; bool stop; };
+
+__device__ __forceinline__ ChunkDecode decode_chunk(uint32_t w, uint32_t k0, uint32_t len, int lane)
+{
+    ChunkDecode d;
+    bool anyz = false;
+    uint32_t byte[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        byte[i] = (w >> (8 * i)) & 255u;
+        d.valid[i] = k0 + i < len;
+        d.bit[i] = byte[i] & 1u;
+        anyz = anyz || (d.valid[i] && byte[i] == 0u);
+    }
+    const uint64_t z = __ballot(anyz);
+    d.stop = z != 0;
+    if (z) {
+        const int first = __ffsll((unsigned long long)z) - 1;
+        bool dead = lane > first;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (lane == first && byte[i] == 0u) dead = true;
+            d.valid[i] = d.valid[i] && !dead;
+        }
+    }
+    d.run = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { d.l[i] = d.valid[i] ? rle_len(byte[i]) : 0u; d.before[i] = d.run; d.run += d.l[i]; }
+    return d;
+}
+
+// bit of the last valid byte of the chunk (wave-uniform), 0 if the chunk is empty
+__device__ __forceinline__ uint32_t chunk_last_bit(const ChunkDecode &d, int lane)
+{
+    uint32_t nv = 0, lastb = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (d.valid[i]) { ++nv; lastb = d.bit[i]; }
+    const uint64_t has = __ballot(nv != 0u);
+    if (!has) return 0u;
+    const int top = 63 - __builtin_clzll((unsigned long long)has);
+    return (uint32_t)__builtin_amdgcn_readlane((int)lastb, top);
+}
+
+__device__ __forceinline__ void chunk_toggles(const ScanArgs &a, uint2 *bd, const ChunkDecode &d, uint32_t pos,
+                                              uint32_t prevbit, int lane, int seg_shift, uint32_t *segtab)
+{
+    const uint32_t m = (uint32_t)a.m;
+    const uint32_t incl = wave_incl_add(d.run);
+    const uint32_t lane_start = pos + incl - d.run;
+    const uint32_t chunk_end = pos + lane63(incl);
+    // bit of the byte before this lane's first byte: the last valid byte of the lane below (chunks are
+    // dense, so a lane below a lane with data is full)
+    uint32_t lastb = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (d.valid[i]) lastb = d.bit[i];
+    uint32_t pb = wave_shr1(lastb, prevbit);
+    bool tog[4];
+    uint32_t start[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        start[i] = lane_start + d.before[i];
+        tog[i] = d.valid[i] && d.bit[i] != pb && start[i] < m;
+        if (tog[i] && !(a.debug_skip & 64)) atomicXor(&bd[start[i] >> 5].x, 0xffffffffu << (start[i] & 31));
+        if (d.valid[i]) pb = d.bit[i];
+    }
+    // segment tables: reduce inside the wave first (every toggle of a segment would otherwise hit the same
+    // LDS word), then one atomic per segment the chunk touches -- usually one or two
+    if (chunk_end > pos && pos < m && !(a.debug_skip & 32)) {
+        const uint32_t last = (chunk_end < m ? chunk_end : m) - 1u;
+        for (uint32_t sg = pos >> seg_shift; sg <= last >> seg_shift; ++sg) {
+            const uint32_t lo = sg << seg_shift, hi = lo + (1u << seg_shift);
+            uint32_t par = 0, ones = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                par ^= (uint32_t)__popcll(__ballot(tog[i] && start[i] >= lo && start[i] < hi));
+                if (d.valid[i] && d.bit[i]) {
+                    const uint32_t e0 = start[i] + d.l[i] < m ? start[i] + d.l[i] : m;
+                    const uint32_t b0 = start[i] > lo ? start[i] : lo, b1 = e0 < hi ? e0 : hi;
+                    if (b1 > b0) ones += b1 - b0;
+                }
+            }
+            ones = lane63(wave_incl_add(ones));
+            if (lane == 0) {
+                if (par & 1u) atomicXor(&segtab[2 * sg], 1u);
+                if (ones) atomicAdd(&segtab[2 * sg + 1], ones);
+            }
         }
     }
 }
 
 // whole plane-row by one wave
-__device__ __forceinline__ void build_plane_row(const ScanArgs &a, uint2 *bd, uint32_t *n0_out, uint64_t desc,
-                                                uint32_t pre0, uint32_t pre1, int lane, uint32_t tail_mask)
+__device__ __forceinline__ void build_plane_row(const ScanArgs &a, const uint8_t *__restrict__ rle, uint2 *bd,
+                                                uint32_t *n0_out, uint64_t desc, uint32_t pre0, uint32_t pre1, int lane,
+                                                uint32_t tail_mask)
 {
     const int nw = a.nw;
     for (int i = lane; i < nw; i += 64) bd[i] = make_uint2(0u, 0u);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    if (!(a.debug_skip & 2)) rle_toggles(a, bd, desc, pre0, pre1, 0u, 0u, 2, lane);
+    if (!(a.debug_skip & 2)) rle_toggles<false>(a, rle, bd, desc, pre0, pre1, 0u, 0u, 2, lane, 0, nullptr);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     uint32_t carry_x = 0, carry_c = 0;
-    if (!(a.debug_skip & 4)) directory_pass<true>(bd, 0, nw, nw, tail_mask, carry_x, carry_c, lane);
+    if (!(a.debug_skip & 4)) directory_pass(bd, 0, nw, nw, tail_mask, carry_x, carry_c, lane);
     if (lane == 0) *n0_out = (uint32_t)a.m - carry_c;
 }
 
 // Template switches:  MULTI = more than one sample group (per-chunk LDS atomics instead of per-wave
 // scalars);  GT = also emit the two bit planes of every row (slot order) for genotype output.
 template <int NT, int CPT, bool MULTI, bool GT>
-__global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a)
-{
+__global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64_t *__restrict__ rowdesc,
+                                                  const uint8_t *__restrict__ rle)
+{   // rowdesc / rle are separate `const __restrict__` arguments (not members of `a`) so that hipcc knows
+    // they are invariant: the wave-uniform descriptor loads then go through the scalar cache (s_load,
+    // lgkmcnt) and do not force a vmcnt(0) that would drain the prefetched string loads.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NWAVE = NT / 64;
     static_assert(CPT % 2 == 0, "columns per thread are stepped in pairs");
@@ -321,9 +447,9 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a)
     // LDS: per plane-row nw entries {bits, ones before} + ONE all-zero sentinel entry.  Padding slots
     // carry the rank 32*nw: they read the sentinel, see bit 0 and "zero ones before", and map to
     // themselves -- so no validity mask is needed anywhere in the row loop.
-    const int m = a.m, nw = a.nw, nwp = nw + 1, K = a.K, G = a.G;
+    const int m = a.m, nw = a.nw, nwp = (nw + 2) & ~1, K = a.K, G = a.G;   // rows 16-byte aligned
     uint2    *BD   = reinterpret_cast<uint2*>(smem);                    // [2K][nwp]
-    int32_t  *lcnt = reinterpret_cast<int32_t*>(smem + (((size_t)16 * K * nwp + 15) & ~(size_t)15));
+    int32_t  *lcnt = reinterpret_cast<int32_t*>(smem + (size_t)16 * K * nwp);
     //   !MULTI: int4 [K][NWAVE] one private slot per wave and row   MULTI: int32 [K][G][3] (LDS atomics)
     uint32_t *n0s  = reinterpret_cast<uint32_t*>(lcnt + (MULTI ? K * G * 3 : K * NWAVE * 4)); // [2K]
     const uint32_t pad_rank = 32u * (uint32_t)nw;
@@ -365,27 +491,45 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a)
     uint64_t dsc[2], dsc_next[2];
     uint32_t pre[2][2];
     auto fetch_desc = [&](int64_t rb_, int i) -> uint64_t {
-        const int p = wpp == 1 ? wave + i * NWAVE : (tw == 0 ? team : 1 << 30);   // team mode: both slots = the team's string
+        const int p = wpp == 1 ? wave + i * NWAVE : team;   // team mode: both slots = the team's string
         const int64_t left = blk_end - rb_;
         const int kc = (int)(left < K ? left : K);
-        return (rb_ < blk_end && p < 2 * kc) ? a.rowdesc[2 * rb_ + p] : 0ull;
+        return (rb_ < blk_end && p < 2 * kc) ? rowdesc[2 * rb_ + p] : 0ull;
     };
     auto fetch_data = [&](uint64_t d, int c) -> uint32_t {
         const uint32_t len = (uint32_t)(d >> kDescLenShift);
         const uint32_t k0 = (uint32_t)c * 256u + 4u * (uint32_t)lane;
-        return k0 < len ? reinterpret_cast<const uint32_t*>(a.rle + (d & kDescOffMask))[c * 64 + lane] : 0u;
+        return k0 < len ? reinterpret_cast<const uint32_t*>(rle + (d & kDescOffMask))[c * 64 + lane] : 0u;
     };
-    const int c1 = wpp == 1 ? 0 : 2;                  // team mode: slot 1 holds chunks 2,3 of the same string
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         dsc[i] = fetch_desc(blk_beg, i);
         dsc_next[i] = fetch_desc(blk_beg + K, i);
-        pre[i][0] = fetch_data(dsc[i], i * c1);
-        pre[i][1] = fetch_data(dsc[i], i * c1 + 1);
+        // wpp == 1: chunks 0,1 of the wave's own two strings; team mode: chunks tw, tw+wpp (slot 0) and,
+        // for the serial fallback of very long strings, nothing more (they read on from memory)
+        // wpp == 1: chunks 0,1 of the wave's own two strings (slot i = plane-row i of the wave);
+        // team mode: slot 0 only, chunks tw and tw + wpp of the team's string
+        pre[i][0] = fetch_data(dsc[i], wpp == 1 ? 0 : tw);
+        pre[i][1] = fetch_data(dsc[i], wpp == 1 ? 1 : tw + wpp);
     }
-
     for (int64_t rb = blk_beg; rb < blk_end; rb += K) {
         const int Kc = (int)((blk_end - rb) < K ? (blk_end - rb) : K);
+
+        // Take the strings fetched during the previous batch and immediately issue the loads of the next
+        // batch (and the descriptors of the one after): they have this whole batch -- phases A, B and C -- to
+        // arrive, whatever vmcnt wait the compiler places at their first use.
+        uint64_t cdsc[2];
+        uint32_t cpre[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { cdsc[i] = dsc[i]; cpre[i][0] = pre[i][0]; cpre[i][1] = pre[i][1]; }
+        asm volatile("" : "+v"(cpre[0][0]), "+v"(cpre[0][1]), "+v"(cpre[1][0]), "+v"(cpre[1][1]));   // arrived: pin the wait here
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            dsc[i] = dsc_next[i];
+            pre[i][0] = fetch_data(dsc[i], wpp == 1 ? 0 : tw);
+            pre[i][1] = fetch_data(dsc[i], wpp == 1 ? 1 : tw + wpp);
+            dsc_next[i] = fetch_desc(rb + 2 * K, i);
+        }
 
         // ================= phase A: build the bit-vectors of Kc rows x 2 planes =================
         if (wpp == 1) {
@@ -393,52 +537,69 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a)
             for (int i = 0; i < 2; ++i) {
                 const int p = wave + i * NWAVE;
                 if (p < 2 * Kc)
-                    build_plane_row(a, BD + (size_t)p * nwp, n0s + p, dsc[i], pre[i][0], pre[i][1], lane, tail_mask);
+                    build_plane_row(a, rle, BD + (size_t)p * nwp, n0s + p, cdsc[i], cpre[i][0], cpre[i][1], lane, tail_mask);
             }
         } else {
+            // team mode: segments of 1 << seg_shift positions (a power of two >= m / wpp) per wave
             const bool active = team < 2 * Kc;
             uint2 *bd = BD + (size_t)team * nwp;
+            uint32_t *segtab = seginfo + 2 * team * wpp;                 // [wpp][2] {toggle parity, ones}
+            uint32_t *chunktab = seginfo + 2 * NWAVE + 4 * team * wpp;   // [2*wpp][2] {symbols, last bit | stop<<1}
+            const uint32_t slen = (uint32_t)(cdsc[0] >> kDescLenShift);
+            const bool parallel_rle = slen <= (uint32_t)(2 * wpp) * 256u;      // else: team wave 0 decodes alone
             if (active) for (int i = tw * 64 + lane; i < nw; i += wpp * 64) bd[i] = make_uint2(0u, 0u);
-            __syncthreads();
-            if (active && tw == 0 && !(a.debug_skip & 2))
-                rle_toggles(a, bd, dsc[0], pre[0][0], pre[0][1], pre[1][0], pre[1][1], 4, lane);
-            __syncthreads();
-            // every wave of the team owns a contiguous segment of the row's words
-            const int seg = (((nw + wpp - 1) / wpp) + 63) & ~63;
-            const int w0 = tw * seg < nw ? tw * seg : nw;
-            const int w1 = w0 + seg < nw ? w0 + seg : nw;
-            if (active) {
-                uint32_t px = 0, pc = 0;
-                directory_pass<false>(bd, w0, w1, nw, tail_mask, px, pc, lane);
-                if (lane == 0) { seginfo[2 * wave] = px; seginfo[2 * wave + 1] = pc; }
-            }
-            __syncthreads();
-            if (active) {
-                // carries into this segment: an earlier segment entered with odd parity is inverted, so it
-                // holds (its valid positions - its measured ones)
-                uint32_t cx = 0, cnt = 0;
-                for (int s2 = 0; s2 < tw; ++s2) {
-                    const int a0 = s2 * seg < nw ? s2 * seg : nw, a1 = a0 + seg < nw ? a0 + seg : nw;
-                    const uint32_t hi = (uint32_t)a1 * 32u < (uint32_t)m ? (uint32_t)a1 * 32u : (uint32_t)m;
-                    const uint32_t lo = (uint32_t)a0 * 32u < (uint32_t)m ? (uint32_t)a0 * 32u : (uint32_t)m;
-                    const uint32_t spx = seginfo[2 * (team * wpp + s2)], spc = seginfo[2 * (team * wpp + s2) + 1];
-                    cnt += cx ? (hi - lo) - spc : spc;
-                    cx ^= spx;
-                }
-                cx = __builtin_amdgcn_readfirstlane(cx); cnt = __builtin_amdgcn_readfirstlane(cnt);
-                directory_pass<true>(bd, w0, w1, nw, tail_mask, cx, cnt, lane);
-                if (tw == wpp - 1 && lane == 0) n0s[team] = (uint32_t)m - cnt;
-            }
-        }
-        // issue the loads of the next batch (data) and of the one after (descriptors) before phase B
+            if (lane < 2) seginfo[2 * wave + lane] = 0u;
+            if (active && parallel_rle && !(a.debug_skip & 2)) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            dsc[i] = dsc_next[i];
-            pre[i][0] = fetch_data(dsc[i], i * c1);
-            pre[i][1] = fetch_data(dsc[i], i * c1 + 1);
-            dsc_next[i] = fetch_desc(rb + 2 * K, i);
+                for (int i = 0; i < 2; ++i) {
+                    const int c = tw + i * wpp;
+                    const ChunkDecode cd = decode_chunk(cpre[0][i], (uint32_t)c * 256u + 4u * (uint32_t)lane, slen, lane);
+                    const uint32_t tot = lane63(wave_incl_add(cd.run));
+                    const uint32_t lb = chunk_last_bit(cd, lane);
+                    if (lane == 0) { chunktab[2 * c] = tot; chunktab[2 * c + 1] = lb | (cd.stop ? 2u : 0u); }
+                }
+            }
+            lds_barrier();
+            if (active && !(a.debug_skip & 2)) {
+                if (parallel_rle) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int c = tw + i * wpp;
+                        // where the chunk starts and the bit before it: lane c2 reads chunk c2's record, one
+                        // wave prefix sum gives every chunk's start (no serial walk over LDS)
+                        const uint32_t t0 = lane < 2 * wpp && (uint32_t)lane * 256u < slen ? chunktab[2 * lane] : 0u;
+                        const uint32_t t1 = lane < 2 * wpp && (uint32_t)lane * 256u < slen ? chunktab[2 * lane + 1] : 0u;
+                        const uint32_t incl_t = wave_incl_add(t0);
+                        const uint32_t pos = c ? (uint32_t)__builtin_amdgcn_readlane((int)incl_t, c ? c - 1 : 0) : 0u;
+                        const uint32_t prevbit = c ? ((uint32_t)__builtin_amdgcn_readlane((int)t1, c ? c - 1 : 0) & 1u) : 0u;
+                        const bool dead = (__ballot((t1 & 2u) != 0u) & ((1ull << c) - 1ull)) != 0ull;
+                        if (!dead && (uint32_t)c * 256u < slen && !(a.debug_skip & 16)) {
+                            // decoded again rather than kept: two registers cross the barrier instead of thirty
+                            const ChunkDecode cd = decode_chunk(cpre[0][i], (uint32_t)c * 256u + 4u * (uint32_t)lane, slen, lane);
+                            chunk_toggles(a, bd, cd, pos, prevbit, lane, a.seg_shift, segtab);
+                        }
+                    }
+                } else if (tw == 0) {
+                    // rare: a string longer than the team's 2*wpp chunks -- one wave walks it from memory
+                    rle_toggles<true>(a, rle, bd, cdsc[0], 0u, 0u, 0u, 0u, 0, lane, a.seg_shift, segtab);
+                }
+            }
+            lds_barrier();
+            if (active && !(a.debug_skip & 4)) {
+                const int seg_words = 1 << (a.seg_shift - 5);
+                const int w0 = tw * seg_words < nw ? tw * seg_words : nw;
+                const int w1 = w0 + seg_words < nw ? w0 + seg_words : nw;
+                // carries from the segments before mine: lane s2 reads segment s2's record
+                const uint32_t spx = lane < wpp ? segtab[2 * lane] : 0u, spc = lane < wpp ? segtab[2 * lane + 1] : 0u;
+                const uint32_t incl_c = wave_incl_add(spc);
+                const uint32_t total = lane63(incl_c);
+                uint32_t cnt = tw ? (uint32_t)__builtin_amdgcn_readlane((int)incl_c, tw ? tw - 1 : 0) : 0u;
+                uint32_t cx = (uint32_t)__popcll(__ballot((spx & 1u) != 0u) & ((1ull << tw) - 1ull)) & 1u;
+                directory_pass(bd, w0, w1, nw, tail_mask, cx, cnt, lane);
+                if (tw == 0 && lane == 0) n0s[team] = (uint32_t)m - total;
+            }
         }
-        __syncthreads();
+        lds_barrier();
 
         // ================= phase B: walk the rows, ranks stay in registers =================
         if (!(a.debug_skip & 1))
@@ -487,7 +648,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a)
                 a.h1[at] = keep1;
             }
         }
-        __syncthreads();
+        lds_barrier();
 
         // ================= phase C: per-row counts of this slice -> HBM =================
         if (MULTI) {
@@ -536,7 +697,7 @@ static hipError_t launch_one(const ScanArgs &a, const Geometry &g, hipStream_t s
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fn, dim3(g.workgroups), dim3(NT), g.lds_bytes, s, a);
+    hipLaunchKernelGGL(fn, dim3(g.workgroups), dim3(NT), g.lds_bytes, s, a, a.rowdesc, a.rle);
     return hipGetLastError();
 }
 
@@ -555,7 +716,7 @@ static const GeomEntry kGeoms[] = {
 static int lds_need(int nw, int K, int G, int threads)
 {
     const int cnt = G > 1 ? K * G * 3 * 4 : K * (threads / 64) * 16;
-    return ((16 * K * (nw + 1) + 15) & ~15) + cnt + 2 * K * 4 + (threads / 64) * 8;
+    return 16 * K * ((nw + 2) & ~1) + cnt + 2 * K * 4 + (threads / 64) * (8 + 16);
 }
 
 // Cost model (cycles per decoded row on one CU; the kernel is VALU-bound at one wave-instruction per
