@@ -528,11 +528,26 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
     a.blk0 = (int32_t)blk0; a.n_blk = (int32_t)(blk1 - blk0 + 1); a.n_slices = geo.slices;
     a.row0 = row0; a.row1 = row1;
     { const char *dbg = getenv("BGTH_DEBUG_SKIP"); a.debug_skip = dbg ? atoi(dbg) : 0; }
+    unsigned long long *d_times = nullptr;
+    if (getenv("BGTH_DEBUG_TIMES")) {                    // profiling aid: per-phase cycle sums over all waves
+        HIP_TRY(hipMalloc((void**)&d_times, 64), return -1);
+        HIP_TRY(hipMemsetAsync(d_times, 0, 64, s), return -1);
+        a.debug_times = d_times;
+    }
     if (timed) HIP_TRY(hipEventRecord(r->ev[0], s), return -1);
     HIP_TRY(hipMemsetAsync(r->raw.p, 0, (size_t)rows * G * 3 * 4, s), return -1);
     if (timed) HIP_TRY(hipEventRecord(r->ev[1], s), return -1);
     HIP_TRY(launch_scan(a, geo, s), return -1);
     if (timed) HIP_TRY(hipEventRecord(r->ev[2], s), return -1);
+    if (d_times) {
+        unsigned long long h[8];
+        HIP_TRY(hipStreamSynchronize(s), return -1);
+        HIP_TRY(hipMemcpy(h, d_times, 64, hipMemcpyDeviceToHost), return -1);
+        hipFree(d_times);
+        const double waves = (double)geo.workgroups * (geo.threads / 64), nb = (double)rows / geo.K;
+        fprintf(stderr, "[bgth debug] cycles per wave and batch: top %.0f | A-zero+pass1 %.0f | wait %.0f | pass2 %.0f | wait %.0f | dir %.0f | wait %.0f | B %.0f\n",
+                h[0] / waves / nb, h[1] / waves / nb, h[2] / waves / nb, h[3] / waves / nb, h[4] / waves / nb, h[5] / waves / nb, h[6] / waves / nb, h[7] / waves / nb);
+    }
     HIP_TRY(launch_finalize((const int32_t*)r->raw.p, d_fin, r->sel.d_group_haps, rows, G, s), return -1);
     if (timed) HIP_TRY(hipEventRecord(r->ev[3], s), return -1);
     return rows;

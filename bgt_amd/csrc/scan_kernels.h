@@ -26,6 +26,7 @@ struct ScanArgs {
     int32_t  m, nw, shift, n_chunks, G, K, wpp, seg_shift;   // seg_shift: log2 positions per team segment
     int32_t  blk0, n_blk, n_slices;
     int64_t  row0, row1;         // rows whose results are emitted; decoding starts at blk0<<shift
+    unsigned long long *debug_times;   // optional [workgroups][8] cycle sums per phase (env BGTH_DEBUG_TIMES)
     int32_t  debug_skip;         // profiling aid (env BGTH_DEBUG_SKIP): 1 = no phase B, 2 = no RLE read, 4 = no directory build
 };
 

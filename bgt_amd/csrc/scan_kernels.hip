@@ -422,6 +422,9 @@ __device__ __forceinline__ void build_plane_row(const ScanArgs &a, const uint8_t
 
 // Template switches:  MULTI = more than one sample group (per-chunk LDS atomics instead of per-wave
 // scalars);  GT = also emit the two bit planes of every row (slot order) for genotype output.
+#define BGTH_TICK(slot) do { if (a.debug_times) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+    tsum[slot] += now_ - tlast; tlast = now_; } } while (0)
+
 template <int NT, int CPT, bool MULTI, bool GT>
 __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64_t *__restrict__ rowdesc,
                                                   const uint8_t *__restrict__ rle)
@@ -512,6 +515,8 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
         pre[i][0] = fetch_data(dsc[i], wpp == 1 ? 0 : tw);
         pre[i][1] = fetch_data(dsc[i], wpp == 1 ? 1 : tw + wpp);
     }
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = a.debug_times ? __builtin_amdgcn_s_memtime() : 0ull;
+
     for (int64_t rb = blk_beg; rb < blk_end; rb += K) {
         const int Kc = (int)((blk_end - rb) < K ? (blk_end - rb) : K);
 
@@ -531,6 +536,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
             dsc_next[i] = fetch_desc(rb + 2 * K, i);
         }
 
+        BGTH_TICK(0);
         // ================= phase A: build the bit-vectors of Kc rows x 2 planes =================
         if (wpp == 1) {
 #pragma unroll
@@ -559,7 +565,9 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
                     if (lane == 0) { chunktab[2 * c] = tot; chunktab[2 * c + 1] = lb | (cd.stop ? 2u : 0u); }
                 }
             }
+            BGTH_TICK(1);
             lds_barrier();
+            BGTH_TICK(2);
             if (active && !(a.debug_skip & 2)) {
                 if (parallel_rle) {
 #pragma unroll
@@ -584,7 +592,9 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
                     rle_toggles<true>(a, rle, bd, cdsc[0], 0u, 0u, 0u, 0u, 0, lane, a.seg_shift, segtab);
                 }
             }
+            BGTH_TICK(3);
             lds_barrier();
+            BGTH_TICK(4);
             if (active && !(a.debug_skip & 4)) {
                 const int seg_words = 1 << (a.seg_shift - 5);
                 const int w0 = tw * seg_words < nw ? tw * seg_words : nw;
@@ -599,7 +609,9 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
                 if (tw == 0 && lane == 0) n0s[team] = (uint32_t)m - total;
             }
         }
+        BGTH_TICK(5);
         lds_barrier();
+        BGTH_TICK(6);
 
         // ================= phase B: walk the rows, ranks stay in registers =================
         if (!(a.debug_skip & 1))
@@ -650,6 +662,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
         }
         lds_barrier();
 
+        BGTH_TICK(7);
         // ================= phase C: per-row counts of this slice -> HBM =================
         if (MULTI) {
             for (int i = tid; i < Kc * G * 3; i += NT) {
@@ -673,6 +686,9 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
         // (the barriers of the next phase A order these reads before the next writes to lcnt)
     }
 
+    if (a.debug_times && lane == 0) {
+        for (int i = 0; i < 8; ++i) atomicAdd(a.debug_times + i, tsum[i]);
+    }
     if (a.final_rank) {
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
