@@ -1,0 +1,66 @@
+"""Parity at BASELINE.json's full sizes through size-independent properties (the oracle would need minutes
+there).  For every site the RLE strings alone determine the number of ones in each bit plane, whatever the
+permutation:  ones(plane 0) = n(ALT) + n(<M>)  and  ones(plane 1) = n(missing) + n(<M>).  The device reports
+AN = m - n(missing), AC = n(ALT), AC<M> = n(<M>), so for the whole cohort
+      AC + ACM == ones0        and        (m - AN) + ACM == ones1            for every one of the sites,
+and sums over sample groups / column slices must reproduce the whole-cohort counts.  A sampled sub-range
+is additionally compared with the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+
+import orc
+
+pytestmark = pytest.mark.gpu
+
+
+def ones_per_string(rle, lens):
+    code = rle >> 1
+    length = (code & 15).astype(np.int64) << (4 * (code >> 4)).astype(np.int64)
+    ones = np.where(rle & 1, length, 0)
+    off = np.concatenate([[0], np.cumsum(lens.astype(np.int64))])[:-1]
+    tot = np.add.reduceat(ones, np.minimum(off, max(rle.size - 1, 0)))
+    tot[lens == 0] = 0
+    return tot.reshape(-1, 2)
+
+
+@pytest.mark.parametrize("n_samples,sites,seed", [(10000, 1000000, 2), (100000, 60000, 3), (2504, 50000, 1)])
+def test_plane_popcounts_match_counts_everywhere(n_samples, sites, seed):
+    import bgt_amd
+    m = 2 * n_samples
+    rle, lens = bgt_amd.synth_rows(m, 0, sites, seed)
+    pbf = bgt_amd.HipPbf.from_rle(m, 13, rle, lens)
+    rd = bgt_amd.HipReader(pbf)
+    counts = rd.scan(0, sites)[:, 0, :].astype(np.int64)
+    ones = ones_per_string(rle, lens)
+    an, ac, acm = counts[:, 0], counts[:, 1], counts[:, 2]
+    assert np.array_equal(ac + acm, ones[:, 0])
+    assert np.array_equal((m - an) + acm, ones[:, 1])
+    assert (an >= 0).all() and (an <= m).all()
+
+    # three sample groups partition the cohort: their counts add up to the whole-cohort counts
+    group = (1 + np.arange(n_samples) % 3).astype(np.uint32)
+    rd.select(np.arange(m), group=group, n_groups=3)
+    lo, hi = sites // 2, min(sites, sites // 2 + 20000)
+    g = rd.scan(lo, hi).astype(np.int64)
+    assert np.array_equal(g[:, 0, :], counts[lo:hi])
+    assert np.array_equal(g[:, 1:, :].sum(1), counts[lo:hi])
+
+    # a sample subset decoded through a different launch geometry agrees with the group it equals
+    sel = np.nonzero(group == 2)[0]
+    cols = np.stack([2 * sel, 2 * sel + 1], 1).reshape(-1)
+    rd.select(cols)
+    sub = rd.scan(lo, hi).astype(np.int64)
+    assert np.array_equal(sub[:, 0, :], g[:, 2, :])
+
+    # a window deep inside the file against the CPU oracle (needs the checkpoints: save and reload)
+    import tempfile
+    w0 = (sites // 8192 // 2) * 8192
+    w1 = min(sites, w0 + (2000 if m > 50000 else 12000))
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "x.pbf")
+        pbf.save(path)
+        data = open(path, "rb").read()
+    oc = orc.Pbf(data).scan(w0, w1).astype(np.int64)
+    assert np.array_equal(oc, counts[w0:w1])
