@@ -544,7 +544,7 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
         HIP_TRY(hipStreamSynchronize(s), return -1);
         HIP_TRY(hipMemcpy(h, d_times, 64, hipMemcpyDeviceToHost), return -1);
         hipFree(d_times);
-        const double waves = (double)geo.workgroups * (geo.threads / 64), nb = (double)rows / geo.K;
+        const double waves = (double)geo.workgroups * ((a.debug_skip & 0x100) ? 1 : geo.threads / 64), nb = (double)rows / geo.K;
         fprintf(stderr, "[bgth debug] cycles per wave and batch: top %.0f | A-zero+pass1 %.0f | wait %.0f | pass2 %.0f | wait %.0f | dir %.0f | wait %.0f | B %.0f\n",
                 h[0] / waves / nb, h[1] / waves / nb, h[2] / waves / nb, h[3] / waves / nb, h[4] / waves / nb, h[5] / waves / nb, h[6] / waves / nb, h[7] / waves / nb);
     }

@@ -384,22 +384,38 @@ __device__ __forceinline__ void chunk_toggles(const ScanArgs &a, uint2 *bd, cons
     // LDS word), then one atomic per segment the chunk touches -- usually one or two
     if (chunk_end > pos && pos < m && !(a.debug_skip & 32)) {
         const uint32_t last = (chunk_end < m ? chunk_end : m) - 1u;
-        for (uint32_t sg = pos >> seg_shift; sg <= last >> seg_shift; ++sg) {
-            const uint32_t lo = sg << seg_shift, hi = lo + (1u << seg_shift);
+        const uint32_t sg0 = pos >> seg_shift;
+        if (sg0 == last >> seg_shift) {
+            // common case: the whole chunk lies in one segment -- four ballots and one wave sum
             uint32_t par = 0, ones = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                par ^= (uint32_t)__popcll(__ballot(tog[i] && start[i] >= lo && start[i] < hi));
-                if (d.valid[i] && d.bit[i]) {
-                    const uint32_t e0 = start[i] + d.l[i] < m ? start[i] + d.l[i] : m;
-                    const uint32_t b0 = start[i] > lo ? start[i] : lo, b1 = e0 < hi ? e0 : hi;
-                    if (b1 > b0) ones += b1 - b0;
-                }
+                par ^= (uint32_t)__popcll(__ballot(tog[i]));
+                if (d.valid[i] && d.bit[i] && start[i] < m) ones += (start[i] + d.l[i] < m ? d.l[i] : m - start[i]);
             }
             ones = lane63(wave_incl_add(ones));
             if (lane == 0) {
-                if (par & 1u) atomicXor(&segtab[2 * sg], 1u);
-                if (ones) atomicAdd(&segtab[2 * sg + 1], ones);
+                if (par & 1u) atomicXor(&segtab[2 * sg0], 1u);
+                if (ones) atomicAdd(&segtab[2 * sg0 + 1], ones);
+            }
+        } else {
+            for (uint32_t sg = sg0; sg <= last >> seg_shift; ++sg) {
+                const uint32_t lo = sg << seg_shift, hi = lo + (1u << seg_shift);
+                uint32_t par = 0, ones = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    par ^= (uint32_t)__popcll(__ballot(tog[i] && start[i] >= lo && start[i] < hi));
+                    if (d.valid[i] && d.bit[i]) {
+                        const uint32_t e0 = start[i] + d.l[i] < m ? start[i] + d.l[i] : m;
+                        const uint32_t b0 = start[i] > lo ? start[i] : lo, b1 = e0 < hi ? e0 : hi;
+                        if (b1 > b0) ones += b1 - b0;
+                    }
+                }
+                ones = lane63(wave_incl_add(ones));
+                if (lane == 0) {
+                    if (par & 1u) atomicXor(&segtab[2 * sg], 1u);
+                    if (ones) atomicAdd(&segtab[2 * sg + 1], ones);
+                }
             }
         }
     }
@@ -581,10 +597,13 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
                         const uint32_t pos = c ? (uint32_t)__builtin_amdgcn_readlane((int)incl_t, c ? c - 1 : 0) : 0u;
                         const uint32_t prevbit = c ? ((uint32_t)__builtin_amdgcn_readlane((int)t1, c ? c - 1 : 0) & 1u) : 0u;
                         const bool dead = (__ballot((t1 & 2u) != 0u) & ((1ull << c) - 1ull)) != 0ull;
+                        if (a.debug_skip & 0x200) BGTH_TICK(0);
                         if (!dead && (uint32_t)c * 256u < slen && !(a.debug_skip & 16)) {
                             // decoded again rather than kept: two registers cross the barrier instead of thirty
                             const ChunkDecode cd = decode_chunk(cpre[0][i], (uint32_t)c * 256u + 4u * (uint32_t)lane, slen, lane);
+                            if (a.debug_skip & 0x200) BGTH_TICK(1);
                             chunk_toggles(a, bd, cd, pos, prevbit, lane, a.seg_shift, segtab);
+                            if (a.debug_skip & 0x200) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); BGTH_TICK(2); }
                         }
                     }
                 } else if (tw == 0) {
@@ -686,7 +705,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
         // (the barriers of the next phase A order these reads before the next writes to lcnt)
     }
 
-    if (a.debug_times && lane == 0) {
+    if (a.debug_times && lane == 0 && (!(a.debug_skip & 0x100) || wave == 0)) {   // 0x100: wave 0 only
         for (int i = 0; i < 8; ++i) atomicAdd(a.debug_times + i, tsum[i]);
     }
     if (a.final_rank) {

@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
 #include <zlib.h>
 #include "../../include/bgt_reader.h"
 #include "../../include/bgt_hip.h"
@@ -372,17 +373,21 @@ void bgt_set_bed(bgt_t *bgt, const void *bed, int excl) { bgt->bed = bed; bgt->b
  * (ref bgt.c:207-246; the subset list is {2s, 2s+1} for every selected sample s) */
 /* the HBM image of prefix.pbf is opened on first need and cached on the file handle, shared by every
  * reader of that file; each reader owns its own device reader (stream, selection, result buffers) */
+static pthread_mutex_t g_open_lock = PTHREAD_MUTEX_INITIALIZER;   /* readers of one file may start on different threads */
+
 static int ensure_device(bgt_t *bgt)
 {
     bgt_file_t *wf = (bgt_file_t*)bgt->f;
     devrd_t *dv = (devrd_t*)bgt->pb;
     if (dv->rd) return 0;
+    pthread_mutex_lock(&g_open_lock);
     if (wf->gpu == NULL) {
         char *fn = (char*)malloc(strlen(wf->prefix) + 8);
         sprintf(fn, "%s.pbf", wf->prefix);
         wf->gpu = bgth_pbf_open(fn, 0);
         free(fn);
     }
+    pthread_mutex_unlock(&g_open_lock);
     if (wf->gpu) dv->rd = bgth_reader_create((bgth_pbf_t*)wf->gpu);
     if (dv->rd == NULL) { fprintf(stderr, "[E::%s] %s\n", __func__, bgth_last_error()); return -1; }
     return 0;
