@@ -117,7 +117,7 @@ struct bgth_reader_s {
     HostBuf h_counts, h_planes;
     float t_ms[3] = {0, 0, 0};
     bool t_pending = false;           // events recorded on a caller stream, not yet read back
-    Geometry geom = {0, 0, 0, 0, 0, 0, 1};
+    Geometry geom = {0, 0, 0, 0, 0, 0, 1, 1};
     int tune_threads = 0, tune_cpt = 0, tune_K = 0;
     // pull interface
     int64_t next = 0, ring0 = 0, ring1 = 0;
@@ -327,7 +327,7 @@ static bool run_block_pass(bgth_pbf_t *p, Selection &all, int64_t blk, int32_t *
     a.rank0 = p->d_rank0; a.rank0_blk_stride = (int64_t)2 * p->m;
     a.slot_col = all.d_slot_col; a.chunk_desc = all.d_chunk_desc;
     a.raw_counts = nullptr; a.h0 = a.h1 = nullptr; a.final_rank = d_final;
-    a.m = p->m; a.nw = (p->m + 31) / 32; a.shift = p->shift; a.n_chunks = all.n_chunks; a.G = 1; a.K = geo.K; a.wpp = geo.wpp; a.seg_shift = 5; while (((int64_t)geo.wpp << a.seg_shift) < a.m || a.seg_shift < 11) ++a.seg_shift;
+    a.m = p->m; a.nw = (p->m + 31) / 32; a.shift = p->shift; a.n_chunks = all.n_chunks; a.G = 1; a.K = geo.K; a.wpp = geo.wpp; a.nbuf = geo.nbuf; a.seg_shift = 5; while (((int64_t)geo.wpp << a.seg_shift) < a.m || a.seg_shift < 11) ++a.seg_shift;
     a.blk0 = (int32_t)blk; a.n_blk = 1; a.n_slices = geo.slices;
     a.row1 = std::min<int64_t>(p->n, (blk + 1) << p->shift);
     a.row0 = a.row1;                      // nothing emitted: only the final ranks are wanted
@@ -524,7 +524,7 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
     a.rank0 = p->d_rank0; a.rank0_blk_stride = (int64_t)2 * p->m;
     a.slot_col = r->sel.d_slot_col; a.chunk_desc = r->sel.d_chunk_desc;
     a.raw_counts = (int32_t*)r->raw.p; a.h0 = d_h0; a.h1 = d_h1; a.final_rank = nullptr;
-    a.m = p->m; a.nw = (p->m + 31) / 32; a.shift = p->shift; a.n_chunks = r->sel.n_chunks; a.G = G; a.K = geo.K; a.wpp = geo.wpp; a.seg_shift = 5; while (((int64_t)geo.wpp << a.seg_shift) < a.m || a.seg_shift < 11) ++a.seg_shift;
+    a.m = p->m; a.nw = (p->m + 31) / 32; a.shift = p->shift; a.n_chunks = r->sel.n_chunks; a.G = G; a.K = geo.K; a.wpp = geo.wpp; a.nbuf = geo.nbuf; a.seg_shift = 5; while (((int64_t)geo.wpp << a.seg_shift) < a.m || a.seg_shift < 11) ++a.seg_shift;
     a.blk0 = (int32_t)blk0; a.n_blk = (int32_t)(blk1 - blk0 + 1); a.n_slices = geo.slices;
     a.row0 = row0; a.row1 = row1;
     { const char *dbg = getenv("BGTH_DEBUG_SKIP"); a.debug_skip = dbg ? atoi(dbg) : 0; }

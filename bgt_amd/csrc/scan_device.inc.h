@@ -1,0 +1,762 @@
+// gfx950 (MI355X, CDNA4) kernels of the BGT genotype-matrix read path.
+//
+// What the reference does per site and plane (pbwt.c:69-90 full decode, :129-170 subset decode,
+// bgt.c:735-757 histogram) is restated here in the inverse / rank-tracking form of SURVEY.md App. B:
+//
+//     every tracked column i keeps R[i] = its current PBWT rank (thread-private, in VGPRs)
+//     per row and plane:   bit  = B[R[i]]                         (B = the row in PBWT order)
+//                          R[i] = bit ? n0 + rank1(R[i]) : R[i] - rank1(R[i])
+//
+// so the permutation state never touches HBM or even LDS.  B is rebuilt per row in LDS from the RLE
+// string as a bit-vector with a rank directory: {32 bits, number of ones before them} per 8-byte entry,
+// so one ds_read_b64 answers both B[r] and rank1(r).  Work decomposition:
+//
+//   grid   = (8192-row checkpoint block) x (column slice); all slices of a block are placed on one XCD
+//            (workgroup id mod 8) so the RLE bytes they share are served by one L2.
+//   wave   = owns CPT consecutive 64-slot chunks; a chunk never mixes sample groups, so the allele
+//            counts of a chunk are popcounts of the two 64-bit ballots (the v_cmp that selects the
+//            new rank already is the ballot).
+//   batch  = K rows: phase A builds the 2K bit-vectors (one wave per plane-row: byte -> run length,
+//            wave prefix sum -> run starts, xor-toggle at every change of bit, prefix-xor -> bits,
+//            popcount prefix sum -> rank directory), phase B walks the K rows with no barrier.
+//
+// No MFMA: this is integer/bit work bound by LDS issue and VALU, not by HBM.
+#pragma once
+#include "scan_kernels.h"
+#include <stdlib.h>
+
+namespace bgth {
+
+// ----------------------------------------------------------------------------------------------------
+// wave-level helpers (64 lanes)
+// ----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lanes_below(uint64_t mask)
+{   // number of set bits of mask in lanes below the caller
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// inclusive prefix sum over the 64 lanes, all in the VALU (DPP row shifts + the two row broadcasts)
+__device__ __forceinline__ uint32_t wave_incl_add(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+// value of the lane below (lane 0 receives `first`)
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v, uint32_t first)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138, 0xf, 0xf, false);   // wave_shr:1
+}
+
+// Workgroup barrier for data exchanged through LDS only.  __syncthreads() also drains vmcnt (its
+// workgroup-scope release covers global memory), which would turn every software-prefetched global load
+// into a stall at the next barrier; LDS traffic only needs lgkmcnt(0).
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__device__ __forceinline__ uint32_t lane63(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
+
+__device__ __forceinline__ uint32_t rle_len(uint32_t byte)
+{   // reference pbwt.c:12-21 as arithmetic: code = byte>>1, len = (code&15) << 4*(code>>4)
+    uint32_t code = byte >> 1;
+    return (code & 15u) << ((code >> 4) << 2);
+}
+
+// ----------------------------------------------------------------------------------------------------
+// the scan kernel
+// ----------------------------------------------------------------------------------------------------
+// ----------------------------------------------------------------------------------------------------
+// The row step.  For one tracked column and one plane:   e = B[r>>5] = {32 bits, ones before them}
+//     bit = e.bits[r&31] ;  ob = e.before + popc(e.bits & low(r&31)) = rank1(r)
+//     r   = bit ? n0 + ob : r - ob                                  (LF-mapping)
+// Ten VALU instructions and one ds_read_b64 per lookup; the v_cmp that steers the select is also the
+// wave ballot of the decoded bit.  Hand-scheduled: left to hipcc the unrolled row body keeps one
+// 64-bit SGPR condition per lookup alive to the end of the row and spills (measured: 151 VGPRs and
+// 333 v_writelane/v_readlane at 16 columns per thread; this form needs 2 VGPRs per column + 12).
+// Two columns x two planes per statement = 4 LDS reads in flight per wave.  Scratch registers are
+// named (v112..v123) and declared as clobbers; every ds_read is waited for inside the statement.
+// ----------------------------------------------------------------------------------------------------
+#define BGTH_TAIL(R, ELO, EHI, T, MASK, N0)            \
+    "v_bfe_u32 " T ", " ELO ", 0, " R "\n\t"           \
+    "v_bcnt_u32_b32 " T ", " T ", " EHI "\n\t"         \
+    "v_bfe_u32 " ELO ", " ELO ", " R ", 1\n\t"         \
+    "v_cmp_ne_u32_e64 " MASK ", 0, " ELO "\n\t"        \
+    "v_sub_u32 " EHI ", " R ", " T "\n\t"              \
+    "v_add_u32 " T ", " N0 ", " T "\n\t"               \
+    "v_cndmask_b32_e64 " R ", " EHI ", " T ", " MASK "\n\t"
+#define BGTH_ADDR(T, R, BASE)                          \
+    "v_lshrrev_b32 " T ", 5, " R "\n\t"                \
+    "v_lshl_add_u32 " T ", " T ", 3, " BASE "\n\t"
+
+// per column, on the scalar unit (keeps the VALU for the lookups): ones of plane 0, ones of plane 1,
+// ones in both.  M0/M1 are the ballots the v_cmp of the two lookups produced.
+#define BGTH_COUNT(M0, M1, CA, CB, CC)                 \
+    "s_bcnt1_i32_b64 vcc_lo, " M0 "\n\t"               \
+    "s_add_u32 " CA ", " CA ", vcc_lo\n\t"             \
+    "s_bcnt1_i32_b64 vcc_lo, " M1 "\n\t"               \
+    "s_add_u32 " CB ", " CB ", vcc_lo\n\t"             \
+    "s_and_b64 vcc, " M0 ", " M1 "\n\t"                \
+    "s_bcnt1_i32_b64 vcc_lo, vcc\n\t"                  \
+    "s_add_u32 " CC ", " CC ", vcc_lo\n\t"
+
+// two columns x two planes: 4 LDS reads in flight
+__device__ __forceinline__ void step2(uint32_t &ra0, uint32_t &ra1, uint32_t &rb0, uint32_t &rb1,
+                                      uint64_t &ma0, uint64_t &ma1, uint64_t &mb0, uint64_t &mb1,
+                                      uint32_t &ca, uint32_t &cb, uint32_t &cc,
+                                      uint32_t base0, uint32_t base1, uint32_t n00, uint32_t n01)
+{
+    asm volatile(
+        "s_waitcnt lgkmcnt(0)\n\t"
+        BGTH_ADDR("v120", "%0", "%11") BGTH_ADDR("v121", "%1", "%12")
+        BGTH_ADDR("v122", "%2", "%11") BGTH_ADDR("v123", "%3", "%12")
+        "ds_read_b64 v[104:105], v120\n\t"
+        "ds_read_b64 v[106:107], v121\n\t"
+        "ds_read_b64 v[108:109], v122\n\t"
+        "ds_read_b64 v[110:111], v123\n\t"
+        "s_waitcnt lgkmcnt(3)\n\t"
+        BGTH_TAIL("%0", "v104", "v105", "v120", "%4", "%13")
+        "s_waitcnt lgkmcnt(2)\n\t"
+        BGTH_TAIL("%1", "v106", "v107", "v121", "%5", "%14")
+        BGTH_COUNT("%4", "%5", "%8", "%9", "%10")
+        "s_waitcnt lgkmcnt(1)\n\t"
+        BGTH_TAIL("%2", "v108", "v109", "v122", "%6", "%13")
+        "s_waitcnt lgkmcnt(0)\n\t"
+        BGTH_TAIL("%3", "v110", "v111", "v123", "%7", "%14")
+        BGTH_COUNT("%6", "%7", "%8", "%9", "%10")
+        : "+v"(ra0), "+v"(ra1), "+v"(rb0), "+v"(rb1), "=&s"(ma0), "=&s"(ma1), "=&s"(mb0), "=&s"(mb1),
+          "+s"(ca), "+s"(cb), "+s"(cc)
+        : "s"(base0), "s"(base1), "s"(n00), "s"(n01)
+        : "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v120", "v121", "v122", "v123",
+          "vcc", "scc", "memory");
+}
+
+// four columns x two planes: 8 LDS reads in flight
+__device__ __forceinline__ void step4(uint32_t (&r0)[4], uint32_t (&r1)[4], uint64_t (&m0)[4], uint64_t (&m1)[4],
+                                      uint32_t &ca, uint32_t &cb, uint32_t &cc,
+                                      uint32_t base0, uint32_t base1, uint32_t n00, uint32_t n01)
+{
+    asm volatile(
+        "s_waitcnt lgkmcnt(0)\n\t"
+        BGTH_ADDR("v120", "%0", "%19") BGTH_ADDR("v121", "%1", "%20")
+        BGTH_ADDR("v122", "%2", "%19") BGTH_ADDR("v123", "%3", "%20")
+        BGTH_ADDR("v124", "%4", "%19") BGTH_ADDR("v125", "%5", "%20")
+        BGTH_ADDR("v126", "%6", "%19") BGTH_ADDR("v127", "%7", "%20")
+        "ds_read_b64 v[104:105], v120\n\t"
+        "ds_read_b64 v[106:107], v121\n\t"
+        "ds_read_b64 v[108:109], v122\n\t"
+        "ds_read_b64 v[110:111], v123\n\t"
+        "ds_read_b64 v[112:113], v124\n\t"
+        "ds_read_b64 v[114:115], v125\n\t"
+        "ds_read_b64 v[116:117], v126\n\t"
+        "ds_read_b64 v[118:119], v127\n\t"
+        "s_waitcnt lgkmcnt(7)\n\t"
+        BGTH_TAIL("%0", "v104", "v105", "v120", "%8", "%21")
+        "s_waitcnt lgkmcnt(6)\n\t"
+        BGTH_TAIL("%1", "v106", "v107", "v121", "%9", "%22")
+        BGTH_COUNT("%8", "%9", "%16", "%17", "%18")
+        "s_waitcnt lgkmcnt(5)\n\t"
+        BGTH_TAIL("%2", "v108", "v109", "v122", "%10", "%21")
+        "s_waitcnt lgkmcnt(4)\n\t"
+        BGTH_TAIL("%3", "v110", "v111", "v123", "%11", "%22")
+        BGTH_COUNT("%10", "%11", "%16", "%17", "%18")
+        "s_waitcnt lgkmcnt(3)\n\t"
+        BGTH_TAIL("%4", "v112", "v113", "v124", "%12", "%21")
+        "s_waitcnt lgkmcnt(2)\n\t"
+        BGTH_TAIL("%5", "v114", "v115", "v125", "%13", "%22")
+        BGTH_COUNT("%12", "%13", "%16", "%17", "%18")
+        "s_waitcnt lgkmcnt(1)\n\t"
+        BGTH_TAIL("%6", "v116", "v117", "v126", "%14", "%21")
+        "s_waitcnt lgkmcnt(0)\n\t"
+        BGTH_TAIL("%7", "v118", "v119", "v127", "%15", "%22")
+        BGTH_COUNT("%14", "%15", "%16", "%17", "%18")
+        : "+v"(r0[0]), "+v"(r1[0]), "+v"(r0[1]), "+v"(r1[1]), "+v"(r0[2]), "+v"(r1[2]), "+v"(r0[3]), "+v"(r1[3]),
+          "=&s"(m0[0]), "=&s"(m1[0]), "=&s"(m0[1]), "=&s"(m1[1]), "=&s"(m0[2]), "=&s"(m1[2]), "=&s"(m0[3]), "=&s"(m1[3]),
+          "+s"(ca), "+s"(cb), "+s"(cc)
+        : "s"(base0), "s"(base1), "s"(n00), "s"(n01)
+        : "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115",
+          "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127",
+          "vcc", "scc", "memory");
+}
+
+// ----------------------------------------------------------------------------------------------------
+// Phase A for one plane-row, executed by ONE wave: RLE string -> bit-vector + rank directory in LDS.
+//   1. clear the row's entries
+//   2. every lane decodes 4 code bytes (strings are packed 4-byte aligned), a wave prefix sum of the
+//      run lengths gives every run's start, and wherever the bit differs from the previous byte's bit
+//      the row "toggles" at the run start: the lane xors the mask ~0 << (start & 31) into the word of
+//      the start (LDS atomic; bytes of zero length cancel out).  After all toggles a word holds the
+//      prefix parity of its own toggles, and its bit 31 their total parity.
+//   3. the row bits are that word, inverted when the parity of the toggles in all earlier words is
+//      odd (ballot of bit 31 + mbcnt); a wave prefix sum of the word popcounts is the rank
+//      directory.  The number of ones falls out as the final carry.
+// LDS operations of one wave complete in order, so no workgroup barrier is needed between the steps;
+// the wavefront fences only pin the compiler's ordering.
+// ----------------------------------------------------------------------------------------------------
+// step 2: RLE string -> toggles (one wave).  SEG: the row is finished by a team of waves, each owning a
+// segment of 1 << seg_shift positions; record per segment the parity of its toggles and its number of
+// ones (known here from the run lengths), so that every wave can start its segment with the right carries.
+template <bool SEG>
+__device__ __forceinline__ void rle_toggles(const ScanArgs &a, const uint8_t *__restrict__ rle, uint2 *bd, uint64_t desc,
+                                            uint32_t pre0, uint32_t pre1, uint32_t pre2, uint32_t pre3, int npre, int lane,
+                                            int seg_shift, uint32_t *segtab)
+{
+    const int m = a.m;
+    const uint32_t *q4 = reinterpret_cast<const uint32_t*>(rle + (desc & kDescOffMask));
+    const uint32_t len = (uint32_t)(desc >> kDescLenShift);
+    uint32_t pos = 0, prevbit = 0;
+    bool stop = false;
+    for (uint32_t base = 0; base < len && !stop; base += 256) {
+        const uint32_t k0 = base + 4u * (uint32_t)lane;
+        // the first 256*npre bytes were fetched one batch ahead; longer strings read on
+        uint32_t w;
+        if (base == 0 && npre > 0) w = pre0;
+        else if (base == 256 && npre > 0) w = pre1;
+        else if (base == 512 && npre > 2) w = pre2;
+        else if (base == 768 && npre > 2) w = pre3;
+        else w = k0 < len ? q4[(base >> 2) + lane] : 0u;
+        uint32_t byte[4], l[4];
+        bool valid[4];
+        bool anyz = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            byte[i] = (w >> (8 * i)) & 255u;
+            valid[i] = k0 + i < len;
+            anyz = anyz || (valid[i] && byte[i] == 0u);
+        }
+        const uint64_t z = __ballot(anyz);                  // a zero byte ends the row (ref pbwt.c:73)
+        if (z) {
+            const int first = __ffsll((unsigned long long)z) - 1;
+            bool dead = lane > first;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (lane == first && byte[i] == 0u) dead = true;
+                valid[i] = valid[i] && !dead;
+            }
+            stop = true;
+        }
+        uint32_t run = 0, before[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { l[i] = valid[i] ? rle_len(byte[i]) : 0u; before[i] = run; run += l[i]; }
+        const uint32_t incl = wave_incl_add(run);
+        const uint32_t lane_start = pos + incl - run;
+        uint32_t pb = wave_shr1(byte[3] & 1u, prevbit);      // bit of the byte before this lane's first
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t b = byte[i] & 1u, start = lane_start + before[i];
+            if (valid[i] && b != pb && start < (uint32_t)m) {
+                atomicXor(&bd[start >> 5].x, 0xffffffffu << (start & 31));
+                if (SEG) atomicXor(&segtab[2 * (start >> seg_shift)], 1u);
+            }
+            if (SEG && b && l[i] && start < (uint32_t)m) {   // ones of this run piece, split at segment borders
+                uint32_t at = start;
+                const uint32_t end = start + l[i] < (uint32_t)m ? start + l[i] : (uint32_t)m;
+                while (at < end) {
+                    const uint32_t sg = at >> seg_shift, lim = (sg + 1u) << seg_shift;
+                    const uint32_t upto = end < lim ? end : lim;
+                    atomicAdd(&segtab[2 * sg + 1], upto - at);
+                    at = upto;
+                }
+            }
+            pb = b;
+        }
+        prevbit = lane63(byte[3] & 1u);
+        pos += lane63(incl);
+    }
+}
+
+// step 3 over the words [w0,w1) of a row (one wave; w0 a multiple of 4).  A lane owns 4 consecutive words
+// per trip (256 words per trip): one ballot/mbcnt for the toggle parity entering the lane and one DPP
+// prefix sum of the lane's ones serve four words, the chain across the four is local arithmetic.
+__device__ __forceinline__ void directory_pass(uint2 *bd, int w0, int w1, int nw, uint32_t tail_mask,
+                                               uint32_t &carry_x, uint32_t &carry_c, int lane)
+{
+    for (int base = w0; base < w1; base += 256) {
+        const int i0 = base + 4 * lane;
+        const uint4 *src = reinterpret_cast<const uint4*>(bd + i0);      // rows are 16-byte aligned
+        uint32_t t[4] = {0u, 0u, 0u, 0u};
+        if (i0 + 3 < w1) { const uint4 lo = src[0], hi = src[1]; t[0] = lo.x; t[1] = lo.z; t[2] = hi.x; t[3] = hi.z; }
+        else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (i0 + k < w1) t[k] = bd[i0 + k].x;
+        }
+        const uint32_t p0 = t[0] >> 31, p1 = t[1] >> 31, p2 = t[2] >> 31, p3 = t[3] >> 31;   // toggle parity per word
+        const uint64_t par = __ballot((p0 ^ p1 ^ p2 ^ p3) != 0u);
+        uint32_t cin = (lanes_below(par) ^ carry_x) & 1u;                // parity of all toggles before word i0
+        uint32_t v[4], pre[4], ones = 0;
+        const uint32_t pk[4] = {p0, p1, p2, p3};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t x = t[k] ^ (0u - cin);                              // inverted when the carry parity is odd
+            if (i0 + k == nw - 1) x &= tail_mask;
+            if (i0 + k >= w1) x = 0u;
+            v[k] = x; pre[k] = ones; ones += (uint32_t)__popc(x);
+            cin ^= pk[k];
+        }
+        const uint32_t incl = wave_incl_add(ones);
+        const uint32_t b = carry_c + incl - ones;
+        if (i0 + 3 < w1) {
+            uint4 *dst = reinterpret_cast<uint4*>(bd + i0);
+            dst[0] = make_uint4(v[0], b, v[1], b + pre[1]);
+            dst[1] = make_uint4(v[2], b + pre[2], v[3], b + pre[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (i0 + k < w1) bd[i0 + k] = make_uint2(v[k], b + pre[k]);
+        }
+        carry_x ^= (uint32_t)__popcll(par) & 1u;
+        carry_c += lane63(incl);
+    }
+}
+
+// ---- team-parallel RLE decode: wave tw of a team owns the 256-byte chunks tw and tw + wpp of the string.
+// Pass 1 measures a chunk (symbols covered, bit of its last byte, whether a terminating zero byte was
+// seen); after a barrier pass 2 turns the chunk into toggles, knowing where it starts.
+struct ChunkDecode { uint32_t l[4], before[4], bit[4], run; bool valid[4]; bool stop; };
+
+__device__ __forceinline__ ChunkDecode decode_chunk(uint32_t w, uint32_t k0, uint32_t len, int lane)
+{
+    ChunkDecode d;
+    bool anyz = false;
+    uint32_t byte[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        byte[i] = (w >> (8 * i)) & 255u;
+        d.valid[i] = k0 + i < len;
+        d.bit[i] = byte[i] & 1u;
+        anyz = anyz || (d.valid[i] && byte[i] == 0u);
+    }
+    const uint64_t z = __ballot(anyz);
+    d.stop = z != 0;
+    if (z) {
+        const int first = __ffsll((unsigned long long)z) - 1;
+        bool dead = lane > first;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (lane == first && byte[i] == 0u) dead = true;
+            d.valid[i] = d.valid[i] && !dead;
+        }
+    }
+    d.run = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { d.l[i] = d.valid[i] ? rle_len(byte[i]) : 0u; d.before[i] = d.run; d.run += d.l[i]; }
+    return d;
+}
+
+// bit of the last valid byte of the chunk (wave-uniform), 0 if the chunk is empty
+__device__ __forceinline__ uint32_t chunk_last_bit(const ChunkDecode &d, int lane)
+{
+    uint32_t nv = 0, lastb = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (d.valid[i]) { ++nv; lastb = d.bit[i]; }
+    const uint64_t has = __ballot(nv != 0u);
+    if (!has) return 0u;
+    const int top = 63 - __builtin_clzll((unsigned long long)has);
+    return (uint32_t)__builtin_amdgcn_readlane((int)lastb, top);
+}
+
+__device__ __forceinline__ void chunk_toggles(const ScanArgs &a, uint2 *bd, const ChunkDecode &d, uint32_t pos,
+                                              uint32_t prevbit, int lane, int seg_shift, uint32_t *segtab)
+{
+    const uint32_t m = (uint32_t)a.m;
+    const uint32_t incl = wave_incl_add(d.run);
+    const uint32_t lane_start = pos + incl - d.run;
+    const uint32_t chunk_end = pos + lane63(incl);
+    // bit of the byte before this lane's first byte: the last valid byte of the lane below (chunks are
+    // dense, so a lane below a lane with data is full)
+    uint32_t lastb = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (d.valid[i]) lastb = d.bit[i];
+    uint32_t pb = wave_shr1(lastb, prevbit);
+    bool tog[4];
+    uint32_t start[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        start[i] = lane_start + d.before[i];
+        tog[i] = d.valid[i] && d.bit[i] != pb && start[i] < m;
+        if (tog[i] && !(a.debug_skip & 64)) atomicXor(&bd[start[i] >> 5].x, 0xffffffffu << (start[i] & 31));
+        if (d.valid[i]) pb = d.bit[i];
+    }
+    // segment tables: reduce inside the wave first (every toggle of a segment would otherwise hit the same
+    // LDS word), then one atomic per segment the chunk touches -- usually one or two
+    if (chunk_end > pos && pos < m && !(a.debug_skip & 32)) {
+        const uint32_t last = (chunk_end < m ? chunk_end : m) - 1u;
+        const uint32_t sg0 = pos >> seg_shift;
+        if (sg0 == last >> seg_shift) {
+            // common case: the whole chunk lies in one segment -- four ballots and one wave sum
+            uint32_t par = 0, ones = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                par ^= (uint32_t)__popcll(__ballot(tog[i]));
+                if (d.valid[i] && d.bit[i] && start[i] < m) ones += (start[i] + d.l[i] < m ? d.l[i] : m - start[i]);
+            }
+            ones = lane63(wave_incl_add(ones));
+            if (lane == 0) {
+                if (par & 1u) atomicXor(&segtab[2 * sg0], 1u);
+                if (ones) atomicAdd(&segtab[2 * sg0 + 1], ones);
+            }
+        } else {
+            for (uint32_t sg = sg0; sg <= last >> seg_shift; ++sg) {
+                const uint32_t lo = sg << seg_shift, hi = lo + (1u << seg_shift);
+                uint32_t par = 0, ones = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    par ^= (uint32_t)__popcll(__ballot(tog[i] && start[i] >= lo && start[i] < hi));
+                    if (d.valid[i] && d.bit[i]) {
+                        const uint32_t e0 = start[i] + d.l[i] < m ? start[i] + d.l[i] : m;
+                        const uint32_t b0 = start[i] > lo ? start[i] : lo, b1 = e0 < hi ? e0 : hi;
+                        if (b1 > b0) ones += b1 - b0;
+                    }
+                }
+                ones = lane63(wave_incl_add(ones));
+                if (lane == 0) {
+                    if (par & 1u) atomicXor(&segtab[2 * sg], 1u);
+                    if (ones) atomicAdd(&segtab[2 * sg + 1], ones);
+                }
+            }
+        }
+    }
+}
+
+// whole plane-row by one wave
+__device__ __forceinline__ void build_plane_row(const ScanArgs &a, const uint8_t *__restrict__ rle, uint2 *bd,
+                                                uint32_t *n0_out, uint64_t desc, uint32_t pre0, uint32_t pre1, int lane,
+                                                uint32_t tail_mask)
+{
+    const int nw = a.nw;
+    for (int i = lane; i < nw; i += 64) bd[i] = make_uint2(0u, 0u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (!(a.debug_skip & 2)) rle_toggles<false>(a, rle, bd, desc, pre0, pre1, 0u, 0u, 2, lane, 0, nullptr);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    uint32_t carry_x = 0, carry_c = 0;
+    if (!(a.debug_skip & 4)) directory_pass(bd, 0, nw, nw, tail_mask, carry_x, carry_c, lane);
+    if (lane == 0) *n0_out = (uint32_t)a.m - carry_c;
+}
+
+// Template switches:  MULTI = more than one sample group (per-chunk LDS atomics instead of per-wave
+// scalars);  GT = also emit the two bit planes of every row (slot order) for genotype output;
+// TEAM = wide cohort: few rows fit the LDS, every plane-row is built by a team of waves (single batch
+// buffer); otherwise a wave builds its plane-rows alone and batches are pipelined over two buffers.
+#define BGTH_TICK(slot) do { if (a.debug_times) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+    tsum[slot] += now_ - tlast; tlast = now_; } } while (0)
+
+template <int NT, int CPT, bool MULTI, bool GT, bool TEAM>
+__global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64_t *__restrict__ rowdesc,
+                                                  const uint8_t *__restrict__ rle)
+{   // rowdesc / rle are separate `const __restrict__` arguments (not members of `a`) so that hipcc knows
+    // they are invariant: the wave-uniform descriptor loads then go through the scalar cache (s_load,
+    // lgkmcnt) and do not force a vmcnt(0) that would drain the prefetched string loads.
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NWAVE = NT / 64;
+    static_assert(CPT % 2 == 0, "columns per thread are stepped in pairs");
+    const int tid  = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // workgroup -> (block, slice); consecutive workgroup ids go round-robin over the 8 XCDs, so
+    // keep  id mod 8  == block mod 8 for every slice of a block.
+    const int S   = a.n_slices;
+    const int wg  = blockIdx.x;
+    const int sup = wg / (8 * S), rem = wg % (8 * S);
+    const int slice = rem >> 3;
+    const int bl    = sup * 8 + (rem & 7);
+    if (bl >= a.n_blk) return;
+
+    // LDS: per plane-row nw entries {bits, ones before} + ONE all-zero sentinel entry.  Padding slots
+    // carry the rank 32*nw: they read the sentinel, see bit 0 and "zero ones before", and map to
+    // themselves -- so no validity mask is needed anywhere in the row loop.
+    const int m = a.m, nw = a.nw, nwp = (nw + 2) & ~1, K = a.K, G = a.G;   // rows 16-byte aligned
+    uint2    *BD   = reinterpret_cast<uint2*>(smem);                    // [nbuf][2K][nwp]
+    int32_t  *lcnt = reinterpret_cast<int32_t*>(smem + (size_t)16 * K * nwp * (TEAM ? 1 : 2));
+    //   !MULTI: int4 [K][NWAVE] one private slot per wave and row   MULTI: int32 [K][G][3] (LDS atomics)
+    uint32_t *n0s  = reinterpret_cast<uint32_t*>(lcnt + (TEAM ? 1 : 2) * (MULTI ? K * G * 3 : K * NWAVE * 4)); // [nbuf][2K]
+    const uint32_t pad_rank = 32u * (uint32_t)nw;
+    const uint32_t lds0 = __builtin_amdgcn_groupstaticsize();            // LDS byte address of smem[0]
+
+    const int64_t blk      = (int64_t)a.blk0 + bl;
+    const int64_t blk_beg  = blk << a.shift;
+    int64_t       blk_end  = (blk + 1) << a.shift;
+    if (blk_end > a.row1) blk_end = a.row1;
+
+    // ---- tracked slots of this thread: chunk c = chunk0 + j, slot = 64c + lane
+    const int chunk0 = (slice * NWAVE + wave) * CPT;
+    uint32_t r0[CPT], r1[CPT];
+    {
+        const int32_t *rk = a.rank0 + blk * a.rank0_blk_stride;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int c = chunk0 + j;
+            const int col = (c < a.n_chunks && !(a.debug_skip & 8)) ? a.slot_col[c * 64 + lane] : -1;
+            r0[j] = col >= 0 ? (uint32_t)rk[col] : pad_rank;
+            r1[j] = col >= 0 ? (uint32_t)rk[m + col] : pad_rank;
+        }
+    }
+    if (MULTI) for (int i = tid; i < (TEAM ? 1 : 2) * K * G * 3; i += NT) lcnt[i] = 0;
+    for (int i = tid; i < (TEAM ? 1 : 2) * 2 * K; i += NT) BD[(size_t)i * nwp + nw] = make_uint2(0u, 0u);
+
+    const uint32_t tail_mask = (m & 31) ? ((1u << (m & 31)) - 1u) : 0xffffffffu;
+
+    // ---- who builds which plane-row of a batch.  wpp == 1: wave w builds plane-rows w and w + NWAVE
+    // on its own (K <= NWAVE).  wpp > 1 (wide cohorts: few rows fit the LDS): a team of wpp waves builds
+    // plane-row (wave / wpp) together, synchronised by workgroup barriers.
+    const int wpp = TEAM ? a.wpp : 1;
+    const int team = wave / wpp, tw = wave - team * wpp;
+    constexpr int nbuf = TEAM ? 1 : 2;                                   // !TEAM: pipelined batches (see below)
+    uint32_t *seginfo = n0s + nbuf * 2 * K;                              // [NWAVE][2] {toggle parity, ones}
+
+    // ---- software prefetch of the RLE strings: the row descriptors run two batches ahead of phase A,
+    // the first 512 bytes of every string one batch ahead.
+    uint64_t dsc[2], dsc_next[2];
+    uint32_t pre[2][2];
+    auto fetch_desc = [&](int64_t rb_, int i) -> uint64_t {
+        const int p = wpp == 1 ? wave + i * NWAVE : team;   // team mode: both slots = the team's string
+        const int64_t left = blk_end - rb_;
+        const int kc = (int)(left < K ? left : K);
+        return (rb_ < blk_end && p < 2 * kc) ? rowdesc[2 * rb_ + p] : 0ull;
+    };
+    auto fetch_data = [&](uint64_t d, int c) -> uint32_t {
+        const uint32_t len = (uint32_t)(d >> kDescLenShift);
+        const uint32_t k0 = (uint32_t)c * 256u + 4u * (uint32_t)lane;
+        return k0 < len ? reinterpret_cast<const uint32_t*>(rle + (d & kDescOffMask))[c * 64 + lane] : 0u;
+    };
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        dsc[i] = fetch_desc(blk_beg, i);
+        dsc_next[i] = fetch_desc(blk_beg + K, i);
+        // wpp == 1: chunks 0,1 of the wave's own two strings (slot i = plane-row i of the wave);
+        // team mode: slot 0 only, chunks tw and tw + wpp of the team's string
+        pre[i][0] = fetch_data(dsc[i], wpp == 1 ? 0 : tw);
+        pre[i][1] = fetch_data(dsc[i], wpp == 1 ? 1 : tw + wpp);
+    }
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = a.debug_times ? __builtin_amdgcn_s_memtime() : 0ull;
+
+    // LDS regions of batch buffer `buf`
+    const size_t bd_stride = (size_t)2 * K * nwp;                        // uint2 entries per buffer
+    const int cnt_stride = MULTI ? K * G * 3 : K * NWAVE * 4;            // ints per buffer
+
+    // ================= phase A: build the bit-vectors of the batch at rows [rbA, rbA+Kc) into buffer buf ===
+    // First take the strings fetched while the previous batch was processed and immediately issue the
+    // loads of the batch after this one (and the descriptors of the one after that): they have a whole
+    // batch to arrive, whatever vmcnt wait the compiler places at their first use.
+    auto phase_a = [&](int buf, int64_t rbA) {
+        const int Kc = (int)((blk_end - rbA) < K ? (blk_end - rbA) : K);
+        uint2 *BDb = BD + buf * bd_stride;
+        uint32_t *n0b = n0s + buf * 2 * K;
+        uint64_t cdsc[2];
+        uint32_t cpre[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { cdsc[i] = dsc[i]; cpre[i][0] = pre[i][0]; cpre[i][1] = pre[i][1]; }
+        asm volatile("" : "+v"(cpre[0][0]), "+v"(cpre[0][1]), "+v"(cpre[1][0]), "+v"(cpre[1][1]));   // arrived: pin the wait here
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            dsc[i] = dsc_next[i];
+            pre[i][0] = fetch_data(dsc[i], wpp == 1 ? 0 : tw);
+            pre[i][1] = fetch_data(dsc[i], wpp == 1 ? 1 : tw + wpp);
+            dsc_next[i] = fetch_desc(rbA + 2 * K, i);
+        }
+        BGTH_TICK(0);
+        if constexpr (!TEAM) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int p = wave + i * NWAVE;
+                if (p < 2 * Kc)
+                    build_plane_row(a, rle, BDb + (size_t)p * nwp, n0b + p, cdsc[i], cpre[i][0], cpre[i][1], lane, tail_mask);
+            }
+        } else {
+            // team mode: segments of 1 << seg_shift positions (a power of two >= m / wpp) per wave
+            const bool active = team < 2 * Kc;
+            uint2 *bd = BDb + (size_t)team * nwp;
+            uint32_t *segtab = seginfo + 2 * team * wpp;                 // [wpp][2] {toggle parity, ones}
+            uint32_t *chunktab = seginfo + 2 * NWAVE + 4 * team * wpp;   // [2*wpp][2] {symbols, last bit | stop<<1}
+            const uint32_t slen = (uint32_t)(cdsc[0] >> kDescLenShift);
+            const bool parallel_rle = slen <= (uint32_t)(2 * wpp) * 256u;      // else: team wave 0 decodes alone
+            if (active) for (int i = tw * 64 + lane; i < nw; i += wpp * 64) bd[i] = make_uint2(0u, 0u);
+            if (lane < 2) seginfo[2 * wave + lane] = 0u;
+            if (active && parallel_rle && !(a.debug_skip & 2)) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int c = tw + i * wpp;
+                    const ChunkDecode cd = decode_chunk(cpre[0][i], (uint32_t)c * 256u + 4u * (uint32_t)lane, slen, lane);
+                    const uint32_t tot = lane63(wave_incl_add(cd.run));
+                    const uint32_t lb = chunk_last_bit(cd, lane);
+                    if (lane == 0) { chunktab[2 * c] = tot; chunktab[2 * c + 1] = lb | (cd.stop ? 2u : 0u); }
+                }
+            }
+            BGTH_TICK(1);
+            lds_barrier();
+            BGTH_TICK(2);
+            if (active && !(a.debug_skip & 2)) {
+                if (parallel_rle) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int c = tw + i * wpp;
+                        // where the chunk starts and the bit before it: lane c2 reads chunk c2's record, one
+                        // wave prefix sum gives every chunk's start (no serial walk over LDS)
+                        const uint32_t t0 = lane < 2 * wpp && (uint32_t)lane * 256u < slen ? chunktab[2 * lane] : 0u;
+                        const uint32_t t1 = lane < 2 * wpp && (uint32_t)lane * 256u < slen ? chunktab[2 * lane + 1] : 0u;
+                        const uint32_t incl_t = wave_incl_add(t0);
+                        const uint32_t pos = c ? (uint32_t)__builtin_amdgcn_readlane((int)incl_t, c ? c - 1 : 0) : 0u;
+                        const uint32_t prevbit = c ? ((uint32_t)__builtin_amdgcn_readlane((int)t1, c ? c - 1 : 0) & 1u) : 0u;
+                        const bool dead = (__ballot((t1 & 2u) != 0u) & ((1ull << c) - 1ull)) != 0ull;
+                        if (!dead && (uint32_t)c * 256u < slen && !(a.debug_skip & 16)) {
+                            // decoded again rather than kept: two registers cross the barrier instead of thirty
+                            const ChunkDecode cd = decode_chunk(cpre[0][i], (uint32_t)c * 256u + 4u * (uint32_t)lane, slen, lane);
+                            chunk_toggles(a, bd, cd, pos, prevbit, lane, a.seg_shift, segtab);
+                        }
+                    }
+                } else if (tw == 0) {
+                    // rare: a string longer than the team's 2*wpp chunks -- one wave walks it from memory
+                    rle_toggles<true>(a, rle, bd, cdsc[0], 0u, 0u, 0u, 0u, 0, lane, a.seg_shift, segtab);
+                }
+            }
+            BGTH_TICK(3);
+            lds_barrier();
+            BGTH_TICK(4);
+            if (active && !(a.debug_skip & 4)) {
+                const int seg_words = 1 << (a.seg_shift - 5);
+                const int w0 = tw * seg_words < nw ? tw * seg_words : nw;
+                const int w1 = w0 + seg_words < nw ? w0 + seg_words : nw;
+                // carries from the segments before mine: lane s2 reads segment s2's record
+                const uint32_t spx = lane < wpp ? segtab[2 * lane] : 0u, spc = lane < wpp ? segtab[2 * lane + 1] : 0u;
+                const uint32_t incl_c = wave_incl_add(spc);
+                const uint32_t total = lane63(incl_c);
+                uint32_t cnt = tw ? (uint32_t)__builtin_amdgcn_readlane((int)incl_c, tw ? tw - 1 : 0) : 0u;
+                uint32_t cx = (uint32_t)__popcll(__ballot((spx & 1u) != 0u) & ((1ull << tw) - 1ull)) & 1u;
+                directory_pass(bd, w0, w1, nw, tail_mask, cx, cnt, lane);
+                if (tw == 0 && lane == 0) n0b[team] = (uint32_t)m - total;
+            }
+        }
+        BGTH_TICK(5);
+    };
+
+    // ================= phase B: walk the Kc rows of buffer buf, ranks stay in registers =================
+    auto phase_b = [&](int buf, int64_t rb, int Kc) {
+        const uint32_t *n0b = n0s + buf * 2 * K;
+        int32_t *lcb = lcnt + buf * cnt_stride;
+        const uint32_t bufbase = lds0 + (uint32_t)(buf * bd_stride) * 8u;
+        if (!(a.debug_skip & 1))
+        for (int k = 0; k < Kc; ++k) {
+            const uint32_t base0 = bufbase + (uint32_t)(2 * k) * (uint32_t)nwp * 8u;    // LDS byte addresses
+            const uint32_t base1 = base0 + (uint32_t)nwp * 8u;
+            const uint32_t n00 = __builtin_amdgcn_readfirstlane(n0b[2 * k]);
+            const uint32_t n01 = __builtin_amdgcn_readfirstlane(n0b[2 * k + 1]);
+            const bool emit = (rb + k) >= a.row0;
+            // ones of plane 0, ones of plane 1, ones in both:  n(code1) = ca - cc, n(code2) = cb - cc
+            uint32_t ca = 0, cb = 0, cc = 0;
+            uint64_t keep0 = 0, keep1 = 0;
+#pragma unroll
+            for (int j = 0; j < CPT; j += 4) {
+                uint64_t m0[4] = {0, 0, 0, 0}, m1[4] = {0, 0, 0, 0};
+                const int NC = (CPT - j) >= 4 ? 4 : 2;                // CPT is even: the tail is one pair
+                if (NC == 4) {
+                    uint32_t q0[4] = {r0[j], r0[j + 1], r0[j + 2], r0[j + 3]};
+                    uint32_t q1[4] = {r1[j], r1[j + 1], r1[j + 2], r1[j + 3]};
+                    step4(q0, q1, m0, m1, ca, cb, cc, base0, base1, n00, n01);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { r0[j + u] = q0[u]; r1[j + u] = q1[u]; }
+                } else {
+                    step2(r0[j], r1[j], r0[j + 1], r1[j + 1], m0[0], m1[0], m0[1], m1[1], ca, cb, cc, base0, base1, n00, n01);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (u >= NC) break;
+                    if (GT && lane == j + u) { keep0 = m0[u]; keep1 = m1[u]; }
+                    if (MULTI) {
+                        const int c = chunk0 + j + u;                        // wave-uniform
+                        if (emit && lane == 0 && c < a.n_chunks) {
+                            int32_t *dst = lcb + ((size_t)k * G + (a.chunk_desc[c] & 255u)) * 3;
+                            atomicAdd(dst + 0, __builtin_amdgcn_readfirstlane(__popcll(m0[u] & ~m1[u])));
+                            atomicAdd(dst + 1, __builtin_amdgcn_readfirstlane(__popcll(~m0[u] & m1[u])));
+                            atomicAdd(dst + 2, __builtin_amdgcn_readfirstlane(__popcll(m0[u] & m1[u])));
+                        }
+                    }
+                }
+            }
+            if (!MULTI && lane == 0)
+                reinterpret_cast<int4*>(lcb)[k * NWAVE + wave] = make_int4((int)(ca - cc), (int)(cb - cc), (int)cc, 0);
+            if (GT && emit && lane < CPT && chunk0 + lane < a.n_chunks) {
+                const size_t at = (size_t)(rb + k - a.row0) * a.n_chunks + chunk0 + lane;
+                a.h0[at] = keep0;
+                a.h1[at] = keep1;
+            }
+        }
+        BGTH_TICK(7);
+    };
+
+    // ================= phase C: per-row counts of this slice, buffer buf -> HBM =================
+    auto phase_c = [&](int buf, int64_t rb, int Kc) {
+        int32_t *lcb = lcnt + buf * cnt_stride;
+        if (MULTI) {
+            for (int i = tid; i < Kc * G * 3; i += NT) {
+                const int32_t v = lcb[i];
+                if (v) {
+                    atomicAdd(a.raw_counts + (size_t)(rb - a.row0) * G * 3 + i, v);
+                    lcb[i] = 0;
+                }
+            }
+        } else {
+            for (int i = tid; i < Kc * 3; i += NT) {
+                const int k = i / 3, comp = i - 3 * k;
+                if (rb + k >= a.row0) {
+                    int32_t v = 0;
+#pragma unroll
+                    for (int w = 0; w < NWAVE; ++w) v += lcb[(k * NWAVE + w) * 4 + comp];
+                    if (v) atomicAdd(a.raw_counts + (size_t)(rb + k - a.row0) * 3 + comp, v);
+                }
+            }
+        }
+    };
+
+    if constexpr (!TEAM) {
+        // Pipelined batches (two LDS buffers, narrow cohorts): one barrier per batch.  In iteration b a wave
+        // flushes the counts of batch b-1, builds its plane-rows of batch b+1 into the other buffer and walks
+        // batch b -- so while some waves sit in the latency-bound build, others keep the VALUs busy with
+        // lookups.  The barrier at the end makes batch b+1 complete and buffer b reusable.
+        int b = -1;                                    // iteration -1 only builds batch 0
+        int64_t rb = blk_beg - K;
+        for (; rb < blk_end; rb += K, ++b) {
+            if (b > 0) phase_c((b - 1) & 1, rb - K, K);
+            if (rb + K < blk_end) phase_a((b + 1) & 1, rb + K);
+            BGTH_TICK(6);
+            if (b >= 0) phase_b(b & 1, rb, (int)((blk_end - rb) < K ? (blk_end - rb) : K));
+            lds_barrier();
+        }
+        if (b > 0) {
+            const int64_t last = rb - K;
+            phase_c((b - 1) & 1, last, (int)((blk_end - last) < K ? (blk_end - last) : K));
+        }
+    } else {
+        for (int64_t rb = blk_beg; rb < blk_end; rb += K) {
+            const int Kc = (int)((blk_end - rb) < K ? (blk_end - rb) : K);
+            phase_a(0, rb);
+            lds_barrier();
+            BGTH_TICK(6);
+            phase_b(0, rb, Kc);
+            lds_barrier();
+            phase_c(0, rb, Kc);
+            // (the barriers of the next phase A order these reads before the next writes to the counters)
+        }
+    }
+
+    if (a.debug_times && lane == 0 && (!(a.debug_skip & 0x100) || wave == 0)) {   // 0x100: wave 0 only
+        for (int i = 0; i < 8; ++i) atomicAdd(a.debug_times + i, tsum[i]);
+    }
+    if (a.final_rank) {
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int c = chunk0 + j;
+            if (c < a.n_chunks) {
+                const int col = a.slot_col[c * 64 + lane];
+                if (col >= 0) { a.final_rank[col] = (int32_t)r0[j]; a.final_rank[m + col] = (int32_t)r1[j]; }
+            }
+        }
+    }
+}
+
+
+}  // namespace bgth

@@ -23,14 +23,19 @@ struct ScanArgs {
     int32_t        *raw_counts;  // [(row1-row0)][G][3] += {n(code1), n(code2), n(code3)}
     uint64_t       *h0, *h1;     // optional [(row1-row0)][n_chunks] bit planes in slot order
     int32_t        *final_rank;  // optional [2][m]: ranks by column after the last row of the launch
-    int32_t  m, nw, shift, n_chunks, G, K, wpp, seg_shift;   // seg_shift: log2 positions per team segment
+    int32_t  m, nw, shift, n_chunks, G, K, wpp, nbuf, seg_shift;   // seg_shift: log2 positions per team segment
     int32_t  blk0, n_blk, n_slices;
     int64_t  row0, row1;         // rows whose results are emitted; decoding starts at blk0<<shift
     unsigned long long *debug_times;   // optional [workgroups][8] cycle sums per phase (env BGTH_DEBUG_TIMES)
     int32_t  debug_skip;         // profiling aid (env BGTH_DEBUG_SKIP): 1 = no phase B, 2 = no RLE read, 4 = no directory build
 };
 
-struct Geometry { int threads, cpt, slices, K, lds_bytes, workgroups, wpp; };
+// columns per thread instantiated for each workgroup size (keep in sync with kGeoms in scan_kernels.hip)
+#define BGTH_CPT_256(X)  X(2) X(4) X(8) X(12) X(16) X(20)
+#define BGTH_CPT_512(X)  X(4) X(8) X(10) X(12) X(16) X(20) X(24) X(32) X(40) X(48)
+#define BGTH_CPT_1024(X) X(4) X(8) X(10) X(12) X(16) X(20) X(24)
+
+struct Geometry { int threads, cpt, slices, K, lds_bytes, workgroups, wpp, nbuf; };
 
 // Picks threads/columns-per-thread/slices/K for a selection of n_chunks*64 slots over n_blk blocks.
 // Returns false if the row bit-vectors of this m cannot fit in LDS.
