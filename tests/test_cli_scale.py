@@ -60,3 +60,22 @@ def test_generated_pbf_is_what_the_reference_encoder_writes(c1, tmp_path):
     with open(re, "wb") as f:
         subprocess.check_call([pbfview, "-Sb", str(pim)], stdout=f)
     assert open(re, "rb").read() == open(small + ".pbf", "rb").read()
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref not present")
+def test_two_database_group_join_like_config5(tmp_path):
+    """Shape of BASELINE.json configs[4]: two databases over the same positions with independent alleles, two
+    sample groups, `-f'AC1>0&&AC2==0'`; plus the variants with genotypes and with three groups."""
+    import bgt_amd
+    bgt_amd.build_library()
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bgt_amd", "host")])
+    a, b = str(tmp_path / "dba"), str(tmp_path / "dbb")
+    subprocess.check_call([BGT, "synth", a, "5000", "30000", "5"])
+    subprocess.check_call([BGT, "synth", b, "4000", "30000", "6"])
+    for args in (["-G", "-s", "pop==\"A\"", "-s", "pop==\"B\"", "-f", "AC1>0&&AC2==0"],
+                 ["-G", "-C"], ["-G", "-s", "idx<100", "-s", "idx>=100&&idx<300", "-s", "pop==\"C\"", "-f", "AC3>AC1"],
+                 ["-s", "idx%1000==0", "-r", "11:100000-140000", "-C"]):
+        mine = md5_of([BGT, "view"] + args + [a, b])
+        ref = md5_of([REF, "view"] + args + [a, b])
+        assert mine[0] == ref[0] == 0, (mine, ref)
+        assert mine[2] > 0 and mine[1:3] == ref[1:3], (args, mine, ref)
