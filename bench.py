@@ -3,12 +3,12 @@
 
 One "step" = one pass of the hot path over the rank's whole shard: PBWT run-length decode of both bit
 planes of every site, rank-tracking column reconstruction, AC/AN reduction (all on the GPU, through the
-C ABI of libbgt_hip.so), then the site filter AC>0 on the counts delivered to the host.  Inputs (RLE
+C ABI of libbgt_hip.so), the site filter AC>0 on the device, counts + pass flags delivered to the host.  Inputs (RLE
 strings, row directory, checkpoints) are resident in HBM before the timed region starts.
 
   N = 1   workload C2 of BASELINE.json: synthetic 10,000 samples (m = 20,000 haplotypes) x 1,000,000 sites.
   N > 1   weak scaling: rank r scans sites [r*1M, (r+1)*1M) of the same cohort (site-range sharding, no
-          data-path collective), then ONE all_gather over RCCL/xGMI of the per-shard allele counts.
+          data-path collective), then an all_gather over RCCL/xGMI of the per-shard allele counts and pass flags.
 
 Prints one JSON line (rank 0).  `roofline.achieved` prices the decode kernel with the reference's
 ALGORITHMIC bytes (16*T + r + 12 per site); the kernel keeps that permutation state in
@@ -79,25 +79,51 @@ def main():
     rd.tune(args.threads, args.cpt, args.batch)
     T = rd.width
 
-    counts = torch.empty((sites, 1, 3), dtype=torch.int32, device=dev)
-    gathered = torch.empty((world * sites, 1, 3), dtype=torch.int32, device=dev) if world > 1 else counts
-    host = torch.empty((world * sites, 1, 3), dtype=torch.int32).pin_memory() if rank == 0 else None
-    stream = torch.cuda.current_stream()
+    # Two result buffers: the D2H copy of step i (rank 0, side stream) overlaps the scan of step i+1.
+    flt = bgt_amd.HipFilter("AC>0", n_groups=1, device=local)            # -f'AC>0', evaluated on the device
+    main = torch.cuda.current_stream()
+    side = torch.cuda.Stream(device=dev)
+    counts = [torch.empty((sites, 1, 3), dtype=torch.int32, device=dev) for _ in range(2)]
+    flags = [torch.empty(sites, dtype=torch.uint8, device=dev) for _ in range(2)]
+    n_pass_d = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(2)]
+    if world > 1:
+        g_counts = [torch.empty((world * sites, 1, 3), dtype=torch.int32, device=dev) for _ in range(2)]
+        g_flags = [torch.empty(world * sites, dtype=torch.uint8, device=dev) for _ in range(2)]
+    else:
+        g_counts, g_flags = counts, flags
+    if rank == 0:
+        host = [torch.empty((world * sites, 1, 3), dtype=torch.int32).pin_memory() for _ in range(2)]
+        host_flags = [torch.empty(world * sites, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        host_n_pass = [torch.zeros(1, dtype=torch.int64).pin_memory() for _ in range(2)]
+    ready = [torch.cuda.Event() for _ in range(2)]
+    copied = [torch.cuda.Event() for _ in range(2)]
+    for e in copied:
+        e.record(main)
     kernel_ms = []
+    n_steps_done = [0]
 
     def step():
-        rd.scan_device(0, sites, counts.data_ptr(), stream=stream.cuda_stream)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, counts)                # per-shard AN/AC over xGMI
-        n_pass = 0
+        b = n_steps_done[0] & 1
+        n_steps_done[0] += 1
+        main.wait_event(copied[b])                                       # buffer b has left the device
+        rd.scan_device(0, sites, counts[b].data_ptr(), stream=main.cuda_stream)
+        n_pass_d[b].zero_()
+        flt.apply_device(counts[b].data_ptr(), sites, 3, flags[b].data_ptr(), n_pass_d[b].data_ptr(),
+                         main.cuda_stream)
+        if world > 1:                                                    # per-shard AN/AC + flags over xGMI
+            dist.all_gather_into_tensor(g_counts[b], counts[b])
+            dist.all_gather_into_tensor(g_flags[b], flags[b])
+            dist.all_reduce(n_pass_d[b])
+        ready[b].record(main)
         if rank == 0:
-            host.copy_(gathered, non_blocking=True)
-            stream.synchronize()
-            n_pass = int((host.numpy()[:, 0, 1] > 0).sum())              # -f'AC>0'
-        else:
-            stream.synchronize()
-        kernel_ms.append(rd.timing()["scan_ms"])
-        return n_pass
+            with torch.cuda.stream(side):
+                side.wait_event(ready[b])
+                host[b].copy_(g_counts[b], non_blocking=True)
+                host_flags[b].copy_(g_flags[b], non_blocking=True)
+                host_n_pass[b].copy_(n_pass_d[b], non_blocking=True)
+                copied[b].record(side)
+        kernel_ms.append(rd.timing()["scan_ms"])                         # waits for the scan kernel only
+        return b
 
     def barrier():
         if world > 1:
@@ -109,11 +135,15 @@ def main():
     kernel_ms.clear()
     barrier()
     t0 = time.perf_counter()
-    n_pass = 0
+    last = 0
     for _ in range(args.steps):
-        n_pass = step()
-    barrier()
+        last = step()
+    barrier()                                                            # includes the side stream: all results on the host
     dt = time.perf_counter() - t0
+    n_pass = int(host_n_pass[last].item()) if rank == 0 else 0
+    if rank == 0:
+        host = host[last]
+        assert n_pass == int(host_flags[last].numpy().sum())
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -148,6 +178,8 @@ def main():
                        "haplotypes": m, "tracked_columns": T, "sites_per_gpu": sites,
                        "sharding": "site-range x%d + all_gather(counts)" % world if world > 1 else "single GPU",
                        "rle_bytes_per_site": round(rle_bytes_per_site, 1), "sites_passing_filter": n_pass,
+                       "filter": "AC>0 evaluated on the device (bgth_filter_apply_device); counts + flags copied "
+                                 "to pinned host memory, the copy of step i overlapping the scan of step i+1",
                        "launch": geo},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -183,7 +215,8 @@ def main():
             oc = p.scan(0, ns)
             n_pass_cpu = int((oc[:, 1] > 0).sum())
             t_cpu = time.perf_counter() - t0
-            same = bool(np.array_equal(oc.reshape(ns, 1, 3), host.numpy()[:ns]))
+            same = bool(np.array_equal(oc.reshape(ns, 1, 3), host.numpy()[:ns])) and \
+                bool(np.array_equal(oc[:, 1] > 0, host_flags[last].numpy()[:ns] != 0))
             port = {"value": ns / t_cpu, "unit": "sites/s", "cores": 1, "kind": "port",
                     "sample": "first %d sites of the same cohort (oracle/liborc.so: decode both planes + AC/AN + "
                               "AC>0, one thread, %.1f s)" % (ns, t_cpu),

@@ -711,6 +711,36 @@ extern "C" int bgth_reader_config(bgth_reader_t *r, int want_planes, int64_t max
 extern "C" const int32_t *bgth_reader_last_counts(const bgth_reader_t *r) { return r->last_counts; }
 
 // ----------------------------------------------------------------------------------------------------
+// site filter on the device
+// ----------------------------------------------------------------------------------------------------
+struct bgth_filter_s { int device; FilterProgram prog; };
+
+extern "C" bgth_filter_t *bgth_filter_create(int device, int n_items, const int32_t *op, const int64_t *ival,
+                                             const double *rval, const int32_t *slot)
+{
+    if (n_items <= 0 || n_items > kFilterMaxItems) { set_err("[E::bgth_filter_create] %d program items (1..%d supported)", n_items, kFilterMaxItems); return nullptr; }
+    bgth_filter_t *f = new bgth_filter_s();
+    f->device = device; f->prog.n = n_items;
+    for (int i = 0; i < n_items; ++i) {
+        if (!(op[i] == 0 || op[i] == 1 || op[i] == 2 || (op[i] >= 17 && op[i] <= 40))) { set_err("[E::bgth_filter_create] item %d: unsupported op %d", i, op[i]); delete f; return nullptr; }
+        f->prog.op[i] = op[i]; f->prog.slot[i] = slot ? slot[i] : -1; f->prog.ival[i] = ival[i]; f->prog.rval[i] = rval[i];
+    }
+    return f;
+}
+
+extern "C" void bgth_filter_destroy(bgth_filter_t *f) { delete f; }
+
+extern "C" int bgth_filter_apply_device(const bgth_filter_t *f, const void *d_counts, int64_t n_rows, int ints_per_row,
+                                        void *d_flags, void *d_n_pass, void *stream)
+{
+    if (!f || !d_counts || !d_flags || !d_n_pass) { set_err("[E::bgth_filter_apply_device] NULL argument"); return -1; }
+    if (!use_device(f->device)) return -1;
+    HIP_TRY(launch_filter(f->prog, (const int32_t*)d_counts, n_rows, ints_per_row, (uint8_t*)d_flags,
+                          (unsigned long long*)d_n_pass, (hipStream_t)stream), return -1);
+    return 0;
+}
+
+// ----------------------------------------------------------------------------------------------------
 // diagnostics
 // ----------------------------------------------------------------------------------------------------
 extern "C" int bgth_debug_stream_read(int device, size_t bytes, int width, int repeats)

@@ -56,6 +56,12 @@ hipError_t launch_unpack_bytes(const uint64_t *h0, const uint64_t *h1, const int
                                uint8_t *a0, uint8_t *a1, int64_t n_rows, int n_chunks, int width,
                                hipStream_t s);
 
+// compiled `-f` expression (reverse Polish): op 0 = int constant, 1 = real constant, 2 = variable read from
+// counts[slot], 16 + k = operator k in the numbering of filter_expr.c
+constexpr int kFilterMaxItems = 48;
+struct FilterProgram { int32_t n; int32_t op[kFilterMaxItems]; int32_t slot[kFilterMaxItems]; long long ival[kFilterMaxItems]; double rval[kFilterMaxItems]; };
+hipError_t launch_filter(const FilterProgram &prog, const int32_t *counts, int64_t n_rows, int ints_per_row,
+                         uint8_t *flags, unsigned long long *n_pass, hipStream_t s);
 hipError_t launch_stream_read(const void *src, size_t bytes, int width, uint32_t *sink, hipStream_t s);
 
 }  // namespace bgth

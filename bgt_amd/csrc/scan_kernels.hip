@@ -226,6 +226,90 @@ hipError_t launch_unpack_bytes(const uint64_t *h0, const uint64_t *h1, const int
 
 
 // ----------------------------------------------------------------------------------------------------
+// Site filter on the device: the reverse-Polish program of a `-f` expression (exported by the host parser,
+// filter_expr.c ke_export) evaluated per site on the counts the scan produced.  Same value model as the host
+// evaluator (reference kexpr.c:105-153): every slot carries an int64 and a double view plus a type;
+// `/` yields a real, `//` `%` `<<` `>>` `&` `|` `^` integers, comparisons use the reals if either side is
+// real, an unbound variable fails the site.
+// ----------------------------------------------------------------------------------------------------
+__global__ void filter_kernel(const FilterProgram prog, const int32_t *counts, int64_t n_rows, int ints_per_row,
+                              uint8_t *flags, unsigned long long *n_pass)
+{
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool pass = false;
+    if (row < n_rows) {
+        const int32_t *c = counts + row * ints_per_row;
+        long long si[kFilterMaxItems];
+        double sr[kFilterMaxItems];
+        bool real[kFilterMaxItems];
+        int top = 0;
+        bool err = false;
+        for (int k = 0; k < prog.n; ++k) {
+            const int op = prog.op[k];
+            if (op == 0 || op == 1) {                              // the parser keeps BOTH views of a literal ("010" is 8 and 10.0)
+                si[top] = prog.ival[k]; sr[top] = prog.rval[k]; real[top] = op == 1; ++top; }
+            else if (op == 2) {
+                const int slot = prog.slot[k];
+                if (slot < 0 || slot >= ints_per_row) { err = true; si[top] = 0; sr[top] = 0.; real[top] = true; }
+                else { si[top] = c[slot]; sr[top] = (double)c[slot]; real[top] = false; }
+                ++top;
+            } else {
+                const int o = op - 16;
+                if (o >= 1 && o <= 4) {                           // unary: + - ~ !
+                    long long &i = si[top - 1]; double &r = sr[top - 1];
+                    if (o == 2) { i = -i; r = -r; }
+                    else if (o == 3) { i = ~i; r = (double)i; real[top - 1] = false; }
+                    else if (o == 4) { i = !i; r = (double)i; real[top - 1] = false; }
+                } else {
+                    --top;
+                    long long &i = si[top - 1]; double &r = sr[top - 1];
+                    const long long qi = si[top]; const double qr = sr[top];
+                    const bool anyreal = real[top - 1] || real[top];
+                    bool cmp = false, iscmp = false;
+                    switch (o) {
+                    case 5:  r = pow(r, qr); i = (long long)(r + .5); real[top - 1] = anyreal; break;
+                    case 6:  i *= qi; r *= qr; real[top - 1] = anyreal; break;
+                    case 7:  r /= qr; i = (long long)(r + .5); real[top - 1] = true; break;
+                    case 8:  if (qi == 0) { err = true; i = 0; } else i /= qi; r = (double)i; real[top - 1] = false; break;
+                    case 9:  if (qi == 0) { err = true; i = 0; } else i %= qi; r = (double)i; real[top - 1] = false; break;
+                    case 10: i += qi; r += qr; real[top - 1] = anyreal; break;
+                    case 11: i -= qi; r -= qr; real[top - 1] = anyreal; break;
+                    case 12: i <<= qi; r = (double)i; real[top - 1] = false; break;
+                    case 13: i >>= qi; r = (double)i; real[top - 1] = false; break;
+                    case 14: iscmp = true; cmp = anyreal ? r <  qr : i <  qi; break;
+                    case 15: iscmp = true; cmp = anyreal ? r <= qr : i <= qi; break;
+                    case 16: iscmp = true; cmp = anyreal ? r >  qr : i >  qi; break;
+                    case 17: iscmp = true; cmp = anyreal ? r >= qr : i >= qi; break;
+                    case 18: iscmp = true; cmp = anyreal ? r == qr : i == qi; break;
+                    case 19: iscmp = true; cmp = anyreal ? r != qr : i != qi; break;
+                    case 20: i &= qi; r = (double)i; real[top - 1] = false; break;
+                    case 21: i ^= qi; r = (double)i; real[top - 1] = false; break;
+                    case 22: i |= qi; r = (double)i; real[top - 1] = false; break;
+                    case 23: iscmp = true; cmp = i && qi; break;
+                    case 24: iscmp = true; cmp = i || qi; break;
+                    default: err = true; break;
+                    }
+                    if (iscmp) { i = cmp; r = (double)cmp; real[top - 1] = false; }
+                }
+            }
+        }
+        pass = !err && top >= 1 && si[0] != 0;
+        flags[row] = pass ? 1 : 0;
+    }
+    const unsigned long long b = __ballot(pass);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_pass, (unsigned long long)__popcll(b));
+}
+
+hipError_t launch_filter(const FilterProgram &prog, const int32_t *counts, int64_t n_rows, int ints_per_row,
+                         uint8_t *flags, unsigned long long *n_pass, hipStream_t s)
+{
+    if (n_rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(filter_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, s,
+                       prog, counts, n_rows, ints_per_row, flags, n_pass);
+    return hipGetLastError();
+}
+
+// ----------------------------------------------------------------------------------------------------
 // PMC calibration aid: stream a buffer of known size with the access width of the scan kernel (one
 // dword per lane) or with 16-byte loads, so that rocprofv3's FETCH_SIZE can be scaled to real bytes
 // (MI355X_MICROARCH.md, HBM: "calibrate on a known byte count in your own access pattern").

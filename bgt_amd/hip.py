@@ -26,7 +26,19 @@ def build_library(force=False):
     return _LIB_PATH
 
 
+def _hip_runtime_first():
+    """torch ships its own libamdhip64.so (DT_NEEDED without the version suffix, so the dynamic loader does not
+    match it with /opt/rocm's libamdhip64.so.7).  If this library pulled in the system runtime first and torch
+    its own afterwards, the process would hold two HIP runtimes and the second one finds no device.  Loading
+    torch first makes both resolve to the same runtime.  Processes that never import torch are unaffected."""
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+
+
 def _load():
+    _hip_runtime_first()
     if not os.path.exists(_LIB_PATH):
         raise RuntimeError("bgt_amd: %s is missing -- build it with `make -C bgt_amd/csrc` "
                            "(there is no CPU fallback)" % _LIB_PATH)
@@ -275,3 +287,90 @@ def synth_rows(m, row0, n_rows, seed, n_threads=0):
     finally:
         L.bgth_synth_free(h)
     return rle, lens
+
+
+# ---------------------------------------------------------------------------------------------------
+# site filter on the device (bgth_filter_*): expression parsed by the host shell's parser (libbgt.so)
+# ---------------------------------------------------------------------------------------------------
+_HOST_LIB_PATH = os.path.join(_HERE, "lib", "libbgt.so")
+_host_lib = None
+
+
+def host_lib():
+    """libbgt.so: the reader API / expression parser of the host shell (bgt_amd/host)."""
+    global _host_lib
+    if _host_lib is None:
+        _hip_runtime_first()
+        if not os.path.exists(_HOST_LIB_PATH):
+            raise RuntimeError("bgt_amd: %s is missing -- build it with `make -C bgt_amd/host`" % _HOST_LIB_PATH)
+        H = C.CDLL(_HOST_LIB_PATH)
+        H.ke_parse.restype = C.c_void_p
+        H.ke_parse.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
+        H.ke_destroy.argtypes = [C.c_void_p]
+        H.ke_export.restype = C.c_int
+        H.ke_export.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _host_lib = H
+    return _host_lib
+
+
+def count_slot(name, n_groups=1):
+    """Index of variable `name` in one site's counts vector int32[1+Gx][3] (AN, AC, AN<g>, AC<g>); -1 = unbound."""
+    for prefix, field in (("AN", 0), ("AC", 1)):
+        if name == prefix:
+            return field
+        if name.startswith(prefix) and name[2:].isdigit() and not name[2:].startswith("0"):
+            g = int(name[2:])
+            if n_groups > 1 and 1 <= g <= n_groups:
+                return 3 * g + field
+    return -1
+
+
+class HipFilter:
+    """A `-f` site filter compiled for the device: flags[site] = expression(counts[site]) != 0."""
+    MAX_ITEMS = 48
+
+    def __init__(self, expr, n_groups=1, device=0):
+        H, L = host_lib(), lib()
+        err = C.c_int(0)
+        ke = H.ke_parse(expr.encode(), C.byref(err))
+        if not ke or err.value:
+            raise ValueError("cannot parse filter %r (error 0x%x)" % (expr, err.value))
+        try:
+            n = self.MAX_ITEMS
+            op = np.zeros(n, np.int32); iv = np.zeros(n, np.int64); rv = np.zeros(n, np.float64)
+            names = (C.c_char_p * n)()
+            k = H.ke_export(ke, n, op.ctypes.data, iv.ctypes.data, rv.ctypes.data, names)
+            if k <= 0:
+                raise ValueError("filter %r cannot run on the device (strings, functions or > %d items)" % (expr, n))
+            slot = np.full(n, -1, np.int32)
+            for i in range(k):
+                if op[i] == 2:
+                    slot[i] = count_slot(names[i].decode(), n_groups)
+        finally:
+            H.ke_destroy(ke)
+        L.bgth_filter_create.restype = C.c_void_p
+        L.bgth_filter_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.bgth_filter_destroy.argtypes = [C.c_void_p]
+        L.bgth_filter_apply_device.restype = C.c_int
+        L.bgth_filter_apply_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
+                                               C.c_void_p]
+        self.expr, self.n_items = expr, k
+        self.h = L.bgth_filter_create(device, k, op.ctypes.data, iv.ctypes.data, rv.ctypes.data, slot.ctypes.data)
+        if not self.h:
+            raise RuntimeError(last_error())
+
+    def apply_device(self, d_counts_ptr, n_rows, ints_per_row, d_flags_ptr, d_n_pass_ptr, stream=None):
+        if lib().bgth_filter_apply_device(self.h, d_counts_ptr, n_rows, ints_per_row, d_flags_ptr, d_n_pass_ptr,
+                                          stream) != 0:
+            raise RuntimeError(last_error())
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().bgth_filter_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

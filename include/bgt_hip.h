@@ -113,6 +113,19 @@ int bgth_reader_last_geometry(const bgth_reader_t *r, int out[6]);
 /* Override the automatic launch geometry (0 = automatic). For tuning and tests. */
 int bgth_reader_tune(bgth_reader_t *r, int threads, int cols_per_thread, int rows_per_batch);
 
+/* ---- site filter on the device (bgtm_pass_site_flt, reference bgt.c:700-719, for counts that stay in HBM) ----
+ * The `-f` expression is parsed on the host (ke_parse) and exported as a reverse-Polish program (ke_export of
+ * libbgt.so): op[i] = 0 integer constant ival[i], 1 real constant rval[i], 2 variable = counts[slot[i]] of the
+ * site (slot = entry*3 + field in the layout of bgth_reader_scan: AN 0, AC 1, AN1 3, AC1 4, AN2 6 ...; -1 =
+ * unbound, which fails every site as in the reference), 16+k = operator k.  d_flags: uint8 per site,
+ * d_n_pass: one uint64 the number of passing sites is ADDED to. */
+typedef struct bgth_filter_s bgth_filter_t;
+bgth_filter_t *bgth_filter_create(int device, int n_items, const int32_t *op, const int64_t *ival,
+                                  const double *rval, const int32_t *slot);
+void bgth_filter_destroy(bgth_filter_t *f);
+int  bgth_filter_apply_device(const bgth_filter_t *f, const void *d_counts, int64_t n_rows, int ints_per_row,
+                              void *d_flags, void *d_n_pass, void *stream);
+
 /* Diagnostics: stream `bytes` of HBM `repeats` times with `width`-byte loads per lane (4 or 16); used under
  * rocprofv3 to calibrate the FETCH_SIZE counter against a known byte count. */
 int bgth_debug_stream_read(int device, size_t bytes, int width, int repeats);
