@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -76,7 +77,32 @@ struct bgth_pbf_s {
     uint8_t  *d_rle = nullptr;
     uint64_t *d_rowdesc = nullptr;
     int32_t  *d_rank0 = nullptr;      // [n_blk][2][m] ranks by column at every checkpoint
+    // row index (scan_kernels.h), built on the first wide-cohort (team-mode) launch
+    uint32_t *d_chunkinfo = nullptr, *d_segc = nullptr;
+    int32_t   S8 = 0;
+    int64_t   rowindex_bytes = 0;
+    std::mutex rowindex_lock;         // an image is shared by readers on different threads
 };
+
+// Builds the row index once per image; later calls only return it.  The build is enqueued on `s`, the
+// stream of the scan that needs it, and waited for, so that other streams may use the index afterwards.
+static bool ensure_rowindex(bgth_pbf_t *p, hipStream_t s)
+{
+    std::lock_guard<std::mutex> guard(p->rowindex_lock);
+    if (p->d_chunkinfo) return true;
+    const int64_t n_str = p->n * p->g;
+    const int S8 = (p->m + 8191) >> 13;
+    const size_t n_ci = (size_t)(p->packed_bytes >> 8) + (size_t)n_str + 2;
+    const size_t n_sc = (size_t)n_str * (size_t)(S8 + 1) + 1;
+    uint32_t *ci = nullptr, *sc = nullptr;
+    HIP_TRY(hipMalloc((void**)&ci, n_ci * 4), return false);
+    HIP_TRY(hipMalloc((void**)&sc, n_sc * 4), { hipFree(ci); return false; });
+    HIP_TRY(launch_rowindex(p->d_rowdesc, p->d_rle, n_str, p->m, S8, ci, sc, s), { hipFree(ci); hipFree(sc); return false; });
+    HIP_TRY(hipStreamSynchronize(s), { hipFree(ci); hipFree(sc); return false; });
+    p->d_chunkinfo = ci; p->d_segc = sc; p->S8 = S8;
+    p->rowindex_bytes = (int64_t)(n_ci + n_sc) * 4;
+    return true;
+}
 
 struct DevBuf {
     void *p = nullptr;
@@ -217,6 +243,8 @@ extern "C" void bgth_pbf_close(bgth_pbf_t *p)
     if (p->d_rle) hipFree(p->d_rle);
     if (p->d_rowdesc) hipFree(p->d_rowdesc);
     if (p->d_rank0) hipFree(p->d_rank0);
+    if (p->d_chunkinfo) hipFree(p->d_chunkinfo);
+    if (p->d_segc) hipFree(p->d_segc);
     delete p;
 }
 
@@ -327,7 +355,8 @@ static bool run_block_pass(bgth_pbf_t *p, Selection &all, int64_t blk, int32_t *
     a.rank0 = p->d_rank0; a.rank0_blk_stride = (int64_t)2 * p->m;
     a.slot_col = all.d_slot_col; a.chunk_desc = all.d_chunk_desc;
     a.raw_counts = nullptr; a.h0 = a.h1 = nullptr; a.final_rank = d_final;
-    a.m = p->m; a.nw = (p->m + 31) / 32; a.shift = p->shift; a.n_chunks = all.n_chunks; a.G = 1; a.K = geo.K; a.wpp = geo.wpp; a.nbuf = geo.nbuf; a.seg_shift = 5; while (((int64_t)geo.wpp << a.seg_shift) < a.m || a.seg_shift < 11) ++a.seg_shift;
+    a.m = p->m; a.nw = (p->m + 31) / 32; a.shift = p->shift; a.n_chunks = all.n_chunks; a.G = 1; a.K = geo.K; a.wpp = geo.wpp; a.nbuf = geo.nbuf;
+    if (geo.wpp > 1) { if (!ensure_rowindex(p, s)) return false; a.chunkinfo = p->d_chunkinfo; a.segc = p->d_segc; a.S8 = p->S8; }
     a.blk0 = (int32_t)blk; a.n_blk = 1; a.n_slices = geo.slices;
     a.row1 = std::min<int64_t>(p->n, (blk + 1) << p->shift);
     a.row0 = a.row1;                      // nothing emitted: only the final ranks are wanted
@@ -443,7 +472,7 @@ extern "C" int64_t bgth_pbf_get_n(const bgth_pbf_t *p) { return p->n; }
 extern "C" int64_t bgth_pbf_rle_bytes(const bgth_pbf_t *p) { return p->rle_bytes; }
 extern "C" int64_t bgth_pbf_hbm_bytes(const bgth_pbf_t *p)
 {
-    return p->packed_bytes + 256 + p->n * 2 * 8 + p->n_blk * 2 * (int64_t)p->m * 4;
+    return p->packed_bytes + 256 + p->n * 2 * 8 + p->n_blk * 2 * (int64_t)p->m * 4 + p->rowindex_bytes;
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -524,7 +553,8 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
     a.rank0 = p->d_rank0; a.rank0_blk_stride = (int64_t)2 * p->m;
     a.slot_col = r->sel.d_slot_col; a.chunk_desc = r->sel.d_chunk_desc;
     a.raw_counts = (int32_t*)r->raw.p; a.h0 = d_h0; a.h1 = d_h1; a.final_rank = nullptr;
-    a.m = p->m; a.nw = (p->m + 31) / 32; a.shift = p->shift; a.n_chunks = r->sel.n_chunks; a.G = G; a.K = geo.K; a.wpp = geo.wpp; a.nbuf = geo.nbuf; a.seg_shift = 5; while (((int64_t)geo.wpp << a.seg_shift) < a.m || a.seg_shift < 11) ++a.seg_shift;
+    a.m = p->m; a.nw = (p->m + 31) / 32; a.shift = p->shift; a.n_chunks = r->sel.n_chunks; a.G = G; a.K = geo.K; a.wpp = geo.wpp; a.nbuf = geo.nbuf;
+    if (geo.wpp > 1) { if (!ensure_rowindex(p, s)) return -1; a.chunkinfo = p->d_chunkinfo; a.segc = p->d_segc; a.S8 = p->S8; }
     a.blk0 = (int32_t)blk0; a.n_blk = (int32_t)(blk1 - blk0 + 1); a.n_slices = geo.slices;
     a.row0 = row0; a.row1 = row1;
     { const char *dbg = getenv("BGTH_DEBUG_SKIP"); a.debug_skip = dbg ? atoi(dbg) : 0; }

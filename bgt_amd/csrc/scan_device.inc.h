@@ -199,13 +199,9 @@ __device__ __forceinline__ void step4(uint32_t (&r0)[4], uint32_t (&r1)[4], uint
 // LDS operations of one wave complete in order, so no workgroup barrier is needed between the steps;
 // the wavefront fences only pin the compiler's ordering.
 // ----------------------------------------------------------------------------------------------------
-// step 2: RLE string -> toggles (one wave).  SEG: the row is finished by a team of waves, each owning a
-// segment of 1 << seg_shift positions; record per segment the parity of its toggles and its number of
-// ones (known here from the run lengths), so that every wave can start its segment with the right carries.
-template <bool SEG>
+// step 2: RLE string -> toggles (one wave walks the whole string)
 __device__ __forceinline__ void rle_toggles(const ScanArgs &a, const uint8_t *__restrict__ rle, uint2 *bd, uint64_t desc,
-                                            uint32_t pre0, uint32_t pre1, uint32_t pre2, uint32_t pre3, int npre, int lane,
-                                            int seg_shift, uint32_t *segtab)
+                                            uint32_t pre0, uint32_t pre1, uint32_t pre2, uint32_t pre3, int npre, int lane)
 {
     const int m = a.m;
     const uint32_t *q4 = reinterpret_cast<const uint32_t*>(rle + (desc & kDescOffMask));
@@ -250,20 +246,8 @@ __device__ __forceinline__ void rle_toggles(const ScanArgs &a, const uint8_t *__
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t b = byte[i] & 1u, start = lane_start + before[i];
-            if (valid[i] && b != pb && start < (uint32_t)m) {
+            if (valid[i] && b != pb && start < (uint32_t)m)
                 atomicXor(&bd[start >> 5].x, 0xffffffffu << (start & 31));
-                if (SEG) atomicXor(&segtab[2 * (start >> seg_shift)], 1u);
-            }
-            if (SEG && b && l[i] && start < (uint32_t)m) {   // ones of this run piece, split at segment borders
-                uint32_t at = start;
-                const uint32_t end = start + l[i] < (uint32_t)m ? start + l[i] : (uint32_t)m;
-                while (at < end) {
-                    const uint32_t sg = at >> seg_shift, lim = (sg + 1u) << seg_shift;
-                    const uint32_t upto = end < lim ? end : lim;
-                    atomicAdd(&segtab[2 * sg + 1], upto - at);
-                    at = upto;
-                }
-            }
             pb = b;
         }
         prevbit = lane63(byte[3] & 1u);
@@ -279,29 +263,40 @@ __device__ __forceinline__ void directory_pass(uint2 *bd, int w0, int w1, int nw
 {
     for (int base = w0; base < w1; base += 256) {
         const int i0 = base + 4 * lane;
-        const uint4 *src = reinterpret_cast<const uint4*>(bd + i0);      // rows are 16-byte aligned
+        const bool full = base + 256 <= w1 && base + 256 < nw;           // wave-uniform: no partial lane, no tail word
         uint32_t t[4] = {0u, 0u, 0u, 0u};
-        if (i0 + 3 < w1) { const uint4 lo = src[0], hi = src[1]; t[0] = lo.x; t[1] = lo.z; t[2] = hi.x; t[3] = hi.z; }
-        else {
+        if (full || i0 + 3 < w1) {
+            const uint4 *src = reinterpret_cast<const uint4*>(bd + i0);  // rows are 16-byte aligned
+            const uint4 lo = src[0], hi = src[1];
+            t[0] = lo.x; t[1] = lo.z; t[2] = hi.x; t[3] = hi.z;
+        } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) if (i0 + k < w1) t[k] = bd[i0 + k].x;
         }
-        const uint32_t p0 = t[0] >> 31, p1 = t[1] >> 31, p2 = t[2] >> 31, p3 = t[3] >> 31;   // toggle parity per word
-        const uint64_t par = __ballot((p0 ^ p1 ^ p2 ^ p3) != 0u);
-        uint32_t cin = (lanes_below(par) ^ carry_x) & 1u;                // parity of all toggles before word i0
+        // bit 31 of a word = parity of its toggles; parity of the lane's four words = sign of their xor
+        const uint64_t par = __ballot((int32_t)(t[0] ^ t[1] ^ t[2] ^ t[3]) < 0);
+        // cm = all ones when the parity of all toggles before the word is odd (the word is then inverted)
+        uint32_t cm = 0u - ((lanes_below(par) ^ carry_x) & 1u);
         uint32_t v[4], pre[4], ones = 0;
-        const uint32_t pk[4] = {p0, p1, p2, p3};
+        if (full) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            uint32_t x = t[k] ^ (0u - cin);                              // inverted when the carry parity is odd
-            if (i0 + k == nw - 1) x &= tail_mask;
-            if (i0 + k >= w1) x = 0u;
-            v[k] = x; pre[k] = ones; ones += (uint32_t)__popc(x);
-            cin ^= pk[k];
+            for (int k = 0; k < 4; ++k) {
+                v[k] = t[k] ^ cm; pre[k] = ones; ones += (uint32_t)__popc(v[k]);
+                cm ^= (uint32_t)((int32_t)t[k] >> 31);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t x = t[k] ^ cm;
+                if (i0 + k == nw - 1) x &= tail_mask;
+                if (i0 + k >= w1) x = 0u;
+                v[k] = x; pre[k] = ones; ones += (uint32_t)__popc(x);
+                cm ^= (uint32_t)((int32_t)t[k] >> 31);
+            }
         }
         const uint32_t incl = wave_incl_add(ones);
         const uint32_t b = carry_c + incl - ones;
-        if (i0 + 3 < w1) {
+        if (full || i0 + 3 < w1) {
             uint4 *dst = reinterpret_cast<uint4*>(bd + i0);
             dst[0] = make_uint4(v[0], b, v[1], b + pre[1]);
             dst[1] = make_uint4(v[2], b + pre[2], v[3], b + pre[3]);
@@ -314,9 +309,9 @@ __device__ __forceinline__ void directory_pass(uint2 *bd, int w0, int w1, int nw
     }
 }
 
-// ---- team-parallel RLE decode: wave tw of a team owns the 256-byte chunks tw and tw + wpp of the string.
-// Pass 1 measures a chunk (symbols covered, bit of its last byte, whether a terminating zero byte was
-// seen); after a barrier pass 2 turns the chunk into toggles, knowing where it starts.
+// ---- team-parallel RLE decode (wide cohorts): wave tw of a team owns the 256-byte chunks tw, tw + wpp, ...
+// of the string.  Where a chunk starts in the row and the bit before it come from the ROW INDEX, a side
+// table built once per file (rowindex_kernel), so a chunk becomes toggles without waiting for the others.
 struct ChunkDecode { uint32_t l[4], before[4], bit[4], run; bool valid[4]; bool stop; };
 
 __device__ __forceinline__ ChunkDecode decode_chunk(uint32_t w, uint32_t k0, uint32_t len, int lane)
@@ -361,65 +356,23 @@ __device__ __forceinline__ uint32_t chunk_last_bit(const ChunkDecode &d, int lan
 }
 
 __device__ __forceinline__ void chunk_toggles(const ScanArgs &a, uint2 *bd, const ChunkDecode &d, uint32_t pos,
-                                              uint32_t prevbit, int lane, int seg_shift, uint32_t *segtab)
+                                              uint32_t prevbit, int lane)
 {
     const uint32_t m = (uint32_t)a.m;
     const uint32_t incl = wave_incl_add(d.run);
     const uint32_t lane_start = pos + incl - d.run;
-    const uint32_t chunk_end = pos + lane63(incl);
     // bit of the byte before this lane's first byte: the last valid byte of the lane below (chunks are
     // dense, so a lane below a lane with data is full)
     uint32_t lastb = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) if (d.valid[i]) lastb = d.bit[i];
     uint32_t pb = wave_shr1(lastb, prevbit);
-    bool tog[4];
-    uint32_t start[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        start[i] = lane_start + d.before[i];
-        tog[i] = d.valid[i] && d.bit[i] != pb && start[i] < m;
-        if (tog[i] && !(a.debug_skip & 64)) atomicXor(&bd[start[i] >> 5].x, 0xffffffffu << (start[i] & 31));
+        const uint32_t start = lane_start + d.before[i];
+        if (d.valid[i] && d.bit[i] != pb && start < m && !(a.debug_skip & 64))
+            atomicXor(&bd[start >> 5].x, 0xffffffffu << (start & 31));
         if (d.valid[i]) pb = d.bit[i];
-    }
-    // segment tables: reduce inside the wave first (every toggle of a segment would otherwise hit the same
-    // LDS word), then one atomic per segment the chunk touches -- usually one or two
-    if (chunk_end > pos && pos < m && !(a.debug_skip & 32)) {
-        const uint32_t last = (chunk_end < m ? chunk_end : m) - 1u;
-        const uint32_t sg0 = pos >> seg_shift;
-        if (sg0 == last >> seg_shift) {
-            // common case: the whole chunk lies in one segment -- four ballots and one wave sum
-            uint32_t par = 0, ones = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                par ^= (uint32_t)__popcll(__ballot(tog[i]));
-                if (d.valid[i] && d.bit[i] && start[i] < m) ones += (start[i] + d.l[i] < m ? d.l[i] : m - start[i]);
-            }
-            ones = lane63(wave_incl_add(ones));
-            if (lane == 0) {
-                if (par & 1u) atomicXor(&segtab[2 * sg0], 1u);
-                if (ones) atomicAdd(&segtab[2 * sg0 + 1], ones);
-            }
-        } else {
-            for (uint32_t sg = sg0; sg <= last >> seg_shift; ++sg) {
-                const uint32_t lo = sg << seg_shift, hi = lo + (1u << seg_shift);
-                uint32_t par = 0, ones = 0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    par ^= (uint32_t)__popcll(__ballot(tog[i] && start[i] >= lo && start[i] < hi));
-                    if (d.valid[i] && d.bit[i]) {
-                        const uint32_t e0 = start[i] + d.l[i] < m ? start[i] + d.l[i] : m;
-                        const uint32_t b0 = start[i] > lo ? start[i] : lo, b1 = e0 < hi ? e0 : hi;
-                        if (b1 > b0) ones += b1 - b0;
-                    }
-                }
-                ones = lane63(wave_incl_add(ones));
-                if (lane == 0) {
-                    if (par & 1u) atomicXor(&segtab[2 * sg], 1u);
-                    if (ones) atomicAdd(&segtab[2 * sg + 1], ones);
-                }
-            }
-        }
     }
 }
 
@@ -431,7 +384,7 @@ __device__ __forceinline__ void build_plane_row(const ScanArgs &a, const uint8_t
     const int nw = a.nw;
     for (int i = lane; i < nw; i += 64) bd[i] = make_uint2(0u, 0u);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    if (!(a.debug_skip & 2)) rle_toggles<false>(a, rle, bd, desc, pre0, pre1, 0u, 0u, 2, lane, 0, nullptr);
+    if (!(a.debug_skip & 2)) rle_toggles(a, rle, bd, desc, pre0, pre1, 0u, 0u, 2, lane);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     uint32_t carry_x = 0, carry_c = 0;
     if (!(a.debug_skip & 4)) directory_pass(bd, 0, nw, nw, tail_mask, carry_x, carry_c, lane);
@@ -447,7 +400,9 @@ __device__ __forceinline__ void build_plane_row(const ScanArgs &a, const uint8_t
 
 template <int NT, int CPT, bool MULTI, bool GT, bool TEAM>
 __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64_t *__restrict__ rowdesc,
-                                                  const uint8_t *__restrict__ rle)
+                                                  const uint8_t *__restrict__ rle,
+                                                  const uint32_t *__restrict__ chunkinfo,
+                                                  const uint32_t *__restrict__ segc)
 {   // rowdesc / rle are separate `const __restrict__` arguments (not members of `a`) so that hipcc knows
     // they are invariant: the wave-uniform descriptor loads then go through the scalar cache (s_load,
     // lgkmcnt) and do not force a vmcnt(0) that would drain the prefetched string loads.
@@ -506,15 +461,16 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
     // plane-row (wave / wpp) together, synchronised by workgroup barriers.
     const int wpp = TEAM ? a.wpp : 1;
     const int team = wave / wpp, tw = wave - team * wpp;
-    constexpr int nbuf = TEAM ? 1 : 2;                                   // !TEAM: pipelined batches (see below)
-    uint32_t *seginfo = n0s + nbuf * 2 * K;                              // [NWAVE][2] {toggle parity, ones}
 
     // ---- software prefetch of the RLE strings: the row descriptors run two batches ahead of phase A,
     // the first 512 bytes of every string one batch ahead.
+    //   !TEAM: slot i = plane-row (wave + i*NWAVE) of the batch, pre[i][0..1] = its chunks 0 and 1
+    //   TEAM : both slots describe the team's string; pre[0][j] = data of chunk tw + j*wpp,
+    //          pre[1][j] = that chunk's row-index record {start position | bit before << 31}
     uint64_t dsc[2], dsc_next[2];
     uint32_t pre[2][2];
     auto fetch_desc = [&](int64_t rb_, int i) -> uint64_t {
-        const int p = wpp == 1 ? wave + i * NWAVE : team;   // team mode: both slots = the team's string
+        const int p = wpp == 1 ? wave + i * NWAVE : team;
         const int64_t left = blk_end - rb_;
         const int kc = (int)(left < K ? left : K);
         return (rb_ < blk_end && p < 2 * kc) ? rowdesc[2 * rb_ + p] : 0ull;
@@ -524,15 +480,24 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
         const uint32_t k0 = (uint32_t)c * 256u + 4u * (uint32_t)lane;
         return k0 < len ? reinterpret_cast<const uint32_t*>(rle + (d & kDescOffMask))[c * 64 + lane] : 0u;
     };
+    auto fetch_info = [&](uint64_t d, int c, int64_t rb_) -> uint32_t {          // TEAM only
+        const uint32_t len = (uint32_t)(d >> kDescLenShift);
+        return (uint32_t)c * 256u < len ? chunkinfo[(((d & kDescOffMask) + (uint64_t)c * 256u) >> 8) + (uint64_t)(2 * rb_ + team)] : 0u;
+    };
+    auto fetch_pre = [&](int64_t rb_) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (!TEAM) { pre[i][0] = fetch_data(dsc[i], 0); pre[i][1] = fetch_data(dsc[i], 1); }
+            else if (i == 0) { pre[0][0] = fetch_data(dsc[0], tw); pre[0][1] = fetch_data(dsc[0], tw + wpp); }
+            else { pre[1][0] = fetch_info(dsc[0], tw, rb_); pre[1][1] = fetch_info(dsc[0], tw + wpp, rb_); }
+        }
+    };
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         dsc[i] = fetch_desc(blk_beg, i);
         dsc_next[i] = fetch_desc(blk_beg + K, i);
-        // wpp == 1: chunks 0,1 of the wave's own two strings (slot i = plane-row i of the wave);
-        // team mode: slot 0 only, chunks tw and tw + wpp of the team's string
-        pre[i][0] = fetch_data(dsc[i], wpp == 1 ? 0 : tw);
-        pre[i][1] = fetch_data(dsc[i], wpp == 1 ? 1 : tw + wpp);
     }
+    fetch_pre(blk_beg);
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = a.debug_times ? __builtin_amdgcn_s_memtime() : 0ull;
 
     // LDS regions of batch buffer `buf`
@@ -553,12 +518,10 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
         for (int i = 0; i < 2; ++i) { cdsc[i] = dsc[i]; cpre[i][0] = pre[i][0]; cpre[i][1] = pre[i][1]; }
         asm volatile("" : "+v"(cpre[0][0]), "+v"(cpre[0][1]), "+v"(cpre[1][0]), "+v"(cpre[1][1]));   // arrived: pin the wait here
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            dsc[i] = dsc_next[i];
-            pre[i][0] = fetch_data(dsc[i], wpp == 1 ? 0 : tw);
-            pre[i][1] = fetch_data(dsc[i], wpp == 1 ? 1 : tw + wpp);
-            dsc_next[i] = fetch_desc(rbA + 2 * K, i);
-        }
+        for (int i = 0; i < 2; ++i) dsc[i] = dsc_next[i];
+        fetch_pre(rbA + K);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) dsc_next[i] = fetch_desc(rbA + 2 * K, i);
         BGTH_TICK(0);
         if constexpr (!TEAM) {
 #pragma unroll
@@ -568,67 +531,54 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
                     build_plane_row(a, rle, BDb + (size_t)p * nwp, n0b + p, cdsc[i], cpre[i][0], cpre[i][1], lane, tail_mask);
             }
         } else {
-            // team mode: segments of 1 << seg_shift positions (a power of two >= m / wpp) per wave
+            // team mode: wave tw of team `team` (= plane-row of the batch) takes the string's chunks tw, tw+wpp, ..
+            // and the directory trips (256 words each) tw, tw+wpp, ..; both start from row-index records, so the
+            // only synchronisation is  clear | toggles | directory.
             const bool active = team < 2 * Kc;
             uint2 *bd = BDb + (size_t)team * nwp;
-            uint32_t *segtab = seginfo + 2 * team * wpp;                 // [wpp][2] {toggle parity, ones}
-            uint32_t *chunktab = seginfo + 2 * NWAVE + 4 * team * wpp;   // [2*wpp][2] {symbols, last bit | stop<<1}
+            const int64_t sidx = 2 * rbA + team;
             const uint32_t slen = (uint32_t)(cdsc[0] >> kDescLenShift);
-            const bool parallel_rle = slen <= (uint32_t)(2 * wpp) * 256u;      // else: team wave 0 decodes alone
-            if (active) for (int i = tw * 64 + lane; i < nw; i += wpp * 64) bd[i] = make_uint2(0u, 0u);
-            if (lane < 2) seginfo[2 * wave + lane] = 0u;
-            if (active && parallel_rle && !(a.debug_skip & 2)) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int c = tw + i * wpp;
-                    const ChunkDecode cd = decode_chunk(cpre[0][i], (uint32_t)c * 256u + 4u * (uint32_t)lane, slen, lane);
-                    const uint32_t tot = lane63(wave_incl_add(cd.run));
-                    const uint32_t lb = chunk_last_bit(cd, lane);
-                    if (lane == 0) { chunktab[2 * c] = tot; chunktab[2 * c + 1] = lb | (cd.stop ? 2u : 0u); }
-                }
+            const int ntrip = (nw + 255) >> 8;
+            // carries of this wave's directory trips (lane u <-> trip tw + u*wpp) and the row's number of ones:
+            // in flight during the toggles
+            uint32_t cyl = 0, tot1 = 0;
+            if (active) {
+                const uint32_t *sc = segc + (size_t)sidx * (size_t)(a.S8 + 1);
+                const int t = tw + lane * wpp;
+                cyl = t < ntrip ? sc[t] : 0u;
+                tot1 = sc[a.S8];
+            }
+            if (active) {                                               // clear the row, two entries per store
+                uint4 *z = reinterpret_cast<uint4*>(bd);
+                for (int i = tw * 64 + lane; 2 * i < nw; i += wpp * 64) z[i] = make_uint4(0u, 0u, 0u, 0u);
             }
             BGTH_TICK(1);
             lds_barrier();
             BGTH_TICK(2);
             if (active && !(a.debug_skip & 2)) {
-                if (parallel_rle) {
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const int c = tw + i * wpp;
-                        // where the chunk starts and the bit before it: lane c2 reads chunk c2's record, one
-                        // wave prefix sum gives every chunk's start (no serial walk over LDS)
-                        const uint32_t t0 = lane < 2 * wpp && (uint32_t)lane * 256u < slen ? chunktab[2 * lane] : 0u;
-                        const uint32_t t1 = lane < 2 * wpp && (uint32_t)lane * 256u < slen ? chunktab[2 * lane + 1] : 0u;
-                        const uint32_t incl_t = wave_incl_add(t0);
-                        const uint32_t pos = c ? (uint32_t)__builtin_amdgcn_readlane((int)incl_t, c ? c - 1 : 0) : 0u;
-                        const uint32_t prevbit = c ? ((uint32_t)__builtin_amdgcn_readlane((int)t1, c ? c - 1 : 0) & 1u) : 0u;
-                        const bool dead = (__ballot((t1 & 2u) != 0u) & ((1ull << c) - 1ull)) != 0ull;
-                        if (!dead && (uint32_t)c * 256u < slen && !(a.debug_skip & 16)) {
-                            // decoded again rather than kept: two registers cross the barrier instead of thirty
-                            const ChunkDecode cd = decode_chunk(cpre[0][i], (uint32_t)c * 256u + 4u * (uint32_t)lane, slen, lane);
-                            chunk_toggles(a, bd, cd, pos, prevbit, lane, a.seg_shift, segtab);
-                        }
-                    }
-                } else if (tw == 0) {
-                    // rare: a string longer than the team's 2*wpp chunks -- one wave walks it from memory
-                    rle_toggles<true>(a, rle, bd, cdsc[0], 0u, 0u, 0u, 0u, 0, lane, a.seg_shift, segtab);
+                int i = 0;
+                for (int c = tw; (uint32_t)c * 256u < slen; c += wpp, ++i) {
+                    uint32_t w, ci;
+                    if (i == 0) { w = cpre[0][0]; ci = cpre[1][0]; }
+                    else if (i == 1) { w = cpre[0][1]; ci = cpre[1][1]; }
+                    else { w = fetch_data(cdsc[0], c); ci = fetch_info(cdsc[0], c, rbA); }
+                    if (ci & kChunkDead) break;                      // behind a terminating zero byte
+                    const ChunkDecode cd = decode_chunk(w, (uint32_t)c * 256u + 4u * (uint32_t)lane, slen, lane);
+                    chunk_toggles(a, bd, cd, ci & kChunkPosMask, ci >> 31, lane);
                 }
             }
             BGTH_TICK(3);
             lds_barrier();
             BGTH_TICK(4);
             if (active && !(a.debug_skip & 4)) {
-                const int seg_words = 1 << (a.seg_shift - 5);
-                const int w0 = tw * seg_words < nw ? tw * seg_words : nw;
-                const int w1 = w0 + seg_words < nw ? w0 + seg_words : nw;
-                // carries from the segments before mine: lane s2 reads segment s2's record
-                const uint32_t spx = lane < wpp ? segtab[2 * lane] : 0u, spc = lane < wpp ? segtab[2 * lane + 1] : 0u;
-                const uint32_t incl_c = wave_incl_add(spc);
-                const uint32_t total = lane63(incl_c);
-                uint32_t cnt = tw ? (uint32_t)__builtin_amdgcn_readlane((int)incl_c, tw ? tw - 1 : 0) : 0u;
-                uint32_t cx = (uint32_t)__popcll(__ballot((spx & 1u) != 0u) & ((1ull << tw) - 1ull)) & 1u;
-                directory_pass(bd, w0, w1, nw, tail_mask, cx, cnt, lane);
-                if (tw == 0 && lane == 0) n0b[team] = (uint32_t)m - total;
+                int u = 0;
+                for (int t = tw; t < ntrip; t += wpp, ++u) {
+                    const uint32_t cy = (uint32_t)__builtin_amdgcn_readlane((int)cyl, u);
+                    uint32_t cx = cy >> 31, cnt = cy & 0x7fffffffu;
+                    const int w0 = t << 8, w1 = (w0 + 256) < nw ? (w0 + 256) : nw;
+                    directory_pass(bd, w0, w1, nw, tail_mask, cx, cnt, lane);
+                }
+                if (tw == 0 && lane == 0) n0b[team] = (uint32_t)m - tot1;
             }
         }
         BGTH_TICK(5);
@@ -648,7 +598,8 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
             const bool emit = (rb + k) >= a.row0;
             // ones of plane 0, ones of plane 1, ones in both:  n(code1) = ca - cc, n(code2) = cb - cc
             uint32_t ca = 0, cb = 0, cc = 0;
-            uint64_t keep0 = 0, keep1 = 0;
+            constexpr int NKEEP = (CPT + 63) / 64;                     // lane l keeps the masks of chunks l, l + 64
+            uint64_t keep0[NKEEP] = {}, keep1[NKEEP] = {};
 #pragma unroll
             for (int j = 0; j < CPT; j += 4) {
                 uint64_t m0[4] = {0, 0, 0, 0}, m1[4] = {0, 0, 0, 0};
@@ -665,7 +616,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     if (u >= NC) break;
-                    if (GT && lane == j + u) { keep0 = m0[u]; keep1 = m1[u]; }
+                    if (GT && lane == ((j + u) & 63)) { keep0[(j + u) >> 6] = m0[u]; keep1[(j + u) >> 6] = m1[u]; }
                     if (MULTI) {
                         const int c = chunk0 + j + u;                        // wave-uniform
                         if (emit && lane == 0 && c < a.n_chunks) {
@@ -679,10 +630,16 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
             }
             if (!MULTI && lane == 0)
                 reinterpret_cast<int4*>(lcb)[k * NWAVE + wave] = make_int4((int)(ca - cc), (int)(cb - cc), (int)cc, 0);
-            if (GT && emit && lane < CPT && chunk0 + lane < a.n_chunks) {
-                const size_t at = (size_t)(rb + k - a.row0) * a.n_chunks + chunk0 + lane;
-                a.h0[at] = keep0;
-                a.h1[at] = keep1;
+            if (GT && emit) {
+#pragma unroll
+                for (int q = 0; q < NKEEP; ++q) {
+                    const int c = q * 64 + lane;
+                    if (c < CPT && chunk0 + c < a.n_chunks) {
+                        const size_t at = (size_t)(rb + k - a.row0) * a.n_chunks + chunk0 + c;
+                        a.h0[at] = keep0[q];
+                        a.h1[at] = keep1[q];
+                    }
+                }
             }
         }
         BGTH_TICK(7);

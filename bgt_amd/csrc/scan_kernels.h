@@ -9,6 +9,17 @@ namespace bgth {
 constexpr int      kDescLenShift = 40;
 constexpr uint64_t kDescOffMask  = (1ull << kDescLenShift) - 1;
 
+// Row index (wide cohorts, built once per file by rowindex_kernel):
+//   chunkinfo[slot]  one record per 256-byte chunk c of string i, slot = ((offset_i + 256 c) >> 8) + i
+//                    (injective because strings do not overlap):  start position of the chunk in the row
+//                    (bits 0..29) | kChunkDead if the chunk lies behind a terminating zero byte | bit of the
+//                    last byte before the chunk << 31
+//   segc[i][s]       s = 0..S8-1, S8 = ceil(m / 8192): ones before position 8192 s (bits 0..30) | bit at
+//                    position 8192 s - 1 << 31 -- the carries a directory trip of 256 words starts from;
+//   segc[i][S8]      number of ones in the row
+constexpr uint32_t kChunkPosMask = 0x3fffffffu;
+constexpr uint32_t kChunkDead    = 0x40000000u;
+
 // Chunk descriptor (one per 64 tracked slots): group id (bits 0..7, 0-based) | valid slots (bits 8..14).
 // Slots are laid out group by group, each group padded to a multiple of 64, so a 64-slot chunk never
 // mixes groups and the per-chunk ballot/popcount reduction needs no per-lane group lookup.
@@ -23,7 +34,9 @@ struct ScanArgs {
     int32_t        *raw_counts;  // [(row1-row0)][G][3] += {n(code1), n(code2), n(code3)}
     uint64_t       *h0, *h1;     // optional [(row1-row0)][n_chunks] bit planes in slot order
     int32_t        *final_rank;  // optional [2][m]: ranks by column after the last row of the launch
-    int32_t  m, nw, shift, n_chunks, G, K, wpp, nbuf, seg_shift;   // seg_shift: log2 positions per team segment
+    const uint32_t *chunkinfo;   // row index (see above); only read by the team (wide-cohort) kernels
+    const uint32_t *segc;
+    int32_t  m, nw, shift, n_chunks, G, K, wpp, nbuf, S8;
     int32_t  blk0, n_blk, n_slices;
     int64_t  row0, row1;         // rows whose results are emitted; decoding starts at blk0<<shift
     unsigned long long *debug_times;   // optional [workgroups][8] cycle sums per phase (env BGTH_DEBUG_TIMES)
@@ -34,6 +47,9 @@ struct ScanArgs {
 #define BGTH_CPT_256(X)  X(2) X(4) X(8) X(12) X(16) X(20)
 #define BGTH_CPT_512(X)  X(4) X(8) X(10) X(12) X(16) X(20) X(24) X(32) X(40) X(48)
 #define BGTH_CPT_1024(X) X(4) X(8) X(10) X(12) X(16) X(20) X(24)
+// team kernels only (wide cohorts: as many columns per workgroup as the 256 VGPRs of a 512-thread
+// workgroup hold, so that few column slices repeat the per-row bit-vector build)
+#define BGTH_CPT_512_WIDE(X) X(64) X(80) X(92)
 
 struct Geometry { int threads, cpt, slices, K, lds_bytes, workgroups, wpp, nbuf; };
 
@@ -42,6 +58,9 @@ struct Geometry { int threads, cpt, slices, K, lds_bytes, workgroups, wpp, nbuf;
 bool choose_geometry(int m, int n_chunks, int G, int n_blk, int want_threads, int want_cpt, int want_K,
                      Geometry *g);
 hipError_t launch_scan(const ScanArgs &a, const Geometry &g, hipStream_t s);
+// row index of n_str strings (see above); chunkinfo must hold packed_bytes/256 + n_str + 1 records
+hipError_t launch_rowindex(const uint64_t *rowdesc, const uint8_t *rle, int64_t n_str, int m, int S8,
+                           uint32_t *chunkinfo, uint32_t *segc, hipStream_t s);
 
 // raw {c1,c2,c3} per group -> {AN,AC,AC<M>} for total (+ per group when G>1)
 hipError_t launch_finalize(const int32_t *raw, int32_t *out, const int32_t *group_haps, int64_t n_rows,

@@ -14,7 +14,10 @@ static const int kLdsBytes = 160 * 1024;
 #define BGTH_GEOMS(X) \
     X(256, 2) X(256, 4) X(256, 8) X(256, 12) X(256, 16) X(256, 20) \
     X(512, 4) X(512, 8) X(512, 10) X(512, 12) X(512, 16) X(512, 20) X(512, 24) X(512, 32) X(512, 40) X(512, 48) \
-    X(1024, 4) X(1024, 8) X(1024, 10) X(1024, 12) X(1024, 16) X(1024, 20) X(1024, 24)
+    X(1024, 4) X(1024, 8) X(1024, 10) X(1024, 12) X(1024, 16) X(1024, 20) X(1024, 24) \
+    X(512, 64) X(512, 80) X(512, 92)          /* team mode only (scan_wide.hip) */
+
+static bool team_only(int nt, int cpt) { return nt == 512 && cpt > 48; }
 
 struct GeomEntry { int nt, cpt; };
 static const GeomEntry kGeoms[] = {
@@ -46,7 +49,7 @@ static long model_cost(int nw, int n_chunks, int n_blk, int nt, int cpt, int K, 
 {
     const int nwave = nt / 64, cap = nwave * cpt;
     const int slices = (n_chunks + cap - 1) / cap;
-    const long tB = (long)cpt * 72 * (nt / 256);
+    const long tB = (long)cpt * 72 * (nt / 256) * (nt == 1024 ? 100 : 115) / 100;   // measured: 2 waves per SIMD fill the VALU less well
     const long lat = 8 + 5 * (nt / 256);                 // cycles per dependent instruction of a building wave
     const int wpp = wpp_for(nt, K);
     long tA;
@@ -54,7 +57,14 @@ static long model_cost(int nw, int n_chunks, int n_blk, int nt, int cpt, int K, 
         const int rounds = (2 * K + nwave - 1) / nwave;  // plane-rows per wave and batch
         tA = (long)rounds * (120 + (long)(nw * 4) / 10) * lat / K;
     } else {
-        tA = (320 + (long)(nw * 56) / (100 * wpp)) * lat / K;   // serial RLE decode + two directory passes / wpp
+        // team mode (wide cohorts), per row and wave: chunks of the string -> toggles (~260 instructions per
+        // 256-byte chunk), directory trips of 256 words (~75), clearing the row, four barriers.  A wave gets one
+        // instruction per 4 cycles x waves per SIMD.
+        const int chunks = (40 + (nw * 10) / 65 + 255) / 256, ntrip = (nw + 255) / 256;
+        const long instr = (long)((chunks + wpp - 1) / wpp) * 260 + (long)((ntrip + wpp - 1) / wpp) * 60 +
+                           3 * (nw / (64 * wpp) + 1) + 150;
+        const long per_instr = nt == 1024 ? 16 : nt == 512 ? 13 : 12;       // measured (m = 200 k, MI355X)
+        tA = (instr * per_instr + 1600) / K;
     }
     const long wgs = (long)n_blk * slices;
     const long per_cu = (wgs + 255) / 256;
@@ -77,6 +87,12 @@ bool choose_geometry(int m, int n_chunks, int G, int n_blk, int want_threads, in
         int K = want_K > 0 ? want_K : nt / 64;
         if (K > nt / 64) K = nt / 64;
         while (K > 1 && lds_need(nw, K, G, nt) > kLdsBytes) --K;
+        if (team_only(nt, cpt)) {                        // instantiated for team mode only: skip where the
+            int K2 = want_K > 0 ? want_K : nt / 64;      // narrow (two-buffer) mode would be chosen below
+            if (K2 > nt / 64) K2 = nt / 64;
+            while (K2 > 1 && lds_need(nw, K2, G, nt, 2) > kLdsBytes) --K2;
+            if (lds_need(nw, K2, G, nt, 2) <= kLdsBytes && wpp_for(nt, K2) == 1) continue;
+        }
         int slices;
         const long cost = model_cost(nw, n_chunks, n_blk, nt, cpt, K, &slices);
         // ties: fewer idle slots, then more threads (more waves to hide LDS latency)
@@ -111,10 +127,12 @@ bool choose_geometry(int m, int n_chunks, int G, int n_blk, int want_threads, in
 hipError_t launch_scan_nt256(const ScanArgs &a, const Geometry &g, hipStream_t s);
 hipError_t launch_scan_nt512(const ScanArgs &a, const Geometry &g, hipStream_t s);
 hipError_t launch_scan_nt1024(const ScanArgs &a, const Geometry &g, hipStream_t s);
+hipError_t launch_scan_wide(const ScanArgs &a, const Geometry &g, hipStream_t s);
 
 hipError_t launch_scan(const ScanArgs &a, const Geometry &g, hipStream_t s)
 {
     if (g.threads == 256) return launch_scan_nt256(a, g, s);
+    if (team_only(g.threads, g.cpt)) return launch_scan_wide(a, g, s);
     if (g.threads == 512) return launch_scan_nt512(a, g, s);
     if (g.threads == 1024) return launch_scan_nt1024(a, g, s);
     return hipErrorInvalidConfiguration;

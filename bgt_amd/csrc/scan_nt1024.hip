@@ -14,7 +14,7 @@ static hipError_t launch_one(const ScanArgs &a, const Geometry &g, hipStream_t s
                                        hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes);
     if (e != hipSuccess) return e;
     (void)kLdsBytesLocal;
-    hipLaunchKernelGGL(fn, dim3(g.workgroups), dim3(NT), g.lds_bytes, s, a, a.rowdesc, a.rle);
+    hipLaunchKernelGGL(fn, dim3(g.workgroups), dim3(NT), g.lds_bytes, s, a, a.rowdesc, a.rle, a.chunkinfo, a.segc);
     return hipGetLastError();
 }
 

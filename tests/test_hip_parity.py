@@ -163,7 +163,8 @@ def test_sample_groups(hip, seed, m, rows, shift, G):
                                            (256, 20, 1), (512, 4, 8), (512, 8, 4), (512, 10, 3), (512, 12, 2),
                                            (512, 16, 5), (512, 20, 8), (1024, 4, 16), (1024, 8, 2), (1024, 10, 9),
                                            (1024, 12, 3), (1024, 16, 7), (1024, 20, 5), (1024, 24, 1), (512, 24, 1),
-                                           (512, 32, 2), (512, 40, 4), (512, 48, 1), (256, 2, 2), (1024, 8, 4)])
+                                           (512, 32, 2), (512, 40, 4), (512, 48, 1), (256, 2, 2), (1024, 8, 4),
+                                           (512, 64, 1), (512, 80, 1), (512, 92, 1)])
 def test_every_launch_geometry(hip, threads, cpt, K):
     """Force each kernel instantiation (and multi-slice launches) on one cohort."""
     mat, data, rng = make_case(41, 5008, 130, 5, n_founders=7, switch=0.04)
@@ -183,6 +184,36 @@ def test_every_launch_geometry(hip, threads, cpt, K):
     c2 = rd.scan(0, 130)
     o2, _ = oracle_scan(data, 0, 130, group=group, n_groups=2)
     assert np.array_equal(c2, o2)
+
+
+@pytest.mark.parametrize("threads,cpt,K", [(0, 0, 0), (512, 80, 1), (512, 64, 1), (512, 92, 1), (1024, 24, 1),
+                                           (1024, 8, 1), (512, 20, 1), (256, 20, 1), (1024, 16, 2)])
+def test_wide_cohort_team_mode(hip, threads, cpt, K):
+    """Team mode on a cohort wide enough for several 256-byte chunks per string, several directory trips and
+    several 8192-position segments of the row index -- noisy rows (many runs), rows of one long run, a row
+    whose string stops short of m -- whole cohort, a sparse subset and two groups."""
+    rng = np.random.default_rng(77)
+    m, rows, shift = 41000, 24, 3
+    mat = scenarios.ld_matrix(rng, rows, m, n_founders=40, switch=0.2)
+    mat[3] = 0; mat[4] = 1; mat[5] = 3; mat[6, :20000] = 2; mat[6, 20000:] = 0
+    mat[7] = rng.integers(0, 4, m)                              # every nibble boundary, ~30k runs per plane
+    data = orc.encode_pbf(mat, 2, shift)
+    pbf = hip.HipPbf.from_bytes(data)
+    rd = hip.HipReader(pbf)
+    rd.tune(threads, cpt, K)
+    oc, ogt = oracle_scan(data, 0, rows)
+    counts, gt = rd.scan(0, rows, want_gt=True)
+    assert np.array_equal(counts, oc) and np.array_equal(gt, ogt), rd.geometry()
+    assert np.array_equal(unpack_gt(gt, m), mat)
+    assert np.array_equal(rd.scan(5, 21), oc[5:21])
+    cols = np.sort(rng.choice(m // 2, 700, replace=False))
+    cols = np.stack([2 * cols, 2 * cols + 1], 1).reshape(-1)
+    group = (1 + (np.arange(700) % 3)).astype(np.uint32)
+    rd.select(cols, group=group, n_groups=3)
+    rd.tune(threads if threads != 512 or cpt < 64 else 512, cpt if cpt < 64 else 8, K)
+    c2, g2 = rd.scan(0, rows, want_gt=True)
+    o2, og2 = oracle_scan(data, 0, rows, cols=cols, group=group, n_groups=3)
+    assert np.array_equal(c2, o2) and np.array_equal(g2, og2)
 
 
 def split_rle(data):
