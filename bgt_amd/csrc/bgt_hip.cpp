@@ -84,6 +84,10 @@ struct bgth_pbf_s {
     std::mutex rowindex_lock;         // an image is shared by readers on different threads
 };
 
+// profiling / test knob: bits of the environment variable BGTH_DEBUG_SKIP (0x200 = team mode without the separate
+// toggle array, i.e. the code path of cohorts too wide for it)
+static bool debug_flag(int bit) { const char *d = getenv("BGTH_DEBUG_SKIP"); return d && (atoi(d) & bit); }
+
 // Builds the row index once per image; later calls only return it.  The build is enqueued on `s`, the
 // stream of the scan that needs it, and waited for, so that other streams may use the index afterwards.
 static bool ensure_rowindex(bgth_pbf_t *p, hipStream_t s)
@@ -348,7 +352,7 @@ extern "C" bgth_pbf_t *bgth_pbf_open(const char *path, int device)
 static bool run_block_pass(bgth_pbf_t *p, Selection &all, int64_t blk, int32_t *d_final, hipStream_t s)
 {
     Geometry geo;
-    if (!choose_geometry(p->m, all.n_chunks, 1, 1, 0, 0, 0, &geo)) { set_err("[E::bgth] geometry"); return false; }
+    if (!choose_geometry(p->m, all.n_chunks, 1, 1, 0, 0, 0, &geo, !debug_flag(0x200))) { set_err("[E::bgth] geometry"); return false; }
     ScanArgs a;
     memset(&a, 0, sizeof(a));
     a.rle = p->d_rle; a.rowdesc = p->d_rowdesc;
@@ -356,7 +360,7 @@ static bool run_block_pass(bgth_pbf_t *p, Selection &all, int64_t blk, int32_t *
     a.slot_col = all.d_slot_col; a.chunk_desc = all.d_chunk_desc;
     a.raw_counts = nullptr; a.h0 = a.h1 = nullptr; a.final_rank = d_final;
     a.m = p->m; a.nw = (p->m + 31) / 32; a.shift = p->shift; a.n_chunks = all.n_chunks; a.G = 1; a.K = geo.K; a.wpp = geo.wpp; a.nbuf = geo.nbuf;
-    if (geo.wpp > 1) { if (!ensure_rowindex(p, s)) return false; a.chunkinfo = p->d_chunkinfo; a.segc = p->d_segc; a.S8 = p->S8; }
+    if (geo.wpp > 1) { if (!ensure_rowindex(p, s)) return false; a.chunkinfo = p->d_chunkinfo; a.segc = p->d_segc; a.S8 = p->S8; a.tog_off = geo.tog_off; }
     a.blk0 = (int32_t)blk; a.n_blk = 1; a.n_slices = geo.slices;
     a.row1 = std::min<int64_t>(p->n, (blk + 1) << p->shift);
     a.row0 = a.row1;                      // nothing emitted: only the final ranks are wanted
@@ -541,7 +545,7 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
     const int G = r->sel.G;
     const int64_t blk0 = row0 >> p->shift, blk1 = (row1 - 1) >> p->shift;
     Geometry geo;
-    if (!choose_geometry(p->m, r->sel.n_chunks, G, (int)(blk1 - blk0 + 1), r->tune_threads, r->tune_cpt, r->tune_K, &geo)) {
+    if (!choose_geometry(p->m, r->sel.n_chunks, G, (int)(blk1 - blk0 + 1), r->tune_threads, r->tune_cpt, r->tune_K, &geo, !debug_flag(0x200))) {
         set_err("[E::bgth_reader_scan] no launch geometry for m=%d (threads=%d cpt=%d)", p->m, r->tune_threads, r->tune_cpt);
         return -1;
     }
@@ -554,7 +558,7 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
     a.slot_col = r->sel.d_slot_col; a.chunk_desc = r->sel.d_chunk_desc;
     a.raw_counts = (int32_t*)r->raw.p; a.h0 = d_h0; a.h1 = d_h1; a.final_rank = nullptr;
     a.m = p->m; a.nw = (p->m + 31) / 32; a.shift = p->shift; a.n_chunks = r->sel.n_chunks; a.G = G; a.K = geo.K; a.wpp = geo.wpp; a.nbuf = geo.nbuf;
-    if (geo.wpp > 1) { if (!ensure_rowindex(p, s)) return -1; a.chunkinfo = p->d_chunkinfo; a.segc = p->d_segc; a.S8 = p->S8; }
+    if (geo.wpp > 1) { if (!ensure_rowindex(p, s)) return -1; a.chunkinfo = p->d_chunkinfo; a.segc = p->d_segc; a.S8 = p->S8; a.tog_off = geo.tog_off; }
     a.blk0 = (int32_t)blk0; a.n_blk = (int32_t)(blk1 - blk0 + 1); a.n_slices = geo.slices;
     a.row0 = row0; a.row1 = row1;
     { const char *dbg = getenv("BGTH_DEBUG_SKIP"); a.debug_skip = dbg ? atoi(dbg) : 0; }

@@ -309,6 +309,60 @@ __device__ __forceinline__ void directory_pass(uint2 *bd, int w0, int w1, int nw
     }
 }
 
+// Directory trips of a team wave when the toggles live in their own array `tog` (one uint32 per row word,
+// rows padded to a multiple of 4 words with words that are never toggled): trip t covers words
+// [256 t, 256 t + 256), its carries come from the row index, so trips are independent -- two are processed
+// at a time to overlap their LDS latencies and scan chains.  The toggle words are cleared as they are read,
+// which leaves the array ready for the next row.
+struct TripCarry { uint32_t cx, cnt; };
+
+__device__ __forceinline__ void directory_trips_tog(uint32_t *tog, uint2 *bd, int tw, int wpp, int ntrip, int nw,
+                                                    uint32_t tail_mask, uint32_t cyl, int lane)
+{
+    int u = 0;
+    for (int t = tw; t < ntrip; t += 2 * wpp, u += 2) {
+        const int tt[2] = {t, t + wpp};
+        const bool on[2] = {true, t + wpp < ntrip};                      // wave-uniform
+        uint4 q[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            uint4 *src = reinterpret_cast<uint4*>(tog + (tt[j] << 8)) + lane;
+            const bool in = on[j] && (tt[j] << 8) + 4 * lane < nw;
+            q[j] = in ? *src : make_uint4(0u, 0u, 0u, 0u);
+            if (in) *src = make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t cy = (uint32_t)__builtin_amdgcn_readlane((int)cyl, u + j);
+            const int i0 = (tt[j] << 8) + 4 * lane;
+            const uint32_t tq[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+            const uint64_t par = __ballot((int32_t)(tq[0] ^ tq[1] ^ tq[2] ^ tq[3]) < 0);
+            uint32_t cm = 0u - ((lanes_below(par) ^ (cy >> 31)) & 1u);
+            uint32_t v[4], pre[4], ones = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t x = tq[k] ^ cm;
+                if (i0 + k == nw - 1) x &= tail_mask;
+                if (i0 + k >= nw) x = 0u;
+                v[k] = x; pre[k] = ones; ones += (uint32_t)__popc(x);
+                cm ^= (uint32_t)((int32_t)tq[k] >> 31);
+            }
+            const uint32_t incl = wave_incl_add(ones);
+            const uint32_t b = (cy & 0x7fffffffu) + incl - ones;
+            if (on[j]) {
+                if (i0 + 3 < nw) {
+                    uint4 *dst = reinterpret_cast<uint4*>(bd + i0);
+                    dst[0] = make_uint4(v[0], b, v[1], b + pre[1]);
+                    dst[1] = make_uint4(v[2], b + pre[2], v[3], b + pre[3]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (i0 + k < nw) bd[i0 + k] = make_uint2(v[k], b + pre[k]);
+                }
+            }
+        }
+    }
+}
+
 // ---- team-parallel RLE decode (wide cohorts): wave tw of a team owns the 256-byte chunks tw, tw + wpp, ...
 // of the string.  Where a chunk starts in the row and the bit before it come from the ROW INDEX, a side
 // table built once per file (rowindex_kernel), so a chunk becomes toggles without waiting for the others.
@@ -355,8 +409,10 @@ __device__ __forceinline__ uint32_t chunk_last_bit(const ChunkDecode &d, int lan
     return (uint32_t)__builtin_amdgcn_readlane((int)lastb, top);
 }
 
-__device__ __forceinline__ void chunk_toggles(const ScanArgs &a, uint2 *bd, const ChunkDecode &d, uint32_t pos,
-                                              uint32_t prevbit, int lane)
+// words[stride * w] is the toggle word of row word w (stride 2: the .x of the {bits, before} entries; stride 1: a
+// separate toggle array)
+__device__ __forceinline__ void chunk_toggles(const ScanArgs &a, uint32_t *words, int stride, const ChunkDecode &d,
+                                              uint32_t pos, uint32_t prevbit, int lane)
 {
     const uint32_t m = (uint32_t)a.m;
     const uint32_t incl = wave_incl_add(d.run);
@@ -371,7 +427,7 @@ __device__ __forceinline__ void chunk_toggles(const ScanArgs &a, uint2 *bd, cons
     for (int i = 0; i < 4; ++i) {
         const uint32_t start = lane_start + d.before[i];
         if (d.valid[i] && d.bit[i] != pb && start < m && !(a.debug_skip & 64))
-            atomicXor(&bd[start >> 5].x, 0xffffffffu << (start & 31));
+            atomicXor(words + (size_t)(start >> 5) * stride, 0xffffffffu << (start & 31));
         if (d.valid[i]) pb = d.bit[i];
     }
 }
@@ -430,6 +486,9 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
     int32_t  *lcnt = reinterpret_cast<int32_t*>(smem + (size_t)16 * K * nwp * (TEAM ? 1 : 2));
     //   !MULTI: int4 [K][NWAVE] one private slot per wave and row   MULTI: int32 [K][G][3] (LDS atomics)
     uint32_t *n0s  = reinterpret_cast<uint32_t*>(lcnt + (TEAM ? 1 : 2) * (MULTI ? K * G * 3 : K * NWAVE * 4)); // [nbuf][2K]
+    // team mode, when it fits: toggles of the NEXT batch go to their own array [2K][nwt] while the current one is walked
+    const int nwt = (nw + 4) & ~3;
+    uint32_t *TOG = (TEAM && a.tog_off) ? reinterpret_cast<uint32_t*>(smem + a.tog_off) : nullptr;
     const uint32_t pad_rank = 32u * (uint32_t)nw;
     const uint32_t lds0 = __builtin_amdgcn_groupstaticsize();            // LDS byte address of smem[0]
 
@@ -453,6 +512,10 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
     }
     if (MULTI) for (int i = tid; i < (TEAM ? 1 : 2) * K * G * 3; i += NT) lcnt[i] = 0;
     for (int i = tid; i < (TEAM ? 1 : 2) * 2 * K; i += NT) BD[(size_t)i * nwp + nw] = make_uint2(0u, 0u);
+    if (TEAM && TOG) {                                                   // cleared before any wave toggles into it
+        for (int i = tid; i < 2 * K * nwt; i += NT) TOG[i] = 0u;
+        lds_barrier();
+    }
 
     const uint32_t tail_mask = (m & 31) ? ((1u << (m & 31)) - 1u) : 0xffffffffu;
 
@@ -564,7 +627,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
                     else { w = fetch_data(cdsc[0], c); ci = fetch_info(cdsc[0], c, rbA); }
                     if (ci & kChunkDead) break;                      // behind a terminating zero byte
                     const ChunkDecode cd = decode_chunk(w, (uint32_t)c * 256u + 4u * (uint32_t)lane, slen, lane);
-                    chunk_toggles(a, bd, cd, ci & kChunkPosMask, ci >> 31, lane);
+                    chunk_toggles(a, &bd[0].x, 2, cd, ci & kChunkPosMask, ci >> 31, lane);
                 }
             }
             BGTH_TICK(3);
@@ -580,6 +643,57 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
                 }
                 if (tw == 0 && lane == 0) n0b[team] = (uint32_t)m - tot1;
             }
+        }
+        BGTH_TICK(5);
+    };
+
+    // ================= team mode with a separate toggle array: phase A in two halves =================
+    // toggles(rbA) may run while other waves still walk the previous batch (it touches only TOG);
+    // directory(rbA) rewrites the bit-vectors and needs every wave past its walk.
+    uint32_t keep_cyl = 0, keep_tot = 0;
+    auto team_toggles = [&](int64_t rbA) {
+        const int Kc = (int)((blk_end - rbA) < K ? (blk_end - rbA) : K);
+        const uint64_t cd0 = dsc[0];
+        uint32_t c00 = pre[0][0], c01 = pre[0][1], c10 = pre[1][0], c11 = pre[1][1];
+        asm volatile("" : "+v"(c00), "+v"(c01), "+v"(c10), "+v"(c11));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) dsc[i] = dsc_next[i];
+        fetch_pre(rbA + K);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) dsc_next[i] = fetch_desc(rbA + 2 * K, i);
+        BGTH_TICK(0);
+        const bool active = team < 2 * Kc;
+        const int64_t sidx = 2 * rbA + team;
+        const uint32_t slen = (uint32_t)(cd0 >> kDescLenShift);
+        const int ntrip = (nw + 255) >> 8;
+        keep_cyl = 0; keep_tot = 0;
+        if (active) {
+            const uint32_t *sc = segc + (size_t)sidx * (size_t)(a.S8 + 1);
+            const int t = tw + lane * wpp;
+            keep_cyl = t < ntrip ? sc[t] : 0u;
+            keep_tot = sc[a.S8];
+        }
+        if (active && !(a.debug_skip & 2)) {
+            uint32_t *trow = TOG + (size_t)team * nwt;
+            int i = 0;
+            for (int c = tw; (uint32_t)c * 256u < slen; c += wpp, ++i) {
+                uint32_t w, ci;
+                if (i == 0) { w = c00; ci = c10; }
+                else if (i == 1) { w = c01; ci = c11; }
+                else { w = fetch_data(cd0, c); ci = fetch_info(cd0, c, rbA); }
+                if (ci & kChunkDead) break;
+                const ChunkDecode cd = decode_chunk(w, (uint32_t)c * 256u + 4u * (uint32_t)lane, slen, lane);
+                chunk_toggles(a, trow, 1, cd, ci & kChunkPosMask, ci >> 31, lane);
+            }
+        }
+        BGTH_TICK(3);
+    };
+    auto team_directory = [&](int64_t rbA) {
+        const int Kc = (int)((blk_end - rbA) < K ? (blk_end - rbA) : K);
+        if (team < 2 * Kc && !(a.debug_skip & 4)) {
+            directory_trips_tog(TOG + (size_t)team * nwt, BD + (size_t)team * nwp, tw, wpp, (nw + 255) >> 8, nw, tail_mask,
+                                keep_cyl, lane);
+            if (tw == 0 && lane == 0) n0s[team] = (uint32_t)m - keep_tot;
         }
         BGTH_TICK(5);
     };
@@ -688,15 +802,23 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
             phase_c((b - 1) & 1, last, (int)((blk_end - last) < K ? (blk_end - last) : K));
         }
     } else {
-        for (int64_t rb = blk_beg; rb < blk_end; rb += K) {
+        // Team mode, one loop for both variants (iteration -1 only prepares batch 0):
+        //   separate toggle array:  walk(b) + toggles(b+1) | counts(b) + directory(b+1) |      two barriers per batch
+        //   toggles in place     :  walk(b) | counts(b) + clear | toggles | directory(b+1) |   four
+        for (int64_t rb = blk_beg - K; rb < blk_end; rb += K) {
             const int Kc = (int)((blk_end - rb) < K ? (blk_end - rb) : K);
-            phase_a(0, rb);
+            const bool cur = rb >= blk_beg, more = rb + K < blk_end;
+            if (cur) phase_b(0, rb, Kc);
+            if (more && TOG) team_toggles(rb + K);
+            lds_barrier();
+            BGTH_TICK(4);
+            if (cur) phase_c(0, rb, Kc);
+            if (more) {
+                if (TOG) team_directory(rb + K);
+                else phase_a(0, rb + K);
+            }
             lds_barrier();
             BGTH_TICK(6);
-            phase_b(0, rb, Kc);
-            lds_barrier();
-            phase_c(0, rb, Kc);
-            // (the barriers of the next phase A order these reads before the next writes to the counters)
         }
     }
 

@@ -37,6 +37,7 @@ struct ScanArgs {
     const uint32_t *chunkinfo;   // row index (see above); only read by the team (wide-cohort) kernels
     const uint32_t *segc;
     int32_t  m, nw, shift, n_chunks, G, K, wpp, nbuf, S8;
+    int32_t  tog_off;            // team mode: byte offset in LDS of the separate toggle array [2K][(nw+4)&~3], 0 = toggles in place
     int32_t  blk0, n_blk, n_slices;
     int64_t  row0, row1;         // rows whose results are emitted; decoding starts at blk0<<shift
     unsigned long long *debug_times;   // optional [workgroups][8] cycle sums per phase (env BGTH_DEBUG_TIMES)
@@ -49,14 +50,14 @@ struct ScanArgs {
 #define BGTH_CPT_1024(X) X(4) X(8) X(10) X(12) X(16) X(20) X(24)
 // team kernels only (wide cohorts: as many columns per workgroup as the 256 VGPRs of a 512-thread
 // workgroup hold, so that few column slices repeat the per-row bit-vector build)
-#define BGTH_CPT_512_WIDE(X) X(64) X(80) X(92)
+#define BGTH_CPT_512_WIDE(X) X(64) X(80)
 
-struct Geometry { int threads, cpt, slices, K, lds_bytes, workgroups, wpp, nbuf; };
+struct Geometry { int threads, cpt, slices, K, lds_bytes, workgroups, wpp, nbuf, tog_off; };
 
 // Picks threads/columns-per-thread/slices/K for a selection of n_chunks*64 slots over n_blk blocks.
 // Returns false if the row bit-vectors of this m cannot fit in LDS.
 bool choose_geometry(int m, int n_chunks, int G, int n_blk, int want_threads, int want_cpt, int want_K,
-                     Geometry *g);
+                     Geometry *g, bool allow_tog = true);
 hipError_t launch_scan(const ScanArgs &a, const Geometry &g, hipStream_t s);
 // row index of n_str strings (see above); chunkinfo must hold packed_bytes/256 + n_str + 1 records
 hipError_t launch_rowindex(const uint64_t *rowdesc, const uint8_t *rle, int64_t n_str, int m, int S8,

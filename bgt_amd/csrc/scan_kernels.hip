@@ -15,7 +15,7 @@ static const int kLdsBytes = 160 * 1024;
     X(256, 2) X(256, 4) X(256, 8) X(256, 12) X(256, 16) X(256, 20) \
     X(512, 4) X(512, 8) X(512, 10) X(512, 12) X(512, 16) X(512, 20) X(512, 24) X(512, 32) X(512, 40) X(512, 48) \
     X(1024, 4) X(1024, 8) X(1024, 10) X(1024, 12) X(1024, 16) X(1024, 20) X(1024, 24) \
-    X(512, 64) X(512, 80) X(512, 92)          /* team mode only (scan_wide.hip) */
+    X(512, 64) X(512, 80)                     /* team mode only (scan_wide.hip) */
 
 static bool team_only(int nt, int cpt) { return nt == 512 && cpt > 48; }
 
@@ -73,7 +73,7 @@ static long model_cost(int nw, int n_chunks, int n_blk, int nt, int cpt, int K, 
 }
 
 bool choose_geometry(int m, int n_chunks, int G, int n_blk, int want_threads, int want_cpt, int want_K,
-                     Geometry *g)
+                     Geometry *g, bool allow_tog)
 {
     const int nw = (m + 31) / 32;
     if (lds_need(nw, 1, G, 1024) > kLdsBytes) return false;
@@ -120,6 +120,12 @@ bool choose_geometry(int m, int n_chunks, int G, int n_blk, int want_threads, in
         }
     }
     g->lds_bytes = (lds_need(nw, g->K, G, g->threads, g->nbuf) + 15) & ~15;
+    // team mode: a separate toggle array (two barriers per batch instead of four) when the LDS has room for it
+    g->tog_off = 0;
+    if (g->nbuf == 1 && allow_tog) {
+        const int tog_bytes = 2 * g->K * 4 * ((nw + 4) & ~3);
+        if (g->lds_bytes + tog_bytes <= kLdsBytes) { g->tog_off = g->lds_bytes; g->lds_bytes += tog_bytes; }
+    }
     g->workgroups = ((n_blk + 7) / 8) * 8 * g->slices;
     return true;
 }
