@@ -63,7 +63,7 @@ static long model_cost(int nw, int n_chunks, int n_blk, int nt, int cpt, int K, 
         const int chunks = (40 + (nw * 10) / 65 + 255) / 256, ntrip = (nw + 255) / 256;
         const long instr = (long)((chunks + wpp - 1) / wpp) * 260 + (long)((ntrip + wpp - 1) / wpp) * 60 +
                            3 * (nw / (64 * wpp) + 1) + 150;
-        const long per_instr = nt == 1024 ? 16 : nt == 512 ? 13 : 12;       // measured (m = 200 k, MI355X)
+        const long per_instr = nt >= 512 ? 13 : 12;                         // cycles, measured (m = 200 k, MI355X)
         tA = (instr * per_instr + 1600) / K;
     }
     const long wgs = (long)n_blk * slices;

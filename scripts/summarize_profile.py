@@ -12,6 +12,8 @@ import shutil
 import sys
 
 tag = sys.argv[1]
+workload = sys.argv[2] if len(sys.argv) > 2 else "c2"          # what bench.py was run with under rocprofv3
+sites = int(sys.argv[3]) if len(sys.argv) > 3 else 1000000
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles", tag)
@@ -50,8 +52,10 @@ if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                                    "fetch_scale_from_calibration": k}
     meta = json.load(open(os.path.join(root, "gpurun_out", "bench_for_%s.json" % tag))) if os.path.exists(
         os.path.join(root, "gpurun_out", "bench_for_%s.json" % tag)) else {}
-    json.dump({"tag": tag, "workload": "c2", "sites": 1000000, "hbm_bytes_per_launch": fetch + write,
-               "fetch_bytes": fetch, "write_bytes": write, "fetch_scale": k, "kernel": kname},
-              open(os.path.join(root, "profiles", "traffic_latest.json"), "w"), indent=1)
+    traffic = {"tag": tag, "workload": workload, "sites": sites, "hbm_bytes_per_launch": fetch + write,
+               "fetch_bytes": fetch, "write_bytes": write, "fetch_scale": k, "kernel": kname}
+    json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+    if workload == "c2" and sites == 1000000:        # the headline configuration: what bench.py reports as roofline.traffic
+        json.dump(traffic, open(os.path.join(root, "profiles", "traffic_latest.json"), "w"), indent=1)
 json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])
