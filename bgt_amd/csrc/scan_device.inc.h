@@ -73,27 +73,31 @@ __device__ __forceinline__ uint32_t rle_len(uint32_t byte)
 // the scan kernel
 // ----------------------------------------------------------------------------------------------------
 // ----------------------------------------------------------------------------------------------------
-// The row step.  For one tracked column and one plane:   e = B[r>>5] = {32 bits, ones before them}
-//     bit = e.bits[r&31] ;  ob = e.before + popc(e.bits & low(r&31)) = rank1(r)
-//     r   = bit ? n0 + ob : r - ob                                  (LF-mapping)
-// Ten VALU instructions and one ds_read_b64 per lookup; the v_cmp that steers the select is also the
+// The row step.  For one tracked column and one plane:   e = B[r>>5] = {32 row bits, ones before them}
+//     bit = e.bits[r&31] ;  rank1(r) = e.before + popc(e.bits & low(r&31))
+//     r   = bit ? n0 + rank1(r) : r - rank1(r)                      (LF-mapping)
+// The registers hold the COMPLEMENT q = ~r, which saves an instruction: the shift amount q&31 = 31-(r&31)
+// puts bit r&31 of the word into the sign position and drops the bits above it in one v_lshlrev, so
+//     t   = e.bits << (q & 31)          bit = t < 0          oi = e.before + popc(t)   (ones up to and incl. r)
+//     q   = bit ? (-n0) - oi : q + oi
+// and the word address base + 8 (r>>5) = (base - 8) - 8 (q >>arith 5) is one v_mad_i32_i24.
+// Eight VALU instructions and one ds_read_b64 per lookup; the v_cmp that steers the select is also the
 // wave ballot of the decoded bit.  Hand-scheduled: left to hipcc the unrolled row body keeps one
 // 64-bit SGPR condition per lookup alive to the end of the row and spills (measured: 151 VGPRs and
-// 333 v_writelane/v_readlane at 16 columns per thread; this form needs 2 VGPRs per column + 12).
-// Two columns x two planes per statement = 4 LDS reads in flight per wave.  Scratch registers are
-// named (v112..v123) and declared as clobbers; every ds_read is waited for inside the statement.
+// 333 v_writelane/v_readlane at 16 columns per thread; this form needs 2 VGPRs per column + 24).
+// Scratch registers are named (v104..v127) and declared as clobbers; every ds_read is waited for
+// inside the statement.  BASE operands are (LDS address of the plane-row) - 8, N0 operands are -n0.
 // ----------------------------------------------------------------------------------------------------
-#define BGTH_TAIL(R, ELO, EHI, T, MASK, N0)            \
-    "v_bfe_u32 " T ", " ELO ", 0, " R "\n\t"           \
-    "v_bcnt_u32_b32 " T ", " T ", " EHI "\n\t"         \
-    "v_bfe_u32 " ELO ", " ELO ", " R ", 1\n\t"         \
-    "v_cmp_ne_u32_e64 " MASK ", 0, " ELO "\n\t"        \
-    "v_sub_u32 " EHI ", " R ", " T "\n\t"              \
-    "v_add_u32 " T ", " N0 ", " T "\n\t"               \
-    "v_cndmask_b32_e64 " R ", " EHI ", " T ", " MASK "\n\t"
-#define BGTH_ADDR(T, R, BASE)                          \
-    "v_lshrrev_b32 " T ", 5, " R "\n\t"                \
-    "v_lshl_add_u32 " T ", " T ", 3, " BASE "\n\t"
+#define BGTH_TAIL(Q, ELO, EHI, T, MASK, N0)            \
+    "v_lshlrev_b32 " ELO ", " Q ", " ELO "\n\t"        \
+    "v_bcnt_u32_b32 " EHI ", " ELO ", " EHI "\n\t"     \
+    "v_cmp_gt_i32_e64 " MASK ", 0, " ELO "\n\t"        \
+    "v_sub_u32 " T ", " N0 ", " EHI "\n\t"             \
+    "v_add_u32 " EHI ", " Q ", " EHI "\n\t"            \
+    "v_cndmask_b32_e64 " Q ", " EHI ", " T ", " MASK "\n\t"
+#define BGTH_ADDR(T, Q, BASE)                          \
+    "v_ashrrev_i32 " T ", 5, " Q "\n\t"                \
+    "v_mad_i32_i24 " T ", " T ", -8, " BASE "\n\t"
 
 // per column, on the scalar unit (keeps the VALU for the lookups): ones of plane 0, ones of plane 1,
 // ones in both.  M0/M1 are the ballots the v_cmp of the two lookups produced.
@@ -506,8 +510,8 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
         for (int j = 0; j < CPT; ++j) {
             const int c = chunk0 + j;
             const int col = (c < a.n_chunks && !(a.debug_skip & 8)) ? a.slot_col[c * 64 + lane] : -1;
-            r0[j] = col >= 0 ? (uint32_t)rk[col] : pad_rank;
-            r1[j] = col >= 0 ? (uint32_t)rk[m + col] : pad_rank;
+            r0[j] = ~(col >= 0 ? (uint32_t)rk[col] : pad_rank);             // complemented ranks (see the row step)
+            r1[j] = ~(col >= 0 ? (uint32_t)rk[m + col] : pad_rank);
         }
     }
     if (MULTI) for (int i = tid; i < (TEAM ? 1 : 2) * K * G * 3; i += NT) lcnt[i] = 0;
@@ -705,10 +709,11 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
         const uint32_t bufbase = lds0 + (uint32_t)(buf * bd_stride) * 8u;
         if (!(a.debug_skip & 1))
         for (int k = 0; k < Kc; ++k) {
-            const uint32_t base0 = bufbase + (uint32_t)(2 * k) * (uint32_t)nwp * 8u;    // LDS byte addresses
+            // operands of the row step: (LDS byte address of the plane-row) - 8 and -n0 (see BGTH_TAIL)
+            const uint32_t base0 = bufbase + (uint32_t)(2 * k) * (uint32_t)nwp * 8u - 8u;
             const uint32_t base1 = base0 + (uint32_t)nwp * 8u;
-            const uint32_t n00 = __builtin_amdgcn_readfirstlane(n0b[2 * k]);
-            const uint32_t n01 = __builtin_amdgcn_readfirstlane(n0b[2 * k + 1]);
+            const uint32_t n00 = 0u - (uint32_t)__builtin_amdgcn_readfirstlane(n0b[2 * k]);
+            const uint32_t n01 = 0u - (uint32_t)__builtin_amdgcn_readfirstlane(n0b[2 * k + 1]);
             const bool emit = (rb + k) >= a.row0;
             // ones of plane 0, ones of plane 1, ones in both:  n(code1) = ca - cc, n(code2) = cb - cc
             uint32_t ca = 0, cb = 0, cc = 0;
@@ -831,7 +836,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
             const int c = chunk0 + j;
             if (c < a.n_chunks) {
                 const int col = a.slot_col[c * 64 + lane];
-                if (col >= 0) { a.final_rank[col] = (int32_t)r0[j]; a.final_rank[m + col] = (int32_t)r1[j]; }
+                if (col >= 0) { a.final_rank[col] = (int32_t)~r0[j]; a.final_rank[m + col] = (int32_t)~r1[j]; }
             }
         }
     }

@@ -34,7 +34,7 @@ static int lds_need(int nw, int K, int G, int threads, int nbuf = 1)
 
 // Cost model (cycles per decoded row on one CU; the kernel is VALU-bound at one wave-instruction per
 // 4 cycles and SIMD, measured on MI355X):
-//   phase B   9 VALU per lookup -> cpt * 2 planes * 9 * 4 cycles * (threads/256 waves per SIMD)
+//   phase B   8 VALU per lookup -> cpt * 2 planes * 8 * 4 cycles * (threads/256 waves per SIMD)
 //   phase A   ~(120 + 0.4 * nw) wave-instructions per plane-row, two plane-rows per row, built by
 //             (threads/64) waves over a batch of K rows
 // Workgroups (blocks x slices) are spread over the 256 CUs; a CU's workgroups share its VALUs.
@@ -49,7 +49,7 @@ static long model_cost(int nw, int n_chunks, int n_blk, int nt, int cpt, int K, 
 {
     const int nwave = nt / 64, cap = nwave * cpt;
     const int slices = (n_chunks + cap - 1) / cap;
-    const long tB = (long)cpt * 72 * (nt / 256) * (nt == 1024 ? 100 : 115) / 100;   // measured: 2 waves per SIMD fill the VALU less well
+    const long tB = (long)cpt * 64 * (nt / 256) * (nt == 1024 ? 100 : 115) / 100;   // measured: 2 waves per SIMD fill the VALU less well
     const long lat = 8 + 5 * (nt / 256);                 // cycles per dependent instruction of a building wave
     const int wpp = wpp_for(nt, K);
     long tA;
