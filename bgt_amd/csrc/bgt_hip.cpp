@@ -71,12 +71,14 @@ struct Selection {
 struct bgth_pbf_s {
     int device = 0;
     int32_t m = 0, g = 0, shift = 0;
-    int64_t n = 0, n_blk = 0;
+    int32_t sub_shift = 0;            // sub-checkpoints every 1 << sub_shift rows (<= shift), see derive_sub_checkpoints
+    int64_t n = 0, n_blk = 0;         // n_blk: file blocks of 1 << shift rows
+    int64_t n_sub = 0;                // sub-blocks of 1 << sub_shift rows: the unit the kernels work on
     int64_t rle_bytes = 0;            // RLE payload as in the file
     int64_t packed_bytes = 0;         // payload + padding of every string to 4 bytes
     uint8_t  *d_rle = nullptr;
     uint64_t *d_rowdesc = nullptr;
-    int32_t  *d_rank0 = nullptr;      // [n_blk][2][m] ranks by column at every checkpoint
+    int32_t  *d_rank0 = nullptr;      // [n_sub][2][m] ranks by column at every (sub-)checkpoint
     // row index (scan_kernels.h), built on the first wide-cohort (team-mode) launch
     uint32_t *d_chunkinfo = nullptr, *d_segc = nullptr;
     int32_t   S8 = 0;
@@ -225,6 +227,13 @@ static bool build_selection(Selection &s, int m, int n_sub, const int32_t *sub, 
 // ----------------------------------------------------------------------------------------------------
 // .pbf image -> HBM
 // ----------------------------------------------------------------------------------------------------
+static void set_rows(bgth_pbf_t *p, int64_t n)
+{
+    p->n = n;
+    p->n_blk = (n + ((int64_t)1 << p->shift) - 1) >> p->shift;
+    p->n_sub = (n + ((int64_t)1 << p->sub_shift) - 1) >> p->sub_shift;
+}
+
 static bgth_pbf_t *pbf_alloc(int device, int m, int g, int shift, int64_t n)
 {
     if (g != 2) { set_err("[E::bgth_pbf] only g=2 bit planes are supported (BGT writes 2, import.c:68); got %d", g); return nullptr; }
@@ -235,8 +244,14 @@ static bgth_pbf_t *pbf_alloc(int device, int m, int g, int shift, int64_t n)
         return nullptr;
     }
     bgth_pbf_t *p = new bgth_pbf_s();
-    p->device = device; p->m = m; p->g = g; p->shift = shift; p->n = n;
-    p->n_blk = (n + ((int64_t)1 << shift) - 1) >> shift;
+    p->device = device; p->m = m; p->g = g; p->shift = shift;
+    // Sub-checkpoints: the file carries the permutation every 1 << shift (8192) rows; the image keeps the rank
+    // form every 1 << sub_shift rows, derived once on the device.  Finer units = more workgroups per launch (a
+    // whole-cohort scan of few blocks fills the GPU without slicing columns, which would repeat the per-row
+    // bit-vector build) and shorter pre-rolls for region queries.  Costs rows * m / 2^(sub_shift-3) bytes of HBM.
+    p->sub_shift = std::min(shift, 11);
+    if (const char *e = getenv("BGTH_SUB_SHIFT")) p->sub_shift = std::max(0, std::min(shift, atoi(e)));
+    set_rows(p, n);
     return p;
 }
 
@@ -251,6 +266,8 @@ extern "C" void bgth_pbf_close(bgth_pbf_t *p)
     if (p->d_segc) hipFree(p->d_segc);
     delete p;
 }
+
+static bool derive_sub_checkpoints(bgth_pbf_t *p);
 
 // Walks the record stream of an image (format: SURVEY.md App. A; ref pbwt.c:288-311 writer,
 // :313-337 reader) and splits it into packed RLE bytes, row descriptors and checkpoint permutations.
@@ -307,8 +324,7 @@ extern "C" bgth_pbf_t *bgth_pbf_open_mem(const void *image, size_t len, int devi
     }
     if (n_footer >= 0 && n_footer != row) { set_err("[E::bgth_pbf_open] footer says %lld rows, stream has %lld", (long long)n_footer, (long long)row); goto fail; }
     if (rle.size() >= ((size_t)1 << kDescLenShift)) { set_err("[E::bgth_pbf_open] RLE payload too large"); goto fail; }
-    p->n = row;
-    p->n_blk = (row + blk_rows - 1) >> shift;
+    set_rows(p, row);
     p->rle_bytes = payload;
     p->packed_bytes = (int64_t)rle.size();
     {
@@ -318,16 +334,20 @@ extern "C" bgth_pbf_t *bgth_pbf_open_mem(const void *image, size_t len, int devi
         if (!rle.empty()) HIP_TRY(hipMemcpy(p->d_rle, rle.data(), rle.size(), hipMemcpyHostToDevice), goto fail);
         HIP_TRY(hipMalloc((void**)&p->d_rowdesc, std::max<size_t>(desc.size(), 1) * 8), goto fail);
         if (!desc.empty()) HIP_TRY(hipMemcpy(p->d_rowdesc, desc.data(), desc.size() * 8, hipMemcpyHostToDevice), goto fail);
-        // checkpoints: permutation (rank -> column) to rank form (column -> rank), on the device
-        const size_t np = perms.size();
+        // checkpoints: permutation (rank -> column) to rank form (column -> rank), on the device, each at the
+        // sub-block index of its row; then one decode pass fills the sub-checkpoints in between
+        const size_t np = perms.size(), per = (size_t)2 * m;
         if (np) {
+            const int d = p->shift - p->sub_shift;
             int32_t *d_perm = nullptr;
             HIP_TRY(hipMalloc((void**)&d_perm, np * 4), goto fail);
-            HIP_TRY(hipMalloc((void**)&p->d_rank0, np * 4), { hipFree(d_perm); goto fail; });
+            HIP_TRY(hipMalloc((void**)&p->d_rank0, std::max<int64_t>(p->n_sub, 1) * per * 4), { hipFree(d_perm); goto fail; });
             HIP_TRY(hipMemcpy(d_perm, perms.data(), np * 4, hipMemcpyHostToDevice), { hipFree(d_perm); goto fail; });
-            HIP_TRY(launch_invert(d_perm, p->d_rank0, m, (int64_t)(np / m), nullptr), { hipFree(d_perm); goto fail; });
+            for (size_t b = 0; b < np / per; ++b)
+                HIP_TRY(launch_invert(d_perm + b * per, p->d_rank0 + ((size_t)b << d) * per, m, 2, nullptr), { hipFree(d_perm); goto fail; });
             HIP_TRY(hipDeviceSynchronize(), { hipFree(d_perm); goto fail; });
             hipFree(d_perm);
+            if (!derive_sub_checkpoints(p)) goto fail;
         }
     }
     return p;
@@ -349,23 +369,37 @@ extern "C" bgth_pbf_t *bgth_pbf_open(const char *path, int device)
     return bgth_pbf_open_mem(buf.data(), buf.size(), device);
 }
 
-static bool run_block_pass(bgth_pbf_t *p, Selection &all, int64_t blk, int32_t *d_final, hipStream_t s)
+// Decode pass over the FILE blocks [blk, blk + n_blk) that emits nothing but ranks: the sub-checkpoints inside
+// the blocks (always) and the ranks after the last row (d_final, optional: the next block's checkpoint when an
+// image is built from bare RLE strings).
+static bool run_block_pass(bgth_pbf_t *p, Selection &all, int64_t blk, int64_t n_blk, int32_t *d_final, hipStream_t s)
 {
     Geometry geo;
-    if (!choose_geometry(p->m, all.n_chunks, 1, 1, 0, 0, 0, &geo, !debug_flag(0x200))) { set_err("[E::bgth] geometry"); return false; }
+    if (!choose_geometry(p->m, all.n_chunks, 1, (int)n_blk, 0, 0, 0, &geo, !debug_flag(0x200))) { set_err("[E::bgth] geometry"); return false; }
     ScanArgs a;
     memset(&a, 0, sizeof(a));
     a.rle = p->d_rle; a.rowdesc = p->d_rowdesc;
-    a.rank0 = p->d_rank0; a.rank0_blk_stride = (int64_t)2 * p->m;
+    a.rank0 = p->d_rank0; a.rank0_blk_stride = ((int64_t)2 * p->m) << (p->shift - p->sub_shift);   // file block b -> its sub index
     a.slot_col = all.d_slot_col; a.chunk_desc = all.d_chunk_desc;
     a.raw_counts = nullptr; a.h0 = a.h1 = nullptr; a.final_rank = d_final;
+    if (p->sub_shift < p->shift) { a.snap = p->d_rank0; a.snap_shift = p->sub_shift; }
     a.m = p->m; a.nw = (p->m + 31) / 32; a.shift = p->shift; a.n_chunks = all.n_chunks; a.G = 1; a.K = geo.K; a.wpp = geo.wpp; a.nbuf = geo.nbuf;
     if (geo.wpp > 1) { if (!ensure_rowindex(p, s)) return false; a.chunkinfo = p->d_chunkinfo; a.segc = p->d_segc; a.S8 = p->S8; a.tog_off = geo.tog_off; }
-    a.blk0 = (int32_t)blk; a.n_blk = 1; a.n_slices = geo.slices;
-    a.row1 = std::min<int64_t>(p->n, (blk + 1) << p->shift);
-    a.row0 = a.row1;                      // nothing emitted: only the final ranks are wanted
+    a.blk0 = (int32_t)blk; a.n_blk = (int32_t)n_blk; a.n_slices = geo.slices;
+    a.row1 = std::min<int64_t>(p->n, (blk + n_blk) << p->shift);
+    a.row0 = a.row1;                      // nothing emitted: only ranks are wanted
     HIP_TRY(launch_scan(a, geo, s), return false);
     return true;
+}
+
+static bool derive_sub_checkpoints(bgth_pbf_t *p)
+{
+    if (p->sub_shift >= p->shift || p->n <= ((int64_t)1 << p->sub_shift)) return true;
+    Selection all;
+    bool ok = build_selection(all, p->m, 0, nullptr, nullptr, 1) && run_block_pass(p, all, 0, p->n_blk, nullptr, nullptr);
+    if (ok && hipDeviceSynchronize() != hipSuccess) { set_err("[E::bgth_pbf_open] sub-checkpoint pass failed"); ok = false; }
+    all.release();
+    return ok;
 }
 
 extern "C" bgth_pbf_t *bgth_pbf_from_rle(int m, int g, int shift, int64_t n_rows, const uint8_t *rle,
@@ -401,14 +435,15 @@ extern "C" bgth_pbf_t *bgth_pbf_from_rle(int m, int g, int shift, int64_t n_rows
         HIP_TRY(hipMalloc((void**)&p->d_rowdesc, std::max<size_t>(desc.size(), 1) * 8), goto fail);
         if (!desc.empty()) HIP_TRY(hipMemcpy(p->d_rowdesc, desc.data(), desc.size() * 8, hipMemcpyHostToDevice), goto fail);
         const size_t per = (size_t)2 * m;
-        HIP_TRY(hipMalloc((void**)&p->d_rank0, std::max<int64_t>(p->n_blk, 1) * per * 4), goto fail);
+        HIP_TRY(hipMalloc((void**)&p->d_rank0, std::max<int64_t>(p->n_sub, 1) * per * 4), goto fail);
         std::vector<int32_t> ident(per);
         for (int k = 0; k < 2; ++k) for (int j = 0; j < m; ++j) ident[(size_t)k * m + j] = j;   // ref pbwt.c:103
         HIP_TRY(hipMemcpy(p->d_rank0, ident.data(), per * 4, hipMemcpyHostToDevice), goto fail);
         if (!build_selection(all, m, 0, nullptr, nullptr, 1)) goto fail;
         // block b's final ranks are block b+1's checkpoint: strictly sequential, one launch per block
-        for (int64_t b = 0; b + 1 < p->n_blk; ++b)
-            if (!run_block_pass(p, all, b, p->d_rank0 + (size_t)(b + 1) * per, nullptr)) goto fail;
+        // (the pass over a block also leaves the block's sub-checkpoints)
+        for (int64_t b = 0; b < p->n_blk; ++b)
+            if (!run_block_pass(p, all, b, 1, b + 1 < p->n_blk ? p->d_rank0 + ((size_t)(b + 1) << (p->shift - p->sub_shift)) * per : nullptr, nullptr)) goto fail;
         HIP_TRY(hipDeviceSynchronize(), goto fail);
     }
     all.release();
@@ -441,7 +476,7 @@ extern "C" int64_t bgth_pbf_save(const bgth_pbf_t *p, const char *path)
         fwrite("PBF\1", 1, 4, fp); fwrite(hdr, 4, 3, fp);
         for (int64_t r = 0; r < p->n; ++r) {
             if ((r & (((int64_t)1 << p->shift) - 1)) == 0) {
-                const int64_t b = r >> p->shift;
+                const int64_t b = r >> p->sub_shift;                    // the sub-checkpoint at a file block's first row
                 HIP_TRY(launch_invert(p->d_rank0 + (size_t)b * per, d_perm, m, 2, nullptr), goto done);
                 HIP_TRY(hipMemcpy(perm.data(), d_perm, per * 4, hipMemcpyDeviceToHost), goto done);
                 idx.push_back((uint64_t)ftell(fp));
@@ -476,7 +511,7 @@ extern "C" int64_t bgth_pbf_get_n(const bgth_pbf_t *p) { return p->n; }
 extern "C" int64_t bgth_pbf_rle_bytes(const bgth_pbf_t *p) { return p->rle_bytes; }
 extern "C" int64_t bgth_pbf_hbm_bytes(const bgth_pbf_t *p)
 {
-    return p->packed_bytes + 256 + p->n * 2 * 8 + p->n_blk * 2 * (int64_t)p->m * 4 + p->rowindex_bytes;
+    return p->packed_bytes + 256 + p->n * 2 * 8 + p->n_sub * 2 * (int64_t)p->m * 4 + p->rowindex_bytes;
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -543,7 +578,7 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
     const int64_t rows = row1 - row0;
     if (rows == 0) return 0;
     const int G = r->sel.G;
-    const int64_t blk0 = row0 >> p->shift, blk1 = (row1 - 1) >> p->shift;
+    const int64_t blk0 = row0 >> p->sub_shift, blk1 = (row1 - 1) >> p->sub_shift;      // sub-blocks
     Geometry geo;
     if (!choose_geometry(p->m, r->sel.n_chunks, G, (int)(blk1 - blk0 + 1), r->tune_threads, r->tune_cpt, r->tune_K, &geo, !debug_flag(0x200))) {
         set_err("[E::bgth_reader_scan] no launch geometry for m=%d (threads=%d cpt=%d)", p->m, r->tune_threads, r->tune_cpt);
@@ -557,7 +592,7 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
     a.rank0 = p->d_rank0; a.rank0_blk_stride = (int64_t)2 * p->m;
     a.slot_col = r->sel.d_slot_col; a.chunk_desc = r->sel.d_chunk_desc;
     a.raw_counts = (int32_t*)r->raw.p; a.h0 = d_h0; a.h1 = d_h1; a.final_rank = nullptr;
-    a.m = p->m; a.nw = (p->m + 31) / 32; a.shift = p->shift; a.n_chunks = r->sel.n_chunks; a.G = G; a.K = geo.K; a.wpp = geo.wpp; a.nbuf = geo.nbuf;
+    a.m = p->m; a.nw = (p->m + 31) / 32; a.shift = p->sub_shift; a.n_chunks = r->sel.n_chunks; a.G = G; a.K = geo.K; a.wpp = geo.wpp; a.nbuf = geo.nbuf;
     if (geo.wpp > 1) { if (!ensure_rowindex(p, s)) return -1; a.chunkinfo = p->d_chunkinfo; a.segc = p->d_segc; a.S8 = p->S8; a.tog_off = geo.tog_off; }
     a.blk0 = (int32_t)blk0; a.n_blk = (int32_t)(blk1 - blk0 + 1); a.n_slices = geo.slices;
     a.row0 = row0; a.row1 = row1;
@@ -624,14 +659,14 @@ extern "C" int64_t bgth_reader_scan(bgth_reader_t *r, int64_t row0, int64_t row1
     if (gt) {
         const int64_t per_row = (int64_t)r->sel.n_chunks * 16 + nb;
         int64_t max_rows = ((int64_t)1 << 30) / std::max<int64_t>(per_row, 1);
-        const int64_t blk_rows = (int64_t)1 << p->shift;
+        const int64_t blk_rows = (int64_t)1 << p->sub_shift;
         max_rows = std::max<int64_t>(blk_rows, max_rows / blk_rows * blk_rows);
         piece = std::min(piece, max_rows);
     }
     for (int64_t a0 = row0; a0 < row1;) {
         // pieces end on block boundaries so that no block is decoded twice
         int64_t a1 = std::min(row1, a0 + piece);
-        if (a1 < row1) a1 = std::max<int64_t>(a0 + 1, (a1 >> p->shift) << p->shift);
+        if (a1 < row1) a1 = std::max<int64_t>(a0 + 1, (a1 >> p->sub_shift) << p->sub_shift);
         const int64_t rows = a1 - a0;
         if (!r->fin.reserve((size_t)rows * cstride * 4)) { set_err("[E::bgth_reader_scan] out of HBM"); return -1; }
         uint64_t *d_h0 = nullptr, *d_h1 = nullptr;
@@ -680,7 +715,7 @@ extern "C" int bgth_reader_seek(bgth_reader_t *r, int64_t row)
 static bool refill(bgth_reader_t *r)
 {
     bgth_pbf_t *p = r->pbf;
-    const int64_t blk_rows = (int64_t)1 << p->shift;
+    const int64_t blk_rows = (int64_t)1 << p->sub_shift;
     const int width = r->sel.width;
     const int gx = gx_of(r->sel.G);
     const size_t cstride = (size_t)(1 + gx) * 3;
@@ -690,7 +725,7 @@ static bool refill(bgth_reader_t *r)
     if (r->max_ahead > 0) max_rows = std::min(max_rows, r->max_ahead);
     max_rows = std::max<int64_t>(blk_rows, max_rows / blk_rows * blk_rows);
     const int64_t row0 = r->next;
-    int64_t row1 = std::min<int64_t>(p->n, ((row0 >> p->shift) << p->shift) + max_rows);
+    int64_t row1 = std::min<int64_t>(p->n, ((row0 >> p->sub_shift) << p->sub_shift) + max_rows);
     const int64_t rows = row1 - row0;
     const size_t pl = (size_t)rows * r->sel.n_chunks * 8, by = (size_t)rows * width;
     if (!r->fin.reserve((size_t)rows * cstride * 4) || !r->h_counts.reserve((size_t)rows * cstride * 4)) {

@@ -715,6 +715,16 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
             const uint32_t n00 = 0u - (uint32_t)__builtin_amdgcn_readfirstlane(n0b[2 * k]);
             const uint32_t n01 = 0u - (uint32_t)__builtin_amdgcn_readfirstlane(n0b[2 * k + 1]);
             const bool emit = (rb + k) >= a.row0;
+            if (a.snap && rb + k > blk_beg && ((rb + k) & (((int64_t)1 << a.snap_shift) - 1)) == 0) {
+                // sub-checkpoint: the ranks before this row (image-open pass only)
+                int32_t *dst = a.snap + ((rb + k) >> a.snap_shift) * (int64_t)(2 * m);
+#pragma unroll
+                for (int j = 0; j < CPT; ++j) {
+                    const int c = chunk0 + j;
+                    const int col = c < a.n_chunks ? a.slot_col[c * 64 + lane] : -1;
+                    if (col >= 0) { dst[col] = (int32_t)~r0[j]; dst[m + col] = (int32_t)~r1[j]; }
+                }
+            }
             // ones of plane 0, ones of plane 1, ones in both:  n(code1) = ca - cc, n(code2) = cb - cc
             uint32_t ca = 0, cb = 0, cc = 0;
             constexpr int NKEEP = (CPT + 63) / 64;                     // lane l keeps the masks of chunks l, l + 64

@@ -34,6 +34,8 @@ struct ScanArgs {
     int32_t        *raw_counts;  // [(row1-row0)][G][3] += {n(code1), n(code2), n(code3)}
     uint64_t       *h0, *h1;     // optional [(row1-row0)][n_chunks] bit planes in slot order
     int32_t        *final_rank;  // optional [2][m]: ranks by column after the last row of the launch
+    int32_t        *snap;        // optional: sub-checkpoints, ranks by column BEFORE every row that is a multiple of
+    int32_t         snap_shift;  //   1 << snap_shift (block starts excepted), at snap[(row >> snap_shift) * 2m]
     const uint32_t *chunkinfo;   // row index (see above); only read by the team (wide-cohort) kernels
     const uint32_t *segc;
     int32_t  m, nw, shift, n_chunks, G, K, wpp, nbuf, S8;

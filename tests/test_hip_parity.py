@@ -220,6 +220,37 @@ def test_wide_cohort_team_mode(hip, threads, cpt, K, in_place, monkeypatch):
     assert np.array_equal(c2, o2) and np.array_equal(g2, og2)
 
 
+@pytest.mark.parametrize("sub", [None, "9", "13"])
+def test_sub_checkpoints(hip, tmp_path, monkeypatch, sub):
+    """The image keeps rank-form checkpoints every 2^11 rows (derived on the device from the file's 'S' records
+    every 2^13): scans and seeks that start inside a file block, and the saved file, must not notice."""
+    if sub:
+        monkeypatch.setenv("BGTH_SUB_SHIFT", sub)
+    mat, data, rng = make_case(61, 300, 20000, 13, n_founders=12, switch=0.03)
+    oc, ogt = oracle_scan(data, 0, 20000)
+    for maker in ("bytes", "rle"):
+        if maker == "bytes":
+            pbf = hip.HipPbf.from_bytes(data)
+        else:
+            m_, shift_, strings = split_rle(data)
+            pbf = hip.HipPbf.from_rle(300, 13, np.frombuffer(b"".join(strings), np.uint8),
+                                      np.array([len(x) for x in strings], np.uint32))
+        rd = hip.HipReader(pbf)
+        counts, gt = rd.scan(0, 20000, want_gt=True)
+        assert np.array_equal(counts, oc) and np.array_equal(gt, ogt)
+        for a, b in [(2047, 2050), (2048, 4096), (5000, 5001), (8191, 8193), (10240, 19999), (16384, 20000)]:
+            c2, g2 = rd.scan(a, b, want_gt=True)
+            assert np.array_equal(c2, oc[a:b]) and np.array_equal(g2, ogt[a:b]), (a, b)
+        cols = np.array([5, 4, 299, 0, 17, 16], np.int32)
+        rd.select(cols)
+        rd.seek(12345)
+        got = np.stack([rd.read() for _ in range(3)])
+        assert np.array_equal(got[:, 0] | (got[:, 1] << 1), mat[12345:12348][:, cols])
+        out = str(tmp_path / ("re_%s.pbf" % maker))
+        pbf.save(out)
+        assert open(out, "rb").read() == data
+
+
 def split_rle(data):
     m, g, shift = struct.unpack("<iii", data[4:16])
     pos, strings = 16, []
