@@ -84,9 +84,10 @@ __device__ __forceinline__ uint32_t rle_len(uint32_t byte)
 // Eight VALU instructions and one ds_read_b64 per lookup; the v_cmp that steers the select is also the
 // wave ballot of the decoded bit.  Hand-scheduled: left to hipcc the unrolled row body keeps one
 // 64-bit SGPR condition per lookup alive to the end of the row and spills (measured: 151 VGPRs and
-// 333 v_writelane/v_readlane at 16 columns per thread; this form needs 2 VGPRs per column + 24).
-// Scratch registers are named (v104..v127) and declared as clobbers; every ds_read is waited for
-// inside the statement.  BASE operands are (LDS address of the plane-row) - 8, N0 operands are -n0.
+// 333 v_writelane/v_readlane at 16 columns per thread; this form needs 2 VGPRs per column + 16).
+// Scratch registers are named (v104..v119) and declared as clobbers; every ds_read is waited for
+// inside the statement; a lookup needs two of them: the low one is first the LDS address, then the shifted
+// word, then the candidate for bit = 1.  BASE operands are (LDS address of the plane-row) - 8, N0 operands are -n0.
 // ----------------------------------------------------------------------------------------------------
 #define BGTH_TAIL(Q, ELO, EHI, T, MASK, N0)            \
     "v_lshlrev_b32 " ELO ", " Q ", " ELO "\n\t"        \
@@ -118,27 +119,26 @@ __device__ __forceinline__ void step2(uint32_t &ra0, uint32_t &ra1, uint32_t &rb
 {
     asm volatile(
         "s_waitcnt lgkmcnt(0)\n\t"
-        BGTH_ADDR("v120", "%0", "%11") BGTH_ADDR("v121", "%1", "%12")
-        BGTH_ADDR("v122", "%2", "%11") BGTH_ADDR("v123", "%3", "%12")
-        "ds_read_b64 v[104:105], v120\n\t"
-        "ds_read_b64 v[106:107], v121\n\t"
-        "ds_read_b64 v[108:109], v122\n\t"
-        "ds_read_b64 v[110:111], v123\n\t"
+        BGTH_ADDR("v104", "%0", "%11") BGTH_ADDR("v106", "%1", "%12")
+        BGTH_ADDR("v108", "%2", "%11") BGTH_ADDR("v110", "%3", "%12")
+        "ds_read_b64 v[104:105], v104\n\t"
+        "ds_read_b64 v[106:107], v106\n\t"
+        "ds_read_b64 v[108:109], v108\n\t"
+        "ds_read_b64 v[110:111], v110\n\t"
         "s_waitcnt lgkmcnt(3)\n\t"
-        BGTH_TAIL("%0", "v104", "v105", "v120", "%4", "%13")
+        BGTH_TAIL("%0", "v104", "v105", "v104", "%4", "%13")
         "s_waitcnt lgkmcnt(2)\n\t"
-        BGTH_TAIL("%1", "v106", "v107", "v121", "%5", "%14")
+        BGTH_TAIL("%1", "v106", "v107", "v106", "%5", "%14")
         BGTH_COUNT("%4", "%5", "%8", "%9", "%10")
         "s_waitcnt lgkmcnt(1)\n\t"
-        BGTH_TAIL("%2", "v108", "v109", "v122", "%6", "%13")
+        BGTH_TAIL("%2", "v108", "v109", "v108", "%6", "%13")
         "s_waitcnt lgkmcnt(0)\n\t"
-        BGTH_TAIL("%3", "v110", "v111", "v123", "%7", "%14")
+        BGTH_TAIL("%3", "v110", "v111", "v110", "%7", "%14")
         BGTH_COUNT("%6", "%7", "%8", "%9", "%10")
         : "+v"(ra0), "+v"(ra1), "+v"(rb0), "+v"(rb1), "=&s"(ma0), "=&s"(ma1), "=&s"(mb0), "=&s"(mb1),
           "+s"(ca), "+s"(cb), "+s"(cc)
         : "s"(base0), "s"(base1), "s"(n00), "s"(n01)
-        : "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v120", "v121", "v122", "v123",
-          "vcc", "scc", "memory");
+        : "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "vcc", "scc", "memory");
 }
 
 // four columns x two planes: 8 LDS reads in flight
@@ -148,45 +148,44 @@ __device__ __forceinline__ void step4(uint32_t (&r0)[4], uint32_t (&r1)[4], uint
 {
     asm volatile(
         "s_waitcnt lgkmcnt(0)\n\t"
-        BGTH_ADDR("v120", "%0", "%19") BGTH_ADDR("v121", "%1", "%20")
-        BGTH_ADDR("v122", "%2", "%19") BGTH_ADDR("v123", "%3", "%20")
-        BGTH_ADDR("v124", "%4", "%19") BGTH_ADDR("v125", "%5", "%20")
-        BGTH_ADDR("v126", "%6", "%19") BGTH_ADDR("v127", "%7", "%20")
-        "ds_read_b64 v[104:105], v120\n\t"
-        "ds_read_b64 v[106:107], v121\n\t"
-        "ds_read_b64 v[108:109], v122\n\t"
-        "ds_read_b64 v[110:111], v123\n\t"
-        "ds_read_b64 v[112:113], v124\n\t"
-        "ds_read_b64 v[114:115], v125\n\t"
-        "ds_read_b64 v[116:117], v126\n\t"
-        "ds_read_b64 v[118:119], v127\n\t"
+        BGTH_ADDR("v104", "%0", "%19") BGTH_ADDR("v106", "%1", "%20")
+        BGTH_ADDR("v108", "%2", "%19") BGTH_ADDR("v110", "%3", "%20")
+        BGTH_ADDR("v112", "%4", "%19") BGTH_ADDR("v114", "%5", "%20")
+        BGTH_ADDR("v116", "%6", "%19") BGTH_ADDR("v118", "%7", "%20")
+        "ds_read_b64 v[104:105], v104\n\t"
+        "ds_read_b64 v[106:107], v106\n\t"
+        "ds_read_b64 v[108:109], v108\n\t"
+        "ds_read_b64 v[110:111], v110\n\t"
+        "ds_read_b64 v[112:113], v112\n\t"
+        "ds_read_b64 v[114:115], v114\n\t"
+        "ds_read_b64 v[116:117], v116\n\t"
+        "ds_read_b64 v[118:119], v118\n\t"
         "s_waitcnt lgkmcnt(7)\n\t"
-        BGTH_TAIL("%0", "v104", "v105", "v120", "%8", "%21")
+        BGTH_TAIL("%0", "v104", "v105", "v104", "%8", "%21")
         "s_waitcnt lgkmcnt(6)\n\t"
-        BGTH_TAIL("%1", "v106", "v107", "v121", "%9", "%22")
+        BGTH_TAIL("%1", "v106", "v107", "v106", "%9", "%22")
         BGTH_COUNT("%8", "%9", "%16", "%17", "%18")
         "s_waitcnt lgkmcnt(5)\n\t"
-        BGTH_TAIL("%2", "v108", "v109", "v122", "%10", "%21")
+        BGTH_TAIL("%2", "v108", "v109", "v108", "%10", "%21")
         "s_waitcnt lgkmcnt(4)\n\t"
-        BGTH_TAIL("%3", "v110", "v111", "v123", "%11", "%22")
+        BGTH_TAIL("%3", "v110", "v111", "v110", "%11", "%22")
         BGTH_COUNT("%10", "%11", "%16", "%17", "%18")
         "s_waitcnt lgkmcnt(3)\n\t"
-        BGTH_TAIL("%4", "v112", "v113", "v124", "%12", "%21")
+        BGTH_TAIL("%4", "v112", "v113", "v112", "%12", "%21")
         "s_waitcnt lgkmcnt(2)\n\t"
-        BGTH_TAIL("%5", "v114", "v115", "v125", "%13", "%22")
+        BGTH_TAIL("%5", "v114", "v115", "v114", "%13", "%22")
         BGTH_COUNT("%12", "%13", "%16", "%17", "%18")
         "s_waitcnt lgkmcnt(1)\n\t"
-        BGTH_TAIL("%6", "v116", "v117", "v126", "%14", "%21")
+        BGTH_TAIL("%6", "v116", "v117", "v116", "%14", "%21")
         "s_waitcnt lgkmcnt(0)\n\t"
-        BGTH_TAIL("%7", "v118", "v119", "v127", "%15", "%22")
+        BGTH_TAIL("%7", "v118", "v119", "v118", "%15", "%22")
         BGTH_COUNT("%14", "%15", "%16", "%17", "%18")
         : "+v"(r0[0]), "+v"(r1[0]), "+v"(r0[1]), "+v"(r1[1]), "+v"(r0[2]), "+v"(r1[2]), "+v"(r0[3]), "+v"(r1[3]),
           "=&s"(m0[0]), "=&s"(m1[0]), "=&s"(m0[1]), "=&s"(m1[1]), "=&s"(m0[2]), "=&s"(m1[2]), "=&s"(m0[3]), "=&s"(m1[3]),
           "+s"(ca), "+s"(cb), "+s"(cc)
         : "s"(base0), "s"(base1), "s"(n00), "s"(n01)
         : "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115",
-          "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127",
-          "vcc", "scc", "memory");
+          "v116", "v117", "v118", "v119", "vcc", "scc", "memory");
 }
 
 // ----------------------------------------------------------------------------------------------------
