@@ -717,10 +717,12 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
             if (a.snap && rb + k > blk_beg && ((rb + k) & (((int64_t)1 << a.snap_shift) - 1)) == 0) {
                 // sub-checkpoint: the ranks before this row (image-open pass only)
                 int32_t *dst = a.snap + ((rb + k) >> a.snap_shift) * (int64_t)(2 * m);
+                int ln = lane;
+                asm volatile("" : "+v"(ln));      // keeps the CPT slot addresses from being hoisted out of the row loop (VGPRs)
 #pragma unroll
                 for (int j = 0; j < CPT; ++j) {
                     const int c = chunk0 + j;
-                    const int col = c < a.n_chunks ? a.slot_col[c * 64 + lane] : -1;
+                    const int col = c < a.n_chunks ? a.slot_col[c * 64 + ln] : -1;
                     if (col >= 0) { dst[col] = (int32_t)~r0[j]; dst[m + col] = (int32_t)~r1[j]; }
                 }
             }
