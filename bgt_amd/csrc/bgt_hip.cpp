@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -269,6 +270,18 @@ extern "C" void bgth_pbf_close(bgth_pbf_t *p)
 
 static bool derive_sub_checkpoints(bgth_pbf_t *p);
 
+// BGTH_TRACE=1: wall-clock of the image-open stages on stderr (tuning aid)
+struct Trace {
+    bool on; std::chrono::steady_clock::time_point t0;
+    Trace() : on(getenv("BGTH_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void lap(const char *what) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[bgth trace] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 // Walks the record stream of an image (format: SURVEY.md App. A; ref pbwt.c:288-311 writer,
 // :313-337 reader) and splits it into packed RLE bytes, row descriptors and checkpoint permutations.
 extern "C" bgth_pbf_t *bgth_pbf_open_mem(const void *image, size_t len, int device)
@@ -285,7 +298,9 @@ extern "C" bgth_pbf_t *bgth_pbf_open_mem(const void *image, size_t len, int devi
         memcpy(&off, buf + len - 8, 8);
         if (off >= 16 && off + 13 <= len && buf[off] == 'I') { memcpy(&n_footer, buf + off + 1, 8); end = (size_t)off; }
     }
+    Trace tr;
     if (!use_device(device)) return nullptr;
+    tr.lap("device init");
     bgth_pbf_t *p = pbf_alloc(device, m, g, shift, 0);
     if (!p) return nullptr;
 
@@ -325,6 +340,7 @@ extern "C" bgth_pbf_t *bgth_pbf_open_mem(const void *image, size_t len, int devi
     if (n_footer >= 0 && n_footer != row) { set_err("[E::bgth_pbf_open] footer says %lld rows, stream has %lld", (long long)n_footer, (long long)row); goto fail; }
     if (rle.size() >= ((size_t)1 << kDescLenShift)) { set_err("[E::bgth_pbf_open] RLE payload too large"); goto fail; }
     set_rows(p, row);
+    tr.lap("parse records");
     p->rle_bytes = payload;
     p->packed_bytes = (int64_t)rle.size();
     {
@@ -334,6 +350,7 @@ extern "C" bgth_pbf_t *bgth_pbf_open_mem(const void *image, size_t len, int devi
         if (!rle.empty()) HIP_TRY(hipMemcpy(p->d_rle, rle.data(), rle.size(), hipMemcpyHostToDevice), goto fail);
         HIP_TRY(hipMalloc((void**)&p->d_rowdesc, std::max<size_t>(desc.size(), 1) * 8), goto fail);
         if (!desc.empty()) HIP_TRY(hipMemcpy(p->d_rowdesc, desc.data(), desc.size() * 8, hipMemcpyHostToDevice), goto fail);
+        tr.lap("upload strings");
         // checkpoints: permutation (rank -> column) to rank form (column -> rank), on the device, each at the
         // sub-block index of its row; then one decode pass fills the sub-checkpoints in between
         const size_t np = perms.size(), per = (size_t)2 * m;
@@ -347,7 +364,9 @@ extern "C" bgth_pbf_t *bgth_pbf_open_mem(const void *image, size_t len, int devi
                 HIP_TRY(launch_invert(d_perm + b * per, p->d_rank0 + ((size_t)b << d) * per, m, 2, nullptr), { hipFree(d_perm); goto fail; });
             HIP_TRY(hipDeviceSynchronize(), { hipFree(d_perm); goto fail; });
             hipFree(d_perm);
+            tr.lap("checkpoints -> rank form");
             if (!derive_sub_checkpoints(p)) goto fail;
+            tr.lap("sub-checkpoint pass");
         }
     }
     return p;
