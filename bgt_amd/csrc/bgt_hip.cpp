@@ -146,19 +146,21 @@ struct bgth_reader_s {
     Selection sel;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    DevBuf raw, fin, h0, h1, gt, planes;
-    HostBuf h_counts, h_planes;
+    DevBuf raw, fin, h0, h1, gt, planes, gt8, gttext;
+    HostBuf h_counts, h_planes, h_gt8, h_gttext;
     float t_ms[3] = {0, 0, 0};
     bool t_pending = false;           // events recorded on a caller stream, not yet read back
     Geometry geom = {0, 0, 0, 0, 0, 0, 1, 1};
     int tune_threads = 0, tune_cpt = 0, tune_K = 0;
     // pull interface
     int64_t next = 0, ring0 = 0, ring1 = 0;
-    bool ring_has_planes = false;
-    bool want_planes = true;          // pull interface: also deliver byte planes (else counts only)
+    int ring_has = 0;                 // BGTH_WANT_* bits the ring was filled with
+    int want = BGTH_WANT_PLANES;      // pull interface: what a refill materialises besides the counts
     int64_t max_ahead = 0;            // rows per refill (0 = automatic)
     const uint8_t *ret[2] = {nullptr, nullptr};
     const int32_t *last_counts = nullptr;
+    const int8_t *last_gt8 = nullptr;
+    const char *last_gttext = nullptr;
 };
 
 static bool use_device(int device)
@@ -555,7 +557,8 @@ extern "C" void bgth_reader_destroy(bgth_reader_t *r)
     if (r->stream) hipStreamSynchronize(r->stream);
     r->sel.release();
     r->raw.release(); r->fin.release(); r->h0.release(); r->h1.release(); r->gt.release(); r->planes.release();
-    r->h_counts.release(); r->h_planes.release();
+    r->gt8.release(); r->gttext.release();
+    r->h_counts.release(); r->h_planes.release(); r->h_gt8.release(); r->h_gttext.release();
     for (int i = 0; i < 4; ++i) if (r->ev[i]) hipEventDestroy(r->ev[i]);
     if (r->stream) hipStreamDestroy(r->stream);
     delete r;
@@ -740,7 +743,11 @@ static bool refill(bgth_reader_t *r)
     const size_t cstride = (size_t)(1 + gx) * 3;
     // Decode to the end of a block, several blocks per refill: with byte planes while they stay under
     // 256 MiB, with counts only a wide window (the whole point of the device: one launch, many sites).
-    int64_t max_rows = r->want_planes ? ((int64_t)256 << 20) / std::max(1, 2 * width) : (int64_t)1 << 22;
+    Trace tr;
+    const int want = r->want;
+    const bool need_bits = want != 0;                            // any genotype output needs the bit planes H0/H1
+    const int per_hap = (want & BGTH_WANT_PLANES ? 2 : 0) + (want & BGTH_WANT_GT8 ? 1 : 0) + (want & BGTH_WANT_GTTEXT ? 2 : 0);
+    int64_t max_rows = need_bits ? ((int64_t)256 << 20) / std::max(1, per_hap * width) : (int64_t)1 << 22;
     if (r->max_ahead > 0) max_rows = std::min(max_rows, r->max_ahead);
     max_rows = std::max<int64_t>(blk_rows, max_rows / blk_rows * blk_rows);
     const int64_t row0 = r->next;
@@ -751,21 +758,37 @@ static bool refill(bgth_reader_t *r)
         set_err("[E::bgth_reader_read] out of memory for a %lld-row batch", (long long)rows);
         return false;
     }
-    if (r->want_planes && (!r->h0.reserve(pl) || !r->h1.reserve(pl) || !r->planes.reserve(2 * by) || !r->h_planes.reserve(2 * by))) {
+    if ((want & (BGTH_WANT_GT8 | BGTH_WANT_GTTEXT)) && (width & 1)) {
+        set_err("[E::bgth_reader_read] genotype vectors need whole samples (an even number of columns), have %d", width);
+        return false;
+    }
+    if ((need_bits && (!r->h0.reserve(pl) || !r->h1.reserve(pl))) ||
+        ((want & BGTH_WANT_PLANES) && (!r->planes.reserve(2 * by) || !r->h_planes.reserve(2 * by))) ||
+        ((want & BGTH_WANT_GT8) && (!r->gt8.reserve(by) || !r->h_gt8.reserve(by))) ||
+        ((want & BGTH_WANT_GTTEXT) && (!r->gttext.reserve(2 * by) || !r->h_gttext.reserve(2 * by)))) {
         set_err("[E::bgth_reader_read] out of memory for a %lld-row batch", (long long)rows);
         return false;
     }
-    uint64_t *d_h0 = r->want_planes ? (uint64_t*)r->h0.p : nullptr, *d_h1 = r->want_planes ? (uint64_t*)r->h1.p : nullptr;
+    tr.lap("refill: buffers");
+    uint64_t *d_h0 = need_bits ? (uint64_t*)r->h0.p : nullptr, *d_h1 = need_bits ? (uint64_t*)r->h1.p : nullptr;
     if (enqueue_scan(r, row0, row1, (int32_t*)r->fin.p, d_h0, d_h1, r->stream, true) < 0) return false;
-    if (r->want_planes) {
+    if (want & BGTH_WANT_PLANES) {
         uint8_t *d_a0 = (uint8_t*)r->planes.p, *d_a1 = d_a0 + by;
         HIP_TRY(launch_unpack_bytes(d_h0, d_h1, r->sel.d_slot_of_out, d_a0, d_a1, rows, r->sel.n_chunks, width, r->stream), return false);
         HIP_TRY(hipMemcpyAsync(r->h_planes.p, r->planes.p, 2 * by, hipMemcpyDeviceToHost, r->stream), return false);
     }
+    if (want & (BGTH_WANT_GT8 | BGTH_WANT_GTTEXT)) {
+        uint8_t *d_gt8 = (want & BGTH_WANT_GT8) ? (uint8_t*)r->gt8.p : nullptr;
+        uint32_t *d_txt = (want & BGTH_WANT_GTTEXT) ? (uint32_t*)r->gttext.p : nullptr;
+        HIP_TRY(launch_emit_gt(d_h0, d_h1, r->sel.d_slot_of_out, d_gt8, d_txt, rows, r->sel.n_chunks, width, r->stream), return false);
+        if (d_gt8) HIP_TRY(hipMemcpyAsync(r->h_gt8.p, d_gt8, by, hipMemcpyDeviceToHost, r->stream), return false);
+        if (d_txt) HIP_TRY(hipMemcpyAsync(r->h_gttext.p, d_txt, 2 * by, hipMemcpyDeviceToHost, r->stream), return false);
+    }
     HIP_TRY(hipMemcpyAsync(r->h_counts.p, r->fin.p, (size_t)rows * cstride * 4, hipMemcpyDeviceToHost, r->stream), return false);
     HIP_TRY(hipStreamSynchronize(r->stream), return false);
+    tr.lap("refill: scan + copies");
     collect_timing(r);
-    r->ring0 = row0; r->ring1 = row1; r->ring_has_planes = r->want_planes;
+    r->ring0 = row0; r->ring1 = row1; r->ring_has = want;
     return true;
 }
 
@@ -775,14 +798,16 @@ extern "C" const uint8_t **bgth_reader_read(bgth_reader_t *r)
     bgth_pbf_t *p = r->pbf;
     if (r->next >= p->n) return nullptr;                         // ref pbwt.c:336: no more 'B' records
     if (!use_device(p->device)) return nullptr;
-    if (r->next < r->ring0 || r->next >= r->ring1 || (r->want_planes && !r->ring_has_planes)) if (!refill(r)) return nullptr;
+    if (r->next < r->ring0 || r->next >= r->ring1 || (r->want & ~r->ring_has)) if (!refill(r)) return nullptr;
     const int width = r->sel.width;
     const size_t by = (size_t)(r->ring1 - r->ring0) * width;
     const size_t k = (size_t)(r->next - r->ring0);
-    if (r->want_planes) {
+    if (r->want & BGTH_WANT_PLANES) {
         r->ret[0] = (const uint8_t*)r->h_planes.p + k * width;
         r->ret[1] = (const uint8_t*)r->h_planes.p + by + k * width;
     } else r->ret[0] = r->ret[1] = nullptr;
+    r->last_gt8 = (r->want & BGTH_WANT_GT8) ? (const int8_t*)r->h_gt8.p + k * width : nullptr;
+    r->last_gttext = (r->want & BGTH_WANT_GTTEXT) ? (const char*)r->h_gttext.p + 2 * k * width : nullptr;
     r->last_counts = (const int32_t*)r->h_counts.p + k * (size_t)(1 + gx_of(r->sel.G)) * 3;
     ++r->next;
     return r->ret;
@@ -791,12 +816,15 @@ extern "C" const uint8_t **bgth_reader_read(bgth_reader_t *r)
 extern "C" int bgth_reader_config(bgth_reader_t *r, int want_planes, int64_t max_rows_ahead)
 {
     if (!r) return -1;
-    r->want_planes = want_planes != 0;
+    if (want_planes & ~(BGTH_WANT_PLANES | BGTH_WANT_GT8 | BGTH_WANT_GTTEXT)) { set_err("[E::bgth_reader_config] unknown output bits 0x%x", want_planes); return -1; }
+    r->want = want_planes;
     r->max_ahead = max_rows_ahead;
     return 0;
 }
 
 extern "C" const int32_t *bgth_reader_last_counts(const bgth_reader_t *r) { return r->last_counts; }
+extern "C" const int8_t *bgth_reader_last_gt8(const bgth_reader_t *r) { return r->last_gt8; }
+extern "C" const char *bgth_reader_last_gt_text(const bgth_reader_t *r) { return r->last_gttext; }
 
 // ----------------------------------------------------------------------------------------------------
 // site filter on the device

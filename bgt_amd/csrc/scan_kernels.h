@@ -78,6 +78,11 @@ hipError_t launch_unpack_bytes(const uint64_t *h0, const uint64_t *h1, const int
                                uint8_t *a0, uint8_t *a1, int64_t n_rows, int n_chunks, int width,
                                hipStream_t s);
 
+// slot-ordered bit planes -> BCF GT bytes (1 per haplotype) and/or VCF GT text (2 characters per haplotype), output
+// order; width must be even (haplotype pairs = samples); either output may be NULL
+hipError_t launch_emit_gt(const uint64_t *h0, const uint64_t *h1, const int32_t *slot_of_out, uint8_t *gt8,
+                          uint32_t *text, int64_t n_rows, int n_chunks, int width, hipStream_t s);
+
 // compiled `-f` expression (reverse Polish): op 0 = int constant, 1 = real constant, 2 = variable read from
 // counts[slot], 16 + k = operator k in the numbering of filter_expr.c
 constexpr int kFilterMaxItems = 48;

@@ -248,6 +248,45 @@ hipError_t launch_unpack_bytes(const uint64_t *h0, const uint64_t *h1, const int
     return hipGetLastError();
 }
 
+// The genotype vector bgt_gen_gt builds (reference bgt.c:290-313, table bgt_bits2gt bgt.c:250) and its VCF text
+// (reference vcf.c:940-969 for a GT-only FORMAT), straight from the bit planes: per haplotype i of the output
+//   gt8[i]  = (allele + 1) << 1 = {2, 4, 0, 6}[code]           code = a1 << 1 | a0; 0 REF, 1 ALT, 2 missing, 3 <M>
+//   text    = '\t' | '/' (first | second haplotype of the sample) then '0' '1' '.' '2'
+// One thread per sample (two haplotypes): 2 bytes of gt8, 4 characters of text.
+__global__ void emit_gt_kernel(const uint64_t *h0, const uint64_t *h1, const int32_t *slot_of_out, uint8_t *gt8,
+                               uint32_t *text, int64_t n_rows, int n_chunks, int n_samples)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows * n_samples) return;
+    const int64_t row = i / n_samples;
+    const int smp = (int)(i - row * n_samples);
+    uint32_t code[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int s = slot_of_out[2 * smp + k];
+        const uint32_t a0 = (uint32_t)(h0[row * n_chunks + (s >> 6)] >> (s & 63)) & 1u;
+        const uint32_t a1 = (uint32_t)(h1[row * n_chunks + (s >> 6)] >> (s & 63)) & 1u;
+        code[k] = a1 << 1 | a0;
+    }
+    if (gt8) {
+        const uint32_t tab = 0x06000402u;                      // bytes {2, 4, 0, 6}
+        reinterpret_cast<uint16_t*>(gt8)[i] = (uint16_t)(((tab >> (8 * code[0])) & 255u) | (((tab >> (8 * code[1])) & 255u) << 8));
+    }
+    if (text) {
+        const uint32_t chr = 0x322e3130u;                      // bytes "01.2"
+        text[i] = (uint32_t)'\t' | ((chr >> (8 * code[0])) & 255u) << 8 | (uint32_t)'/' << 16 | ((chr >> (8 * code[1])) & 255u) << 24;
+    }
+}
+
+hipError_t launch_emit_gt(const uint64_t *h0, const uint64_t *h1, const int32_t *slot_of_out, uint8_t *gt8,
+                          uint32_t *text, int64_t n_rows, int n_chunks, int width, hipStream_t s)
+{
+    const int64_t total = n_rows * (width / 2);
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(emit_gt_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                       h0, h1, slot_of_out, gt8, text, n_rows, n_chunks, width / 2);
+    return hipGetLastError();
+}
 
 // ----------------------------------------------------------------------------------------------------
 // Site filter on the device: the reverse-Polish program of a `-f` expression (exported by the host parser,

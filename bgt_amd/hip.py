@@ -240,12 +240,40 @@ class HipReader:
         if lib().bgth_reader_seek(self.h, row) < 0:
             raise RuntimeError(last_error())
 
+    WANT_PLANES, WANT_GT8, WANT_GTTEXT = 1, 2, 4
+
+    def config(self, want=1, max_rows_ahead=0):
+        """What the pull interface materialises per row besides the counts (mask of WANT_*)."""
+        L = lib()
+        L.bgth_reader_config.restype = C.c_int
+        L.bgth_reader_config.argtypes = [C.c_void_p, C.c_int, C.c_int64]
+        if L.bgth_reader_config(self.h, want, max_rows_ahead) < 0:
+            raise RuntimeError(last_error())
+        self._want = want
+
     def read(self):
+        """Next row: the two byte planes (uint8[2][width]), or True when planes are not configured; None at the end."""
         r = lib().bgth_reader_read(self.h)
         if not r:
             return None
+        if not (getattr(self, "_want", 1) & 1):
+            return True
         w = self.width
         return np.stack([np.ctypeslib.as_array(r[k], (w,)).copy() for k in range(2)])
+
+    def last_gt8(self):
+        L = lib()
+        L.bgth_reader_last_gt8.restype = C.POINTER(C.c_int8)
+        L.bgth_reader_last_gt8.argtypes = [C.c_void_p]
+        p = L.bgth_reader_last_gt8(self.h)
+        return np.ctypeslib.as_array(p, (self.width,)).copy() if p else None
+
+    def last_gt_text(self):
+        L = lib()
+        L.bgth_reader_last_gt_text.restype = C.POINTER(C.c_char)
+        L.bgth_reader_last_gt_text.argtypes = [C.c_void_p]
+        p = L.bgth_reader_last_gt_text(self.h)
+        return C.string_at(p, 2 * self.width) if p else None
 
     def last_counts(self):
         p = lib().bgth_reader_last_counts(self.h)

@@ -130,7 +130,12 @@ static int st_cmp(const sitetab_t *a, int64_t i, const sitetab_t *b, int64_t j)
  * ------------------------------------------------------------------------------------------------ */
 typedef struct { int64_t next; } cursor_t;                   /* bgt_t::bcf */
 typedef struct { int tid, beg, end; int64_t at; int done; } region_t;   /* bgt_t::itr */
-typedef struct { bgth_reader_t *rd; int64_t site; const int32_t *counts; int skip_device; } devrd_t;   /* bgt_t::pb */
+typedef struct {                                              /* bgt_t::pb */
+    bgth_reader_t *rd; int64_t site; const int32_t *counts; int skip_device;
+    int want;                  /* BGTH_WANT_* bits the device delivers per site for this reader */
+    int text_mode;             /* the caller formats VCF text (bgtm_read_vcf): also ask for the genotype text */
+    const int8_t *gt8; const char *gttext;   /* genotype vector / text of the current site (device formatted) */
+} devrd_t;
 
 /* ------------------------------------------------------------------------------------------------
  * files
@@ -471,6 +476,7 @@ static int read_rec(bgt_t *bgt, bgt_rec_t *r)
         return -2;
     }
     dv->counts = bgth_reader_last_counts(dv->rd);
+    dv->gt8 = bgth_reader_last_gt8(dv->rd); dv->gttext = bgth_reader_last_gt_text(dv->rd);
     r->b0 = bgt->b0; r->a[0] = a[0]; r->a[1] = a[1];
     return t->row[i];
 }
@@ -488,6 +494,20 @@ static void gen_gt(const bcf_hdr_t *h, bcf1_t *b, int m, const uint8_t *const *a
     ks_need(&b->indiv, (size_t)m2 * 2 + 1);
     for (i = 0; i < m << 1; ++i)
         if (!mgs || mgs[i >> 1] <= 1) b->indiv.s[b->indiv.l++] = (char)bits2gt[a[1][i] << 1 | a[0][i]];
+    b->indiv.s[b->indiv.l] = 0;
+}
+
+/* the same from the vector the device already built (BGTH_WANT_GT8): 2m bytes, every sample kept */
+static void gen_gt8(const bcf_hdr_t *h, bcf1_t *b, int m, const uint8_t *gt8)
+{
+    b->indiv.l = 0;
+    if (m == 0) return;
+    b->n_fmt = 1; b->n_sample = (uint32_t)m;
+    bcf_enc_int1(&b->indiv, bcf_id2int(h, BCF_DT_ID, "GT"));
+    bcf_enc_size(&b->indiv, 2, BCF_BT_INT8);
+    ks_need(&b->indiv, (size_t)m * 2 + 1);
+    memcpy(b->indiv.s + b->indiv.l, gt8, (size_t)m * 2);
+    b->indiv.l += (size_t)m * 2;
     b->indiv.s[b->indiv.l] = 0;
 }
 
@@ -675,12 +695,21 @@ int bgtm_prepare(bgtm_t *bm)
     bcf_hdr_parse(bm->h_out);
 
     bm->a[0] = (uint8_t*)realloc(bm->a[0], (size_t)(bm->n_out ? bm->n_out : 1) << 1);
-    bm->a[1] = (uint8_t*)realloc(bm->a[1], (size_t)(bm->n_out ? bm->n_out : 1) << 1);
+    bm->a[1] = (uint8_t*)realloc(bm->a[1], (size_t)(bm->n_out ? bm->n_out : 1) << 2);   /* planes: 2 B, text: 4 B per sample */
 
-    /* what the device has to deliver per site: byte planes only if genotypes are printed */
-    for (i = 0; i < bm->n_bgt; ++i) {
-        devrd_t *dv = (devrd_t*)bm->bgt[i]->pb;
-        if (dv->rd) bgth_reader_config(dv->rd, !(bm->flag & BGT_F_NO_GT), 0);
+    /* What the device has to deliver per site.  Nothing but counts with -G.  Otherwise the finished genotype
+     * vector of bgt_gen_gt (and its VCF text when the caller writes VCF): then bm->a[0] holds the merged vector
+     * and bm->a[1] the merged text instead of the two byte planes.  The byte planes themselves are only needed
+     * when a per-sample mask drops samples from the output (mgs > 1, ref bgt.c:300-311). */
+    {
+        int want = 0;
+        for (i = m = 0; i < bm->n_out; ++i) if (bm->mgs[i] <= 1) ++m;
+        if (!(bm->flag & BGT_F_NO_GT)) want = m == bm->n_out ? BGTH_WANT_GT8 : BGTH_WANT_PLANES;
+        for (i = 0; i < bm->n_bgt; ++i) {
+            devrd_t *dv = (devrd_t*)bm->bgt[i]->pb;
+            dv->want = want | ((want & BGTH_WANT_GT8) && dv->text_mode ? BGTH_WANT_GTTEXT : 0);
+            if (dv->rd) bgth_reader_config(dv->rd, dv->want, 0);
+        }
     }
     return rc;
 }
@@ -778,14 +807,22 @@ static int read_core(bgtm_t *bm, bcf1_t *b)
                 memcpy(bm->a[0] + off, bm->r[i].a[0], (size_t)bgt->n_out << 1);
                 memcpy(bm->a[1] + off, bm->r[i].a[1], (size_t)bgt->n_out << 1);
             }
+            if (dv->gt8) memcpy(bm->a[0] + off, dv->gt8, (size_t)bgt->n_out << 1);
+            if (dv->gttext) memcpy(bm->a[1] + 2 * (size_t)off, dv->gttext, (size_t)bgt->n_out << 2);
             ss.an += c[0]; ss.ac[0] += c[1]; ss.ac[1] += c[2];
             if (bm->n_groups > 1)
                 for (g = 0; g < bm->n_groups; ++g) {
                     ss.gan[g] += c[3 * (1 + g)]; ss.gac[g][0] += c[3 * (1 + g) + 1]; ss.gac[g][1] += c[3 * (1 + g) + 2];
                 }
-        } else if (!(bm->flag & BGT_F_NO_GT)) {               /* this database lacks the site: all missing */
+        } else if (dv->want & BGTH_WANT_PLANES) {             /* this database lacks the site: all missing */
             memset(bm->a[0] + off, 0, (size_t)bgt->n_out << 1);
             memset(bm->a[1] + off, 1, (size_t)bgt->n_out << 1);
+        } else if (dv->want & BGTH_WANT_GT8) {                /* the same in vector / text form: 0 bytes, "./." */
+            memset(bm->a[0] + off, 0, (size_t)bgt->n_out << 1);
+            if (dv->want & BGTH_WANT_GTTEXT) {
+                int k;
+                for (k = 0; k < bgt->n_out; ++k) memcpy(bm->a[1] + 2 * (size_t)off + 4 * (size_t)k, "\t./.", 4);
+            }
         }
         off += bgt->n_out << 1;
     }
@@ -801,7 +838,35 @@ int bgtm_read(bgtm_t *bm, bcf1_t *b)                          /* ref bgt.c:880-8
     int ret;
     if (bm->h_out == NULL) bgtm_prepare(bm);
     while ((ret = read_core(bm, b)) > 0) {}
-    if (ret >= 0 && (bm->flag & BGT_F_NO_GT) == 0)
-        gen_gt(bm->h_out, b, bm->n_out, (const uint8_t *const*)bm->a, bm->mgs);
+    if (ret >= 0 && (bm->flag & BGT_F_NO_GT) == 0) {
+        if (bm->n_bgt > 0 && (((devrd_t*)bm->bgt[0]->pb)->want & BGTH_WANT_GT8)) gen_gt8(bm->h_out, b, bm->n_out, bm->a[0]);
+        else gen_gt(bm->h_out, b, bm->n_out, (const uint8_t *const*)bm->a, bm->mgs);
+    }
+    return ret;
+}
+
+/* Extension (not in the reference): the next site as one VCF text line without the newline -- exactly what
+ * vcf_format1(bm->h_out, b, s) gives after bgtm_read(bm, b) -- with the genotype columns taken from the text
+ * the device formatted (b then carries the site and INFO only). */
+void bgtm_want_vcf_text(bgtm_t *bm)      /* call before bgtm_prepare: the caller will use bgtm_read_vcf */
+{
+    int i;
+    for (i = 0; i < bm->n_bgt; ++i) ((devrd_t*)bm->bgt[i]->pb)->text_mode = 1;
+}
+
+int bgtm_read_vcf(bgtm_t *bm, bcf1_t *b, kstring_t *s)
+{
+    int ret;
+    if (bm->h_out == NULL) { bgtm_want_vcf_text(bm); bgtm_prepare(bm); }
+    if (bm->n_bgt == 0 || !(((devrd_t*)bm->bgt[0]->pb)->want & BGTH_WANT_GTTEXT) || bm->n_out == 0) {
+        if ((ret = bgtm_read(bm, b)) >= 0) vcf_format1(bm->h_out, b, s);
+        return ret;
+    }
+    while ((ret = read_core(bm, b)) > 0) {}
+    if (ret < 0) return ret;
+    b->n_fmt = 0; b->n_sample = 0; b->indiv.l = 0;
+    vcf_format1(bm->h_out, b, s);
+    ks_puts(s, "\tGT");
+    ks_putn(s, (const char*)bm->a[1], (size_t)bm->n_out << 2);
     return ret;
 }

@@ -80,6 +80,7 @@ int main_view(int argc, char *argv[])
             fprintf(stderr, "[E::%s] failed to add sample group '%s'.\n", __func__, gexpr[i]);
             return 1;
         }
+    if (!out_bcf) bgtm_want_vcf_text(bm);
     if (bgtm_prepare(bm) < 0) { fprintf(stderr, "[E::%s] failed to prepare the readers.\n", __func__); return 1; }
 
     /* the reference builds the mode string "wb%d" and takes its first digit as the level, so the default
@@ -88,9 +89,9 @@ int main_view(int argc, char *argv[])
     else vcf_hdr_write_text(stdout, bm->h_out);
 
     b = bcf_init1();
-    while (bgtm_read(bm, b) >= 0 && n_read < n_rec) {
+    while ((bz ? bgtm_read(bm, b) : bgtm_read_vcf(bm, b, &line)) >= 0 && n_read < n_rec) {
         if (bz) bcf_write1_stream(bz, b);
-        else { vcf_format1(bm->h_out, b, &line); fwrite(line.s, 1, line.l, stdout); fputc('\n', stdout); }
+        else { fwrite(line.s, 1, line.l, stdout); fputc('\n', stdout); }
         ++n_read;
     }
     bcf_destroy1(b);

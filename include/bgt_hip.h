@@ -97,10 +97,22 @@ int     bgth_reader_slot_map(const bgth_reader_t *r, int32_t *slot_of_output); /
  * and served from a host ring.  NULL at end of file. */
 int             bgth_reader_seek(bgth_reader_t *r, int64_t row);
 const uint8_t **bgth_reader_read(bgth_reader_t *r);
-/* What the pull interface delivers: want_planes = 0 keeps only the counts (the `-G` path: the returned
- * array then holds two NULL plane pointers) and lets one refill cover millions of rows;
- * max_rows_ahead bounds a refill (0 = automatic). */
+/* What the pull interface delivers per row besides the counts: want_planes is a mask of BGTH_WANT_* bits.
+ * 0 keeps only the counts (the `-G` path: the returned array then holds two NULL plane pointers) and lets one
+ * refill cover millions of rows; max_rows_ahead bounds a refill (0 = automatic).
+ *   BGTH_WANT_PLANES  the byte-per-column planes of pbf_read (default)
+ *   BGTH_WANT_GT8     the genotype vector bgt_gen_gt builds from them (reference bgt.c:290-313, :250): one int8
+ *                     per haplotype, (allele+1)<<1, in output order -- the payload of the BCF GT field
+ *   BGTH_WANT_GTTEXT  the same as VCF text (reference vcf.c:940-969 with FORMAT = GT): "\tA/B" per sample,
+ *                     A, B in {0, 1, ., 2}; 4 characters per sample, no terminator
+ * GT8 / GTTEXT need an even number of selected columns (whole samples). */
+#define BGTH_WANT_PLANES 1
+#define BGTH_WANT_GT8    2
+#define BGTH_WANT_GTTEXT 4
 int             bgth_reader_config(bgth_reader_t *r, int want_planes, int64_t max_rows_ahead);
+/* genotype vector / text of the row returned by the last bgth_reader_read (NULL unless configured) */
+const int8_t   *bgth_reader_last_gt8(const bgth_reader_t *r);
+const char     *bgth_reader_last_gt_text(const bgth_reader_t *r);
 /* counts of the row returned by the last bgth_reader_read: int32[1+Gx][3] */
 const int32_t  *bgth_reader_last_counts(const bgth_reader_t *r);
 

@@ -111,6 +111,10 @@ int bgtm_add_group(bgtm_t *bm, const char *expr);
 int bgtm_prepare(bgtm_t *bm);
 int bgtm_test_mgs(const bgtm_t *bm);
 int bgtm_read(bgtm_t *bm, bcf1_t *b);
+/* extension (not in the reference): the next site as one VCF text line (no newline), identical to
+ * vcf_format1(bm->h_out, b, s) after bgtm_read(bm, b); genotype columns come formatted from the device */
+int bgtm_read_vcf(bgtm_t *bm, bcf1_t *b, kstring_t *s);
+void bgtm_want_vcf_text(bgtm_t *bm);   /* before bgtm_prepare, if bgtm_read_vcf will be used */
 
 bgt_hapcnt_t *bgtm_hapcnt(const bgtm_t *bm, int *n_hap);
 char *bgtm_hapcnt_print_destroy(const bgtm_t *bm, int n_hap, bgt_hapcnt_t *hc);

@@ -220,6 +220,42 @@ def test_wide_cohort_team_mode(hip, threads, cpt, K, in_place, monkeypatch):
     assert np.array_equal(c2, o2) and np.array_equal(g2, og2)
 
 
+def test_genotype_vector_and_text_from_the_device(hip):
+    """BGTH_WANT_GT8 / BGTH_WANT_GTTEXT: what bgt_gen_gt (bgt.c:290-313, table :250) and the GT branch of
+    vcf_format1 (vcf.c:940-969) make of the two planes, compared with the same mapping applied to the oracle's codes."""
+    mat, data, rng = make_case(71, 1200, 300, 6, n_founders=9, switch=0.05)
+    pbf = hip.HipPbf.from_bytes(data)
+    rd = hip.HipReader(pbf)
+    samples = np.sort(rng.choice(600, 77, replace=False))
+    cols = np.stack([2 * samples, 2 * samples + 1], 1).reshape(-1).astype(np.int32)
+    bits2gt = np.array([2, 4, 0, 6], np.int8)
+    chars = np.frombuffer(b"01.2", np.uint8)
+    for sel in (None, cols):
+        if sel is not None:
+            rd.select(sel)
+        sub = mat if sel is None else mat[:, sel]
+        for want in (rd.WANT_GT8, rd.WANT_GTTEXT, rd.WANT_GT8 | rd.WANT_GTTEXT, rd.WANT_PLANES | rd.WANT_GT8):
+            rd.config(want, 64)
+            for row in (0, 63, 64, 130, 299):
+                rd.seek(row)
+                got = rd.read()
+                assert got is not None
+                if want & rd.WANT_PLANES:
+                    assert np.array_equal(got[0] | (got[1] << 1), sub[row])
+                if want & rd.WANT_GT8:
+                    assert np.array_equal(rd.last_gt8(), bits2gt[sub[row]])
+                else:
+                    assert rd.last_gt8() is None
+                if want & rd.WANT_GTTEXT:
+                    c = chars[sub[row]].reshape(-1, 2)
+                    want_txt = b"".join(b"\t" + bytes([a]) + b"/" + bytes([b]) for a, b in c)
+                    assert rd.last_gt_text() == want_txt
+    rd.select(np.array([0, 1, 2], np.int32))                      # an odd number of columns cannot form samples
+    rd.config(rd.WANT_GT8, 0)
+    rd.seek(0)
+    assert rd.read() is None and "whole samples" in hip.last_error()
+
+
 @pytest.mark.parametrize("sub", [None, "9", "13"])
 def test_sub_checkpoints(hip, tmp_path, monkeypatch, sub):
     """The image keeps rank-form checkpoints every 2^11 rows (derived on the device from the file's 'S' records
