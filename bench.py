@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c2", choices=sorted(SAMPLES))
     ap.add_argument("--sites", type=int, default=1000000, help="sites per GPU")
+    ap.add_argument("--every", type=int, default=0, help="select every N-th sample only (C3: --workload c3 --every 20)")
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--cpu-sample", type=int, default=262144, help="sites for the CPU baseline (0 = skip)")
     ap.add_argument("--threads", type=int, default=0)
@@ -76,6 +77,9 @@ def main():
     t_load = time.time() - t0
     rle_bytes_per_site = rle.size / sites
     rd = bgt_amd.HipReader(pbf)
+    if args.every > 1:                                          # sample subset (-s): fewer tracked columns, same rows
+        sel = np.arange(0, n_samples, args.every)
+        rd.select(np.stack([2 * sel, 2 * sel + 1], 1).reshape(-1))
     rd.tune(args.threads, args.cpt, args.batch)
     T = rd.width
 
@@ -174,7 +178,8 @@ def main():
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": "C2: synthetic %d samples x %d sites per GPU, whole cohort, -G -f'AC>0'"
                                    % (n_samples, sites) if args.workload == "c2" else
-                                   "%s: %d samples x %d sites per GPU" % (args.workload, n_samples, sites),
+                                   "%s: %d samples x %d sites per GPU%s" % (args.workload, n_samples, sites,
+                                   ", every %d-th sample selected" % args.every if args.every > 1 else ""),
                        "haplotypes": m, "tracked_columns": T, "sites_per_gpu": sites,
                        "sharding": "site-range x%d + all_gather(counts)" % world if world > 1 else "single GPU",
                        "rle_bytes_per_site": round(rle_bytes_per_site, 1), "sites_passing_filter": n_pass,
@@ -196,7 +201,7 @@ def main():
     # /root/reference in the build container and shipped with the repo) running the metric's own command
     # line on a database this repo writes; its stdout is also compared with this repo's `bgt view`.
     # Always: the CPU oracle (port) on the same rows, compared with the counts the GPU delivered.
-    if rank == 0 and world == 1 and args.cpu_sample > 0:
+    if rank == 0 and world == 1 and args.cpu_sample > 0 and args.every <= 1:
         import hashlib
         import subprocess
         sys.path.insert(0, os.path.join(ROOT, "tests"))
