@@ -300,6 +300,8 @@ extern "C" bgth_pbf_t *bgth_pbf_open_mem(const void *image, size_t len, int devi
         memcpy(&off, buf + len - 8, 8);
         if (off >= 16 && off + 13 <= len && buf[off] == 'I') { memcpy(&n_footer, buf + off + 1, 8); end = (size_t)off; }
     }
+    // the reference reader finds everything through the footer (pbwt.c:228-235); an image without one is truncated
+    if (n_footer < 0) { set_err("[E::bgth_pbf_open] no index footer: truncated or not a PBF image"); return nullptr; }
     Trace tr;
     if (!use_device(device)) return nullptr;
     tr.lap("device init");

@@ -328,3 +328,42 @@ def test_bad_inputs_fail_loudly(hip):
         rd.select([0, 1], group=[3], n_groups=2)
     with pytest.raises(RuntimeError):
         rd.seek(10)
+
+
+def test_edge_shapes(hip, tmp_path):
+    """Empty image, one row, one column, a selection of one sample, 32 groups of one sample each, the last
+    sub-block shorter than the others, truncated images."""
+    # no rows at all: header + footer only (what the reference writer leaves for an empty input, pbwt.c:264-276)
+    empty = orc.encode_pbf(np.zeros((0, 6), np.uint8), 2, 13)
+    pbf = hip.HipPbf.from_bytes(empty)
+    rd = hip.HipReader(pbf)
+    assert rd.scan(0, 0).shape[0] == 0 and rd.read() is None
+    out = str(tmp_path / "empty.pbf")
+    pbf.save(out)
+    assert open(out, "rb").read() == empty
+    # a single row / a single column
+    for m, rows in ((1, 1), (2, 1), (1, 40), (3, 2049)):
+        rng = np.random.default_rng(m * 100 + rows)
+        mat = rng.integers(0, 4, (rows, m)).astype(np.uint8)
+        data = orc.encode_pbf(mat, 2, 13)
+        rd = hip.HipReader(hip.HipPbf.from_bytes(data))
+        counts, gt = rd.scan(0, rows, want_gt=True)
+        oc, ogt = oracle_scan(data, 0, rows)
+        assert np.array_equal(counts, oc) and np.array_equal(gt, ogt), (m, rows)
+    # one sample out of many; 32 groups of one sample each (BGT_MAX_GROUPS, bgt.h:13)
+    mat, data, rng = make_case(91, 200, 2100, 13, n_founders=6, switch=0.05)
+    rd = hip.HipReader(hip.HipPbf.from_bytes(data))
+    rd.select(np.array([198, 199], np.int32))
+    oc, ogt = oracle_scan(data, 0, 2100, cols=np.array([198, 199], np.int32))
+    counts, gt = rd.scan(0, 2100, want_gt=True)
+    assert np.array_equal(counts, oc) and np.array_equal(gt, ogt)
+    cols = np.arange(64, dtype=np.int32)
+    group = np.arange(1, 33, dtype=np.uint32)
+    rd.select(cols, group=group, n_groups=32)
+    o32, _ = oracle_scan(data, 0, 2100, cols=cols, group=group, n_groups=32)
+    assert np.array_equal(rd.scan(0, 2100), o32)
+    assert np.array_equal(rd.scan(2047, 2100), o32[2047:])           # starts one row before the second sub-block
+    # truncated images fail at open, whatever the cut
+    for cut in (15, 17, len(data) // 2, len(data) - 9):
+        with pytest.raises(RuntimeError):
+            hip.HipPbf.from_bytes(data[:cut])
