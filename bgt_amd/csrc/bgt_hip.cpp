@@ -392,6 +392,33 @@ extern "C" bgth_pbf_t *bgth_pbf_open(const char *path, int device)
     return bgth_pbf_open_mem(buf.data(), buf.size(), device);
 }
 
+// The part of the kernel arguments that only depends on the image, the selection and the launch geometry.
+static bool common_scan_args(ScanArgs &a, bgth_pbf_t *p, const Selection &sel, const Geometry &geo, hipStream_t s)
+{
+    memset(&a, 0, sizeof(a));
+    a.rle = p->d_rle;
+    a.rowdesc = p->d_rowdesc;
+    a.rank0 = p->d_rank0;
+    a.slot_col = sel.d_slot_col;
+    a.chunk_desc = sel.d_chunk_desc;
+    a.m = p->m;
+    a.nw = (p->m + 31) / 32;
+    a.n_chunks = sel.n_chunks;
+    a.G = sel.G;
+    a.K = geo.K;
+    a.wpp = geo.wpp;
+    a.nbuf = geo.nbuf;
+    a.n_slices = geo.slices;
+    if (geo.wpp > 1) {                                   // team (wide-cohort) kernels read the row index
+        if (!ensure_rowindex(p, s)) return false;
+        a.chunkinfo = p->d_chunkinfo;
+        a.segc = p->d_segc;
+        a.S8 = p->S8;
+        a.tog_off = geo.tog_off;
+    }
+    return true;
+}
+
 // Decode pass over the FILE blocks [blk, blk + n_blk) that emits nothing but ranks: the sub-checkpoints inside
 // the blocks (always) and the ranks after the last row (d_final, optional: the next block's checkpoint when an
 // image is built from bare RLE strings).
@@ -400,15 +427,13 @@ static bool run_block_pass(bgth_pbf_t *p, Selection &all, int64_t blk, int64_t n
     Geometry geo;
     if (!choose_geometry(p->m, all.n_chunks, 1, (int)n_blk, 0, 0, 0, &geo, !debug_flag(0x200))) { set_err("[E::bgth] geometry"); return false; }
     ScanArgs a;
-    memset(&a, 0, sizeof(a));
-    a.rle = p->d_rle; a.rowdesc = p->d_rowdesc;
-    a.rank0 = p->d_rank0; a.rank0_blk_stride = ((int64_t)2 * p->m) << (p->shift - p->sub_shift);   // file block b -> its sub index
-    a.slot_col = all.d_slot_col; a.chunk_desc = all.d_chunk_desc;
-    a.raw_counts = nullptr; a.h0 = a.h1 = nullptr; a.final_rank = d_final;
+    if (!common_scan_args(a, p, all, geo, s)) return false;
+    a.shift = p->shift;                                                                   // units = file blocks,
+    a.rank0_blk_stride = ((int64_t)2 * p->m) << (p->shift - p->sub_shift);               // whose checkpoint sits at its sub index
+    a.final_rank = d_final;
     if (p->sub_shift < p->shift) { a.snap = p->d_rank0; a.snap_shift = p->sub_shift; }
-    a.m = p->m; a.nw = (p->m + 31) / 32; a.shift = p->shift; a.n_chunks = all.n_chunks; a.G = 1; a.K = geo.K; a.wpp = geo.wpp; a.nbuf = geo.nbuf;
-    if (geo.wpp > 1) { if (!ensure_rowindex(p, s)) return false; a.chunkinfo = p->d_chunkinfo; a.segc = p->d_segc; a.S8 = p->S8; a.tog_off = geo.tog_off; }
-    a.blk0 = (int32_t)blk; a.n_blk = (int32_t)n_blk; a.n_slices = geo.slices;
+    a.blk0 = (int32_t)blk;
+    a.n_blk = (int32_t)n_blk;
     a.row1 = std::min<int64_t>(p->n, (blk + n_blk) << p->shift);
     a.row0 = a.row1;                      // nothing emitted: only ranks are wanted
     HIP_TRY(launch_scan(a, geo, s), return false);
@@ -611,15 +636,16 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
     r->geom = geo;
     if (!r->raw.reserve((size_t)rows * G * 3 * 4)) { set_err("[E::bgth_reader_scan] out of HBM"); return -1; }
     ScanArgs a;
-    memset(&a, 0, sizeof(a));
-    a.rle = p->d_rle; a.rowdesc = p->d_rowdesc;
-    a.rank0 = p->d_rank0; a.rank0_blk_stride = (int64_t)2 * p->m;
-    a.slot_col = r->sel.d_slot_col; a.chunk_desc = r->sel.d_chunk_desc;
-    a.raw_counts = (int32_t*)r->raw.p; a.h0 = d_h0; a.h1 = d_h1; a.final_rank = nullptr;
-    a.m = p->m; a.nw = (p->m + 31) / 32; a.shift = p->sub_shift; a.n_chunks = r->sel.n_chunks; a.G = G; a.K = geo.K; a.wpp = geo.wpp; a.nbuf = geo.nbuf;
-    if (geo.wpp > 1) { if (!ensure_rowindex(p, s)) return -1; a.chunkinfo = p->d_chunkinfo; a.segc = p->d_segc; a.S8 = p->S8; a.tog_off = geo.tog_off; }
-    a.blk0 = (int32_t)blk0; a.n_blk = (int32_t)(blk1 - blk0 + 1); a.n_slices = geo.slices;
-    a.row0 = row0; a.row1 = row1;
+    if (!common_scan_args(a, p, r->sel, geo, s)) return -1;
+    a.shift = p->sub_shift;                              // units = sub-blocks
+    a.rank0_blk_stride = (int64_t)2 * p->m;
+    a.raw_counts = (int32_t*)r->raw.p;
+    a.h0 = d_h0;
+    a.h1 = d_h1;
+    a.blk0 = (int32_t)blk0;
+    a.n_blk = (int32_t)(blk1 - blk0 + 1);
+    a.row0 = row0;
+    a.row1 = row1;
     { const char *dbg = getenv("BGTH_DEBUG_SKIP"); a.debug_skip = dbg ? atoi(dbg) : 0; }
     unsigned long long *d_times = nullptr;
     if (getenv("BGTH_DEBUG_TIMES")) {                    // profiling aid: per-phase cycle sums over all waves
