@@ -612,7 +612,43 @@ static int not_built(const char *what)
     fprintf(stderr, "[E::bgt] %s is not part of this build (genotype-matrix read path only; SURVEY.md 8f)\n", what);
     return -1;
 }
-int bgtm_set_table(bgtm_t *bm, const char *fmt) { (void)bm; (void)fmt; return not_built("tabular output (-t)"); }
+/* -t: comma-separated expressions, commas inside parentheses do not split (ref bgt.c:547-593) */
+int bgtm_set_table(bgtm_t *bm, const char *fmt)
+{
+    int n = 0, m = 0, depth = 0, i, ok = 1;
+    char **piece = NULL;
+    const char *p, *q;
+    for (i = 0; i < bm->n_fields; ++i) ke_destroy(bm->fields[i]);
+    free(bm->fields); bm->fields = NULL; bm->n_fields = 0;
+    for (q = p = fmt;; ++p) {
+        if (*p == '(') ++depth;
+        else if (*p == ')') --depth;
+        else if (*p == 0 || (*p == ',' && depth == 0)) {
+            if (n == m) { m = m ? m << 1 : 16; piece = (char**)realloc(piece, (size_t)m * sizeof(char*)); }
+            piece[n] = (char*)calloc((size_t)(p - q) + 1, 1);
+            memcpy(piece[n++], q, (size_t)(p - q));
+            q = p + 1;
+            if (*p == 0) break;
+        }
+    }
+    if (depth != 0) ok = 0;
+    if (ok) {
+        bm->fields = (kexpr_t**)calloc((size_t)n, sizeof(kexpr_t*));
+        for (i = 0; i < n; ++i) {
+            int err;
+            bm->fields[i] = ke_parse(piece[i], &err);
+            if (err) { ok = 0; break; }
+        }
+        if (!ok) {
+            int j;
+            for (j = 0; j <= i && j < n; ++j) if (bm->fields[j]) ke_destroy(bm->fields[j]);
+            free(bm->fields); bm->fields = NULL;
+        } else bm->n_fields = n;
+    }
+    for (i = 0; i < n; ++i) free(piece[i]);
+    free(piece);
+    return ok ? 0 : -1;
+}
 int bgtm_set_alleles(bgtm_t *bm, const char *expr, const fmf_t *f, const char *fn)
 { (void)bm; (void)expr; (void)f; (void)fn; return not_built("allele-set queries (-a/-S/-H)"); }
 bgt_hapcnt_t *bgtm_hapcnt(const bgtm_t *bm, int *n_hap) { (void)bm; *n_hap = 0; not_built("haplotype counting (-H)"); return NULL; }
@@ -731,19 +767,56 @@ static char *group_key(char key[5], char nc, int g)           /* AN1..AN32 / AC1
     return key;
 }
 
-static int pass_site_flt(const bgt_info_t *ss, kexpr_t *flt)  /* ref bgt.c:700-719 */
+static void assign_counts(kexpr_t *e, const bgt_info_t *ss)   /* ref bgt.c:700-710 */
 {
-    int i, err, yes;
+    int i;
     char key[5];
-    if (flt == NULL) return 1;
-    ke_set_int(flt, "AN", ss->an);
-    ke_set_int(flt, "AC", ss->ac[0]);
+    ke_set_int(e, "AN", ss->an);
+    ke_set_int(e, "AC", ss->ac[0]);
     for (i = 0; i < ss->n_groups; ++i) {
-        ke_set_int(flt, group_key(key, 'N', i), ss->gan[i]);
-        ke_set_int(flt, group_key(key, 'C', i), ss->gac[i][0]);
+        ke_set_int(e, group_key(key, 'N', i), ss->gan[i]);
+        ke_set_int(e, group_key(key, 'C', i), ss->gac[i][0]);
     }
+}
+
+static int pass_site_flt(const bgt_info_t *ss, kexpr_t *flt)  /* ref bgt.c:712-719 */
+{
+    int err, yes;
+    if (flt == NULL) return 1;
+    assign_counts(flt, ss);
     yes = !!ke_eval_int(flt, &err);
     return err ? 0 : yes;
+}
+
+/* one line of `-t` output: every field expression evaluated on the counts and on CHROM / POS / END / REF / ALT of
+ * the site; an evaluation error prints `*` (ref bgt.c:759-795) */
+static void gen_tbl_line(bgtm_t *bm, const bgt_info_t *ss, const bcf1_t *b, const char *ref, int l_ref,
+                         const char *alt, int l_alt)
+{
+    int i;
+    kstring_t *s = &bm->tbl_line;
+    char *r = (char*)malloc((size_t)l_ref + 1), *a = (char*)malloc((size_t)l_alt + 1);
+    memcpy(r, ref, (size_t)l_ref); r[l_ref] = 0;
+    memcpy(a, alt, (size_t)l_alt); a[l_alt] = 0;
+    s->l = 0;
+    for (i = 0; i < bm->n_fields; ++i) {
+        kexpr_t *e = bm->fields[i];
+        int64_t vi; double vr; const char *vs; int type, err;
+        if (i) ks_putc(s, '\t');
+        assign_counts(e, ss);
+        ke_set_str(e, "CHROM", bm->h_out->id[BCF_DT_CTG][b->rid].key);
+        ke_set_int(e, "POS", b->pos + 1);
+        ke_set_int(e, "END", b->pos + b->rlen);
+        ke_set_str(e, "REF", r);
+        ke_set_str(e, "ALT", a);
+        err = ke_eval(e, &vi, &vr, &vs, &type);
+        if (err) ks_putc(s, '*');
+        else if (type == KEV_INT) ks_printf(s, "%ld", (long)vi);
+        else if (type == KEV_REAL) ks_printf(s, "%lg", vr);
+        else if (type == KEV_STR) ks_puts(s, vs);
+    }
+    ks_need(s, 1); s->s[s->l] = 0;
+    free(r); free(a);
 }
 
 static void fill_info(const bcf_hdr_t *h, const bgt_info_t *ss, bcf1_t *b)   /* ref bgt.c:721-733 */
@@ -828,6 +901,8 @@ static int read_core(bgtm_t *bm, bcf1_t *b)
     }
     if ((bm->flag & BGT_F_SET_AC) || bm->site_flt || bm->n_fields > 0 || bm->n_groups > 1) {
         fill_info(bm->h_out, &ss, b);
+        if (bm->n_fields > 0)
+            gen_tbl_line(bm, &ss, b, bt->pool + bt->ref_off[bs], bt->ref_len[bs], bt->pool + bt->alt_off[bs], bt->alt_len[bs]);
         if (!pass_site_flt(&ss, bm->site_flt)) return 1;
     }
     return 0;

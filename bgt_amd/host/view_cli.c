@@ -1,6 +1,6 @@
 /* view_cli.c -- `bgt view`: option handling and the pull loop of reference view.c:14-183, on the MI355X
- * reader.  Options outside the genotype-matrix read path (-B/-e BED, -a/-d/-M/-S/-H allele queries,
- * -t tables) are recognised and refused. */
+ * reader.  Options outside the genotype-matrix read path (-B/-e BED, -a/-d/-M/-S/-H allele queries) are
+ * recognised and refused. */
 #include <limits.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -23,9 +23,9 @@ static int usage(const char *cmd)
 
 int main_view(int argc, char *argv[])
 {
-    int i, c, n_files, out_bcf = 0, clevel = -1, flag = 0, u_set = 0, n_groups = 0;
+    int i, c, n_files, out_bcf = 0, clevel = -1, flag = 0, u_set = 0, n_groups = 0, not_vcf = 0;
     long seekn = -1, n_rec = LONG_MAX, n_read = 0;
-    char *reg = NULL, *site_flt = NULL, *gexpr[BGT_MAX_GROUPS];
+    char *reg = NULL, *site_flt = NULL, *fmt = NULL, *gexpr[BGT_MAX_GROUPS];
     bgt_file_t **files;
     bgtm_t *bm;
     bcf1_t *b;
@@ -45,7 +45,8 @@ int main_view(int argc, char *argv[])
         case 'n': n_rec = atol(optarg); break;
         case 'f': site_flt = optarg; break;
         case 's': if (n_groups < BGT_MAX_GROUPS) gexpr[n_groups++] = optarg; break;
-        case 'B': case 'e': case 'a': case 'd': case 'M': case 'S': case 'H': case 't':
+        case 't': fmt = optarg; not_vcf = 1; break;                 /* tabular output instead of VCF (ref view.c:43) */
+        case 'B': case 'e': case 'a': case 'd': case 'M': case 'S': case 'H':
             fprintf(stderr, "[E::%s] option -%c is outside the genotype-matrix read path and not part of this build.\n", __func__, c);
             return 1;
         default: break;
@@ -74,24 +75,30 @@ int main_view(int argc, char *argv[])
         fprintf(stderr, "[E::%s] failed to set region. Region format error?\n", __func__);
         return 1;
     }
+    if (fmt && bgtm_set_table(bm, fmt) < 0) {
+        fprintf(stderr, "[E::%s] failed to set tabular output.\n", __func__);
+        return 1;
+    }
     if (seekn > 0) bgtm_set_start(bm, seekn);
     for (i = 0; i < n_groups; ++i)
         if (bgtm_add_group(bm, gexpr[i]) < 0) {
             fprintf(stderr, "[E::%s] failed to add sample group '%s'.\n", __func__, gexpr[i]);
             return 1;
         }
-    if (!out_bcf) bgtm_want_vcf_text(bm);
+    if (!out_bcf && !not_vcf) bgtm_want_vcf_text(bm);
     if (bgtm_prepare(bm) < 0) { fprintf(stderr, "[E::%s] failed to prepare the readers.\n", __func__); return 1; }
 
     /* the reference builds the mode string "wb%d" and takes its first digit as the level, so the default
      * -1 compresses at level 1 (view.c:144-146, bgzf.c:138-146) */
-    if (out_bcf) { bz = bgzw_open(stdout, clevel < 0 ? 1 : clevel); bcf_hdr_write_stream(bz, bm->h_out); }
+    if (not_vcf) out_bcf = 0;
+    else if (out_bcf) { bz = bgzw_open(stdout, clevel < 0 ? 1 : clevel); bcf_hdr_write_stream(bz, bm->h_out); }
     else vcf_hdr_write_text(stdout, bm->h_out);
 
     b = bcf_init1();
-    while ((bz ? bgtm_read(bm, b) : bgtm_read_vcf(bm, b, &line)) >= 0 && n_read < n_rec) {
+    while (((bz || not_vcf) ? bgtm_read(bm, b) : bgtm_read_vcf(bm, b, &line)) >= 0 && n_read < n_rec) {
         if (bz) bcf_write1_stream(bz, b);
-        else { fwrite(line.s, 1, line.l, stdout); fputc('\n', stdout); }
+        else if (!not_vcf) { fwrite(line.s, 1, line.l, stdout); fputc('\n', stdout); }
+        if (fmt && bm->n_fields > 0) puts(bm->tbl_line.s);
         ++n_read;
     }
     bcf_destroy1(b);

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Adds the `bgt view -t` (tabular output, reference bgt.c:547-593,775-795, view.c:43,120,153) goldens: runs the
+COMPILED REFERENCE (oracle/_ref/bgt) on the committed trios of tests/golden/bgt and stores stdout + rc.
+Run in the build container only:  python tests/golden/make_table_golden.py"""
+import hashlib
+import json
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+BGT = os.path.join(ROOT, "oracle", "_ref", "bgt")
+X, Y = 'pop=="X"', 'pop=="Y"'
+TABLE_CMDS = {
+    "ex2_t": (["-t", "CHROM,POS,END,REF,ALT,AC,AN"], ["ex2"]),
+    "ex3_t_G": (["-G", "-t", "POS,AC,AN,AC/AN"], ["ex3"]),
+    "synA_t_ratio": (["-G", "-t", "CHROM,POS,AC/AN,AC//2,AN%7,1.5*AC", "-f", "AC>0"], ["synA"]),
+    "synA_t_grp": (["-G", "-s", X, "-s", Y, "-t", "POS,AC1,AN1,AC2/AN2,AC3"], ["synA"]),
+    "synA_t_str": (["-G", "-t", 'REF=="A",ALT,(AC+1)*2,abs(AC-AN),END-POS'], ["synA"]),
+    "synA_t_region": (["-t", "CHROM,POS,AC", "-r", "11:1000-1100", "-n", "5"], ["synA"]),
+    "synAB_t": (["-t", "CHROM,POS,REF,ALT,AC,AN"], ["synA", "synB"]),
+    "synA_t_paren": (["-G", "-t", "POS,(AC,AN)"], ["synA"]),
+    "synA_t_bad": (["-G", "-t", "AC+"], ["synA"]),
+}
+
+out_dir = os.path.join(HERE, "bgt")
+exp = os.path.join(out_dir, "expected")
+manifest = json.load(open(os.path.join(out_dir, "manifest.json")))
+for name, (args, prefixes) in TABLE_CMDS.items():
+    res = subprocess.run([BGT, "view"] + args + prefixes, cwd=out_dir, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    open(os.path.join(exp, name + ".out"), "wb").write(res.stdout)
+    manifest["views"][name] = {"args": args, "prefixes": prefixes, "rc": res.returncode,
+                               "md5": hashlib.md5(res.stdout).hexdigest(), "bytes": len(res.stdout)}
+    print("view %-16s rc=%d %6d B  %s" % (name, res.returncode, len(res.stdout), res.stderr.decode()[:80].strip()))
+json.dump(manifest, open(os.path.join(out_dir, "manifest.json"), "w"), indent=1, sort_keys=True)

@@ -114,7 +114,7 @@ def test_metadata_selection_matches_reference_counts():
 
 
 def test_refused_options_fail_loudly():
-    for opt in (["-S", "-a", "x"], ["-t", "AC"], ["-B", "x.bed"]):
+    for opt in (["-S", "-a", "x"], ["-H", "-a", "x"], ["-B", "x.bed"]):
         res = run_view(opt, ["synA"])
         assert res.returncode != 0 and b"not part of this build" in res.stderr
     assert run_view(["-G"], ["nosuchprefix"]).returncode != 0
@@ -124,7 +124,8 @@ def test_refused_options_fail_loudly():
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(MANIFEST["views"].keys()))
 def test_cli_every_golden_view_on_gpu(name):
-    """25 `bgt view` commands whose expected stdout was produced by the compiled reference."""
+    """34 `bgt view` commands (VCF, BCF, `-t` tables, failures) whose expected stdout and exit code were produced by
+    the compiled reference."""
     v = MANIFEST["views"][name]
     res = run_view(v["args"], v["prefixes"])
     assert res.returncode == v["rc"], res.stderr.decode()
