@@ -462,7 +462,14 @@ static int read_rec(bgt_t *bgt, bgt_rec_t *r)
     int64_t i;
     r->b0 = NULL; r->a[0] = r->a[1] = NULL;
     if (bgt->n_out == 0) return -1;
-    if ((i = next_site(bgt)) < 0) return -1;
+    for (;;) {                                                /* -B / -e: sites by BED overlap (ref bgt.c:315-331) */
+        if ((i = next_site(bgt)) < 0) return -1;
+        if (bgt->bed) {
+            const int hit = bed_overlap(bgt->bed, bgt->f->h0->id[BCF_DT_CTG][t->rid[i]].key, t->pos[i], t->pos[i] + t->rlen[i]);
+            if (bgt->bed_excl ? hit : !hit) continue;
+        }
+        break;
+    }
     fill_b0(bgt, i);
     dv->site = i;
     if (dv->skip_device) {                                    /* `view -G` without -C/-f/-s groups: the output does */

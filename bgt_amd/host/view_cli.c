@@ -1,6 +1,5 @@
 /* view_cli.c -- `bgt view`: option handling and the pull loop of reference view.c:14-183, on the MI355X
- * reader.  Options outside the genotype-matrix read path (-B/-e BED, -a/-d/-M/-S/-H allele queries) are
- * recognised and refused. */
+ * reader.  The allele-set queries (-a/-d/-M/-S/-H) are recognised and refused. */
 #include <limits.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -23,7 +22,8 @@ static int usage(const char *cmd)
 
 int main_view(int argc, char *argv[])
 {
-    int i, c, n_files, out_bcf = 0, clevel = -1, flag = 0, u_set = 0, n_groups = 0, not_vcf = 0;
+    int i, c, n_files, out_bcf = 0, clevel = -1, flag = 0, u_set = 0, n_groups = 0, not_vcf = 0, excl = 0;
+    void *bed = NULL;
     long seekn = -1, n_rec = LONG_MAX, n_read = 0;
     char *reg = NULL, *site_flt = NULL, *fmt = NULL, *gexpr[BGT_MAX_GROUPS];
     bgt_file_t **files;
@@ -46,7 +46,9 @@ int main_view(int argc, char *argv[])
         case 'f': site_flt = optarg; break;
         case 's': if (n_groups < BGT_MAX_GROUPS) gexpr[n_groups++] = optarg; break;
         case 't': fmt = optarg; not_vcf = 1; break;                 /* tabular output instead of VCF (ref view.c:43) */
-        case 'B': case 'e': case 'a': case 'd': case 'M': case 'S': case 'H':
+        case 'B': bed = bed_read(optarg); break;                     /* ref view.c:34 */
+        case 'e': excl = 1; break;
+        case 'a': case 'd': case 'M': case 'S': case 'H':
             fprintf(stderr, "[E::%s] option -%c is outside the genotype-matrix read path and not part of this build.\n", __func__, c);
             return 1;
         default: break;
@@ -75,6 +77,7 @@ int main_view(int argc, char *argv[])
         fprintf(stderr, "[E::%s] failed to set region. Region format error?\n", __func__);
         return 1;
     }
+    if (bed) bgtm_set_bed(bm, bed, excl);
     if (fmt && bgtm_set_table(bm, fmt) < 0) {
         fprintf(stderr, "[E::%s] failed to set tabular output.\n", __func__);
         return 1;
@@ -106,6 +109,7 @@ int main_view(int argc, char *argv[])
     fflush(stdout);
     free(line.s);
     bgtm_reader_destroy(bm);
+    if (bed) bed_destroy(bed);
     for (i = 0; i < n_files; ++i) bgt_close(files[i]);
     free(files);
     return 0;

@@ -92,6 +92,10 @@ void bgt_close(bgt_file_t *bgt);
 
 bgt_t *bgt_reader_init(const bgt_file_t *bf);
 void bgt_reader_destroy(bgt_t *bgt);
+/* BED interval sets (reference bedidx.c): keep / drop sites overlapping an interval */
+void *bed_read(const char *fn);
+int   bed_overlap(const void *bed, const char *chr, int beg, int end);
+void  bed_destroy(void *bed);
 void bgt_set_bed(bgt_t *bgt, const void *bed, int excl);
 int bgt_set_region(bgt_t *bgt, const char *reg);
 int bgt_set_start(bgt_t *bgt, int64_t n);

@@ -21,6 +21,12 @@ TABLE_CMDS = {
     "synAB_t": (["-t", "CHROM,POS,REF,ALT,AC,AN"], ["synA", "synB"]),
     "synA_t_paren": (["-G", "-t", "POS,(AC,AN)"], ["synA"]),
     "synA_t_bad": (["-G", "-t", "AC+"], ["synA"]),
+    # -B / -e: BED overlap (reference bedidx.c); regions.bed and points.bed are fixtures of this repo
+    "synA_bed": (["-G", "-B", "regions.bed"], ["synA"]),
+    "synA_bed_excl": (["-CG", "-B", "regions.bed", "-e"], ["synA"]),
+    "synA_bed_points_gt": (["-B", "points.bed", "-s", 'pop=="X"'], ["synA"]),
+    "synAB_bed_f": (["-G", "-B", "regions.bed", "-f", "AC>2"], ["synA", "synB"]),
+    "synA_bed_t": (["-B", "points.bed", "-e", "-t", "CHROM,POS,END,AC", "-n", "6"], ["synA"]),
 }
 
 out_dir = os.path.join(HERE, "bgt")

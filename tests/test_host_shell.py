@@ -96,7 +96,10 @@ def test_cli_genotype_independent_goldens(name):
                                            (["-G", "-i", "29"], ["synA", "synB"]), (["-G", "-n", "0"], ["synA"]),
                                            (["-G", "-i", "1000"], ["synA"]), (["-G", "-s", "pop==\"X\""], ["synA"]),
                                            (["-G"], ["ex3"]), (["-G", "-r", "13"], ["synA"]), (["-bG"], ["synA"]),
-                                           (["-uG"], ["synB", "synA"]), (["-G", "-l", "1", "-b"], ["synA"])])
+                                           (["-uG"], ["synB", "synA"]), (["-G", "-l", "1", "-b"], ["synA"]),
+                                           (["-G", "-B", "regions.bed"], ["synA", "synB"]), (["-G", "-B", "points.bed", "-e"], ["synB"]),
+                                           (["-G", "-B", "regions.bed", "-r", "11:1000-1200"], ["synA"]),
+                                           (["-G", "-B", "nosuchfile.bed"], ["synA"])])
 def test_cli_live_against_reference_without_genotypes(args, prefixes):
     mine, ref = run_view(args, prefixes), run_view(args, prefixes, exe=REF_BGT)
     assert mine.returncode == ref.returncode
@@ -114,7 +117,7 @@ def test_metadata_selection_matches_reference_counts():
 
 
 def test_refused_options_fail_loudly():
-    for opt in (["-S", "-a", "x"], ["-H", "-a", "x"], ["-B", "x.bed"]):
+    for opt in (["-S", "-a", "x"], ["-H", "-a", "x"], ["-a", "11:1000:1:A"]):
         res = run_view(opt, ["synA"])
         assert res.returncode != 0 and b"not part of this build" in res.stderr
     assert run_view(["-G"], ["nosuchprefix"]).returncode != 0
@@ -124,7 +127,7 @@ def test_refused_options_fail_loudly():
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(MANIFEST["views"].keys()))
 def test_cli_every_golden_view_on_gpu(name):
-    """34 `bgt view` commands (VCF, BCF, `-t` tables, failures) whose expected stdout and exit code were produced by
+    """39 `bgt view` commands (VCF, BCF, `-t` tables, `-B/-e` BED filters, failures) whose expected stdout and exit code were produced by
     the compiled reference."""
     v = MANIFEST["views"][name]
     res = run_view(v["args"], v["prefixes"])
