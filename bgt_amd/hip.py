@@ -26,6 +26,12 @@ def build_library(force=False):
     return _LIB_PATH
 
 
+def build_host_shell():
+    """Compile the C host shell (bgt_amd/host -> lib/libbgt.so, bin/bgt); needs lib/libbgt_hip.so."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "host")])
+    return os.path.join(_HERE, "lib", "libbgt.so")
+
+
 def _hip_runtime_first():
     """torch ships its own libamdhip64.so (DT_NEEDED without the version suffix, so the dynamic loader does not
     match it with /opt/rocm's libamdhip64.so.7).  If this library pulled in the system runtime first and torch
@@ -329,8 +335,11 @@ def host_lib():
     global _host_lib
     if _host_lib is None:
         _hip_runtime_first()
-        if not os.path.exists(_HOST_LIB_PATH):
-            raise RuntimeError("bgt_amd: %s is missing -- build it with `make -C bgt_amd/host`" % _HOST_LIB_PATH)
+        if not os.path.exists(_HOST_LIB_PATH):                  # plain C, seconds to build: do it rather than fail
+            try:
+                build_host_shell()
+            except (OSError, subprocess.CalledProcessError) as e:
+                raise RuntimeError("bgt_amd: %s is missing and `make -C bgt_amd/host` failed: %s" % (_HOST_LIB_PATH, e))
         H = C.CDLL(_HOST_LIB_PATH)
         H.ke_parse.restype = C.c_void_p
         H.ke_parse.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
