@@ -323,6 +323,9 @@ static void fmt_array(kstring_t *s, int n, int type, const uint8_t *p)
     }
 }
 
+/* size + type of a typed BCF2 value at p; *q = first byte of its payload (for readers outside this file) */
+int bcf_dec_size(const uint8_t *p, const uint8_t **q, int *type) { return dec_size(p, q, type); }
+
 int vcf_format1(const bcf_hdr_t *h, const bcf1_t *v, kstring_t *s)
 {
     const uint8_t *p = (const uint8_t*)v->shared.s, *q;

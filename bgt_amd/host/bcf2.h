@@ -73,6 +73,7 @@ int  bcf_append_info_ints(const bcf_hdr_t *h, bcf1_t *b, const char *key, int n,
 void bcf_set_site(bcf1_t *b, int rid, int pos, int rlen, const char *ref, int l_ref, const char *alt, int l_alt,
                   const char *alt2);
 
+int  bcf_dec_size(const uint8_t *p, const uint8_t **q, int *type);   /* typed value: size, type, payload */
 int  vcf_format1(const bcf_hdr_t *h, const bcf1_t *v, kstring_t *s);
 void vcf_hdr_write_text(FILE *fp, const bcf_hdr_t *h);
 void bcf_hdr_write_stream(bgzw_t *fp, const bcf_hdr_t *h);

@@ -7,6 +7,7 @@
  * :364-676 (multi reader set-up), :692-757 (INFO and filter), :797-888 (merge loop).
  */
 #include <assert.h>
+#include <ctype.h>
 #include <limits.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -128,6 +129,9 @@ static int st_cmp(const sitetab_t *a, int64_t i, const sitetab_t *b, int64_t j)
 /* ------------------------------------------------------------------------------------------------
  * private state behind the opaque pointers of bgt_t
  * ------------------------------------------------------------------------------------------------ */
+typedef struct { int n, m; char **key; } alset_t;             /* bgtm_t::h_al / bgt_t::h_al: formatted alleles of -a */
+static int al_present(const alset_t *h, const char *chr, int rid, int pos, int rlen, const char *ref, int l_ref,
+                      const char *alt, int l_alt);
 typedef struct { int64_t next; } cursor_t;                   /* bgt_t::bcf */
 typedef struct { int tid, beg, end; int64_t at; int done; } region_t;   /* bgt_t::itr */
 typedef struct {                                              /* bgt_t::pb */
@@ -468,6 +472,9 @@ static int read_rec(bgt_t *bgt, bgt_rec_t *r)
             const int hit = bed_overlap(bgt->bed, bgt->f->h0->id[BCF_DT_CTG][t->rid[i]].key, t->pos[i], t->pos[i] + t->rlen[i]);
             if (bgt->bed_excl ? hit : !hit) continue;
         }
+        if (bgt->h_al && !al_present((const alset_t*)bgt->h_al, bgt->f->h0->id[BCF_DT_CTG][t->rid[i]].key, t->rid[i], t->pos[i],
+                                     t->rlen[i], t->pool + t->ref_off[i], t->ref_len[i], t->pool + t->alt_off[i], t->alt_len[i]))
+            continue;                                         /* -a: sites of the allele set only (ref bgt.c:326) */
         break;
     }
     fill_b0(bgt, i);
@@ -565,6 +572,13 @@ void bgtm_reader_destroy(bgtm_t *bm)
     int i;
     if (!bm) return;
     free(bm->hap); free(bm->alcnt);
+    for (i = 0; i < bm->n_aal; ++i) free(bm->aal[i].chr.s);
+    free(bm->aal);
+    if (bm->h_al) {
+        alset_t *h = (alset_t*)bm->h_al;
+        for (i = 0; i < h->n; ++i) free(h->key[i]);
+        free(h->key); free(h);
+    }
     if (bm->site_flt) ke_destroy(bm->site_flt);
     free(bm->mgs); free(bm->group); free(bm->sample_idx);
     if (bm->h_out) bcf_hdr_destroy(bm->h_out);
@@ -656,12 +670,64 @@ int bgtm_set_table(bgtm_t *bm, const char *fmt)
     free(piece);
     return ok ? 0 : -1;
 }
-int bgtm_set_alleles(bgtm_t *bm, const char *expr, const fmf_t *f, const char *fn)
-{ (void)bm; (void)expr; (void)f; (void)fn; return not_built("allele-set queries (-a/-S/-H)"); }
-bgt_hapcnt_t *bgtm_hapcnt(const bgtm_t *bm, int *n_hap) { (void)bm; *n_hap = 0; not_built("haplotype counting (-H)"); return NULL; }
-char *bgtm_hapcnt_print_destroy(const bgtm_t *bm, int n_hap, bgt_hapcnt_t *hc) { (void)bm; (void)n_hap; (void)hc; return NULL; }
-char *bgtm_alcnt_print(const bgtm_t *bm) { (void)bm; return NULL; }
-int bgt_al_parse(const char *al, bgt_allele_t *a) { (void)al; (void)a; return not_built("allele parsing"); }
+/* ------------------------------------------------------------------------------------------------
+ * allele sets (-a): "chr:pos:rlen:alt" / "chr:pos:REF:ALT" / "chr:pos::REF" strings, one per comma or per
+ * line of a file.  An allele is kept as {chr, 0-based pos, rlen, alt} with the bases common to both ends of
+ * REF and ALT removed; a record matches the set through its first ALT (or, for a "reference allele" query,
+ * through its REF).  Restated from reference bgt.c:976-1060 (parsing, normal form), :252-270 (matching),
+ * :477-544 (the set, and the region it implies).
+ * ------------------------------------------------------------------------------------------------ */
+
+static int alset_has(const alset_t *h, const char *k)
+{
+    int i;
+    for (i = 0; i < h->n; ++i) if (strcmp(h->key[i], k) == 0) return 1;
+    return 0;
+}
+
+int bgt_al_parse(const char *al, bgt_allele_t *a)
+{
+    const char *p = al, *ref = NULL, *alt;
+    int off, i, tmp;
+    a->chr.l = 0; a->al = NULL; a->pos = -1; a->rlen = -1; a->rid = -1;
+    while (*p && *p != ':') ++p;
+    if (*p == 0) return -1;
+    ks_putn(&a->chr, al, (size_t)(p - al)); ks_putc(&a->chr, 0);
+    ++p;
+    if (!isdigit((unsigned char)*p)) return -1;
+    a->pos = (int)strtol(p, (char**)&p, 10) - 1;
+    if (*p != ':') return -1;
+    ++p;
+    if (isdigit((unsigned char)*p)) a->rlen = (int)strtol(p, (char**)&p, 10);       /* reference length ... */
+    else if (isalpha((unsigned char)*p)) {                                            /* ... or the reference bases */
+        ref = p;
+        while (isalpha((unsigned char)*p)) ++p;
+        a->rlen = (int)(p - ref);
+    }                                                                                 /* or empty: as long as the allele */
+    if (*p != ':') return -1;
+    alt = ++p;
+    if (a->rlen < 0) { for (i = 0; isalpha((unsigned char)alt[i]); ++i) {} a->rlen = i; }
+    for (off = 0; *p && isalpha((unsigned char)*p); ++p) {                            /* bases shared at the left end */
+        if (ref && toupper((unsigned char)*p) == toupper((unsigned char)ref[off])) ++off;
+        else break;
+    }
+    a->pos += off; a->rlen -= off;
+    tmp = (int)a->chr.l;
+    ks_puts(&a->chr, alt + off);
+    a->al = a->chr.s + tmp;
+    if (ref) {                                                                        /* and at the right end */
+        const int l_alt = (int)(a->chr.s + a->chr.l - a->al);
+        const int min_l = l_alt < a->rlen ? l_alt : a->rlen;
+        ref += off;
+        for (off = 0; off < min_l && isalpha((unsigned char)ref[a->rlen - 1 - off]) &&
+             toupper((unsigned char)ref[a->rlen - 1 - off]) == toupper((unsigned char)a->al[l_alt - 1 - off]); ++off) {}
+        a->rlen -= off;
+        a->al[l_alt - off] = 0;
+        a->chr.l -= (size_t)off;
+    }
+    return 0;
+}
+
 void bgt_al_format(const bgt_allele_t *a, kstring_t *s)
 {
     s->l = 0;
@@ -669,8 +735,114 @@ void bgt_al_format(const bgt_allele_t *a, kstring_t *s)
     ks_puti(s, a->pos); ks_putc(s, ':'); ks_puti(s, a->rlen); ks_putc(s, ':');
     ks_putn(s, a->al, (size_t)(a->chr.s + a->chr.l - a->al));
 }
+
+/* the first ALT of a record (and optionally its REF) in the same normal form */
+static void al_from_site(const char *chr, int rid, int pos, int rlen, const char *ref, int l_ref, const char *alt, int l_alt,
+                         bgt_allele_t *a, bgt_allele_t *r)
+{
+    const int min_l = l_ref < l_alt ? l_ref : l_alt, l_chr = (int)strlen(chr);
+    int shift;
+    for (shift = 0; shift < min_l && ref[shift] == alt[shift]; ++shift) {}
+    a->rid = rid; a->pos = pos + shift; a->rlen = rlen - shift;
+    a->chr.l = 0;
+    ks_putn(&a->chr, chr, (size_t)l_chr); ks_putc(&a->chr, 0);
+    ks_putn(&a->chr, alt + shift, (size_t)(l_alt - shift));
+    a->al = a->chr.s + l_chr + 1;
+    if (r) {
+        r->rid = rid; r->pos = pos + shift; r->rlen = rlen - shift;
+        r->chr.l = 0;
+        ks_putn(&r->chr, chr, (size_t)l_chr); ks_putc(&r->chr, 0);
+        ks_putn(&r->chr, ref + shift, (size_t)(l_ref - shift));
+        r->al = r->chr.s + l_chr + 1;
+    }
+}
+
 void bgt_al_from_bcf(const bcf_hdr_t *h, const bcf1_t *b, bgt_allele_t *a, bgt_allele_t *r)
-{ (void)h; (void)b; (void)a; (void)r; not_built("allele extraction"); }
+{
+    const uint8_t *p = (const uint8_t*)b->shared.s, *q, *ref, *alt;
+    int type, n, l_ref, l_alt;
+    n = bcf_dec_size(p, &q, &type); p = q + n;                                        /* ID */
+    l_ref = bcf_dec_size(p, &q, &type); ref = q; p = q + l_ref;
+    l_alt = b->n_allele > 1 ? bcf_dec_size(p, &q, &type) : 0; alt = q;
+    al_from_site(h->id[BCF_DT_CTG][b->rid].key, b->rid, b->pos, b->rlen, (const char*)ref, l_ref, (const char*)alt, l_alt, a, r);
+}
+
+/* 0 = the site is not in the set, 1 = its first ALT is, 2 = its REF is (ref bgt.c:252-270) */
+static int al_present(const alset_t *h, const char *chr, int rid, int pos, int rlen, const char *ref, int l_ref,
+                      const char *alt, int l_alt)
+{
+    bgt_allele_t a, r;
+    kstring_t s = {0, 0, 0};
+    int ret = 0;
+    memset(&a, 0, sizeof(a)); memset(&r, 0, sizeof(r));
+    al_from_site(chr, rid, pos, rlen, ref, l_ref, alt, l_alt, &a, &r);
+    bgt_al_format(&a, &s);
+    if (alset_has(h, s.s)) ret = 1;
+    else { bgt_al_format(&r, &s); if (alset_has(h, s.s)) ret = 2; }
+    free(s.s); free(a.chr.s); free(r.chr.s);
+    return ret;
+}
+
+int bgtm_set_alleles(bgtm_t *bm, const char *expr, const fmf_t *f, const char *fn)
+{
+    int i, n = 0, n_al = 0, diff_chr = 0, min_pos = INT_MAX, max_pos = INT_MIN;
+    char **lines;
+    bgt_allele_t *al;
+    alset_t *h;
+    kstring_t s = {0, 0, 0};
+    if (f || fn) return not_built("allele selection from a variant annotation database (-d)");
+    if ((lines = read_names(expr, &n)) == NULL) return -1;         /* ",a,b" / ":a,b" / a file, one allele per line */
+    al = (bgt_allele_t*)calloc((size_t)(n ? n : 1), sizeof(*al));
+    for (i = 0; i < n; ++i) {
+        if (bgt_al_parse(lines[i], &al[n_al]) == 0) ++n_al;
+        free(lines[i]);
+    }
+    free(lines);
+    if (n_al == 0) { for (i = 0; i < n; ++i) free(al[i].chr.s); free(al); return 0; }
+    h = (alset_t*)calloc(1, sizeof(*h));
+    for (i = 0; i < n_al; ++i) {
+        bgt_al_format(&al[i], &s);
+        if (!alset_has(h, s.s)) {
+            if (h->n == h->m) { h->m = h->m ? h->m << 1 : 16; h->key = (char**)realloc(h->key, (size_t)h->m * sizeof(char*)); }
+            h->key[h->n++] = strdup(s.s);
+            if (al[i].pos < min_pos) min_pos = al[i].pos;
+            if (al[i].pos > max_pos) max_pos = al[i].pos;
+            if (strcmp(al[i].chr.s, al[0].chr.s) != 0) diff_chr = 1;
+        }
+    }
+    free(s.s);
+    if (!diff_chr && bm->n_bgt > 0 && bm->bgt[0]->itr == NULL) {  /* one chromosome, no -r: the span of the alleles */
+        char *reg = (char*)malloc(strlen(al[0].chr.s) + 32);
+        sprintf(reg, "%s:%d-%d", al[0].chr.s, min_pos + 1, max_pos + 1);
+        bgtm_set_region(bm, reg);
+        free(reg);
+    }
+    for (i = 0; i < n; ++i) free(al[i].chr.s);
+    free(al);
+    bm->h_al = h;
+    for (i = 0; i < bm->n_bgt; ++i) bm->bgt[i]->h_al = h;
+    return h->n;
+}
+
+/* -H: the output order of the reference depends on the tie behaviour of its sort (bgt.c:896-930); not built */
+bgt_hapcnt_t *bgtm_hapcnt(const bgtm_t *bm, int *n_hap) { (void)bm; *n_hap = 0; not_built("haplotype counting (-H)"); return NULL; }
+char *bgtm_hapcnt_print_destroy(const bgtm_t *bm, int n_hap, bgt_hapcnt_t *hc) { (void)bm; (void)n_hap; (void)hc; return NULL; }
+
+/* -S: the samples that carry every allele of the set (ref bgt.c:957-970) */
+char *bgtm_alcnt_print(const bgtm_t *bm)
+{
+    kstring_t s = {0, 0, 0};
+    int i;
+    if (bm->alcnt == NULL) return NULL;
+    for (i = 0; i < bm->n_out; ++i) {
+        if (bm->alcnt[i] == bm->n_aal) {
+            const bgt_t *bgt = bm->bgt[bm->sample_idx[i] >> 32];
+            if (bm->mgs[i] > 1) continue;
+            ks_printf(&s, "SP\t%s\t%d\n", bgt->f->f->rows[(uint32_t)bm->sample_idx[i]].name, (int)(bm->sample_idx[i] >> 32) + 1);
+        }
+    }
+    return s.s;
+}
 
 /* merged sample list, groups, output header, device selections (ref bgt.c:597-676) */
 int bgtm_prepare(bgtm_t *bm)
@@ -682,7 +854,8 @@ int bgtm_prepare(bgtm_t *bm)
     /* does any output depend on a genotype?  not for `-G` without -C / -f / several groups (ref bgt.c:850) */
     need_counts = (bm->flag & BGT_F_SET_AC) || bm->site_flt || bm->n_fields > 0 || bm->n_groups > 1;
     for (i = bm->n_out = 0; i < bm->n_bgt; ++i) {
-        if (prepare_one(bm->bgt[i], bm->n_groups, !(bm->flag & BGT_F_NO_GT) || need_counts) < 0) rc = -1;
+        if (prepare_one(bm->bgt[i], bm->n_groups, !(bm->flag & BGT_F_NO_GT) || need_counts ||
+                        (bm->h_al && (bm->flag & (BGT_F_CNT_AL | BGT_F_CNT_HAP)))) < 0) rc = -1;
         bm->n_out += bm->bgt[i]->n_out;
     }
     bm->mgs = (int32_t*)realloc(bm->mgs, (size_t)(bm->n_out ? bm->n_out : 1) * 4);
@@ -740,6 +913,15 @@ int bgtm_prepare(bgtm_t *bm)
     bm->a[0] = (uint8_t*)realloc(bm->a[0], (size_t)(bm->n_out ? bm->n_out : 1) << 1);
     bm->a[1] = (uint8_t*)realloc(bm->a[1], (size_t)(bm->n_out ? bm->n_out : 1) << 2);   /* planes: 2 B, text: 4 B per sample */
 
+    if (bm->h_al) {                                           /* ref bgt.c:668-674 */
+        free(bm->alcnt); bm->alcnt = NULL;
+        if (bm->flag & BGT_F_CNT_AL) bm->alcnt = (int*)calloc((size_t)(bm->n_out ? bm->n_out : 1), sizeof(int));
+        for (i = 0; i < bm->n_aal; ++i) free(bm->aal[i].chr.s);
+        free(bm->aal);
+        bm->n_aal = 0;
+        bm->aal = (bgt_allele_t*)calloc((size_t)((const alset_t*)bm->h_al)->n * 2 + 1, sizeof(bgt_allele_t));
+    }
+
     /* What the device has to deliver per site.  Nothing but counts with -G.  Otherwise the finished genotype
      * vector of bgt_gen_gt (and its VCF text when the caller writes VCF): then bm->a[0] holds the merged vector
      * and bm->a[1] the merged text instead of the two byte planes.  The byte planes themselves are only needed
@@ -748,6 +930,7 @@ int bgtm_prepare(bgtm_t *bm)
         int want = 0;
         for (i = m = 0; i < bm->n_out; ++i) if (bm->mgs[i] <= 1) ++m;
         if (!(bm->flag & BGT_F_NO_GT)) want = m == bm->n_out ? BGTH_WANT_GT8 : BGTH_WANT_PLANES;
+        if (bm->h_al && (bm->flag & (BGT_F_CNT_AL | BGT_F_CNT_HAP))) want = BGTH_WANT_PLANES;   /* -S reads the codes */
         for (i = 0; i < bm->n_bgt; ++i) {
             devrd_t *dv = (devrd_t*)bm->bgt[i]->pb;
             dv->want = want | ((want & BGTH_WANT_GT8) && dv->text_mode ? BGTH_WANT_GTTEXT : 0);
@@ -846,7 +1029,7 @@ static void fill_info(const bcf_hdr_t *h, const bgt_info_t *ss, bcf1_t *b)   /* 
  * without the site contributes code 2 = missing, which adds to no count, ref :837-840,755-756). */
 static int read_core(bgtm_t *bm, bcf1_t *b)
 {
-    int i, off = 0, n_rest = 0, max_allele = 0, best = -1, l_ref;
+    int i, off = 0, n_rest = 0, max_allele = 0, best = -1, l_ref, al_ret = 0;
     const sitetab_t *bt = NULL;
     int64_t bs = -1;
     bgt_info_t ss;
@@ -872,6 +1055,10 @@ static int read_core(bgtm_t *bm, bcf1_t *b)
     l_ref = bt->ref_len[bs];
     if (l_ref != b->rlen) { int32_t val = b->pos + b->rlen; bcf_append_info_ints(bm->h_out, b, "END", 1, &val); }
 
+    if (bm->h_al) {                                           /* ref bgt.c:843-848 */
+        al_ret = al_present((const alset_t*)bm->h_al, bm->h_out->id[BCF_DT_CTG][b->rid].key, b->rid, b->pos, b->rlen,
+                            bt->pool + bt->ref_off[bs], bt->ref_len[bs], bt->pool + bt->alt_off[bs], bt->alt_len[bs]);
+    }
     memset(&ss, 0, sizeof(ss));
     ss.n_groups = bm->n_groups;
     for (i = 0; i < bm->n_bgt; ++i) {                         /* consume the databases that have this site */
@@ -906,11 +1093,23 @@ static int read_core(bgtm_t *bm, bcf1_t *b)
         }
         off += bgt->n_out << 1;
     }
+    if (bm->h_al && al_ret == 0) return 1;                    /* not an allele of the set */
     if ((bm->flag & BGT_F_SET_AC) || bm->site_flt || bm->n_fields > 0 || bm->n_groups > 1) {
         fill_info(bm->h_out, &ss, b);
         if (bm->n_fields > 0)
             gen_tbl_line(bm, &ss, b, bt->pool + bt->ref_off[bs], bt->ref_len[bs], bt->pool + bt->alt_off[bs], bt->alt_len[bs]);
         if (!pass_site_flt(&ss, bm->site_flt)) return 1;
+    }
+    if (bm->h_al) {                                           /* ref bgt.c:859-876 */
+        if ((bm->flag & BGT_F_CNT_AL) && bm->alcnt) {         /* +1 for every sample that carries the allele */
+            const int want = al_ret == 2 ? 0 : 1;             /* a reference-allele query counts code 0 */
+            for (i = 0; i < bm->n_out; ++i) {
+                const int g1 = bm->a[0][i << 1] | bm->a[1][i << 1] << 1, g2 = bm->a[0][i << 1 | 1] | bm->a[1][i << 1 | 1] << 1;
+                bm->alcnt[i] += (g1 == want || g2 == want);
+            }
+        }
+        al_from_site(bm->h_out->id[BCF_DT_CTG][b->rid].key, b->rid, b->pos, b->rlen, bt->pool + bt->ref_off[bs], bt->ref_len[bs],
+                     bt->pool + bt->alt_off[bs], bt->alt_len[bs], &bm->aal[bm->n_aal++], NULL);
     }
     return 0;
 }

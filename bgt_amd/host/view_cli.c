@@ -1,5 +1,5 @@
 /* view_cli.c -- `bgt view`: option handling and the pull loop of reference view.c:14-183, on the MI355X
- * reader.  The allele-set queries (-a/-d/-M/-S/-H) are recognised and refused. */
+ * reader.  -d/-M (variant annotation database) and -H (haplotype counting) are recognised and refused. */
 #include <limits.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -25,7 +25,7 @@ int main_view(int argc, char *argv[])
     int i, c, n_files, out_bcf = 0, clevel = -1, flag = 0, u_set = 0, n_groups = 0, not_vcf = 0, excl = 0;
     void *bed = NULL;
     long seekn = -1, n_rec = LONG_MAX, n_read = 0;
-    char *reg = NULL, *site_flt = NULL, *fmt = NULL, *gexpr[BGT_MAX_GROUPS];
+    char *reg = NULL, *site_flt = NULL, *fmt = NULL, *aexpr = NULL, *gexpr[BGT_MAX_GROUPS];
     bgt_file_t **files;
     bgtm_t *bm;
     bcf1_t *b;
@@ -48,7 +48,9 @@ int main_view(int argc, char *argv[])
         case 't': fmt = optarg; not_vcf = 1; break;                 /* tabular output instead of VCF (ref view.c:43) */
         case 'B': bed = bed_read(optarg); break;                     /* ref view.c:34 */
         case 'e': excl = 1; break;
-        case 'a': case 'd': case 'M': case 'S': case 'H':
+        case 'a': aexpr = optarg; break;                            /* ref view.c:46 */
+        case 'S': flag |= BGT_F_NO_GT | BGT_F_CNT_AL; not_vcf = 1; break;
+        case 'd': case 'M': case 'H':
             fprintf(stderr, "[E::%s] option -%c is outside the genotype-matrix read path and not part of this build.\n", __func__, c);
             return 1;
         default: break;
@@ -83,6 +85,11 @@ int main_view(int argc, char *argv[])
         return 1;
     }
     if (seekn > 0) bgtm_set_start(bm, seekn);
+    if (aexpr) {                                                    /* ref view.c:125-133 */
+        const int n_al = bgtm_set_alleles(bm, aexpr, NULL, NULL);
+        if (n_al < 0) { fprintf(stderr, "[E::%s] failed to set alleles.\n", __func__); return 1; }
+        if (n_al == 0) fprintf(stderr, "[W::%s] no alleles selected.\n", __func__);
+    }
     for (i = 0; i < n_groups; ++i)
         if (bgtm_add_group(bm, gexpr[i]) < 0) {
             fprintf(stderr, "[E::%s] failed to add sample group '%s'.\n", __func__, gexpr[i]);
@@ -105,6 +112,11 @@ int main_view(int argc, char *argv[])
         ++n_read;
     }
     bcf_destroy1(b);
+    if (not_vcf && bm->n_aal > 0 && (bm->flag & BGT_F_CNT_AL)) {    /* ref view.c:158-173 */
+        char *s = bgtm_alcnt_print(bm);
+        if (s) fputs(s, stdout);
+        free(s);
+    }
     if (bz) bgzw_close(bz);
     fflush(stdout);
     free(line.s);

@@ -26,6 +26,15 @@ TABLE_CMDS = {
     "synA_bed_excl": (["-CG", "-B", "regions.bed", "-e"], ["synA"]),
     "synA_bed_points_gt": (["-B", "points.bed", "-s", 'pop=="X"'], ["synA"]),
     "synAB_bed_f": (["-G", "-B", "regions.bed", "-f", "AC>2"], ["synA", "synB"]),
+    # -a / -S: allele sets (reference bgt.c:477-544, :843-876, :957-970); alleles.txt is a fixture of this repo
+    "synA_al": (["-a", ",11:1010:1:A,11:1050:1:C"], ["synA"]),
+    "synA_al_G": (["-G", "-C", "-a", "alleles.txt"], ["synA"]),
+    "synA_al_S": (["-S", "-a", "alleles.txt"], ["synA"]),
+    "synA_al_S2": (["-S", "-a", ":11:1010:T:A,11:1100:CAG:C"], ["synA"]),
+    "synA_al_S1": (["-S", "-a", ",11:1010:1:C", "-s", "idx<25"], ["synA"]),
+    "synAB_al_S": (["-S", "-a", ",11:1060:1:G,11:1040:1:G", "-s", 'pop=="X"', "-s", 'pop=="Y"'], ["synA", "synB"]),
+    "synA_al_refquery": (["-S", "-a", ",11:1060::C"], ["synA"]),
+    "synA_al_none": (["-G", "-a", ",13:5:1:A,nonsense"], ["synA"]),
     "synA_bed_t": (["-B", "points.bed", "-e", "-t", "CHROM,POS,END,AC", "-n", "6"], ["synA"]),
 }
 

@@ -79,3 +79,30 @@ def test_two_database_group_join_like_config5(tmp_path):
         ref = md5_of([REF, "view"] + args + [a, b])
         assert mine[0] == ref[0] == 0, (mine, ref)
         assert mine[2] > 0 and mine[1:3] == ref[1:3], (args, mine, ref)
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref not present")
+def test_tables_bed_and_allele_sets_like_reference(c1, tmp_path):
+    """-t tables, -B/-e BED filters and -a/-S allele sets on the C1-shaped database; the allele strings are taken
+    from sites the reference itself reports (every 997th site with AC > 20), in REF:ALT and in rlen:ALT form."""
+    bed = tmp_path / "r.bed"
+    bed.write_text("".join("11\t%d\t%d\n" % (1000 + 977 * k, 1000 + 977 * k + 300 * (k % 7)) for k in range(1, 400)) +
+                   "11\t250000\n12\t1\t1000\n")
+    sites = subprocess.run([REF, "view", "-G", "-f", "AC>20", "-t", "CHROM,POS,REF,ALT,AC", c1], stdout=subprocess.PIPE,
+                           check=True).stdout.decode().splitlines()
+    assert len(sites) > 5000
+    picks = [s.split("\t") for s in sites[::997]][:12]
+    als = ",".join(["%s:%s:%s:%s" % (c, p, r, a) for c, p, r, a, _ in picks[:6]] +
+                   ["%s:%s:%d:%s" % (c, p, len(r), a) for c, p, r, a, _ in picks[6:]])
+    alfile = tmp_path / "alleles.txt"
+    alfile.write_text("\n".join("%s:%s:%s:%s\tnote" % (c, p, r, a) for c, p, r, a, _ in picks[:3]) + "\n")
+    for args in (["-G", "-t", "CHROM,POS,END,REF,ALT,AC,AN,AC/AN,AC//3,AN%11", "-f", "AC>0", "-n", "20000"],
+                 ["-G", "-s", "pop==\"A\"", "-s", "pop==\"B\"", "-t", "POS,AC1,AN1,AC2,AN2,AC1/AN1-AC2/AN2,AC3"],
+                 ["-CG", "-B", str(bed)], ["-CG", "-B", str(bed), "-e", "-r", "11:1000-200000"],
+                 ["-G", "-a", "," + als, "-C"], ["-a", str(alfile), "-s", "idx<50"],
+                 ["-S", "-a", "," + ",".join(als.split(",")[:2])], ["-S", "-a", str(alfile), "-s", "pop==\"A\""],
+                 ["-S", "-a", ",%s:%s::%s" % (picks[0][0], picks[0][1], picks[0][2])]):
+        mine = md5_of([BGT, "view"] + args + [c1])
+        ref = md5_of([REF, "view"] + args + [c1])
+        assert mine[0] == ref[0] == 0, (args, mine, ref)
+        assert mine[1:3] == ref[1:3], (args, mine, ref)
