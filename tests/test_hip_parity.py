@@ -367,3 +367,43 @@ def test_edge_shapes(hip, tmp_path):
     for cut in (15, 17, len(data) // 2, len(data) - 9):
         with pytest.raises(RuntimeError):
             hip.HipPbf.from_bytes(data[:cut])
+
+
+def test_readers_on_threads_share_one_image(hip):
+    """SURVEY 8b threading: distinct readers over one image may run on different OS threads (the Go server's
+    per-request readers).  Four threads scan different selections of one image -- narrow and wide enough for the
+    lazily built row index -- repeatedly; every result must equal the single-threaded one."""
+    import threading
+    rng = np.random.default_rng(5)
+    mat = scenarios.ld_matrix(rng, 600, 41000, n_founders=20, switch=0.05)
+    data = orc.encode_pbf(mat, 2, 7)
+    pbf = hip.HipPbf.from_bytes(data)
+    sels = [None] + [np.sort(rng.choice(20500, k, replace=False)) for k in (50, 700, 5000)]
+    sels = [None if s is None else np.stack([2 * s, 2 * s + 1], 1).reshape(-1).astype(np.int32) for s in sels]
+    want = []
+    for s in sels:
+        sub = mat if s is None else mat[:, s]
+        want.append(np.stack([(sub != 2).sum(1), (sub == 1).sum(1), (sub == 3).sum(1)], 1).astype(np.int32))
+    errors = []
+
+    def work(k):
+        try:
+            rd = hip.HipReader(pbf)
+            if sels[k] is not None:
+                rd.select(sels[k])
+            if k == 0:
+                rd.tune(512, 80, 1)                       # team mode: builds the row index while others scan
+            for _ in range(4):
+                got = rd.scan(0, 600)[:, 0]
+                if not np.array_equal(got, want[k]):
+                    errors.append("thread %d: counts differ" % k)
+            rd.close()
+        except Exception as e:                            # noqa: BLE001
+            errors.append("thread %d: %r" % (k, e))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(sels))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
