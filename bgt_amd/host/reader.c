@@ -824,9 +824,120 @@ int bgtm_set_alleles(bgtm_t *bm, const char *expr, const fmf_t *f, const char *f
     return h->n;
 }
 
-/* -H: the output order of the reference depends on the tie behaviour of its sort (bgt.c:896-930); not built */
-bgt_hapcnt_t *bgtm_hapcnt(const bgtm_t *bm, int *n_hap) { (void)bm; *n_hap = 0; not_built("haplotype counting (-H)"); return NULL; }
-char *bgtm_hapcnt_print_destroy(const bgtm_t *bm, int n_hap, bgt_hapcnt_t *hc) { (void)bm; (void)n_hap; (void)hc; return NULL; }
+/* ------------------------------------------------------------------------------------------------
+ * -H: count the distinct haplotypes over the alleles of the set (ref bgt.c:896-955).  Haplotypes are numbered
+ * in order of first appearance and then sorted by decreasing total; the order among EQUAL totals is whatever
+ * the reference's sort leaves (klib introsort: median-of-three quicksort that leaves stretches of <= 16 to
+ * one final insertion sort, comb sort once the depth budget is spent), so the same steps are followed here.
+ * ------------------------------------------------------------------------------------------------ */
+#define HC_BEFORE(x, y) ((x).tot > (y).tot)
+#define HC_SWAP(x, y) do { bgt_hapcnt_t t_ = (x); (x) = (y); (y) = t_; } while (0)
+
+static void hc_insertion(bgt_hapcnt_t *a, int n)
+{
+    int i, j;
+    for (i = 1; i < n; ++i)
+        for (j = i; j > 0 && HC_BEFORE(a[j], a[j - 1]); --j) HC_SWAP(a[j], a[j - 1]);
+}
+
+static void hc_comb(bgt_hapcnt_t *a, int n)
+{
+    const double shrink = 1.2473309501039786540366528676643;
+    int gap = n, swapped, i;
+    do {
+        if (gap > 2) { gap = (int)(gap / shrink); if (gap == 9 || gap == 10) gap = 11; }
+        swapped = 0;
+        for (i = 0; i + gap < n; ++i)
+            if (HC_BEFORE(a[i + gap], a[i])) { HC_SWAP(a[i], a[i + gap]); swapped = 1; }
+    } while (swapped || gap > 2);
+    if (gap != 1) hc_insertion(a, n);
+}
+
+static void hc_sort(bgt_hapcnt_t *a, int n)
+{
+    struct { int lo, hi, depth; } stack[160];
+    int top = 0, lo, hi, depth;
+    if (n < 1) return;
+    if (n == 2) { if (HC_BEFORE(a[1], a[0])) HC_SWAP(a[0], a[1]); return; }
+    for (depth = 2; (1ul << depth) < (unsigned long)n; ++depth) {}
+    depth <<= 1;
+    lo = 0; hi = n - 1;
+    for (;;) {
+        if (lo < hi) {
+            int i = lo, j = hi, k = lo + ((hi - lo) >> 1) + 1;
+            bgt_hapcnt_t pivot;
+            if (--depth == 0) { hc_comb(a + lo, hi - lo + 1); hi = lo; continue; }
+            if (HC_BEFORE(a[k], a[i])) { if (HC_BEFORE(a[k], a[j])) k = j; }      /* median of first, middle, last */
+            else k = HC_BEFORE(a[j], a[i]) ? i : j;
+            pivot = a[k];
+            if (k != hi) HC_SWAP(a[k], a[hi]);
+            for (;;) {
+                do ++i; while (HC_BEFORE(a[i], pivot));
+                do --j; while (i <= j && HC_BEFORE(pivot, a[j]));
+                if (j <= i) break;
+                HC_SWAP(a[i], a[j]);
+            }
+            HC_SWAP(a[i], a[hi]);
+            if (i - lo > hi - i) {                            /* the larger side waits on the stack if it is > 16 */
+                if (i - lo > 16) { stack[top].lo = lo; stack[top].hi = i - 1; stack[top].depth = depth; ++top; }
+                lo = hi - i > 16 ? i + 1 : hi;
+            } else {
+                if (hi - i > 16) { stack[top].lo = i + 1; stack[top].hi = hi; stack[top].depth = depth; ++top; }
+                hi = i - lo > 16 ? i - 1 : lo;
+            }
+        } else if (top == 0) { hc_insertion(a, n); return; }
+        else { --top; lo = stack[top].lo; hi = stack[top].hi; depth = stack[top].depth; }
+    }
+}
+
+bgt_hapcnt_t *bgtm_hapcnt(const bgtm_t *bm, int *n_hap)
+{
+    bgt_hapcnt_t *hc = NULL;
+    int i, j, n = 0, m = 0, n_slot = 64, *slot;
+    *n_hap = 0;
+    if (bm->hap == NULL || bm->n_out == 0) return NULL;
+    while (n_slot < bm->n_out * 4) n_slot <<= 1;              /* open addressing: haplotype -> its number */
+    slot = (int*)malloc((size_t)n_slot * sizeof(int));
+    for (i = 0; i < n_slot; ++i) slot[i] = -1;
+    for (i = 0; i < bm->n_out << 1; ++i) {
+        const uint64_t h = bm->hap[i];
+        uint64_t k = (h * 0x9E3779B97F4A7C15ull) >> 20 & (uint64_t)(n_slot - 1);
+        while (slot[k] >= 0 && hc[slot[k]].hap != h) k = (k + 1) & (uint64_t)(n_slot - 1);
+        if (slot[k] < 0) {                                    /* first appearance */
+            if (n == m) { m = m ? m << 1 : 16; hc = (bgt_hapcnt_t*)realloc(hc, (size_t)m * sizeof(*hc)); }
+            hc[n].hap = h; hc[n].tot = 0; hc[n].cnt = (int*)calloc((size_t)bm->n_groups, sizeof(int));
+            slot[k] = n++;
+        }
+        ++hc[slot[k]].tot;
+        for (j = 0; j < bm->n_groups; ++j)                    /* the group id read as a bit mask, as the reference does */
+            if (bm->group[i >> 1] & 1U << j) ++hc[slot[k]].cnt[j];
+    }
+    free(slot);
+    hc_sort(hc, n);
+    *n_hap = n;
+    return hc;
+}
+
+char *bgtm_hapcnt_print_destroy(const bgtm_t *bm, int n_hap, bgt_hapcnt_t *hc)
+{
+    kstring_t s = {0, 0, 0};
+    int i, j;
+    ks_printf(&s, "NA\t%d\n", bm->n_aal);
+    for (i = 0; i < bm->n_aal; ++i) {
+        const bgt_allele_t *a = &bm->aal[i];
+        ks_printf(&s, "AA\t%s:%d:%d:%s\n", a->chr.s, a->pos + 1, a->rlen, a->al);
+    }
+    ks_printf(&s, "NH\t%d\t%d\n", n_hap, bm->n_groups);
+    for (i = 0; i < n_hap; ++i) {
+        ks_puts(&s, "HC\t");
+        for (j = 0; j < bm->n_aal; ++j) ks_putc(&s, (char)('0' + (hc[i].hap >> j & 1)));
+        for (j = 0; j < bm->n_groups; ++j) ks_printf(&s, "\t%d", hc[i].cnt[j]);
+        ks_putc(&s, '\n');
+        free(hc[i].cnt);
+    }
+    free(hc);
+    return s.s;
+}
 
 /* -S: the samples that carry every allele of the set (ref bgt.c:957-970) */
 char *bgtm_alcnt_print(const bgtm_t *bm)
@@ -916,6 +1027,8 @@ int bgtm_prepare(bgtm_t *bm)
     if (bm->h_al) {                                           /* ref bgt.c:668-674 */
         free(bm->alcnt); bm->alcnt = NULL;
         if (bm->flag & BGT_F_CNT_AL) bm->alcnt = (int*)calloc((size_t)(bm->n_out ? bm->n_out : 1), sizeof(int));
+        free(bm->hap); bm->hap = NULL;
+        if (bm->flag & BGT_F_CNT_HAP) bm->hap = (uint64_t*)calloc((size_t)(bm->n_out ? bm->n_out : 1) << 1, 8);
         for (i = 0; i < bm->n_aal; ++i) free(bm->aal[i].chr.s);
         free(bm->aal);
         bm->n_aal = 0;
@@ -1108,6 +1221,9 @@ static int read_core(bgtm_t *bm, bcf1_t *b)
                 bm->alcnt[i] += (g1 == want || g2 == want);
             }
         }
+        if ((bm->flag & BGT_F_CNT_HAP) && bm->hap)            /* bit n_aal of a haplotype: it carries this allele */
+            for (i = 0; i < bm->n_out << 1; ++i)
+                if (bm->a[0][i] == 1 && bm->a[1][i] == 0) bm->hap[i] |= 1ULL << bm->n_aal;
         al_from_site(bm->h_out->id[BCF_DT_CTG][b->rid].key, b->rid, b->pos, b->rlen, bt->pool + bt->ref_off[bs], bt->ref_len[bs],
                      bt->pool + bt->alt_off[bs], bt->alt_len[bs], &bm->aal[bm->n_aal++], NULL);
     }

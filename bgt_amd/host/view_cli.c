@@ -1,5 +1,5 @@
 /* view_cli.c -- `bgt view`: option handling and the pull loop of reference view.c:14-183, on the MI355X
- * reader.  -d/-M (variant annotation database) and -H (haplotype counting) are recognised and refused. */
+ * reader.  -d/-M (variant annotation database) are recognised and refused. */
 #include <limits.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -17,6 +17,9 @@ static int usage(const char *cmd)
     fprintf(stderr, "  -f STR    site filter on AC, AN, AC#, AN# (e.g. 'AC>0', 'AC1/AN1>=0.1&&AC2==0')\n");
     fprintf(stderr, "  -G        no sample genotypes     -C   write AC/AN (implied by -f or several -s)\n");
     fprintf(stderr, "  -b        BCF output   -l INT   compression level   -u   uncompressed BCF\n");
+    fprintf(stderr, "  -B FILE   sites overlapping the BED intervals   -e   ... not overlapping\n");
+    fprintf(stderr, "  -a EXPR   allele set: ,chr:pos:rlen:alt,... | ,chr:pos:REF:ALT | file   -S   samples carrying all of them\n");
+    fprintf(stderr, "  -H        haplotype counts over the allele set   -t STR   table of comma-separated expressions\n");
     return 1;
 }
 
@@ -50,7 +53,8 @@ int main_view(int argc, char *argv[])
         case 'e': excl = 1; break;
         case 'a': aexpr = optarg; break;                            /* ref view.c:46 */
         case 'S': flag |= BGT_F_NO_GT | BGT_F_CNT_AL; not_vcf = 1; break;
-        case 'd': case 'M': case 'H':
+        case 'H': flag |= BGT_F_NO_GT | BGT_F_CNT_HAP; not_vcf = 1; break;
+        case 'd': case 'M':
             fprintf(stderr, "[E::%s] option -%c is outside the genotype-matrix read path and not part of this build.\n", __func__, c);
             return 1;
         default: break;
@@ -112,10 +116,19 @@ int main_view(int argc, char *argv[])
         ++n_read;
     }
     bcf_destroy1(b);
-    if (not_vcf && bm->n_aal > 0 && (bm->flag & BGT_F_CNT_AL)) {    /* ref view.c:158-173 */
-        char *s = bgtm_alcnt_print(bm);
-        if (s) fputs(s, stdout);
-        free(s);
+    if (not_vcf && bm->n_aal > 0) {                                 /* ref view.c:158-173 */
+        if (bm->flag & BGT_F_CNT_HAP) {
+            int n_hap;
+            bgt_hapcnt_t *hc = bgtm_hapcnt(bm, &n_hap);
+            char *s = bgtm_hapcnt_print_destroy(bm, n_hap, hc);
+            if (s) fputs(s, stdout);
+            free(s);
+        }
+        if (bm->flag & BGT_F_CNT_AL) {
+            char *s = bgtm_alcnt_print(bm);
+            if (s) fputs(s, stdout);
+            free(s);
+        }
     }
     if (bz) bgzw_close(bz);
     fflush(stdout);

@@ -34,6 +34,11 @@ TABLE_CMDS = {
     "synA_al_S1": (["-S", "-a", ",11:1010:1:C", "-s", "idx<25"], ["synA"]),
     "synAB_al_S": (["-S", "-a", ",11:1060:1:G,11:1040:1:G", "-s", 'pop=="X"', "-s", 'pop=="Y"'], ["synA", "synB"]),
     "synA_al_refquery": (["-S", "-a", ",11:1060::C"], ["synA"]),
+    # -H: haplotype counts over the allele set (reference bgt.c:896-955)
+    "synA_hap": (["-H", "-a", "alleles.txt"], ["synA"]),
+    "synA_hap2": (["-H", "-a", ",11:1010:1:A,11:1010:1:C,11:1050:1:A,11:1060:1:G,11:1020:1:T,11:1030:1:C,11:1040:1:G"], ["synA"]),
+    "synAB_hap_grp": (["-H", "-S", "-a", ",11:1060:1:G,11:1040:1:G,11:1080:1:G", "-s", 'pop=="X"', "-s", 'pop=="Y"', "-s", "idx<10"],
+                      ["synA", "synB"]),
     "synA_al_none": (["-G", "-a", ",13:5:1:A,nonsense"], ["synA"]),
     "synA_bed_t": (["-B", "points.bed", "-e", "-t", "CHROM,POS,END,AC", "-n", "6"], ["synA"]),
 }

@@ -101,7 +101,10 @@ def test_tables_bed_and_allele_sets_like_reference(c1, tmp_path):
                  ["-CG", "-B", str(bed)], ["-CG", "-B", str(bed), "-e", "-r", "11:1000-200000"],
                  ["-G", "-a", "," + als, "-C"], ["-a", str(alfile), "-s", "idx<50"],
                  ["-S", "-a", "," + ",".join(als.split(",")[:2])], ["-S", "-a", str(alfile), "-s", "pop==\"A\""],
-                 ["-S", "-a", ",%s:%s::%s" % (picks[0][0], picks[0][1], picks[0][2])]):
+                 ["-S", "-a", ",%s:%s::%s" % (picks[0][0], picks[0][1], picks[0][2])],
+                 ["-H", "-a", "," + ",".join(als.split(",")[:7])],                       # > 16 distinct haplotypes, many ties
+                 ["-H", "-a", "," + als, "-s", "pop==\"A\"", "-s", "pop==\"B\"", "-s", "idx%3==0"],
+                 ["-H", "-S", "-a", str(alfile)]):
         mine = md5_of([BGT, "view"] + args + [c1])
         ref = md5_of([REF, "view"] + args + [c1])
         assert mine[0] == ref[0] == 0, (args, mine, ref)
