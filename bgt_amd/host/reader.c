@@ -783,6 +783,73 @@ static int al_present(const alset_t *h, const char *chr, int rid, int pos, int r
     return ret;
 }
 
+static int is_readable_file(const char *fn)                   /* ref bgt.c:163-173 */
+{
+    FILE *fp;
+    if (bgt_no_file) return 0;
+    if ((fp = fopen(fn, "r")) == NULL) return 0;
+    fclose(fp);
+    return 1;
+}
+
+/* Row names of an FMF file whose metadata satisfy `ke`, reading line by line.  Unlike the in-memory test
+ * (fmf_test) a value typed `f` is bound as a real and `_ROW_` is bound for every row (ref fmf.c:185-218). */
+static char **fmf_stream_select(const char *fn, kexpr_t *ke, int *n_out)
+{
+    gzFile fp = fn && strcmp(fn, "-") ? gzopen(fn, "r") : gzdopen(0, "r");
+    char **names = NULL, *line = NULL;
+    int n = 0, m = 0, c;
+    size_t l = 0, cap = 0;
+    *n_out = 0;
+    if (fp == NULL) return NULL;
+    names = (char**)calloc(1, sizeof(char*));
+    for (;;) {
+        c = gzgetc(fp);
+        if (c != -1 && c != '\n') {
+            if (l + 2 > cap) { cap = cap ? cap << 1 : 256; line = (char*)realloc(line, cap); }
+            line[l++] = (char)c;
+            continue;
+        }
+        if (l > 0) {
+            char *p, *q;
+            int field = 0, err = 0, yes;
+            line[l] = 0;
+            ke_unset(ke);
+            for (p = q = line;; ++p) {
+                if (*p == 0 || *p == '\t') {
+                    const int last = *p == 0;
+                    *p = 0;
+                    if (field == 0) ke_set_str(ke, "_ROW_", q);
+                    else {
+                        char *r = q;
+                        while (*r && *r != ':') ++r;
+                        if (*r == ':' && p - r >= 3) {
+                            *r = 0;
+                            if (r[1] == 'i') ke_set_int(ke, q, strtol(r + 3, NULL, 0));
+                            else if (r[1] == 'f') ke_set_real(ke, q, strtod(r + 3, NULL));
+                            else ke_set_str(ke, q, r + 3);
+                            *r = ':';
+                        }
+                    }
+                    q = p + 1; ++field;
+                    if (last) break;
+                }
+            }
+            yes = !!ke_eval_int(ke, &err);
+            if (!err && yes) {
+                if (n == m) { m = m ? m << 1 : 16; names = (char**)realloc(names, (size_t)m * sizeof(char*)); }
+                names[n++] = strdup(line);                    /* the first field: the tabs were turned into terminators */
+            }
+        }
+        l = 0;
+        if (c == -1) break;
+    }
+    free(line);
+    gzclose(fp);
+    *n_out = n;
+    return names;
+}
+
 int bgtm_set_alleles(bgtm_t *bm, const char *expr, const fmf_t *f, const char *fn)
 {
     int i, n = 0, n_al = 0, diff_chr = 0, min_pos = INT_MAX, max_pos = INT_MIN;
@@ -790,8 +857,20 @@ int bgtm_set_alleles(bgtm_t *bm, const char *expr, const fmf_t *f, const char *f
     bgt_allele_t *al;
     alset_t *h;
     kstring_t s = {0, 0, 0};
-    if (f || fn) return not_built("allele selection from a variant annotation database (-d)");
-    if ((lines = read_names(expr, &n)) == NULL) return -1;         /* ",a,b" / ":a,b" / a file, one allele per line */
+    if (!(*expr == ':' || *expr == ',' || (*expr != '?' && is_readable_file(expr)) || (f == NULL && fn == NULL && is_readable_file(expr)))) {
+        /* an expression on the rows of a variant annotation file (-d): the names of the rows it accepts */
+        int err;
+        kexpr_t *ke;
+        if (f == NULL && fn == NULL) return -1;
+        ke = ke_parse(expr, &err);
+        if (err) { if (ke) ke_destroy(ke); return -1; }
+        if (f) {                                              /* -M: the file is in memory (ref bgt.c:499-502) */
+            lines = (char**)calloc((size_t)(f->n_rows ? f->n_rows : 1), sizeof(char*));
+            for (i = 0; i < f->n_rows; ++i) if (fmf_test(f, i, ke)) lines[n++] = strdup(f->rows[i].name);
+        } else lines = fmf_stream_select(fn, ke, &n);          /* streamed (ref bgt.c:504-509, fmf.c:185-218) */
+        ke_destroy(ke);
+        if (lines == NULL) return -1;
+    } else if ((lines = read_names(expr, &n)) == NULL) return -1;   /* ",a,b" / ":a,b" / a file, one allele per line */
     al = (bgt_allele_t*)calloc((size_t)(n ? n : 1), sizeof(*al));
     for (i = 0; i < n; ++i) {
         if (bgt_al_parse(lines[i], &al[n_al]) == 0) ++n_al;

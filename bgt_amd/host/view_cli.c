@@ -1,5 +1,5 @@
 /* view_cli.c -- `bgt view`: option handling and the pull loop of reference view.c:14-183, on the MI355X
- * reader.  -d/-M (variant annotation database) are recognised and refused. */
+ * reader. */
 #include <limits.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -19,16 +19,18 @@ static int usage(const char *cmd)
     fprintf(stderr, "  -b        BCF output   -l INT   compression level   -u   uncompressed BCF\n");
     fprintf(stderr, "  -B FILE   sites overlapping the BED intervals   -e   ... not overlapping\n");
     fprintf(stderr, "  -a EXPR   allele set: ,chr:pos:rlen:alt,... | ,chr:pos:REF:ALT | file   -S   samples carrying all of them\n");
+    fprintf(stderr, "  -d FILE   variant annotations (FMF): -a EXPR then selects its rows by metadata   -M   load FILE in memory\n");
     fprintf(stderr, "  -H        haplotype counts over the allele set   -t STR   table of comma-separated expressions\n");
     return 1;
 }
 
 int main_view(int argc, char *argv[])
 {
-    int i, c, n_files, out_bcf = 0, clevel = -1, flag = 0, u_set = 0, n_groups = 0, not_vcf = 0, excl = 0;
+    int i, c, n_files, out_bcf = 0, clevel = -1, flag = 0, u_set = 0, n_groups = 0, not_vcf = 0, excl = 0, in_mem = 0;
+    fmf_t *vardb = NULL;
     void *bed = NULL;
     long seekn = -1, n_rec = LONG_MAX, n_read = 0;
-    char *reg = NULL, *site_flt = NULL, *fmt = NULL, *aexpr = NULL, *gexpr[BGT_MAX_GROUPS];
+    char *reg = NULL, *site_flt = NULL, *fmt = NULL, *aexpr = NULL, *dbfn = NULL, *gexpr[BGT_MAX_GROUPS];
     bgt_file_t **files;
     bgtm_t *bm;
     bcf1_t *b;
@@ -54,9 +56,8 @@ int main_view(int argc, char *argv[])
         case 'a': aexpr = optarg; break;                            /* ref view.c:46 */
         case 'S': flag |= BGT_F_NO_GT | BGT_F_CNT_AL; not_vcf = 1; break;
         case 'H': flag |= BGT_F_NO_GT | BGT_F_CNT_HAP; not_vcf = 1; break;
-        case 'd': case 'M':
-            fprintf(stderr, "[E::%s] option -%c is outside the genotype-matrix read path and not part of this build.\n", __func__, c);
-            return 1;
+        case 'd': dbfn = optarg; break;                             /* variant annotations (FMF) for -a EXPR */
+        case 'M': in_mem = 1; break;
         default: break;
         }
     }
@@ -90,7 +91,9 @@ int main_view(int argc, char *argv[])
     }
     if (seekn > 0) bgtm_set_start(bm, seekn);
     if (aexpr) {                                                    /* ref view.c:125-133 */
-        const int n_al = bgtm_set_alleles(bm, aexpr, NULL, NULL);
+        int n_al;
+        if (dbfn && in_mem) vardb = fmf_read(dbfn);                 /* ref view.c:76-84 */
+        n_al = bgtm_set_alleles(bm, aexpr, vardb, in_mem ? NULL : dbfn);
         if (n_al < 0) { fprintf(stderr, "[E::%s] failed to set alleles.\n", __func__); return 1; }
         if (n_al == 0) fprintf(stderr, "[W::%s] no alleles selected.\n", __func__);
     }
@@ -135,6 +138,7 @@ int main_view(int argc, char *argv[])
     free(line.s);
     bgtm_reader_destroy(bm);
     if (bed) bed_destroy(bed);
+    if (vardb) fmf_destroy(vardb);
     for (i = 0; i < n_files; ++i) bgt_close(files[i]);
     free(files);
     return 0;

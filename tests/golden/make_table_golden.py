@@ -39,6 +39,14 @@ TABLE_CMDS = {
     "synA_hap2": (["-H", "-a", ",11:1010:1:A,11:1010:1:C,11:1050:1:A,11:1060:1:G,11:1020:1:T,11:1030:1:C,11:1040:1:G"], ["synA"]),
     "synAB_hap_grp": (["-H", "-S", "-a", ",11:1060:1:G,11:1040:1:G,11:1080:1:G", "-s", 'pop=="X"', "-s", 'pop=="Y"', "-s", "idx<10"],
                       ["synA", "synB"]),
+    # -d / -M: alleles selected from a variant annotation file (vardb.fmf, a fixture of this repo) by expression
+    "synA_db_impact": (["-G", "-C", "-d", "vardb.fmf", "-a", "impact>=2"], ["synA"]),
+    "synA_db_mem": (["-G", "-C", "-d", "vardb.fmf", "-M", "-a", "impact>=2"], ["synA"]),
+    "synA_db_real": (["-G", "-C", "-d", "vardb.fmf", "-a", "cadd>10.5"], ["synA"]),
+    "synA_db_real_mem": (["-G", "-C", "-d", "vardb.fmf", "-M", "-a", "cadd>10.5"], ["synA"]),
+    "synA_db_gene_S": (["-S", "-d", "vardb.fmf", "-a", 'gene=="ABC"'], ["synA"]),
+    "synA_db_row_H": (["-H", "-d", "vardb.fmf", "-M", "-a", '_ROW_!="13:7:1:A"&&impact<9'], ["synA"]),
+    "synA_db_bad": (["-G", "-d", "vardb.fmf", "-a", "impact>="], ["synA"]),
     "synA_al_none": (["-G", "-a", ",13:5:1:A,nonsense"], ["synA"]),
     "synA_bed_t": (["-B", "points.bed", "-e", "-t", "CHROM,POS,END,AC", "-n", "6"], ["synA"]),
 }
