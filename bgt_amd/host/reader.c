@@ -628,11 +628,6 @@ int bgtm_set_mgs(bgtm_t *bm, int mgs_def)
     return 0;
 }
 
-static int not_built(const char *what)
-{
-    fprintf(stderr, "[E::bgt] %s is not part of this build (genotype-matrix read path only; SURVEY.md 8f)\n", what);
-    return -1;
-}
 /* -t: comma-separated expressions, commas inside parentheses do not split (ref bgt.c:547-593) */
 int bgtm_set_table(bgtm_t *bm, const char *fmt)
 {
