@@ -75,6 +75,9 @@ struct bgth_pbf_s {
     int32_t sub_shift = 0;            // sub-checkpoints every 1 << sub_shift rows (<= shift), see derive_sub_checkpoints
     int64_t n = 0, n_blk = 0;         // n_blk: file blocks of 1 << shift rows
     int64_t n_sub = 0;                // sub-blocks of 1 << sub_shift rows: the unit the kernels work on
+    // a partial image (bgth_pbf_open_rows) holds the file blocks that cover a row range: every internal index is
+    // relative to row_off (a multiple of 1 << shift), the C ABI speaks file rows
+    int64_t row_off = 0, n_total = 0;
     int64_t rle_bytes = 0;            // RLE payload as in the file
     int64_t packed_bytes = 0;         // payload + padding of every string to 4 bytes
     uint8_t  *d_rle = nullptr;
@@ -344,6 +347,7 @@ extern "C" bgth_pbf_t *bgth_pbf_open_mem(const void *image, size_t len, int devi
     if (n_footer >= 0 && n_footer != row) { set_err("[E::bgth_pbf_open] footer says %lld rows, stream has %lld", (long long)n_footer, (long long)row); goto fail; }
     if (rle.size() >= ((size_t)1 << kDescLenShift)) { set_err("[E::bgth_pbf_open] RLE payload too large"); goto fail; }
     set_rows(p, row);
+    p->n_total = row;
     tr.lap("parse records");
     p->rle_bytes = payload;
     p->packed_bytes = (int64_t)rle.size();
@@ -440,6 +444,57 @@ static bool run_block_pass(bgth_pbf_t *p, Selection &all, int64_t blk, int64_t n
     return true;
 }
 
+// Partial image: only the file blocks that cover rows [row0, row1) are read (through the footer's block index,
+// pbwt.c:268-276), parsed and uploaded -- what a region query needs instead of the whole file.
+extern "C" bgth_pbf_t *bgth_pbf_open_rows(const char *path, int64_t row0, int64_t row1, int device)
+{
+    FILE *fp = fopen(path, "rb");
+    if (!fp) { set_err("[E::bgth_pbf_open_rows] cannot open '%s'", path); return nullptr; }
+    uint8_t hdr[16], tail[8], rec[13];
+    uint64_t off = 0;
+    int64_t n_total = 0;
+    int32_t n_idx = 0, shift;
+    std::vector<uint64_t> idx;
+    std::vector<uint8_t> img;
+    bgth_pbf_t *p = nullptr;
+    bool ok = fread(hdr, 1, 16, fp) == 16 && memcmp(hdr, "PBF\1", 4) == 0 && fseek(fp, -8, SEEK_END) == 0 && fread(tail, 1, 8, fp) == 8;
+    if (ok) { memcpy(&off, tail, 8); ok = off >= 16 && fseek(fp, (long)off, SEEK_SET) == 0 && fread(rec, 1, 13, fp) == 13 && rec[0] == 'I'; }
+    if (ok) {
+        memcpy(&n_total, rec + 1, 8); memcpy(&n_idx, rec + 9, 4);
+        ok = n_total >= 0 && n_idx >= 0;
+        if (ok) { idx.resize((size_t)n_idx); ok = n_idx == 0 || fread(idx.data(), 8, (size_t)n_idx, fp) == (size_t)n_idx; }
+    }
+    if (!ok) { fclose(fp); set_err("[E::bgth_pbf_open_rows] '%s': no PBF header / index footer", path); return nullptr; }
+    memcpy(&shift, hdr + 12, 4);
+    if (shift < 0 || shift > 30 || row0 < 0 || row1 > n_total || row0 >= row1) {
+        fclose(fp);
+        set_err("[E::bgth_pbf_open_rows] rows [%lld,%lld) outside 0..%lld", (long long)row0, (long long)row1, (long long)n_total);
+        return nullptr;
+    }
+    {
+        const int64_t b0 = row0 >> shift, b1 = (row1 - 1) >> shift;
+        if (b1 >= n_idx) { fclose(fp); set_err("[E::bgth_pbf_open_rows] block index shorter than the file's rows"); return nullptr; }
+        const uint64_t beg = idx[(size_t)b0], end = b1 + 1 < n_idx ? idx[(size_t)b1 + 1] : off;
+        const int64_t n_rows = std::min<int64_t>(n_total, (b1 + 1) << shift) - (b0 << shift);
+        // a small image of its own: header + the blocks + a footer without block index
+        img.resize(16 + (size_t)(end - beg) + 21);
+        memcpy(img.data(), hdr, 16);
+        ok = end >= beg && fseek(fp, (long)beg, SEEK_SET) == 0 && fread(img.data() + 16, 1, (size_t)(end - beg), fp) == (size_t)(end - beg);
+        fclose(fp);
+        if (!ok) { set_err("[E::bgth_pbf_open_rows] short read on '%s'", path); return nullptr; }
+        uint8_t *f = img.data() + 16 + (size_t)(end - beg);
+        const uint64_t foot = 16 + (end - beg);
+        const int32_t zero = 0;
+        f[0] = 'I'; memcpy(f + 1, &n_rows, 8); memcpy(f + 9, &zero, 4); memcpy(f + 13, &foot, 8);
+        p = bgth_pbf_open_mem(img.data(), img.size(), device);
+        if (p) { p->row_off = b0 << shift; p->n_total = n_total; }
+    }
+    return p;
+}
+
+extern "C" int64_t bgth_pbf_first_row(const bgth_pbf_t *p) { return p->row_off; }
+extern "C" int64_t bgth_pbf_loaded_rows(const bgth_pbf_t *p) { return p->n; }
+
 static bool derive_sub_checkpoints(bgth_pbf_t *p)
 {
     if (p->sub_shift >= p->shift || p->n <= ((int64_t)1 << p->sub_shift)) return true;
@@ -456,6 +511,7 @@ extern "C" bgth_pbf_t *bgth_pbf_from_rle(int m, int g, int shift, int64_t n_rows
     if (!use_device(device)) return nullptr;
     bgth_pbf_t *p = pbf_alloc(device, m, g, shift, n_rows);
     if (!p) return nullptr;
+    p->n_total = n_rows;
     std::vector<uint64_t> desc((size_t)n_rows * g);
     std::vector<uint8_t> packed;
     uint64_t off = 0, src = 0;
@@ -505,6 +561,7 @@ fail:
 extern "C" int64_t bgth_pbf_save(const bgth_pbf_t *p, const char *path)
 {
     if (!p) return -1;
+    if (p->row_off != 0 || p->n != p->n_total) { set_err("[E::bgth_pbf_save] a partial image cannot be saved"); return -1; }
     if (!use_device(p->device)) return -1;
     const int m = p->m;
     const size_t per = (size_t)2 * m;
@@ -555,7 +612,7 @@ done:
 extern "C" int bgth_pbf_get_m(const bgth_pbf_t *p) { return p->m; }
 extern "C" int bgth_pbf_get_g(const bgth_pbf_t *p) { return p->g; }
 extern "C" int bgth_pbf_get_shift(const bgth_pbf_t *p) { return p->shift; }
-extern "C" int64_t bgth_pbf_get_n(const bgth_pbf_t *p) { return p->n; }
+extern "C" int64_t bgth_pbf_get_n(const bgth_pbf_t *p) { return p->n_total; }
 extern "C" int64_t bgth_pbf_rle_bytes(const bgth_pbf_t *p) { return p->rle_bytes; }
 extern "C" int64_t bgth_pbf_hbm_bytes(const bgth_pbf_t *p)
 {
@@ -682,12 +739,29 @@ static void collect_timing(bgth_reader_t *r)
     r->t_pending = false;
 }
 
+// file rows [row0,row1) -> rows of the (possibly partial) image; false if they are not all loaded
+static bool to_image_rows(const bgth_pbf_t *p, int64_t &row0, int64_t &row1, const char *who)
+{
+    if (row0 < 0 || row1 > p->n_total || row0 > row1) {
+        set_err("[E::%s] rows [%lld,%lld) outside 0..%lld", who, (long long)row0, (long long)row1, (long long)p->n_total);
+        return false;
+    }
+    if (row0 < p->row_off || row1 > p->row_off + p->n) {
+        set_err("[E::%s] rows [%lld,%lld) are not in this partial image, which holds [%lld,%lld)", who, (long long)row0,
+                (long long)row1, (long long)p->row_off, (long long)(p->row_off + p->n));
+        return false;
+    }
+    row0 -= p->row_off; row1 -= p->row_off;
+    return true;
+}
+
 extern "C" int64_t bgth_reader_scan_device(bgth_reader_t *r, int64_t row0, int64_t row1, void *d_counts,
                                            void *d_h0, void *d_h1, void *stream)
 {
     if (!r || !d_counts) { set_err("[E::bgth_reader_scan_device] NULL argument"); return -1; }
     if (!use_device(r->pbf->device)) return -1;
     hipStream_t s = stream ? (hipStream_t)stream : r->stream;
+    if (!to_image_rows(r->pbf, row0, row1, "bgth_reader_scan_device")) return -1;
     const int64_t n = enqueue_scan(r, row0, row1, (int32_t*)d_counts, (uint64_t*)d_h0, (uint64_t*)d_h1, s, true);
     if (n < 0) return n;
     r->t_pending = true;
@@ -700,7 +774,7 @@ extern "C" int64_t bgth_reader_scan(bgth_reader_t *r, int64_t row0, int64_t row1
     if (!r) return -1;
     bgth_pbf_t *p = r->pbf;
     if (!use_device(p->device)) return -1;
-    if (row0 < 0 || row1 > p->n || row0 > row1) { set_err("[E::bgth_reader_scan] rows [%lld,%lld) outside 0..%lld", (long long)row0, (long long)row1, (long long)p->n); return -1; }
+    if (!to_image_rows(p, row0, row1, "bgth_reader_scan")) return -1;
     const int G = r->sel.G, gx = gx_of(G);
     const size_t cstride = (size_t)(1 + gx) * 3;
     const int nb = (r->sel.width + 3) / 4;
@@ -757,7 +831,8 @@ extern "C" int bgth_reader_last_geometry(const bgth_reader_t *r, int out[6])
 extern "C" int bgth_reader_seek(bgth_reader_t *r, int64_t row)
 {
     if (!r) return -1;
-    if (row < 0 || row >= r->pbf->n) { set_err("[E::bgth_reader_seek] row %lld out of range", (long long)row); return -1; }   // ref pbwt.c:359
+    int64_t row1 = row + 1;
+    if (!to_image_rows(r->pbf, row, row1, "bgth_reader_seek")) return -1;                 // ref pbwt.c:359
     r->next = row;
     return 0;
 }
@@ -824,7 +899,10 @@ extern "C" const uint8_t **bgth_reader_read(bgth_reader_t *r)
 {
     if (!r) return nullptr;
     bgth_pbf_t *p = r->pbf;
-    if (r->next >= p->n) return nullptr;                         // ref pbwt.c:336: no more 'B' records
+    if (r->next >= p->n) {                                       // ref pbwt.c:336: no more 'B' records
+        if (p->row_off + p->n < p->n_total) set_err("[E::bgth_reader_read] row %lld is beyond this partial image", (long long)(p->row_off + r->next));
+        return nullptr;
+    }
     if (!use_device(p->device)) return nullptr;
     if (r->next < r->ring0 || r->next >= r->ring1 || (r->want & ~r->ring_has)) if (!refill(r)) return nullptr;
     const int width = r->sel.width;

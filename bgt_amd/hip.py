@@ -134,6 +134,14 @@ class HipPbf:
         return cls(lib().bgth_pbf_open(os.fsencode(path), device))
 
     @classmethod
+    def open_rows(cls, path, row0, row1, device=0):
+        """Partial image: only the file blocks covering rows [row0,row1)."""
+        L = lib()
+        L.bgth_pbf_open_rows.restype = C.c_void_p
+        L.bgth_pbf_open_rows.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_int]
+        return cls(L.bgth_pbf_open_rows(path.encode(), row0, row1, device))
+
+    @classmethod
     def from_bytes(cls, data, device=0):
         buf = np.frombuffer(data, np.uint8)
         return cls(lib().bgth_pbf_open_mem(buf.ctypes.data, buf.size, device))

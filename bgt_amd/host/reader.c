@@ -139,6 +139,8 @@ typedef struct {                                              /* bgt_t::pb */
     int want;                  /* BGTH_WANT_* bits the device delivers per site for this reader */
     int text_mode;             /* the caller formats VCF text (bgtm_read_vcf): also ask for the genotype text */
     const int8_t *gt8; const char *gttext;   /* genotype vector / text of the current site (device formatted) */
+    bgth_pbf_t *own_img;       /* a partial image of the .pbf that only this reader uses (region / start queries) */
+    int n_groups_total;        /* as passed to the last selection, to re-apply it on another image */
 } devrd_t;
 
 /* ------------------------------------------------------------------------------------------------
@@ -217,7 +219,7 @@ void bgt_reader_destroy(bgt_t *bgt)
     devrd_t *dv;
     if (!bgt) return;
     dv = (devrd_t*)bgt->pb;
-    if (dv) { if (dv->rd) bgth_reader_destroy(dv->rd); free(dv); }
+    if (dv) { if (dv->rd) bgth_reader_destroy(dv->rd); if (dv->own_img) bgth_pbf_close(dv->own_img); free(dv); }
     bcf_destroy1(bgt->b0);
     free(bgt->gtag); free(bgt->group); free(bgt->out); free(bgt->bcf); free(bgt->itr);
     if (bgt->h_out) bcf_hdr_destroy(bgt->h_out);
@@ -384,11 +386,79 @@ void bgt_set_bed(bgt_t *bgt, const void *bed, int excl) { bgt->bed = bed; bgt->b
  * reader of that file; each reader owns its own device reader (stream, selection, result buffers) */
 static pthread_mutex_t g_open_lock = PTHREAD_MUTEX_INITIALIZER;   /* readers of one file may start on different threads */
 
+/* File rows [*r0, *r1) this reader can visit: the sites of its region, or from its start site on; 0 if that is
+ * (nearly) the whole file.  A region query of a large database then loads a few 8192-row blocks of the .pbf
+ * instead of all of it (the reference seeks to the nearest checkpoint, pbwt.c:349-372). */
+static int needed_rows(const bgt_t *bgt, int64_t *r0, int64_t *r1)
+{
+    const sitetab_t *t = (const sitetab_t*)bgt->f->idx;
+    const region_t *r = (const region_t*)bgt->itr;
+    int64_t i, lo, hi, mn = INT64_MAX, mx = -1;
+    if (t->n == 0) return 0;
+    if (r) {
+        lo = r->at;
+        for (hi = lo; hi < t->n && t->rid[hi] == r->tid && t->pos[hi] < r->end; ++hi) {}
+    } else {
+        lo = ((const cursor_t*)bgt->bcf)->next; hi = t->n;
+        if (lo <= 0) return 0;
+    }
+    if (hi <= lo) { *r0 = *r1 = 0; return 1; }                  /* nothing to visit: an empty range */
+    if ((hi - lo) * 2 > t->n) return 0;                         /* most of the file anyway */
+    for (i = lo; i < hi; ++i) { if (t->row[i] < mn) mn = t->row[i]; if (t->row[i] > mx) mx = t->row[i]; }
+    *r0 = mn; *r1 = mx + 1;
+    return 1;
+}
+
 static int ensure_device(bgt_t *bgt)
 {
     bgt_file_t *wf = (bgt_file_t*)bgt->f;
     devrd_t *dv = (devrd_t*)bgt->pb;
+    char *fn;
+    int64_t r0 = 0, r1 = 0;
     if (dv->rd) return 0;
+    fn = (char*)malloc(strlen(wf->prefix) + 8);
+    sprintf(fn, "%s.pbf", wf->prefix);
+    pthread_mutex_lock(&g_open_lock);
+    if (wf->gpu == NULL && needed_rows(bgt, &r0, &r1) && r1 > r0) {
+        pthread_mutex_unlock(&g_open_lock);
+        dv->own_img = bgth_pbf_open_rows(fn, r0, r1, 0);         /* private to this reader */
+        if (dv->own_img) dv->rd = bgth_reader_create(dv->own_img);
+    } else {
+        if (wf->gpu == NULL) wf->gpu = bgth_pbf_open(fn, 0);     /* the whole file, shared by every reader of it */
+        pthread_mutex_unlock(&g_open_lock);
+        if (wf->gpu) dv->rd = bgth_reader_create((bgth_pbf_t*)wf->gpu);
+    }
+    free(fn);
+    if (dv->rd == NULL) { fprintf(stderr, "[E::%s] %s\n", __func__, bgth_last_error()); return -1; }
+    return 0;
+}
+
+/* selection + output configuration of the reader's device side (also after a change of image) */
+static int apply_selection(bgt_t *bgt)
+{
+    devrd_t *dv = (devrd_t*)bgt->pb;
+    int32_t *cols;
+    int i, rc;
+    if (bgt->n_out <= 0 || dv->rd == NULL) return 0;
+    cols = (int32_t*)malloc((size_t)bgt->n_out * 2 * 4);
+    for (i = 0; i < bgt->n_out; ++i) { cols[2 * i] = bgt->out[i] * 2; cols[2 * i + 1] = bgt->out[i] * 2 + 1; }
+    rc = bgth_reader_select(dv->rd, bgt->n_out * 2, cols, dv->n_groups_total > 1 ? bgt->group : NULL,
+                            dv->n_groups_total > 1 ? dv->n_groups_total : 1);
+    if (rc < 0) fprintf(stderr, "[E::%s] %s\n", __func__, bgth_last_error());
+    free(cols);
+    if (rc >= 0) bgth_reader_config(dv->rd, dv->want, 0);
+    return rc;
+}
+
+/* a row outside the reader's partial image was asked for (the region or start changed after the image was
+ * opened): switch to the shared image of the whole file */
+static int promote_to_full(bgt_t *bgt)
+{
+    devrd_t *dv = (devrd_t*)bgt->pb;
+    bgt_file_t *wf = (bgt_file_t*)bgt->f;
+    if (dv->own_img == NULL) return -1;
+    bgth_reader_destroy(dv->rd); dv->rd = NULL;
+    bgth_pbf_close(dv->own_img); dv->own_img = NULL;
     pthread_mutex_lock(&g_open_lock);
     if (wf->gpu == NULL) {
         char *fn = (char*)malloc(strlen(wf->prefix) + 8);
@@ -398,8 +468,8 @@ static int ensure_device(bgt_t *bgt)
     }
     pthread_mutex_unlock(&g_open_lock);
     if (wf->gpu) dv->rd = bgth_reader_create((bgth_pbf_t*)wf->gpu);
-    if (dv->rd == NULL) { fprintf(stderr, "[E::%s] %s\n", __func__, bgth_last_error()); return -1; }
-    return 0;
+    if (dv->rd == NULL) return -1;
+    return apply_selection(bgt);
 }
 
 static int prepare_one(bgt_t *bgt, int n_groups_total, int need_device)
@@ -407,7 +477,6 @@ static int prepare_one(bgt_t *bgt, int n_groups_total, int need_device)
     const fmf_t *f = bgt->f->f;
     devrd_t *dv = (devrd_t*)bgt->pb;
     int i, rc = 0;
-    int32_t *cols;
     dv->skip_device = !need_device;
     if (need_device && ensure_device(bgt) < 0) rc = -1;
     if (bgt->n_groups == 0) add_group_core(bgt, BGT_SET_ALL_SAMPLES, NULL, NULL);
@@ -416,14 +485,8 @@ static int prepare_one(bgt_t *bgt, int n_groups_total, int need_device)
     bgt->group = (uint32_t*)realloc(bgt->group, (size_t)(bgt->n_out ? bgt->n_out : 1) * 4);
     for (i = 0, bgt->n_out = 0; i < f->n_rows; ++i)
         if (bgt->gtag[i] > 0) { bgt->group[bgt->n_out] = bgt->gtag[i]; bgt->out[bgt->n_out++] = i; }
-    if (bgt->n_out > 0 && dv->rd) {
-        cols = (int32_t*)malloc((size_t)bgt->n_out * 2 * 4);
-        for (i = 0; i < bgt->n_out; ++i) { cols[2 * i] = bgt->out[i] * 2; cols[2 * i + 1] = bgt->out[i] * 2 + 1; }
-        rc = bgth_reader_select(dv->rd, bgt->n_out * 2, cols, n_groups_total > 1 ? bgt->group : NULL,
-                                n_groups_total > 1 ? n_groups_total : 1);
-        if (rc < 0) fprintf(stderr, "[E::%s] %s\n", __func__, bgth_last_error());
-        free(cols);
-    }
+    dv->n_groups_total = n_groups_total;
+    if (bgt->n_out > 0 && dv->rd && apply_selection(bgt) < 0) rc = -1;
     dv->site = -1;
     bgt->b0->shared.l = 0;
     return rc;
@@ -486,8 +549,11 @@ static int read_rec(bgt_t *bgt, bgt_rec_t *r)
     }
     if (dv->rd == NULL) return -2;
     if (bgth_reader_seek(dv->rd, t->row[i]) < 0 || (a = bgth_reader_read(dv->rd)) == NULL) {
-        fprintf(stderr, "[E::%s] %s\n", __func__, bgth_last_error());
-        return -2;
+        if (dv->own_img == NULL || promote_to_full(bgt) < 0 ||   /* outside a partial image: take the whole file */
+            bgth_reader_seek(dv->rd, t->row[i]) < 0 || (a = bgth_reader_read(dv->rd)) == NULL) {
+            fprintf(stderr, "[E::%s] %s\n", __func__, bgth_last_error());
+            return -2;
+        }
     }
     dv->counts = bgth_reader_last_counts(dv->rd);
     dv->gt8 = bgth_reader_last_gt8(dv->rd); dv->gttext = bgth_reader_last_gt_text(dv->rd);
@@ -534,7 +600,8 @@ int bgt_read(bgt_t *bgt, bcf1_t *b)                           /* ref bgt.c:347-3
         kstring_t s = {0, 0, 0};
         int i;
         prepare_one(bgt, 1, 1);
-        if (dv->rd) bgth_reader_config(dv->rd, 1, 0);
+        dv->want = BGTH_WANT_PLANES;
+        if (dv->rd) bgth_reader_config(dv->rd, dv->want, 0);
         bgt->h_out = bcf_hdr_init();                          /* input header + FORMAT + the selected samples */
         ks_putn(&s, bgt->f->h0->text, (size_t)bgt->f->h0->l_text);
         while (s.l && s.s[s.l - 1] == 0) --s.l;

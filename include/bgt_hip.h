@@ -40,6 +40,13 @@ const char *bgth_version(void);
 /* ---- .pbf image in HBM  (replaces pbf_open_r / pbf_close / pbf_get_*, pbwt.c:221-286,390-393) ---- */
 bgth_pbf_t *bgth_pbf_open(const char *path, int device);
 bgth_pbf_t *bgth_pbf_open_mem(const void *image, size_t len, int device);
+/* Partial image: only the 1<<shift-row blocks of the file that cover rows [row0,row1) are read (through the
+ * footer's block index, pbwt.c:268-276) and uploaded -- what a region query (pbf_seek to a checkpoint + a few
+ * pbf_read, pbwt.c:349-372) needs of a large file.  Row arguments of the reader stay FILE rows; rows outside the
+ * loaded blocks fail loudly.  bgth_pbf_get_n() still reports the rows of the file. */
+bgth_pbf_t *bgth_pbf_open_rows(const char *path, int64_t row0, int64_t row1, int device);
+int64_t     bgth_pbf_first_row(const bgth_pbf_t *p);     /* first loaded row (0 for a full image)        */
+int64_t     bgth_pbf_loaded_rows(const bgth_pbf_t *p);   /* number of loaded rows                         */
 /* Build an image from bare RLE strings (row-major, plane-minor: row0/plane0,row0/plane1,row1/plane0..)
  * and derive every checkpoint on the device by one sequential decode pass: the device-side
  * equivalent of what pbf_write records while encoding (pbwt.c:292-301).  len[i] is the byte length

@@ -1,5 +1,6 @@
 """GPU parity: the HIP path (through the C ABI of libbgt_hip.so) against the CPU oracle and against the
 golden fixtures the compiled reference produced.  Bit-exact: genotype bytes and AC/AN integers."""
+import ctypes as C
 import os
 import struct
 
@@ -407,3 +408,45 @@ def test_readers_on_threads_share_one_image(hip):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("shift,rows,lo,hi", [(13, 20000, 9000, 9500), (13, 20000, 8192, 16384), (13, 20000, 0, 1),
+                                               (13, 20000, 19999, 20000), (5, 1000, 37, 911), (6, 640, 0, 640)])
+def test_partial_image_of_a_row_range(hip, tmp_path, shift, rows, lo, hi):
+    """bgth_pbf_open_rows loads only the file blocks that cover [lo,hi): scans, seeks and reads inside the loaded
+    blocks give what the whole file gives, file row numbers are kept, anything outside fails loudly."""
+    mat, data, rng = make_case(81, 260, rows, shift, n_founders=10, switch=0.04)
+    path = str(tmp_path / "x.pbf")
+    open(path, "wb").write(data)
+    oc, ogt = oracle_scan(data, 0, rows)
+    pbf = hip.HipPbf.open_rows(path, lo, hi)
+    assert pbf.n == rows                                         # rows of the FILE
+    first = hip.lib().bgth_pbf_first_row
+    first.restype = C.c_int64
+    first.argtypes = [C.c_void_p]
+    assert first(pbf.h) == (lo >> shift) << shift
+    rd = hip.HipReader(pbf)
+    counts, gt = rd.scan(lo, hi, want_gt=True)
+    assert np.array_equal(counts, oc[lo:hi]) and np.array_equal(gt, ogt[lo:hi])
+    rd.select(np.array([7, 6, 259, 0], np.int32))
+    rd.seek(hi - 1)
+    got = rd.read()
+    assert np.array_equal(got[0] | (got[1] << 1), mat[hi - 1][[7, 6, 259, 0]])
+    blk = 1 << shift
+    loaded_end = min(rows, ((hi - 1) // blk + 1) * blk)
+    if loaded_end < rows:
+        with pytest.raises(RuntimeError):
+            rd.scan(lo, loaded_end + 1)
+        with pytest.raises(RuntimeError):
+            rd.seek(loaded_end)
+    if (lo // blk) * blk > 0:
+        with pytest.raises(RuntimeError):
+            rd.scan((lo // blk) * blk - 1, hi)
+    if (lo // blk) * blk > 0 or loaded_end < rows:               # a partial image cannot be written back
+        with pytest.raises(RuntimeError):
+            pbf.save(str(tmp_path / "no.pbf"))
+    else:
+        pbf.save(str(tmp_path / "re.pbf"))
+        assert open(str(tmp_path / "re.pbf"), "rb").read() == data
+    with pytest.raises(RuntimeError):
+        hip.HipPbf.open_rows(path, hi, lo)
