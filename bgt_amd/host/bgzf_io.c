@@ -13,6 +13,7 @@ struct bgzr_s {
     uint8_t *in, *out;
     size_t out_len, out_pos;
     int eof;
+    long blk_coff;                 /* file offset of the block in `out` */
 };
 
 bgzr_t *bgzr_open(const char *path)
@@ -37,6 +38,7 @@ static int next_block(bgzr_t *r)
     unsigned xlen, bsize = 0, i;
     size_t rest;
     z_stream zs;
+    r->blk_coff = ftell(r->fp);
     if (fread(hdr, 1, 12, r->fp) != 12) { r->eof = 1; return 0; }
     if (hdr[0] != 0x1f || hdr[1] != 0x8b || !(hdr[3] & 4)) return -1;
     xlen = hdr[10] | hdr[11] << 8;
@@ -80,6 +82,23 @@ long bgzr_read(bgzr_t *r, void *dst, size_t n)
         r->out_pos += k; got += k;
     }
     return (long)got;
+}
+
+/* virtual file offsets as in the BGZF index formats: compressed offset of a block << 16 | offset inside it */
+int bgzr_seek(bgzr_t *r, uint64_t voff)
+{
+    if (fseek(r->fp, (long)(voff >> 16), SEEK_SET) != 0) return -1;
+    r->out_len = r->out_pos = 0; r->eof = 0;
+    if ((voff & 0xffff) == 0) return 0;                 /* the block is loaded by the next read */
+    if (next_block(r) <= 0 || (voff & 0xffff) > r->out_len) return -1;
+    r->out_pos = (size_t)(voff & 0xffff);
+    return 0;
+}
+
+uint64_t bgzr_tell(bgzr_t *r)
+{
+    if (r->out_len == 0 && r->out_pos == 0) return (uint64_t)ftell(r->fp) << 16;      /* nothing loaded yet */
+    return (uint64_t)r->blk_coff << 16 | (uint64_t)r->out_pos;
 }
 
 void bgzr_close(bgzr_t *r)

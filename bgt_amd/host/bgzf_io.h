@@ -10,6 +10,8 @@
 typedef struct bgzr_s bgzr_t;
 bgzr_t *bgzr_open(const char *path);                 /* NULL if unreadable or not gzip */
 long    bgzr_read(bgzr_t *r, void *dst, size_t n);   /* bytes read (short at EOF), <0 on a corrupt stream */
+int     bgzr_seek(bgzr_t *r, uint64_t voff);          /* to a virtual offset (block offset << 16 | offset in block) */
+uint64_t bgzr_tell(bgzr_t *r);
 void    bgzr_close(bgzr_t *r);
 
 typedef struct bgzw_s bgzw_t;

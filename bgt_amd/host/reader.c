@@ -66,8 +66,45 @@ static int tv_size(const uint8_t *p, const uint8_t **q, int *type)
     { int t = p[1] & 15; *q = p + 2 + tv_bytes(t); return tv_int(p + 2, t); }
 }
 
-/* every record of the site-only BCF: rid/pos/rlen, REF, first ALT, number of alleles and INFO/_row
- * (the row of the genotype matrix; ref bgt.c:272-288 asserts it is present and that there are no samples) */
+/* one record of the site-only BCF appended to the table: rid/pos/rlen, REF, first ALT, number of alleles and
+ * INFO/_row (the row of the genotype matrix; ref bgt.c:272-288 asserts it is present and that there are no
+ * samples).  Returns 0, or <0 for a record this format does not allow. */
+static int st_append(sitetab_t *t, int64_t *cap, const bcf1_t *b, int row_key)
+{
+    const uint8_t *p = (const uint8_t*)b->shared.s, *q;
+    int n, type, i, row = -1;
+    if (t->n == *cap) {
+        const int64_t c = *cap = *cap ? *cap * 2 : 1 << 12;
+        t->rid = (int32_t*)realloc(t->rid, (size_t)c * 4); t->pos = (int32_t*)realloc(t->pos, (size_t)c * 4);
+        t->rlen = (int32_t*)realloc(t->rlen, (size_t)c * 4); t->row = (int32_t*)realloc(t->row, (size_t)c * 4);
+        t->n_allele = (int32_t*)realloc(t->n_allele, (size_t)c * 4);
+        t->ref_off = (uint32_t*)realloc(t->ref_off, (size_t)c * 4); t->alt_off = (uint32_t*)realloc(t->alt_off, (size_t)c * 4);
+        t->ref_len = (uint16_t*)realloc(t->ref_len, (size_t)c * 2); t->alt_len = (uint16_t*)realloc(t->alt_len, (size_t)c * 2);
+    }
+    if (b->n_sample != 0 || b->n_allele < 2) return -3;
+    n = tv_size(p, &q, &type); p = q + n;                                   /* ID */
+    n = tv_size(p, &q, &type);                                              /* REF */
+    t->ref_off[t->n] = st_intern(t, q, n); t->ref_len[t->n] = (uint16_t)n; p = q + n;
+    n = tv_size(p, &q, &type);                                              /* first ALT */
+    t->alt_off[t->n] = st_intern(t, q, n); t->alt_len[t->n] = (uint16_t)n; p = q + n;
+    for (i = 2; i < (int)b->n_allele; ++i) { n = tv_size(p, &q, &type); p = q + n; }
+    n = tv_size(p, &q, &type); p = q + (size_t)n * tv_bytes(type);          /* FILTER */
+    for (i = 0; i < (int)b->n_info; ++i) {
+        int kt, key;
+        tv_size(p, &q, &kt); key = tv_int(q, kt); p = q + tv_bytes(kt);
+        n = tv_size(p, &q, &type);
+        if (key == row_key && n >= 1) row = tv_int(q, type);
+        p = q + (size_t)n * tv_bytes(type);
+    }
+    if (row < 0) return -3;
+    t->rid[t->n] = b->rid; t->pos[t->n] = b->pos; t->rlen[t->n] = b->rlen;
+    t->row[t->n] = row; t->n_allele[t->n] = b->n_allele;
+    if (b->rlen > t->max_rlen) t->max_rlen = b->rlen;
+    ++t->n;
+    return 0;
+}
+
+/* every record of the file */
 static sitetab_t *st_load(bgzr_t *fp, const bcf_hdr_t *h)
 {
     const int row_key = bcf_id2int(h, BCF_DT_ID, "_row");
@@ -76,40 +113,98 @@ static sitetab_t *st_load(bgzr_t *fp, const bcf_hdr_t *h)
     int64_t cap = 0;
     int ret;
     if (row_key < 0) { bcf_destroy1(b); st_free(t); return NULL; }
-    while ((ret = bcf_read1_stream(fp, b)) == 0) {
-        const uint8_t *p = (const uint8_t*)b->shared.s, *q;
-        int n, type, i, row = -1;
-        if (t->n == cap) {
-            cap = cap ? cap * 2 : 1 << 16;
-            t->rid = (int32_t*)realloc(t->rid, (size_t)cap * 4); t->pos = (int32_t*)realloc(t->pos, (size_t)cap * 4);
-            t->rlen = (int32_t*)realloc(t->rlen, (size_t)cap * 4); t->row = (int32_t*)realloc(t->row, (size_t)cap * 4);
-            t->n_allele = (int32_t*)realloc(t->n_allele, (size_t)cap * 4);
-            t->ref_off = (uint32_t*)realloc(t->ref_off, (size_t)cap * 4); t->alt_off = (uint32_t*)realloc(t->alt_off, (size_t)cap * 4);
-            t->ref_len = (uint16_t*)realloc(t->ref_len, (size_t)cap * 2); t->alt_len = (uint16_t*)realloc(t->alt_len, (size_t)cap * 2);
-        }
-        if (b->n_sample != 0 || b->n_allele < 2) { ret = -3; break; }
-        n = tv_size(p, &q, &type); p = q + n;                                   /* ID */
-        n = tv_size(p, &q, &type);                                              /* REF */
-        t->ref_off[t->n] = st_intern(t, q, n); t->ref_len[t->n] = (uint16_t)n; p = q + n;
-        n = tv_size(p, &q, &type);                                              /* first ALT */
-        t->alt_off[t->n] = st_intern(t, q, n); t->alt_len[t->n] = (uint16_t)n; p = q + n;
-        for (i = 2; i < (int)b->n_allele; ++i) { n = tv_size(p, &q, &type); p = q + n; }
-        n = tv_size(p, &q, &type); p = q + (size_t)n * tv_bytes(type);          /* FILTER */
-        for (i = 0; i < (int)b->n_info; ++i) {
-            int kt, key;
-            tv_size(p, &q, &kt); key = tv_int(q, kt); p = q + tv_bytes(kt);
-            n = tv_size(p, &q, &type);
-            if (key == row_key && n >= 1) row = tv_int(q, type);
-            p = q + (size_t)n * tv_bytes(type);
-        }
-        if (row < 0) { ret = -3; break; }
-        t->rid[t->n] = b->rid; t->pos[t->n] = b->pos; t->rlen[t->n] = b->rlen;
-        t->row[t->n] = row; t->n_allele[t->n] = b->n_allele;
-        if (b->rlen > t->max_rlen) t->max_rlen = b->rlen;
-        ++t->n;
-    }
+    while ((ret = bcf_read1_stream(fp, b)) == 0)
+        if ((ret = st_append(t, &cap, b, row_key)) < 0) break;
     bcf_destroy1(b);
     if (ret < -1) { st_free(t); return NULL; }
+    return t;
+}
+
+/* The records that overlap [beg,end) of contig tid, found through prefix.bcf.csi (coordinate-sorted index: bins
+ * of 2^(min_shift+3k) bases, per bin the chunks of the file that hold its records; reference hts.c:725-907) so
+ * that a region query of a large database reads a few BGZF blocks instead of every site.  NULL if the index
+ * cannot be used (then the caller loads the whole table). */
+typedef struct { uint64_t beg, end; } chunk_t;
+static int cmp_chunk(const void *a, const void *b)
+{
+    const uint64_t x = ((const chunk_t*)a)->beg, y = ((const chunk_t*)b)->beg;
+    return x < y ? -1 : x > y;
+}
+
+static sitetab_t *st_load_region(const char *prefix, const bcf_hdr_t *h, int tid, int beg, int end)
+{
+    const int row_key = bcf_id2int(h, BCF_DT_ID, "_row");
+    char *fn = (char*)malloc(strlen(prefix) + 16);
+    bgzr_t *ix, *fp = NULL;
+    sitetab_t *t = NULL;
+    chunk_t *ch = NULL;
+    int32_t hdr4[4], n_ref, r, n_ch = 0, m_ch = 0, i;
+    uint8_t magic[4];
+    int ok = 0;
+    sprintf(fn, "%s.bcf.csi", prefix);
+    ix = bgzr_open(fn);
+    if (ix == NULL || row_key < 0) goto done;
+    if (bgzr_read(ix, magic, 4) != 4 || memcmp(magic, "CSI\1", 4) != 0 || bgzr_read(ix, hdr4, 12) != 12) goto done;
+    {   /* min_shift, depth, l_aux */
+        const int min_shift = hdr4[0], depth = hdr4[1], l_aux = hdr4[2];
+        if (min_shift < 0 || depth < 0 || depth > 10 || l_aux < 0) goto done;
+        for (i = 0; i < l_aux; ++i) { uint8_t c; if (bgzr_read(ix, &c, 1) != 1) goto done; }
+        if (bgzr_read(ix, &n_ref, 4) != 4 || tid < 0 || tid >= n_ref) goto done;
+        if (end > beg) {
+            for (r = 0; r <= tid; ++r) {
+                int32_t n_bin, k;
+                if (bgzr_read(ix, &n_bin, 4) != 4 || n_bin < 0) goto done;
+                for (k = 0; k < n_bin; ++k) {
+                    uint32_t bin; uint64_t loff; int32_t n_chunk, c, want = 0;
+                    if (bgzr_read(ix, &bin, 4) != 4 || bgzr_read(ix, &loff, 8) != 8 || bgzr_read(ix, &n_chunk, 4) != 4 || n_chunk < 0) goto done;
+                    if (r == tid) {                           /* is `bin` one of the bins that overlap [beg,end)? */
+                        int l, s = min_shift + depth * 3;
+                        uint32_t first = 0;
+                        for (l = 0; l <= depth; s -= 3, first += 1u << (l * 3), ++l)
+                            if (bin >= first + (uint32_t)(beg >> s) && bin <= first + (uint32_t)((end - 1) >> s) &&
+                                bin < first + (1u << (l * 3))) want = 1;
+                    }
+                    for (c = 0; c < n_chunk; ++c) {
+                        chunk_t x;
+                        if (bgzr_read(ix, &x, 16) != 16) goto done;
+                        if (want) {
+                            if (n_ch == m_ch) { m_ch = m_ch ? m_ch << 1 : 16; ch = (chunk_t*)realloc(ch, (size_t)m_ch * sizeof(chunk_t)); }
+                            ch[n_ch++] = x;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    sprintf(fn, "%s.bcf", prefix);
+    if ((fp = bgzr_open(fn)) == NULL) goto done;
+    t = (sitetab_t*)calloc(1, sizeof(*t));
+    if (n_ch > 0) {
+        bcf1_t *b = bcf_init1();
+        int64_t cap = 0;
+        int bad = 0;
+        qsort(ch, (size_t)n_ch, sizeof(chunk_t), cmp_chunk);
+        for (i = 0; i < n_ch && !bad;) {                      /* overlapping / touching chunks are read once */
+            uint64_t cb = ch[i].beg, ce = ch[i].end;
+            for (++i; i < n_ch && ch[i].beg <= ce; ++i) if (ch[i].end > ce) ce = ch[i].end;
+            if (bgzr_seek(fp, cb) < 0) { bad = 1; break; }
+            while (bgzr_tell(fp) < ce) {
+                const int ret = bcf_read1_stream(fp, b);
+                if (ret != 0) { bad = ret < -1; break; }
+                if (b->rid != tid || b->pos >= end) { if (b->rid > tid || b->pos >= end) break; else continue; }
+                if (b->pos + b->rlen <= beg) continue;
+                if (st_append(t, &cap, b, row_key) < 0) { bad = 1; break; }
+            }
+        }
+        bcf_destroy1(b);
+        if (bad) { st_free(t); t = NULL; goto done; }
+    }
+    ok = 1;
+done:
+    (void)ok;
+    free(ch); free(fn);
+    if (ix) bgzr_close(ix);
+    if (fp) bgzr_close(fp);
     return t;
 }
 
@@ -132,6 +227,8 @@ static int st_cmp(const sitetab_t *a, int64_t i, const sitetab_t *b, int64_t j)
 typedef struct { int n, m; char **key; } alset_t;             /* bgtm_t::h_al / bgt_t::h_al: formatted alleles of -a */
 static int al_present(const alset_t *h, const char *chr, int rid, int pos, int rlen, const char *ref, int l_ref,
                       const char *alt, int l_alt);
+static const sitetab_t *file_sites(const bgt_file_t *bf);
+static const sitetab_t *sites_of(const bgt_t *bgt);
 typedef struct { int64_t next; } cursor_t;                   /* bgt_t::bcf */
 typedef struct { int tid, beg, end; int64_t at; int done; } region_t;   /* bgt_t::itr */
 typedef struct {                                              /* bgt_t::pb */
@@ -140,6 +237,7 @@ typedef struct {                                              /* bgt_t::pb */
     int text_mode;             /* the caller formats VCF text (bgtm_read_vcf): also ask for the genotype text */
     const int8_t *gt8; const char *gttext;   /* genotype vector / text of the current site (device formatted) */
     bgth_pbf_t *own_img;       /* a partial image of the .pbf that only this reader uses (region / start queries) */
+    void *own_sites;           /* sitetab_t: the sites of this reader's region, loaded through the CSI index */
     int n_groups_total;        /* as passed to the last selection, to re-apply it on another image */
 } devrd_t;
 
@@ -172,8 +270,7 @@ bgt_file_t *bgt_open(const char *prefix)
     sprintf(fn, "%s.bcf.csi", prefix);                       /* the reference refuses a BGT without its index */
     if ((t = fopen(fn, "rb")) == NULL) goto fail;
     fclose(t);
-    if ((bf->idx = st_load(fp, bf->h0)) == NULL) goto fail;
-    sprintf(fn, "%s.spl", prefix);
+    sprintf(fn, "%s.spl", prefix);                            /* (the site table is read on first use: file_sites) */
     if ((bf->f = fmf_read(fn)) == NULL) goto fail;
     bf->prefix = strdup(prefix);
     bf->mgs = (int32_t*)calloc((size_t)(bf->f->n_rows ? bf->f->n_rows : 1), 4);
@@ -219,7 +316,7 @@ void bgt_reader_destroy(bgt_t *bgt)
     devrd_t *dv;
     if (!bgt) return;
     dv = (devrd_t*)bgt->pb;
-    if (dv) { if (dv->rd) bgth_reader_destroy(dv->rd); if (dv->own_img) bgth_pbf_close(dv->own_img); free(dv); }
+    if (dv) { if (dv->rd) bgth_reader_destroy(dv->rd); if (dv->own_img) bgth_pbf_close(dv->own_img); st_free((sitetab_t*)dv->own_sites); free(dv); }
     bcf_destroy1(bgt->b0);
     free(bgt->gtag); free(bgt->group); free(bgt->out); free(bgt->bcf); free(bgt->itr);
     if (bgt->h_out) bcf_hdr_destroy(bgt->h_out);
@@ -343,7 +440,8 @@ static int parse_region(const char *s, int *beg, int *end)
 
 int bgt_set_region(bgt_t *bgt, const char *reg)               /* ref bgt.c:190-196, hts.c:852-866 */
 {
-    const sitetab_t *t = (const sitetab_t*)bgt->f->idx;
+    const sitetab_t *t;
+    devrd_t *dv = (devrd_t*)bgt->pb;
     region_t *r;
     int beg, end, tid, nl;
     char *name;
@@ -355,6 +453,10 @@ int bgt_set_region(bgt_t *bgt, const char *reg)               /* ref bgt.c:190-1
     if ((tid = bcf_id2int(bgt->f->h0, BCF_DT_CTG, name)) < 0) tid = bcf_id2int(bgt->f->h0, BCF_DT_CTG, reg);
     free(name);
     if (tid < 0) return -1;
+    /* while nobody has needed the whole site table yet, read only this region's sites through the CSI index */
+    st_free((sitetab_t*)dv->own_sites); dv->own_sites = NULL;
+    if (bgt->f->idx == NULL) dv->own_sites = st_load_region(bgt->f->prefix, bgt->f->h0, tid, beg, end);
+    t = sites_of(bgt);
     r = (region_t*)calloc(1, sizeof(*r));
     r->tid = tid; r->beg = beg; r->end = end;
     /* first site that can overlap: sites are sorted by (contig, position); a site starting up to
@@ -372,7 +474,7 @@ int bgt_set_region(bgt_t *bgt, const char *reg)               /* ref bgt.c:190-1
 
 int bgt_set_start(bgt_t *bgt, int64_t i)                      /* ref bgt.c:198-201, vcf.c:1195-1209 */
 {
-    const sitetab_t *t = (const sitetab_t*)bgt->f->idx;
+    const sitetab_t *t = sites_of(bgt);
     if (i < 0 || i >= t->n) return -1;                        /* the reference does not move the file then */
     ((cursor_t*)bgt->bcf)->next = i;
     return 0;
@@ -386,12 +488,41 @@ void bgt_set_bed(bgt_t *bgt, const void *bed, int excl) { bgt->bed = bed; bgt->b
  * reader of that file; each reader owns its own device reader (stream, selection, result buffers) */
 static pthread_mutex_t g_open_lock = PTHREAD_MUTEX_INITIALIZER;   /* readers of one file may start on different threads */
 
+/* the site table of the whole file, read on first use */
+static const sitetab_t *file_sites(const bgt_file_t *cbf)
+{
+    bgt_file_t *bf = (bgt_file_t*)cbf;
+    static const sitetab_t empty;
+    pthread_mutex_lock(&g_open_lock);
+    if (bf->idx == NULL) {
+        char *fn = (char*)malloc(strlen(bf->prefix) + 8);
+        bgzr_t *fp;
+        sprintf(fn, "%s.bcf", bf->prefix);
+        if ((fp = bgzr_open(fn)) != NULL) {
+            bcf_hdr_t *h = bcf_hdr_read_stream(fp);              /* skip the header */
+            if (h) { bf->idx = st_load(fp, bf->h0); bcf_hdr_destroy(h); }
+            bgzr_close(fp);
+        }
+        if (bf->idx == NULL) fprintf(stderr, "[E::%s] cannot read the sites of '%s'\n", __func__, fn);
+        free(fn);
+    }
+    pthread_mutex_unlock(&g_open_lock);
+    return bf->idx ? (const sitetab_t*)bf->idx : &empty;
+}
+
+/* the table a reader walks: its own (region) table if it has one, else the file's */
+static const sitetab_t *sites_of(const bgt_t *bgt)
+{
+    const devrd_t *dv = (const devrd_t*)bgt->pb;
+    return dv && dv->own_sites ? (const sitetab_t*)dv->own_sites : file_sites(bgt->f);
+}
+
 /* File rows [*r0, *r1) this reader can visit: the sites of its region, or from its start site on; 0 if that is
  * (nearly) the whole file.  A region query of a large database then loads a few 8192-row blocks of the .pbf
  * instead of all of it (the reference seeks to the nearest checkpoint, pbwt.c:349-372). */
 static int needed_rows(const bgt_t *bgt, int64_t *r0, int64_t *r1)
 {
-    const sitetab_t *t = (const sitetab_t*)bgt->f->idx;
+    const sitetab_t *t = sites_of(bgt);
     const region_t *r = (const region_t*)bgt->itr;
     int64_t i, lo, hi, mn = INT64_MAX, mx = -1;
     if (t->n == 0) return 0;
@@ -403,7 +534,7 @@ static int needed_rows(const bgt_t *bgt, int64_t *r0, int64_t *r1)
         if (lo <= 0) return 0;
     }
     if (hi <= lo) { *r0 = *r1 = 0; return 1; }                  /* nothing to visit: an empty range */
-    if ((hi - lo) * 2 > t->n) return 0;                         /* most of the file anyway */
+    if (((const devrd_t*)bgt->pb)->own_sites == NULL && (hi - lo) * 2 > t->n) return 0;   /* most of the file anyway */
     for (i = lo; i < hi; ++i) { if (t->row[i] < mn) mn = t->row[i]; if (t->row[i] > mx) mx = t->row[i]; }
     *r0 = mn; *r1 = mx + 1;
     return 1;
@@ -415,11 +546,13 @@ static int ensure_device(bgt_t *bgt)
     devrd_t *dv = (devrd_t*)bgt->pb;
     char *fn;
     int64_t r0 = 0, r1 = 0;
+    int partial;
     if (dv->rd) return 0;
     fn = (char*)malloc(strlen(wf->prefix) + 8);
     sprintf(fn, "%s.pbf", wf->prefix);
+    partial = needed_rows(bgt, &r0, &r1) && r1 > r0;           /* (reads the site table: before taking the lock) */
     pthread_mutex_lock(&g_open_lock);
-    if (wf->gpu == NULL && needed_rows(bgt, &r0, &r1) && r1 > r0) {
+    if (wf->gpu == NULL && partial) {
         pthread_mutex_unlock(&g_open_lock);
         dv->own_img = bgth_pbf_open_rows(fn, r0, r1, 0);         /* private to this reader */
         if (dv->own_img) dv->rd = bgth_reader_create(dv->own_img);
@@ -496,7 +629,7 @@ static int prepare_one(bgt_t *bgt, int n_groups_total, int need_device)
  * advances (ref bgt.c:272-288, :315-331; hts.c:868-900) */
 static int64_t next_site(bgt_t *bgt)
 {
-    const sitetab_t *t = (const sitetab_t*)bgt->f->idx;
+    const sitetab_t *t = sites_of(bgt);
     region_t *r = (region_t*)bgt->itr;
     if (r) {
         while (!r->done && r->at < t->n) {
@@ -514,7 +647,7 @@ static int64_t next_site(bgt_t *bgt)
 
 static void fill_b0(bgt_t *bgt, int64_t i)
 {
-    const sitetab_t *t = (const sitetab_t*)bgt->f->idx;
+    const sitetab_t *t = sites_of(bgt);
     bcf_set_site(bgt->b0, t->rid[i], t->pos[i], t->rlen[i], t->pool + t->ref_off[i], t->ref_len[i],
                  t->pool + t->alt_off[i], t->alt_len[i], NULL);
     bgt->b0->n_allele = (uint32_t)t->n_allele[i];
@@ -523,7 +656,7 @@ static void fill_b0(bgt_t *bgt, int64_t i)
 /* pull one site and its genotype row (ref bgt.c:333-345) */
 static int read_rec(bgt_t *bgt, bgt_rec_t *r)
 {
-    const sitetab_t *t = (const sitetab_t*)bgt->f->idx;
+    const sitetab_t *t = sites_of(bgt);
     devrd_t *dv = (devrd_t*)bgt->pb;
     const uint8_t **a;
     int64_t i;
@@ -1294,7 +1427,7 @@ static int read_core(bgtm_t *bm, bcf1_t *b)
     }
     if (n_rest == 0) return -1;
     for (i = 0; i < bm->n_bgt; ++i) {                         /* the smallest look-ahead site */
-        const sitetab_t *t = (const sitetab_t*)bm->bgt[i]->f->idx;
+        const sitetab_t *t = sites_of(bm->bgt[i]);
         const int64_t s = ((devrd_t*)bm->bgt[i]->pb)->site;
         if (bm->r[i].b0 == NULL) continue;
         if (best >= 0) {
@@ -1317,7 +1450,7 @@ static int read_core(bgtm_t *bm, bcf1_t *b)
     ss.n_groups = bm->n_groups;
     for (i = 0; i < bm->n_bgt; ++i) {                         /* consume the databases that have this site */
         bgt_t *bgt = bm->bgt[i];
-        const sitetab_t *t = (const sitetab_t*)bgt->f->idx;
+        const sitetab_t *t = sites_of(bgt);
         devrd_t *dv = (devrd_t*)bgt->pb;
         if (bgt->n_out == 0) continue;
         if (bm->r[i].b0 && st_cmp(bt, bs, t, dv->site) == 0) {
