@@ -28,7 +28,7 @@ def c1(tmp_path_factory):
 
 
 def md5_of(cmd):
-    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     return p.returncode, hashlib.md5(p.stdout).hexdigest(), len(p.stdout), p.stderr.decode()[-300:]
 
 

@@ -25,7 +25,7 @@ def built():
 
 
 def run_view(args, prefixes, exe=BGT):
-    return subprocess.run([exe, "view"] + args + prefixes, cwd=GOLD, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    return subprocess.run([exe, "view"] + args + prefixes, cwd=GOLD, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
 
 
 def test_struct_layouts_are_the_reference_abi(tmp_path):
