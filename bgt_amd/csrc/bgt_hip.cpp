@@ -721,7 +721,7 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
         HIP_TRY(hipMemcpy(h, d_times, 64, hipMemcpyDeviceToHost), return -1);
         hipFree(d_times);
         const double waves = (double)geo.workgroups * ((a.debug_skip & 0x100) ? 1 : geo.threads / 64), nb = (double)rows / geo.K;
-        fprintf(stderr, "[bgth debug] cycles per wave and batch: top %.0f | A-zero+pass1 %.0f | wait %.0f | pass2 %.0f | wait %.0f | dir %.0f | wait %.0f | B %.0f\n",
+        fprintf(stderr, "[bgth debug] memtime ticks per wave and batch: prefetch %.0f | clear %.0f | wait %.0f | toggles %.0f | wait %.0f | directory %.0f | wait %.0f | walk %.0f\n",
                 h[0] / waves / nb, h[1] / waves / nb, h[2] / waves / nb, h[3] / waves / nb, h[4] / waves / nb, h[5] / waves / nb, h[6] / waves / nb, h[7] / waves / nb);
     }
     HIP_TRY(launch_finalize((const int32_t*)r->raw.p, d_fin, r->sel.d_group_haps, rows, G, s), return -1);

@@ -43,7 +43,9 @@ struct ScanArgs {
     int32_t  blk0, n_blk, n_slices;
     int64_t  row0, row1;         // rows whose results are emitted; decoding starts at blk0<<shift
     unsigned long long *debug_times;   // optional [workgroups][8] cycle sums per phase (env BGTH_DEBUG_TIMES)
-    int32_t  debug_skip;         // profiling aid (env BGTH_DEBUG_SKIP): 1 = no phase B, 2 = no RLE read, 4 = no directory build
+    int32_t  debug_skip;         // ablation bits (env BGTH_DEBUG_SKIP): 1 no walk, 2 no RLE read / toggles, 4 no directory build,
+                                 //   8 every lookup reads the sentinel word (no LDS conflicts), 64 no toggle atomics, 0x100 timing
+                                 //   of wave 0 only, 0x200 team mode without the separate toggle array (host-side switch)
 };
 
 // columns per thread instantiated for each workgroup size (keep in sync with kGeoms in scan_kernels.hip)
