@@ -15,6 +15,7 @@ uint64_t bgzr_tell(bgzr_t *r);
 void    bgzr_close(bgzr_t *r);
 
 typedef struct bgzw_s bgzw_t;
+void    bgzw_threads(bgzw_t *w, int n);                /* deflate batches of blocks on n threads (same bytes) */
 bgzw_t *bgzw_open(FILE *fp, int level);              /* level -1 = zlib default, 0 = stored */
 int     bgzw_write(bgzw_t *w, const void *src, size_t n);
 uint64_t bgzw_tell(const bgzw_t *w);                 /* virtual offset: compressed<<16 | in-block */

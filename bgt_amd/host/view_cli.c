@@ -108,7 +108,12 @@ int main_view(int argc, char *argv[])
     /* the reference builds the mode string "wb%d" and takes its first digit as the level, so the default
      * -1 compresses at level 1 (view.c:144-146, bgzf.c:138-146) */
     if (not_vcf) out_bcf = 0;
-    else if (out_bcf) { bz = bgzw_open(stdout, clevel < 0 ? 1 : clevel); bcf_hdr_write_stream(bz, bm->h_out); }
+    else if (out_bcf) {
+        long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+        bz = bgzw_open(stdout, clevel < 0 ? 1 : clevel);
+        bgzw_threads(bz, ncpu > 8 ? 8 : (int)ncpu);                 /* blocks are independent: same bytes, deflated in parallel */
+        bcf_hdr_write_stream(bz, bm->h_out);
+    }
     else vcf_hdr_write_text(stdout, bm->h_out);
 
     b = bcf_init1();

@@ -38,7 +38,9 @@ def md5_of(cmd):
                                   ["-G", "-s", "pop==\"A\"", "-s", "pop==\"B\"", "-f", "AC1>0&&AC2==0"],
                                   ["-C", "-G", "-s", "idx%20==0"], ["-C", "-r", "11:100000-101000", "-s", "idx<40"],
                                   ["-G", "-s", "pop==\"A\"", "-s", "pop==\"C\"", "-f", "AC1/AN1>=0.1&&AC2<5"],
-                                  ["-C", "-r", "11:1000-1500"], ["-bCG", "-n", "3000"]])
+                                  ["-C", "-r", "11:1000-1500"], ["-bCG", "-n", "3000"],
+                                  ["-b", "-i", "100", "-n", "2500"], ["-u", "-n", "700", "-s", "idx<500"],
+                                  ["-b", "-l", "9", "-n", "1500", "-C"]])
 def test_same_bytes_as_reference_binary(c1, args):
     mine = md5_of([BGT, "view"] + args + [c1])
     ref = md5_of([REF, "view"] + args + [c1])
