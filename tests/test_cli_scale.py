@@ -111,3 +111,24 @@ def test_tables_bed_and_allele_sets_like_reference(c1, tmp_path):
         ref = md5_of([REF, "view"] + args + [c1])
         assert mine[0] == ref[0] == 0, (args, mine, ref)
         assert mine[1:3] == ref[1:3], (args, mine, ref)
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref not present")
+def test_wide_cohort_subset_like_config3(tmp_path):
+    """Shape of BASELINE.json configs[2] at reduced length: 100,000 samples (m = 200,000: the team-mode kernels, row
+    index, sub-checkpoints), `-s` picks every 20th sample (5,000 of 100,000), AC/AN; plus a region with genotypes of
+    a few samples.  The reference decodes 200,000-wide rows on the CPU: ~0.5 ms per site."""
+    import bgt_amd
+    bgt_amd.build_library()
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bgt_amd", "host")])
+    db = str(tmp_path / "c3")
+    subprocess.check_call([BGT, "synth", db, "100000", "12000", "3"], timeout=600)
+    for args in (["-G", "-C", "-s", "idx%20==0", "-n", "9000"],
+                 ["-G", "-s", "idx%20==0", "-s", "idx%20==1", "-f", "AC1>0&&AC2==0", "-i", "8000"],
+                 ["-C", "-s", "idx%25000==7", "-r", "11:90000-95000"],
+                 ["-G", "-C", "-i", "8100", "-n", "1500"],                       # the whole 200,000-column cohort
+                 ["-G", "-f", "AC/AN>0.3", "-r", "11:60000-70000"]):
+        mine = md5_of([BGT, "view"] + args + [db])
+        ref = md5_of([REF, "view"] + args + [db])
+        assert mine[0] == ref[0] == 0, (args, mine, ref)
+        assert mine[2] > 0 and mine[1:3] == ref[1:3], (args, mine, ref)
