@@ -111,81 +111,163 @@ __device__ __forceinline__ uint32_t rle_len(uint32_t byte)
     "s_bcnt1_i32_b64 vcc_lo, vcc\n\t"                  \
     "s_add_u32 " CC ", " CC ", vcc_lo\n\t"
 
-// two columns x two planes: 4 LDS reads in flight
+// When plane 1 of the row is all zero (no missing call, no <M>: most sites of a fully called panel) its ranks do not
+// move (reference pbwt.c:135-138) and its lookups are skipped.  The choice is a SCALAR branch inside the
+// statement (operand Z1 != 0), not a second statement: two statements updating the same ranks on two paths made
+// hipcc reconcile the register assignments with ~40 copies per row on the common path.
+#define BGTH_COUNT1(M0, CA)                            \
+    "s_bcnt1_i32_b64 vcc_lo, " M0 "\n\t"               \
+    "s_add_u32 " CA ", " CA ", vcc_lo\n\t"
+
+#define BGTH_STEP2_BOTH                                                                  \
+        BGTH_ADDR("v104", "%0", "%11") BGTH_ADDR("v106", "%1", "%12")                    \
+        BGTH_ADDR("v108", "%2", "%11") BGTH_ADDR("v110", "%3", "%12")                    \
+        "ds_read_b64 v[104:105], v104\n\t"                                               \
+        "ds_read_b64 v[106:107], v106\n\t"                                               \
+        "ds_read_b64 v[108:109], v108\n\t"                                               \
+        "ds_read_b64 v[110:111], v110\n\t"                                               \
+        "s_waitcnt lgkmcnt(3)\n\t"                                                       \
+        BGTH_TAIL("%0", "v104", "v105", "v104", "%4", "%13")                             \
+        "s_waitcnt lgkmcnt(2)\n\t"                                                       \
+        BGTH_TAIL("%1", "v106", "v107", "v106", "%5", "%14")                             \
+        BGTH_COUNT("%4", "%5", "%8", "%9", "%10")                                        \
+        "s_waitcnt lgkmcnt(1)\n\t"                                                       \
+        BGTH_TAIL("%2", "v108", "v109", "v108", "%6", "%13")                             \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                       \
+        BGTH_TAIL("%3", "v110", "v111", "v110", "%7", "%14")                             \
+        BGTH_COUNT("%6", "%7", "%8", "%9", "%10")
+#define BGTH_STEP2_PLANE0                                                                \
+        BGTH_ADDR("v104", "%0", "%11") BGTH_ADDR("v108", "%2", "%11")                    \
+        "ds_read_b64 v[104:105], v104\n\t"                                               \
+        "ds_read_b64 v[108:109], v108\n\t"                                               \
+        "s_mov_b64 %5, 0\n\t"                                                            \
+        "s_mov_b64 %7, 0\n\t"                                                            \
+        "s_waitcnt lgkmcnt(1)\n\t"                                                       \
+        BGTH_TAIL("%0", "v104", "v105", "v104", "%4", "%13")                             \
+        BGTH_COUNT1("%4", "%8")                                                          \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                       \
+        BGTH_TAIL("%2", "v108", "v109", "v108", "%6", "%13")                             \
+        BGTH_COUNT1("%6", "%8")
+#define BGTH_STEP2_OPERANDS                                                                                          \
+        : "+v"(ra0), "+v"(ra1), "+v"(rb0), "+v"(rb1), "=&s"(ma0), "=&s"(ma1), "=&s"(mb0), "=&s"(mb1),               \
+          "+s"(ca), "+s"(cb), "+s"(cc)                                                                               \
+        : "s"(base0), "s"(base1), "s"(n00), "s"(n01)                                                                 \
+        : "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "vcc", "scc", "memory"
+
+// two columns x two planes: 4 LDS reads in flight.  ZP: with the all-zero-plane-1 shortcut, requested by passing
+// base1 = 0 (never a real operand value: a plane-1 row does not start at LDS address 8)
+template <bool ZP>
 __device__ __forceinline__ void step2(uint32_t &ra0, uint32_t &ra1, uint32_t &rb0, uint32_t &rb1,
                                       uint64_t &ma0, uint64_t &ma1, uint64_t &mb0, uint64_t &mb1,
                                       uint32_t &ca, uint32_t &cb, uint32_t &cc,
                                       uint32_t base0, uint32_t base1, uint32_t n00, uint32_t n01)
 {
-    asm volatile(
-        "s_waitcnt lgkmcnt(0)\n\t"
-        BGTH_ADDR("v104", "%0", "%11") BGTH_ADDR("v106", "%1", "%12")
-        BGTH_ADDR("v108", "%2", "%11") BGTH_ADDR("v110", "%3", "%12")
-        "ds_read_b64 v[104:105], v104\n\t"
-        "ds_read_b64 v[106:107], v106\n\t"
-        "ds_read_b64 v[108:109], v108\n\t"
-        "ds_read_b64 v[110:111], v110\n\t"
-        "s_waitcnt lgkmcnt(3)\n\t"
-        BGTH_TAIL("%0", "v104", "v105", "v104", "%4", "%13")
-        "s_waitcnt lgkmcnt(2)\n\t"
-        BGTH_TAIL("%1", "v106", "v107", "v106", "%5", "%14")
-        BGTH_COUNT("%4", "%5", "%8", "%9", "%10")
-        "s_waitcnt lgkmcnt(1)\n\t"
-        BGTH_TAIL("%2", "v108", "v109", "v108", "%6", "%13")
-        "s_waitcnt lgkmcnt(0)\n\t"
-        BGTH_TAIL("%3", "v110", "v111", "v110", "%7", "%14")
-        BGTH_COUNT("%6", "%7", "%8", "%9", "%10")
-        : "+v"(ra0), "+v"(ra1), "+v"(rb0), "+v"(rb1), "=&s"(ma0), "=&s"(ma1), "=&s"(mb0), "=&s"(mb1),
-          "+s"(ca), "+s"(cb), "+s"(cc)
-        : "s"(base0), "s"(base1), "s"(n00), "s"(n01)
-        : "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "vcc", "scc", "memory");
+    if constexpr (ZP) {
+        asm volatile(
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "s_cmp_eq_u32 %12, 0\n\t"                         /* base1 == 0: this row's plane 1 is empty */
+            "s_cbranch_scc1 .Lbgth_z_%=\n\t"
+            BGTH_STEP2_BOTH
+            "s_branch .Lbgth_e_%=\n"
+            ".Lbgth_z_%=:\n\t"
+            BGTH_STEP2_PLANE0
+            ".Lbgth_e_%=:\n\t"
+            BGTH_STEP2_OPERANDS);
+    } else {
+        asm volatile(
+            "s_waitcnt lgkmcnt(0)\n\t"
+            BGTH_STEP2_BOTH
+            BGTH_STEP2_OPERANDS);
+    }
 }
 
+#define BGTH_STEP4_BOTH                                                                  \
+        BGTH_ADDR("v104", "%0", "%19") BGTH_ADDR("v106", "%1", "%20")                    \
+        BGTH_ADDR("v108", "%2", "%19") BGTH_ADDR("v110", "%3", "%20")                    \
+        BGTH_ADDR("v112", "%4", "%19") BGTH_ADDR("v114", "%5", "%20")                    \
+        BGTH_ADDR("v116", "%6", "%19") BGTH_ADDR("v118", "%7", "%20")                    \
+        "ds_read_b64 v[104:105], v104\n\t"                                               \
+        "ds_read_b64 v[106:107], v106\n\t"                                               \
+        "ds_read_b64 v[108:109], v108\n\t"                                               \
+        "ds_read_b64 v[110:111], v110\n\t"                                               \
+        "ds_read_b64 v[112:113], v112\n\t"                                               \
+        "ds_read_b64 v[114:115], v114\n\t"                                               \
+        "ds_read_b64 v[116:117], v116\n\t"                                               \
+        "ds_read_b64 v[118:119], v118\n\t"                                               \
+        "s_waitcnt lgkmcnt(7)\n\t"                                                       \
+        BGTH_TAIL("%0", "v104", "v105", "v104", "%8", "%21")                             \
+        "s_waitcnt lgkmcnt(6)\n\t"                                                       \
+        BGTH_TAIL("%1", "v106", "v107", "v106", "%9", "%22")                             \
+        BGTH_COUNT("%8", "%9", "%16", "%17", "%18")                                      \
+        "s_waitcnt lgkmcnt(5)\n\t"                                                       \
+        BGTH_TAIL("%2", "v108", "v109", "v108", "%10", "%21")                            \
+        "s_waitcnt lgkmcnt(4)\n\t"                                                       \
+        BGTH_TAIL("%3", "v110", "v111", "v110", "%11", "%22")                            \
+        BGTH_COUNT("%10", "%11", "%16", "%17", "%18")                                    \
+        "s_waitcnt lgkmcnt(3)\n\t"                                                       \
+        BGTH_TAIL("%4", "v112", "v113", "v112", "%12", "%21")                            \
+        "s_waitcnt lgkmcnt(2)\n\t"                                                       \
+        BGTH_TAIL("%5", "v114", "v115", "v114", "%13", "%22")                            \
+        BGTH_COUNT("%12", "%13", "%16", "%17", "%18")                                    \
+        "s_waitcnt lgkmcnt(1)\n\t"                                                       \
+        BGTH_TAIL("%6", "v116", "v117", "v116", "%14", "%21")                            \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                       \
+        BGTH_TAIL("%7", "v118", "v119", "v118", "%15", "%22")                            \
+        BGTH_COUNT("%14", "%15", "%16", "%17", "%18")
+#define BGTH_STEP4_PLANE0                                                                \
+        BGTH_ADDR("v104", "%0", "%19") BGTH_ADDR("v108", "%2", "%19")                    \
+        BGTH_ADDR("v112", "%4", "%19") BGTH_ADDR("v116", "%6", "%19")                    \
+        "ds_read_b64 v[104:105], v104\n\t"                                               \
+        "ds_read_b64 v[108:109], v108\n\t"                                               \
+        "ds_read_b64 v[112:113], v112\n\t"                                               \
+        "ds_read_b64 v[116:117], v116\n\t"                                               \
+        "s_mov_b64 %9, 0\n\t"                                                            \
+        "s_mov_b64 %11, 0\n\t"                                                           \
+        "s_mov_b64 %13, 0\n\t"                                                           \
+        "s_mov_b64 %15, 0\n\t"                                                           \
+        "s_waitcnt lgkmcnt(3)\n\t"                                                       \
+        BGTH_TAIL("%0", "v104", "v105", "v104", "%8", "%21")                             \
+        BGTH_COUNT1("%8", "%16")                                                         \
+        "s_waitcnt lgkmcnt(2)\n\t"                                                       \
+        BGTH_TAIL("%2", "v108", "v109", "v108", "%10", "%21")                            \
+        BGTH_COUNT1("%10", "%16")                                                        \
+        "s_waitcnt lgkmcnt(1)\n\t"                                                       \
+        BGTH_TAIL("%4", "v112", "v113", "v112", "%12", "%21")                            \
+        BGTH_COUNT1("%12", "%16")                                                        \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                       \
+        BGTH_TAIL("%6", "v116", "v117", "v116", "%14", "%21")                            \
+        BGTH_COUNT1("%14", "%16")
+#define BGTH_STEP4_OPERANDS                                                                                                  \
+        : "+v"(r0[0]), "+v"(r1[0]), "+v"(r0[1]), "+v"(r1[1]), "+v"(r0[2]), "+v"(r1[2]), "+v"(r0[3]), "+v"(r1[3]),            \
+          "=&s"(m0[0]), "=&s"(m1[0]), "=&s"(m0[1]), "=&s"(m1[1]), "=&s"(m0[2]), "=&s"(m1[2]), "=&s"(m0[3]), "=&s"(m1[3]),    \
+          "+s"(ca), "+s"(cb), "+s"(cc)                                                                                       \
+        : "s"(base0), "s"(base1), "s"(n00), "s"(n01)                                                                         \
+        : "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115",                    \
+          "v116", "v117", "v118", "v119", "vcc", "scc", "memory"
+
 // four columns x two planes: 8 LDS reads in flight
+template <bool ZP>
 __device__ __forceinline__ void step4(uint32_t (&r0)[4], uint32_t (&r1)[4], uint64_t (&m0)[4], uint64_t (&m1)[4],
                                       uint32_t &ca, uint32_t &cb, uint32_t &cc,
                                       uint32_t base0, uint32_t base1, uint32_t n00, uint32_t n01)
 {
-    asm volatile(
-        "s_waitcnt lgkmcnt(0)\n\t"
-        BGTH_ADDR("v104", "%0", "%19") BGTH_ADDR("v106", "%1", "%20")
-        BGTH_ADDR("v108", "%2", "%19") BGTH_ADDR("v110", "%3", "%20")
-        BGTH_ADDR("v112", "%4", "%19") BGTH_ADDR("v114", "%5", "%20")
-        BGTH_ADDR("v116", "%6", "%19") BGTH_ADDR("v118", "%7", "%20")
-        "ds_read_b64 v[104:105], v104\n\t"
-        "ds_read_b64 v[106:107], v106\n\t"
-        "ds_read_b64 v[108:109], v108\n\t"
-        "ds_read_b64 v[110:111], v110\n\t"
-        "ds_read_b64 v[112:113], v112\n\t"
-        "ds_read_b64 v[114:115], v114\n\t"
-        "ds_read_b64 v[116:117], v116\n\t"
-        "ds_read_b64 v[118:119], v118\n\t"
-        "s_waitcnt lgkmcnt(7)\n\t"
-        BGTH_TAIL("%0", "v104", "v105", "v104", "%8", "%21")
-        "s_waitcnt lgkmcnt(6)\n\t"
-        BGTH_TAIL("%1", "v106", "v107", "v106", "%9", "%22")
-        BGTH_COUNT("%8", "%9", "%16", "%17", "%18")
-        "s_waitcnt lgkmcnt(5)\n\t"
-        BGTH_TAIL("%2", "v108", "v109", "v108", "%10", "%21")
-        "s_waitcnt lgkmcnt(4)\n\t"
-        BGTH_TAIL("%3", "v110", "v111", "v110", "%11", "%22")
-        BGTH_COUNT("%10", "%11", "%16", "%17", "%18")
-        "s_waitcnt lgkmcnt(3)\n\t"
-        BGTH_TAIL("%4", "v112", "v113", "v112", "%12", "%21")
-        "s_waitcnt lgkmcnt(2)\n\t"
-        BGTH_TAIL("%5", "v114", "v115", "v114", "%13", "%22")
-        BGTH_COUNT("%12", "%13", "%16", "%17", "%18")
-        "s_waitcnt lgkmcnt(1)\n\t"
-        BGTH_TAIL("%6", "v116", "v117", "v116", "%14", "%21")
-        "s_waitcnt lgkmcnt(0)\n\t"
-        BGTH_TAIL("%7", "v118", "v119", "v118", "%15", "%22")
-        BGTH_COUNT("%14", "%15", "%16", "%17", "%18")
-        : "+v"(r0[0]), "+v"(r1[0]), "+v"(r0[1]), "+v"(r1[1]), "+v"(r0[2]), "+v"(r1[2]), "+v"(r0[3]), "+v"(r1[3]),
-          "=&s"(m0[0]), "=&s"(m1[0]), "=&s"(m0[1]), "=&s"(m1[1]), "=&s"(m0[2]), "=&s"(m1[2]), "=&s"(m0[3]), "=&s"(m1[3]),
-          "+s"(ca), "+s"(cb), "+s"(cc)
-        : "s"(base0), "s"(base1), "s"(n00), "s"(n01)
-        : "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115",
-          "v116", "v117", "v118", "v119", "vcc", "scc", "memory");
+    if constexpr (ZP) {
+        asm volatile(
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "s_cmp_eq_u32 %20, 0\n\t"                         /* base1 == 0: this row's plane 1 is empty */
+            "s_cbranch_scc1 .Lbgth_z_%=\n\t"
+            BGTH_STEP4_BOTH
+            "s_branch .Lbgth_e_%=\n"
+            ".Lbgth_z_%=:\n\t"
+            BGTH_STEP4_PLANE0
+            ".Lbgth_e_%=:\n\t"
+            BGTH_STEP4_OPERANDS);
+    } else {
+        asm volatile(
+            "s_waitcnt lgkmcnt(0)\n\t"
+            BGTH_STEP4_BOTH
+            BGTH_STEP4_OPERANDS);
+    }
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -452,12 +534,13 @@ __device__ __forceinline__ void build_plane_row(const ScanArgs &a, const uint8_t
 
 // Template switches:  MULTI = more than one sample group (per-chunk LDS atomics instead of per-wave
 // scalars);  GT = also emit the two bit planes of every row (slot order) for genotype output;
-// TEAM = wide cohort: few rows fit the LDS, every plane-row is built by a team of waves (single batch
+// ZP = with the shortcut for rows whose plane 1 is all zero (chosen per image: worth a taken branch per statement
+// only if such rows exist);  TEAM = wide cohort: few rows fit the LDS, every plane-row is built by a team of waves (single batch
 // buffer); otherwise a wave builds its plane-rows alone and batches are pipelined over two buffers.
 #define BGTH_TICK(slot) do { if (a.debug_times) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
     tsum[slot] += now_ - tlast; tlast = now_; } } while (0)
 
-template <int NT, int CPT, bool MULTI, bool GT, bool TEAM>
+template <int NT, int CPT, bool MULTI, bool GT, bool TEAM, bool ZP>
 __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64_t *__restrict__ rowdesc,
                                                   const uint8_t *__restrict__ rle,
                                                   const uint32_t *__restrict__ chunkinfo,
@@ -710,10 +793,11 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
         for (int k = 0; k < Kc; ++k) {
             // operands of the row step: (LDS byte address of the plane-row) - 8 and -n0 (see BGTH_TAIL)
             const uint32_t base0 = bufbase + (uint32_t)(2 * k) * (uint32_t)nwp * 8u - 8u;
-            const uint32_t base1 = base0 + (uint32_t)nwp * 8u;
+            uint32_t base1 = base0 + (uint32_t)nwp * 8u;
             const uint32_t n00 = 0u - (uint32_t)__builtin_amdgcn_readfirstlane(n0b[2 * k]);
             const uint32_t n01 = 0u - (uint32_t)__builtin_amdgcn_readfirstlane(n0b[2 * k + 1]);
             const bool emit = (rb + k) >= a.row0;
+            if (ZP && n01 == 0u - (uint32_t)m) base1 = 0u;       // plane 1 all zero: its lookups are skipped (see step2)
             if (a.snap && rb + k > blk_beg && ((rb + k) & (((int64_t)1 << a.snap_shift) - 1)) == 0) {
                 // sub-checkpoint: the ranks before this row (image-open pass only)
                 int32_t *dst = a.snap + ((rb + k) >> a.snap_shift) * (int64_t)(2 * m);
@@ -737,11 +821,11 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
                 if (NC == 4) {
                     uint32_t q0[4] = {r0[j], r0[j + 1], r0[j + 2], r0[j + 3]};
                     uint32_t q1[4] = {r1[j], r1[j + 1], r1[j + 2], r1[j + 3]};
-                    step4(q0, q1, m0, m1, ca, cb, cc, base0, base1, n00, n01);
+                    step4<ZP>(q0, q1, m0, m1, ca, cb, cc, base0, base1, n00, n01);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) { r0[j + u] = q0[u]; r1[j + u] = q1[u]; }
                 } else {
-                    step2(r0[j], r1[j], r0[j + 1], r1[j + 1], m0[0], m1[0], m0[1], m1[1], ca, cb, cc, base0, base1, n00, n01);
+                    step2<ZP>(r0[j], r1[j], r0[j + 1], r1[j + 1], m0[0], m1[0], m0[1], m1[1], ca, cb, cc, base0, base1, n00, n01);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {

@@ -6,10 +6,10 @@ namespace bgth {
 
 static const int kLdsBytesLocal = 160 * 1024;
 
-template <int NT, int CPT, bool MULTI, bool GT, bool TEAM>
+template <int NT, int CPT, bool MULTI, bool GT, bool TEAM, bool ZP>
 static hipError_t launch_one(const ScanArgs &a, const Geometry &g, hipStream_t s)
 {
-    auto fn = scan_kernel<NT, CPT, MULTI, GT, TEAM>;
+    auto fn = scan_kernel<NT, CPT, MULTI, GT, TEAM, ZP>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes);
     if (e != hipSuccess) return e;
@@ -18,25 +18,25 @@ static hipError_t launch_one(const ScanArgs &a, const Geometry &g, hipStream_t s
     return hipGetLastError();
 }
 
-template <int NT, int CPT>
+template <int NT, int CPT, bool ZP>
 static hipError_t launch_variant(const ScanArgs &a, const Geometry &g, hipStream_t s)
 {
     const int v = (a.G > 1 ? 4 : 0) | (a.h0 ? 2 : 0) | (g.wpp > 1 ? 1 : 0);
     switch (v) {
-    case 0: return launch_one<NT, CPT, false, false, false>(a, g, s);
-    case 1: return launch_one<NT, CPT, false, false, true>(a, g, s);
-    case 2: return launch_one<NT, CPT, false, true, false>(a, g, s);
-    case 3: return launch_one<NT, CPT, false, true, true>(a, g, s);
-    case 4: return launch_one<NT, CPT, true, false, false>(a, g, s);
-    case 5: return launch_one<NT, CPT, true, false, true>(a, g, s);
-    case 6: return launch_one<NT, CPT, true, true, false>(a, g, s);
-    default: return launch_one<NT, CPT, true, true, true>(a, g, s);
+    case 0: return launch_one<NT, CPT, false, false, false, ZP>(a, g, s);
+    case 1: return launch_one<NT, CPT, false, false, true, ZP>(a, g, s);
+    case 2: return launch_one<NT, CPT, false, true, false, ZP>(a, g, s);
+    case 3: return launch_one<NT, CPT, false, true, true, ZP>(a, g, s);
+    case 4: return launch_one<NT, CPT, true, false, false, ZP>(a, g, s);
+    case 5: return launch_one<NT, CPT, true, false, true, ZP>(a, g, s);
+    case 6: return launch_one<NT, CPT, true, true, false, ZP>(a, g, s);
+    default: return launch_one<NT, CPT, true, true, true, ZP>(a, g, s);
     }
 }
 
 hipError_t launch_scan_nt1024(const ScanArgs &a, const Geometry &g, hipStream_t s)
 {
-#define X(CPT_) if (g.cpt == CPT_) return launch_variant<1024, CPT_>(a, g, s);
+#define X(CPT_) if (g.cpt == CPT_) return a.zp ? launch_variant<1024, CPT_, true>(a, g, s) : launch_variant<1024, CPT_, false>(a, g, s);
     BGTH_CPT_1024(X)
 #undef X
     return hipErrorInvalidConfiguration;

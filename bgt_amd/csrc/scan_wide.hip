@@ -85,10 +85,10 @@ hipError_t launch_rowindex(const uint64_t *rowdesc, const uint8_t *rle, int64_t 
 }
 
 // ----------------------------------------------------------------------------------------------------
-template <int CPT, bool MULTI, bool GT>
+template <int CPT, bool MULTI, bool GT, bool ZP>
 static hipError_t launch_one(const ScanArgs &a, const Geometry &g, hipStream_t s)
 {
-    auto fn = scan_kernel<512, CPT, MULTI, GT, true>;
+    auto fn = scan_kernel<512, CPT, MULTI, GT, true, ZP>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes);
     if (e != hipSuccess) return e;
@@ -96,21 +96,21 @@ static hipError_t launch_one(const ScanArgs &a, const Geometry &g, hipStream_t s
     return hipGetLastError();
 }
 
-template <int CPT>
+template <int CPT, bool ZP>
 static hipError_t launch_variant(const ScanArgs &a, const Geometry &g, hipStream_t s)
 {
     if (g.wpp <= 1) return hipErrorInvalidConfiguration;          // team mode only
     switch ((a.G > 1 ? 2 : 0) | (a.h0 ? 1 : 0)) {
-    case 0: return launch_one<CPT, false, false>(a, g, s);
-    case 1: return launch_one<CPT, false, true>(a, g, s);
-    case 2: return launch_one<CPT, true, false>(a, g, s);
-    default: return launch_one<CPT, true, true>(a, g, s);
+    case 0: return launch_one<CPT, false, false, ZP>(a, g, s);
+    case 1: return launch_one<CPT, false, true, ZP>(a, g, s);
+    case 2: return launch_one<CPT, true, false, ZP>(a, g, s);
+    default: return launch_one<CPT, true, true, ZP>(a, g, s);
     }
 }
 
 hipError_t launch_scan_wide(const ScanArgs &a, const Geometry &g, hipStream_t s)
 {
-#define X(CPT_) if (g.cpt == CPT_) return launch_variant<CPT_>(a, g, s);
+#define X(CPT_) if (g.cpt == CPT_) return a.zp ? launch_variant<CPT_, true>(a, g, s) : launch_variant<CPT_, false>(a, g, s);
     BGTH_CPT_512_WIDE(X)
 #undef X
     return hipErrorInvalidConfiguration;

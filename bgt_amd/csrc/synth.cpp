@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -138,7 +139,10 @@ void draw_row(int m, uint64_t seed, int64_t row, std::vector<uint8_t> &out, uint
     {   // plane 1: missing / <M>
         Rng g(seed, (uint64_t)row, 1);
         const size_t at = out.size();
-        int64_t ones = g.binomial(m, 1e-3);
+        // (tuning knob: BGTH_SYNTH_MISSING_PPM overrides the 10^-3 missing rate of SURVEY 8d, e.g. 0 for a fully
+        // called panel whose plane 1 is empty except at multi-allelic sites)
+        static const double miss = getenv("BGTH_SYNTH_MISSING_PPM") ? atof(getenv("BGTH_SYNTH_MISSING_PPM")) * 1e-6 : 1e-3;
+        int64_t ones = miss > 0 ? g.binomial(m, miss) : 0;
         if (sd.multi) ones += g.binomial(m, 2e-2);
         const int64_t clusters = std::max<int64_t>(1, ones - (int64_t)g.below((uint64_t)(ones / 4 + 1)));
         draw_plane(g, m, ones, clusters, out);

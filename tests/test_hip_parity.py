@@ -288,6 +288,36 @@ def test_sub_checkpoints(hip, tmp_path, monkeypatch, sub):
         assert open(out, "rb").read() == data
 
 
+@pytest.mark.parametrize("force", [None, "2048", "4096"])
+@pytest.mark.parametrize("threads,cpt,K", [(0, 0, 0), (1024, 20, 0), (512, 10, 3), (256, 8, 2), (512, 80, 1), (1024, 8, 1)])
+def test_rows_with_an_empty_plane(hip, monkeypatch, force, threads, cpt, K):
+    """Rows whose plane 1 (missing / <M>) is all zero take the shortcut of the ZP kernels (reference pbwt.c:135-138);
+    a cohort that mixes such rows with ordinary ones, rows of one repeated code, and a plane-0-empty row, through both
+    kernel families (BGTH_DEBUG_SKIP 2048 = never, 4096 = always use the ZP kernels), whole cohort, groups, genotypes."""
+    if force:
+        monkeypatch.setenv("BGTH_DEBUG_SKIP", force)
+    rng = np.random.default_rng(123)
+    m, rows, shift = 9000, 160, 5
+    mat = scenarios.ld_matrix(rng, rows, m, n_founders=12, switch=0.03)
+    called = rng.random(rows) < 0.7
+    mat[called] &= 1                                                   # fully called rows: codes 0/1 only
+    mat[5] = 0; mat[6] = 1; mat[7] = 2; mat[8] = 3
+    mat[9] = (rng.random(m) < 0.01).astype(np.uint8) * 2               # plane 0 empty, plane 1 sparse
+    data = orc.encode_pbf(mat, 2, shift)
+    rd = hip.HipReader(hip.HipPbf.from_bytes(data))
+    rd.tune(threads, cpt, K)
+    oc, ogt = oracle_scan(data, 0, rows)
+    counts, gt = rd.scan(0, rows, want_gt=True)
+    assert np.array_equal(counts, oc) and np.array_equal(gt, ogt), rd.geometry()
+    assert np.array_equal(rd.scan(3, 150), oc[3:150])
+    ns = m // 2
+    group = (1 + (np.arange(ns) % 3)).astype(np.uint32)
+    rd.select(np.arange(m, dtype=np.int32), group=group, n_groups=3)
+    c3, g3 = rd.scan(0, rows, want_gt=True)
+    o3, og3 = oracle_scan(data, 0, rows, group=group, n_groups=3)
+    assert np.array_equal(c3, o3) and np.array_equal(g3, og3)
+
+
 def split_rle(data):
     m, g, shift = struct.unpack("<iii", data[4:16])
     pos, strings = 16, []
