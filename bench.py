@@ -33,8 +33,8 @@ HBM_PEAK_GBS = 8000.0                      # /opt/skills/guides/MI355X_MICROARCH
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=sorted(SAMPLES))
     ap.add_argument("--sites", type=int, default=1000000, help="sites per GPU")
     ap.add_argument("--every", type=int, default=0, help="select every N-th sample only (C3: --workload c3 --every 20)")
@@ -252,6 +252,26 @@ def main():
                         "cli_stdout_identical_to_reference": cli_same, "cli_stdout_bytes": len(ref_out),
                         "this_repo_cli_same_command_s": round(t_mine, 2),
                         "gpu_matches_cpu_on_sample": same, "port": port}
+                    # the reference is single-threaded; the whole box = one process per 8192-site block range
+                    # (disjoint -r ranges), as many at a time as there are cores
+                    try:
+                        n_blk = (ns + 8191) // 8192
+                        procs = min(n_blk, os.cpu_count() or 1)
+                        t0 = time.perf_counter()
+                        running = []
+                        for k in range(n_blk):
+                            reg = "11:%d-%d" % (1000 + 10 * k * 8192, 1000 + 10 * min(ns, (k + 1) * 8192) - 1)
+                            running.append(subprocess.Popen([ref_bin, "view", "-G", "-f", "AC>0", "-r", reg, prefix],
+                                                            stdout=subprocess.DEVNULL))
+                            if len(running) >= procs:
+                                running.pop(0).wait()
+                        for pr in running:
+                            pr.wait()
+                        t_all = time.perf_counter() - t0
+                        out["cpu_baseline"]["all_cores"] = {"value": ns / t_all, "unit": "sites/s", "processes": procs,
+                                                            "sample": "%d reference processes over disjoint 8192-site regions, %.1f s wall" % (n_blk, t_all)}
+                    except Exception as e:
+                        out["cpu_baseline"]["all_cores"] = {"error": repr(e)[:120]}
                     if not cli_same:
                         out["parity_error"] = "`bgt view` stdout differs from the reference binary"
                 except Exception as e:                        # keep the port numbers, say why
