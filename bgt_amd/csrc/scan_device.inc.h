@@ -11,14 +11,15 @@
 // string as a bit-vector with a rank directory: {32 bits, number of ones before them} per 8-byte entry,
 // so one ds_read_b64 answers both B[r] and rank1(r).  Work decomposition:
 //
-//   grid   = (8192-row checkpoint block) x (column slice); all slices of a block are placed on one XCD
-//            (workgroup id mod 8) so the RLE bytes they share are served by one L2.
+//   grid   = (sub-block: the rows between two rank-form checkpoints, 2048 by default) x (column slice); all slices
+//            of a sub-block are placed on one XCD (workgroup id mod 8) so the RLE bytes they share come from one L2.
 //   wave   = owns CPT consecutive 64-slot chunks; a chunk never mixes sample groups, so the allele
 //            counts of a chunk are popcounts of the two 64-bit ballots (the v_cmp that selects the
 //            new rank already is the ballot).
-//   batch  = K rows: phase A builds the 2K bit-vectors (one wave per plane-row: byte -> run length,
-//            wave prefix sum -> run starts, xor-toggle at every change of bit, prefix-xor -> bits,
-//            popcount prefix sum -> rank directory), phase B walks the K rows with no barrier.
+//   batch  = K rows: phase A builds the 2K bit-vectors (byte -> run length, wave prefix sum -> run starts,
+//            xor-toggle at every change of bit, prefix-xor -> bits, popcount prefix sum -> rank directory),
+//            phase B walks the K rows with no barrier.  Narrow cohorts: one wave per plane-row, two batch buffers,
+//            batches pipelined.  Wide cohorts (TEAM): a team of waves per plane-row, driven by the row index.
 //
 // No MFMA: this is integer/bit work bound by LDS issue and VALU, not by HBM.
 #pragma once
