@@ -295,6 +295,49 @@ hipError_t launch_emit_gt(const uint64_t *h0, const uint64_t *h1, const int32_t 
 // `/` yields a real, `//` `%` `<<` `>>` `&` `|` `^` integers, comparisons use the reals if either side is
 // real, an unbound variable fails the site.
 // ----------------------------------------------------------------------------------------------------
+struct FilterSlot { long long i; double r; bool real; };
+
+// one unary (+ - ~ !) or binary operator on the top of the stack: p = p OP q
+__device__ __forceinline__ void filter_unop(int o, FilterSlot &p)
+{
+    if (o == 2) { p.i = -p.i; p.r = -p.r; }
+    else if (o == 3) { p.i = ~p.i; p.r = (double)p.i; p.real = false; }
+    else if (o == 4) { p.i = !p.i; p.r = (double)p.i; p.real = false; }
+}
+
+__device__ __forceinline__ void filter_binop(int o, FilterSlot &p, const FilterSlot &q, bool &err)
+{
+    const bool anyreal = p.real || q.real;
+    bool cmp = false, iscmp = false;
+    switch (o) {
+    case 5:  p.r = pow(p.r, q.r); p.i = (long long)(p.r + .5); p.real = anyreal; break;
+    case 6:  p.i *= q.i; p.r *= q.r; p.real = anyreal; break;
+    case 7:  p.r /= q.r; p.i = (long long)(p.r + .5); p.real = true; break;
+    case 8:  if (q.i == 0) { err = true; p.i = 0; } else p.i /= q.i; p.r = (double)p.i; p.real = false; break;
+    case 9:  if (q.i == 0) { err = true; p.i = 0; } else p.i %= q.i; p.r = (double)p.i; p.real = false; break;
+    case 10: p.i += q.i; p.r += q.r; p.real = anyreal; break;
+    case 11: p.i -= q.i; p.r -= q.r; p.real = anyreal; break;
+    case 12: p.i <<= q.i; p.r = (double)p.i; p.real = false; break;
+    case 13: p.i >>= q.i; p.r = (double)p.i; p.real = false; break;
+    case 14: iscmp = true; cmp = anyreal ? p.r <  q.r : p.i <  q.i; break;
+    case 15: iscmp = true; cmp = anyreal ? p.r <= q.r : p.i <= q.i; break;
+    case 16: iscmp = true; cmp = anyreal ? p.r >  q.r : p.i >  q.i; break;
+    case 17: iscmp = true; cmp = anyreal ? p.r >= q.r : p.i >= q.i; break;
+    case 18: iscmp = true; cmp = anyreal ? p.r == q.r : p.i == q.i; break;
+    case 19: iscmp = true; cmp = anyreal ? p.r != q.r : p.i != q.i; break;
+    case 20: p.i &= q.i; p.r = (double)p.i; p.real = false; break;
+    case 21: p.i ^= q.i; p.r = (double)p.i; p.real = false; break;
+    case 22: p.i |= q.i; p.r = (double)p.i; p.real = false; break;
+    case 23: iscmp = true; cmp = p.i && q.i; break;
+    case 24: iscmp = true; cmp = p.i || q.i; break;
+    default: err = true; break;
+    }
+    if (iscmp) { p.i = cmp; p.r = (double)cmp; p.real = false; }
+}
+
+// SMALL: the program never holds more than four values and leaves exactly one (checked by launch_filter): the stack
+// is four named slots shifted on push / pop, i.e. registers instead of a dynamically indexed array in scratch memory
+template <bool SMALL>
 __global__ void filter_kernel(const FilterProgram prog, const int32_t *counts, int64_t n_rows, int ints_per_row,
                               uint8_t *flags, unsigned long long *n_pass)
 {
@@ -302,61 +345,45 @@ __global__ void filter_kernel(const FilterProgram prog, const int32_t *counts, i
     bool pass = false;
     if (row < n_rows) {
         const int32_t *c = counts + row * ints_per_row;
-        long long si[kFilterMaxItems];
-        double sr[kFilterMaxItems];
-        bool real[kFilterMaxItems];
-        int top = 0;
         bool err = false;
-        for (int k = 0; k < prog.n; ++k) {
-            const int op = prog.op[k];
-            if (op == 0 || op == 1) {                              // the parser keeps BOTH views of a literal ("010" is 8 and 10.0)
-                si[top] = prog.ival[k]; sr[top] = prog.rval[k]; real[top] = op == 1; ++top; }
-            else if (op == 2) {
-                const int slot = prog.slot[k];
-                if (slot < 0 || slot >= ints_per_row) { err = true; si[top] = 0; sr[top] = 0.; real[top] = true; }
-                else { si[top] = c[slot]; sr[top] = (double)c[slot]; real[top] = false; }
-                ++top;
-            } else {
-                const int o = op - 16;
-                if (o >= 1 && o <= 4) {                           // unary: + - ~ !
-                    long long &i = si[top - 1]; double &r = sr[top - 1];
-                    if (o == 2) { i = -i; r = -r; }
-                    else if (o == 3) { i = ~i; r = (double)i; real[top - 1] = false; }
-                    else if (o == 4) { i = !i; r = (double)i; real[top - 1] = false; }
+        if (SMALL) {
+            FilterSlot s0 = {0, 0., false}, s1 = s0, s2 = s0, s3 = s0;        // s0 = top of the stack
+            for (int k = 0; k < prog.n; ++k) {
+                const int op = prog.op[k];
+                if (op <= 2) {
+                    FilterSlot x;
+                    if (op == 2) {
+                        const int slot = prog.slot[k];
+                        if (slot < 0 || slot >= ints_per_row) { err = true; x.i = 0; x.r = 0.; x.real = true; }
+                        else { x.i = c[slot]; x.r = (double)c[slot]; x.real = false; }
+                    } else { x.i = prog.ival[k]; x.r = prog.rval[k]; x.real = op == 1; }   // a literal keeps BOTH views ("010" is 8 and 10.0)
+                    s3 = s2; s2 = s1; s1 = s0; s0 = x;
                 } else {
-                    --top;
-                    long long &i = si[top - 1]; double &r = sr[top - 1];
-                    const long long qi = si[top]; const double qr = sr[top];
-                    const bool anyreal = real[top - 1] || real[top];
-                    bool cmp = false, iscmp = false;
-                    switch (o) {
-                    case 5:  r = pow(r, qr); i = (long long)(r + .5); real[top - 1] = anyreal; break;
-                    case 6:  i *= qi; r *= qr; real[top - 1] = anyreal; break;
-                    case 7:  r /= qr; i = (long long)(r + .5); real[top - 1] = true; break;
-                    case 8:  if (qi == 0) { err = true; i = 0; } else i /= qi; r = (double)i; real[top - 1] = false; break;
-                    case 9:  if (qi == 0) { err = true; i = 0; } else i %= qi; r = (double)i; real[top - 1] = false; break;
-                    case 10: i += qi; r += qr; real[top - 1] = anyreal; break;
-                    case 11: i -= qi; r -= qr; real[top - 1] = anyreal; break;
-                    case 12: i <<= qi; r = (double)i; real[top - 1] = false; break;
-                    case 13: i >>= qi; r = (double)i; real[top - 1] = false; break;
-                    case 14: iscmp = true; cmp = anyreal ? r <  qr : i <  qi; break;
-                    case 15: iscmp = true; cmp = anyreal ? r <= qr : i <= qi; break;
-                    case 16: iscmp = true; cmp = anyreal ? r >  qr : i >  qi; break;
-                    case 17: iscmp = true; cmp = anyreal ? r >= qr : i >= qi; break;
-                    case 18: iscmp = true; cmp = anyreal ? r == qr : i == qi; break;
-                    case 19: iscmp = true; cmp = anyreal ? r != qr : i != qi; break;
-                    case 20: i &= qi; r = (double)i; real[top - 1] = false; break;
-                    case 21: i ^= qi; r = (double)i; real[top - 1] = false; break;
-                    case 22: i |= qi; r = (double)i; real[top - 1] = false; break;
-                    case 23: iscmp = true; cmp = i && qi; break;
-                    case 24: iscmp = true; cmp = i || qi; break;
-                    default: err = true; break;
-                    }
-                    if (iscmp) { i = cmp; r = (double)cmp; real[top - 1] = false; }
+                    const int o = op - 16;
+                    if (o >= 1 && o <= 4) filter_unop(o, s0);
+                    else { filter_binop(o, s1, s0, err); s0 = s1; s1 = s2; s2 = s3; }
                 }
             }
+            pass = !err && s0.i != 0;
+        } else {
+            FilterSlot st[kFilterMaxItems];
+            int top = 0;
+            for (int k = 0; k < prog.n; ++k) {
+                const int op = prog.op[k];
+                if (op == 0 || op == 1) { st[top].i = prog.ival[k]; st[top].r = prog.rval[k]; st[top].real = op == 1; ++top; }
+                else if (op == 2) {
+                    const int slot = prog.slot[k];
+                    if (slot < 0 || slot >= ints_per_row) { err = true; st[top].i = 0; st[top].r = 0.; st[top].real = true; }
+                    else { st[top].i = c[slot]; st[top].r = (double)c[slot]; st[top].real = false; }
+                    ++top;
+                } else {
+                    const int o = op - 16;
+                    if (o >= 1 && o <= 4) filter_unop(o, st[top - 1]);
+                    else { --top; filter_binop(o, st[top - 1], st[top], err); }
+                }
+            }
+            pass = !err && top >= 1 && st[0].i != 0;
         }
-        pass = !err && top >= 1 && si[0] != 0;
         flags[row] = pass ? 1 : 0;
     }
     const unsigned long long b = __ballot(pass);
@@ -367,8 +394,19 @@ hipError_t launch_filter(const FilterProgram &prog, const int32_t *counts, int64
                          uint8_t *flags, unsigned long long *n_pass, hipStream_t s)
 {
     if (n_rows <= 0) return hipSuccess;
-    hipLaunchKernelGGL(filter_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, s,
-                       prog, counts, n_rows, ints_per_row, flags, n_pass);
+    int depth = 0, deepest = 0;                                 // stack profile of the program
+    bool regular = true;
+    for (int k = 0; k < prog.n; ++k) {
+        const int op = prog.op[k];
+        if (op <= 2) { if (++depth > deepest) deepest = depth; }
+        else if (op - 16 >= 1 && op - 16 <= 4) { if (depth < 1) regular = false; }
+        else { if (depth < 2) regular = false; --depth; }
+    }
+    const dim3 grid((unsigned)((n_rows + 255) / 256)), block(256);
+    if (regular && depth == 1 && deepest <= 4)
+        hipLaunchKernelGGL(filter_kernel<true>, grid, block, 0, s, prog, counts, n_rows, ints_per_row, flags, n_pass);
+    else
+        hipLaunchKernelGGL(filter_kernel<false>, grid, block, 0, s, prog, counts, n_rows, ints_per_row, flags, n_pass);
     return hipGetLastError();
 }
 
