@@ -402,23 +402,25 @@ __device__ __forceinline__ void directory_pass(uint2 *bd, int w0, int w1, int nw
 // which leaves the array ready for the next row.
 struct TripCarry { uint32_t cx, cnt; };
 
+// (NP = trips in flight: 2, or 1 where the registers are needed for columns)
+template <int NP>
 __device__ __forceinline__ void directory_trips_tog(uint32_t *tog, uint2 *bd, int tw, int wpp, int ntrip, int nw,
                                                     uint32_t tail_mask, uint32_t cyl, int lane)
 {
     int u = 0;
-    for (int t = tw; t < ntrip; t += 2 * wpp, u += 2) {
+    for (int t = tw; t < ntrip; t += NP * wpp, u += NP) {
         const int tt[2] = {t, t + wpp};
-        const bool on[2] = {true, t + wpp < ntrip};                      // wave-uniform
+        const bool on[2] = {true, NP > 1 && t + wpp < ntrip};            // wave-uniform
         uint4 q[2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NP; ++j) {
             uint4 *src = reinterpret_cast<uint4*>(tog + (tt[j] << 8)) + lane;
             const bool in = on[j] && (tt[j] << 8) + 4 * lane < nw;
             q[j] = in ? *src : make_uint4(0u, 0u, 0u, 0u);
             if (in) *src = make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NP; ++j) {
             const uint32_t cy = (uint32_t)__builtin_amdgcn_readlane((int)cyl, u + j);
             const int i0 = (tt[j] << 8) + 4 * lane;
             const uint32_t tq[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
@@ -778,7 +780,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
     auto team_directory = [&](int64_t rbA) {
         const int Kc = (int)((blk_end - rbA) < K ? (blk_end - rbA) : K);
         if (team < 2 * Kc && !(a.debug_skip & 4)) {
-            directory_trips_tog(TOG + (size_t)team * nwt, BD + (size_t)team * nwp, tw, wpp, (nw + 255) >> 8, nw, tail_mask,
+            directory_trips_tog<(CPT > 88 ? 1 : 2)>(TOG + (size_t)team * nwt, BD + (size_t)team * nwp, tw, wpp, (nw + 255) >> 8, nw, tail_mask,
                                 keep_cyl, lane);
             if (tw == 0 && lane == 0) n0s[team] = (uint32_t)m - keep_tot;
         }

@@ -55,7 +55,7 @@ struct ScanArgs {
 #define BGTH_CPT_1024(X) X(4) X(8) X(10) X(12) X(16) X(20) X(24)
 // team kernels only (wide cohorts: as many columns per workgroup as the 256 VGPRs of a 512-thread
 // workgroup hold, so that few column slices repeat the per-row bit-vector build)
-#define BGTH_CPT_512_WIDE(X) X(64) X(80)
+#define BGTH_CPT_512_WIDE(X) X(64) X(80) X(98)
 
 struct Geometry { int threads, cpt, slices, K, lds_bytes, workgroups, wpp, nbuf, tog_off; };
 

@@ -15,7 +15,7 @@ static const int kLdsBytes = 160 * 1024;
     X(256, 2) X(256, 4) X(256, 8) X(256, 12) X(256, 16) X(256, 20) \
     X(512, 4) X(512, 8) X(512, 10) X(512, 12) X(512, 16) X(512, 20) X(512, 24) X(512, 32) X(512, 40) X(512, 48) \
     X(1024, 4) X(1024, 8) X(1024, 10) X(1024, 12) X(1024, 16) X(1024, 20) X(1024, 24) \
-    X(512, 64) X(512, 80)                     /* team mode only (scan_wide.hip) */
+    X(512, 64) X(512, 80) X(512, 98)          /* team mode only (scan_wide.hip) */
 
 static bool team_only(int nt, int cpt) { return nt == 512 && cpt > 48; }
 

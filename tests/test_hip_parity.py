@@ -165,7 +165,7 @@ def test_sample_groups(hip, seed, m, rows, shift, G):
                                            (512, 16, 5), (512, 20, 8), (1024, 4, 16), (1024, 8, 2), (1024, 10, 9),
                                            (1024, 12, 3), (1024, 16, 7), (1024, 20, 5), (1024, 24, 1), (512, 24, 1),
                                            (512, 32, 2), (512, 40, 4), (512, 48, 1), (256, 2, 2), (1024, 8, 4),
-                                           (512, 64, 1), (512, 80, 1)])
+                                           (512, 64, 1), (512, 80, 1), (512, 98, 1)])
 def test_every_launch_geometry(hip, threads, cpt, K):
     """Force each kernel instantiation (and multi-slice launches) on one cohort."""
     mat, data, rng = make_case(41, 5008, 130, 5, n_founders=7, switch=0.04)
@@ -187,7 +187,7 @@ def test_every_launch_geometry(hip, threads, cpt, K):
     assert np.array_equal(c2, o2)
 
 
-@pytest.mark.parametrize("threads,cpt,K", [(0, 0, 0), (512, 80, 1), (512, 64, 1), (1024, 24, 1),
+@pytest.mark.parametrize("threads,cpt,K", [(0, 0, 0), (512, 80, 1), (512, 64, 1), (512, 98, 1), (1024, 24, 1),
                                            (1024, 8, 1), (512, 20, 1), (256, 20, 1), (1024, 16, 2)])
 @pytest.mark.parametrize("in_place", [False, True])
 def test_wide_cohort_team_mode(hip, threads, cpt, K, in_place, monkeypatch):
@@ -289,7 +289,7 @@ def test_sub_checkpoints(hip, tmp_path, monkeypatch, sub):
 
 
 @pytest.mark.parametrize("force", [None, "2048", "4096"])
-@pytest.mark.parametrize("threads,cpt,K", [(0, 0, 0), (1024, 20, 0), (512, 10, 3), (256, 8, 2), (512, 80, 1), (1024, 8, 1)])
+@pytest.mark.parametrize("threads,cpt,K", [(0, 0, 0), (1024, 20, 0), (512, 10, 3), (256, 8, 2), (512, 80, 1), (512, 98, 1), (1024, 8, 1)])
 def test_rows_with_an_empty_plane(hip, monkeypatch, force, threads, cpt, K):
     """Rows whose plane 1 (missing / <M>) is all zero take the shortcut of the ZP kernels (reference pbwt.c:135-138);
     a cohort that mixes such rows with ordinary ones, rows of one repeated code, and a plane-0-empty row, through both
