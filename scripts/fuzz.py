@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Differential fuzz on the GPU box: random cohorts / selections / groups / launch geometries / row ranges through
+the C ABI against the CPU oracle.  usage: python scripts/fuzz.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+    sys.path.insert(0, p)
+import bgt_amd  # noqa: E402
+import orc  # noqa: E402
+import scenarios  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+GEOMS = [(0, 0, 0), (256, 2, 1), (256, 8, 3), (256, 20, 2), (512, 4, 1), (512, 10, 2), (512, 20, 5), (512, 48, 1), (512, 64, 1),
+         (512, 80, 1), (512, 98, 1), (1024, 4, 9), (1024, 8, 1), (1024, 10, 0), (1024, 16, 2), (1024, 20, 0), (1024, 24, 1)]
+t_end = time.time() + budget
+n_case = n_check = 0
+while time.time() < t_end:
+    m = int(rng.choice([1, 2, 3, 63, 64, 65, 127, 500, 1000, 2049, 5008, 9000, 33000]))
+    rows = int(rng.integers(1, 400 if m < 10000 else 60))
+    shift = int(rng.integers(2, 9))
+    mat = scenarios.ld_matrix(rng, rows, m, n_founders=int(rng.integers(2, 30)), switch=float(rng.choice([0.0, 0.01, 0.1, 0.5])))
+    style = rng.integers(0, 4)
+    if style == 1:
+        mat &= 1                                              # fully called: plane 1 empty everywhere
+    elif style == 2:
+        mat[rng.random(rows) < 0.5] &= 1
+    elif style == 3 and rows > 3:
+        mat[rng.integers(0, rows)] = rng.integers(0, 4); mat[rng.integers(0, rows)] = 3
+    data = orc.encode_pbf(mat, 2, shift)
+    os.environ.pop("BGTH_DEBUG_SKIP", None)
+    flag = int(rng.choice([0, 0, 512, 2048, 4096, 4096 | 512]))
+    if flag:
+        os.environ["BGTH_DEBUG_SKIP"] = str(flag)
+    os.environ["BGTH_SUB_SHIFT"] = str(int(rng.integers(1, 12)))
+    pbf = bgt_amd.HipPbf.from_bytes(data)
+    for _ in range(3):
+        ora = orc.Pbf(data)
+        rd = bgt_amd.HipReader(pbf)
+        th, cpt, K = GEOMS[int(rng.integers(0, len(GEOMS)))]
+        rd.tune(th, cpt, K)
+        cols = group = None
+        G = 1
+        if m >= 2 and rng.random() < 0.6:
+            ns = m // 2
+            pick = np.sort(rng.choice(ns, int(rng.integers(1, ns + 1)), replace=False))
+            cols = np.stack([2 * pick, 2 * pick + 1], 1).reshape(-1).astype(np.int32)
+            if rng.random() < 0.5:
+                G = int(rng.integers(2, 7))
+                group = rng.integers(1, G + 1, pick.size).astype(np.uint32)
+            rd.select(cols, group=group, n_groups=G)
+            ora.subset(cols)
+        a = int(rng.integers(0, rows)); b = int(rng.integers(a + 1, rows + 1))
+        try:
+            counts, gt = rd.scan(a, b, want_gt=True)
+        except RuntimeError as e:
+            if "no launch geometry" in str(e):
+                continue
+            raise
+        oc, ogt = ora.scan(a, b, group=group, n_groups=G, want_gt=True)
+        ok = np.array_equal(counts.reshape(b - a, -1), oc.reshape(b - a, -1)) and np.array_equal(gt, ogt)
+        n_check += 1
+        if not ok:
+            print("MISMATCH m=%d rows=%d shift=%d geom=%s flag=%d sub=%s range=[%d,%d) G=%d cols=%s" %
+                  (m, rows, shift, (th, cpt, K), flag, os.environ["BGTH_SUB_SHIFT"], a, b, G, None if cols is None else cols.size))
+            sys.exit(1)
+        rd.close()
+    pbf.close()
+    n_case += 1
+print("fuzz ok: %d images, %d scans checked in %.0f s" % (n_case, n_check, budget))
