@@ -16,6 +16,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bgt_amd", "host")])
 
+SYNTH = len(sys.argv) > 3 and sys.argv[3] == "synth"        # third argument: fuzz two generated multi-block databases instead
 REGIONS = ["11", "12", "11:1000-1100", "11:1050-1051", "11:1,100-1,300", "12:500-510", "11:1101", "13", "11:1-999", "12:503"]
 SAMPLES = ['pop=="X"', 'pop=="Y"', 'pop=="Z"', "idx%5==0", "idx<10", "idx>=30", ",A001,A010,A049", ",B002,B039", ":A003,B003", "idx%7==3||pop==\"X\""]
 FILTERS = ["AC>0", "AC==0", "AN>90", "AC/AN>0.2", "AC1>0&&AC2==0", "AC1/AN1>=0.1&&AC2<5", "AC3>0", "AC>1&&AC<10", "AC%2==1", "AN-AC>80"]
@@ -25,10 +26,34 @@ ALLELES = [",11:1010:1:A", ",11:1010:1:A,11:1010:1:C", ",11:1060:1:G,11:1040:1:G
 DBS = [["synA"], ["synB"], ["synA", "synB"], ["synB", "synA"], ["ex2"], ["ex3"]]
 
 
+if SYNTH:
+    import tempfile
+    TMP = tempfile.mkdtemp()
+    GOLD = TMP
+    subprocess.check_call([MINE, "synth", os.path.join(TMP, "s1"), "300", "20000", "7"], stdout=subprocess.DEVNULL)
+    subprocess.check_call([MINE, "synth", os.path.join(TMP, "s2"), "200", "20000", "8"], stdout=subprocess.DEVNULL)
+    for f in ("regions.bed", "points.bed"):
+        with open(os.path.join(TMP, f), "w") as fh:
+            for k in range(40):
+                b = rnd.randint(1000, 200000)
+                fh.write("11\t%d\t%d\n" % (b, b + rnd.choice([1, 5, 50, 3000])) if f[0] == "r" else "11\t%d\n" % b)
+    REGIONS = ["11"] + ["11:%d-%d" % (b, b + w) for b, w in ((rnd.randint(1000, 200000), rnd.choice([1, 30, 500, 9000, 90000])) for _ in range(30))]
+    SAMPLES = ['pop=="A"', 'pop=="B"', 'pop=="C"', "idx%5==0", "idx<10", "idx>=150", "idx%7==3||pop==\"A\""]
+    sites = subprocess.run([REF, "view", "-G", "-t", "CHROM,POS,REF,ALT", os.path.join(TMP, "s1")], stdout=subprocess.PIPE,
+                           check=True).stdout.decode().split("\n")[:-1]
+    pick = [x.split("\t") for x in rnd.sample(sites, 60)]
+    ALLELES = ["," + ",".join("%s:%s:%s:%s" % tuple(x) for x in rnd.sample(pick, rnd.randint(1, 6))) for _ in range(25)]
+    open(os.path.join(TMP, "alleles.txt"), "w").write("\n".join("%s:%s:%s:%s" % tuple(x) for x in pick[:4]) + "\n")
+    ALLELES.append("alleles.txt")
+    open(os.path.join(TMP, "vardb.fmf"), "w").write("".join("%s:%s:%s:%s\tgene:Z:%s\tcadd:f:%.1f\timpact:i:%d\n" %
+                                                    (x[0], x[1], x[2], x[3], rnd.choice(["ABC", "XYZ"]), rnd.random() * 30, rnd.randint(0, 5)) for x in pick))
+    DBS = [["s1"], ["s2"], ["s1", "s2"], ["s2", "s1"]]
+
+
 def make():
     a = []
     dbs = rnd.choice(DBS)
-    syn = dbs[0].startswith("syn")
+    syn = dbs[0].startswith("s")
     if rnd.random() < 0.5:
         a += ["-G"]
     if rnd.random() < 0.4:
@@ -36,9 +61,9 @@ def make():
     if rnd.random() < 0.35:
         a += ["-r", rnd.choice(REGIONS)]
     if rnd.random() < 0.2:
-        a += ["-i", str(rnd.randint(1, 35))]
+        a += ["-i", str(rnd.randint(1, 25000 if SYNTH else 35))]
     if rnd.random() < 0.2:
-        a += ["-n", str(rnd.randint(0, 12))]
+        a += ["-n", str(rnd.randint(0, 3000 if SYNTH else 12))]
     n_grp = 0
     if syn:
         n_grp = rnd.choice([0, 0, 1, 2, 3])
