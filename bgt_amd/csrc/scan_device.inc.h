@@ -62,6 +62,17 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// s_setprio takes an immediate
+__device__ __forceinline__ void set_wave_priority(int p)
+{
+    switch (p) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+
 __device__ __forceinline__ uint32_t lane63(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
 
 __device__ __forceinline__ uint32_t rle_len(uint32_t byte)
@@ -612,6 +623,10 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
     // on its own (K <= NWAVE).  wpp > 1 (wide cohorts: few rows fit the LDS): a team of wpp waves builds
     // plane-row (wave / wpp) together, synchronised by workgroup barriers.
     const int wpp = TEAM ? a.wpp : 1;
+    // Narrow mode: which plane-row of a batch this wave builds.  Even plane-rows are plane 0 (long strings, several
+    // times the build work of plane 1); waves w, w+4, w+8, w+12 share a SIMD, so the parity is flipped for every
+    // second group of four waves: each SIMD then builds two plane-0 and two plane-1 rows per batch.
+    const int build_slot = wave ^ ((wave >> 2) & 1);
     const int team = wave / wpp, tw = wave - team * wpp;
 
     // ---- software prefetch of the RLE strings: the row descriptors run two batches ahead of phase A,
@@ -622,7 +637,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
     uint64_t dsc[2], dsc_next[2];
     uint32_t pre[2][2];
     auto fetch_desc = [&](int64_t rb_, int i) -> uint64_t {
-        const int p = wpp == 1 ? wave + i * NWAVE : team;
+        const int p = wpp == 1 ? build_slot + i * NWAVE : team;
         const int64_t left = blk_end - rb_;
         const int kc = (int)(left < K ? left : K);
         return (rb_ < blk_end && p < 2 * kc) ? rowdesc[2 * rb_ + p] : 0ull;
@@ -678,7 +693,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
         if constexpr (!TEAM) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int p = wave + i * NWAVE;
+                const int p = build_slot + i * NWAVE;
                 if (p < 2 * Kc)
                     build_plane_row(a, rle, BDb + (size_t)p * nwp, n0b + p, cdsc[i], cpre[i][0], cpre[i][1], lane, tail_mask);
             }
@@ -800,6 +815,10 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
             const uint32_t n00 = 0u - (uint32_t)__builtin_amdgcn_readfirstlane(n0b[2 * k]);
             const uint32_t n01 = 0u - (uint32_t)__builtin_amdgcn_readfirstlane(n0b[2 * k + 1]);
             const bool emit = (rb + k) >= a.row0;
+            // The SIMD arbiter prefers its oldest wave: left alone, waves 0-3 race through a batch and idle at the
+            // barrier while waves 12-15 finish it nearly alone (measured: walk 96 vs 189 ticks).  Rotating the user
+            // priority over the rows of a batch gives the four waves of a SIMD equal progress.
+            if (!TEAM && !(a.debug_skip & 0x2000)) set_wave_priority(((wave >> 2) + k) & 3);   // (team mode: one row per barrier, no gain)
             if (ZP && n01 == 0u - (uint32_t)m) base1 = 0u;       // plane 1 all zero: its lookups are skipped (see step2)
             if (a.snap && rb + k > blk_beg && ((rb + k) & (((int64_t)1 << a.snap_shift) - 1)) == 0) {
                 // sub-checkpoint: the ranks before this row (image-open pass only)
@@ -895,10 +914,12 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
         int64_t rb = blk_beg - K;
         for (; rb < blk_end; rb += K, ++b) {
             if (b > 0) phase_c((b - 1) & 1, rb - K, K);
+            BGTH_TICK(2);                                  // (narrow mode: slot 2 = counts flush, slot 1 = barrier wait)
             if (rb + K < blk_end) phase_a((b + 1) & 1, rb + K);
             BGTH_TICK(6);
             if (b >= 0) phase_b(b & 1, rb, (int)((blk_end - rb) < K ? (blk_end - rb) : K));
             lds_barrier();
+            BGTH_TICK(1);
         }
         if (b > 0) {
             const int64_t last = rb - K;
@@ -925,7 +946,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
         }
     }
 
-    if (a.debug_times && lane == 0 && (!(a.debug_skip & 0x100) || wave == 0)) {   // 0x100: wave 0 only
+    if (a.debug_times && lane == 0 && (!(a.debug_skip & 0x100) || wave == ((a.debug_skip >> 16) & 15))) {   // 0x100: one wave only (bits 16..19)
         for (int i = 0; i < 8; ++i) atomicAdd(a.debug_times + i, tsum[i]);
     }
     if (a.final_rank) {
