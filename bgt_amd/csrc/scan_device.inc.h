@@ -691,6 +691,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
         for (int i = 0; i < 2; ++i) dsc_next[i] = fetch_desc(rbA + 2 * K, i);
         BGTH_TICK(0);
         if constexpr (!TEAM) {
+            if (!(a.debug_skip & 0x4000)) set_wave_priority(3);          // the build is a latency chain of few instructions: let it through
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int p = build_slot + i * NWAVE;

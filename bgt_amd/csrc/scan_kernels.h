@@ -47,7 +47,7 @@ struct ScanArgs {
     int32_t  debug_skip;         // ablation bits (env BGTH_DEBUG_SKIP): 1 no walk, 2 no RLE read / toggles, 4 no directory build,
                                  //   8 every lookup reads the sentinel word (no LDS conflicts), 64 no toggle atomics, 0x100 timing
                                  //   of wave 0 only, 0x200 team mode without the separate toggle array (host-side switch), 0x800 / 0x1000 never / always the ZP
-                                 //   kernels (host-side), 0x2000 no priority rotation in the walk
+                                 //   kernels (host-side), 0x2000 no priority rotation in the walk, 0x4000 no raised priority for the build
 };
 
 // columns per thread instantiated for each workgroup size (keep in sync with kGeoms in scan_kernels.hip)
