@@ -87,12 +87,9 @@ bool choose_geometry(int m, int n_chunks, int G, int n_blk, int want_threads, in
         int K = want_K > 0 ? want_K : nt / 64;
         if (K > nt / 64) K = nt / 64;
         while (K > 1 && lds_need(nw, K, G, nt) > kLdsBytes) --K;
-        if (team_only(nt, cpt)) {                        // instantiated for team mode only: skip where the
-            int K2 = want_K > 0 ? want_K : nt / 64;      // narrow (two-buffer) mode would be chosen below
-            if (K2 > nt / 64) K2 = nt / 64;
-            while (K2 > 1 && lds_need(nw, K2, G, nt, 2) > kLdsBytes) --K2;
-            if (lds_need(nw, K2, G, nt, 2) <= kLdsBytes && wpp_for(nt, K2) == 1) continue;
-        }
+        if (team_only(nt, cpt)) {                        // instantiated for team mode only: rows per batch few enough
+            while (K > 1 && wpp_for(nt, K) == 1) --K;    // for teams of waves (mid-width cohorts: one wide column slice
+        }                                                // in team mode can beat three narrow ones)
         int slices;
         const long cost = model_cost(nw, n_chunks, n_blk, nt, cpt, K, &slices);
         // ties: fewer idle slots, then more threads (more waves to hide LDS latency)
@@ -112,7 +109,7 @@ bool choose_geometry(int m, int n_chunks, int G, int n_blk, int want_threads, in
         int K2 = want_K > 0 ? want_K : nt / 64;
         if (K2 > nt / 64) K2 = nt / 64;
         while (K2 > 1 && lds_need(nw, K2, G, nt, 2) > kLdsBytes) --K2;
-        if (lds_need(nw, K2, G, nt, 2) <= kLdsBytes && wpp_for(nt, K2) == 1) { g->K = K2; g->nbuf = 2; g->wpp = 1; }
+        if (!team_only(nt, g->cpt) && lds_need(nw, K2, G, nt, 2) <= kLdsBytes && wpp_for(nt, K2) == 1) { g->K = K2; g->nbuf = 2; g->wpp = 1; }
         else { g->K = best_K; g->nbuf = 1; g->wpp = wpp_for(nt, best_K); if (g->wpp == 1) g->wpp = 2; }
         if (g->nbuf == 1 && 2 * g->K * g->wpp > nt / 64) {            // a team per plane-row must exist
             while (g->K > 1 && 2 * g->K * g->wpp > nt / 64) --g->K;
