@@ -565,6 +565,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NWAVE = NT / 64;
     static_assert(CPT % 2 == 0, "columns per thread are stepped in pairs");
+    static_assert(CPT * 64 < 65536, "per-wave counts of a row are kept in 16 bits");
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -584,8 +585,9 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
     const int m = a.m, nw = a.nw, nwp = (nw + 2) & ~1, K = a.K, G = a.G;   // rows 16-byte aligned
     uint2    *BD   = reinterpret_cast<uint2*>(smem);                    // [nbuf][2K][nwp]
     int32_t  *lcnt = reinterpret_cast<int32_t*>(smem + (size_t)16 * K * nwp * (TEAM ? 1 : 2));
-    //   !MULTI: int4 [K][NWAVE] one private slot per wave and row   MULTI: int32 [K][G][3] (LDS atomics)
-    uint32_t *n0s  = reinterpret_cast<uint32_t*>(lcnt + (TEAM ? 1 : 2) * (MULTI ? K * G * 3 : K * NWAVE * 4)); // [nbuf][2K]
+    //   !MULTI: uint2 [K][NWAVE] one private slot per wave and row, three 16-bit counts (a wave counts at most
+    //           64 * CPT < 65536 per row; 8 bytes instead of 16 let C2 keep 8 rows per batch)   MULTI: int32 [K][G][3] (LDS atomics)
+    uint32_t *n0s  = reinterpret_cast<uint32_t*>(lcnt + (TEAM ? 1 : 2) * (MULTI ? K * G * 3 : K * NWAVE * 2)); // [nbuf][2K]
     // team mode, when it fits: toggles of the NEXT batch go to their own array [2K][nwt] while the current one is walked
     const int nwt = (nw + 4) & ~3;
     uint32_t *TOG = (TEAM && a.tog_off) ? reinterpret_cast<uint32_t*>(smem + a.tog_off) : nullptr;
@@ -669,7 +671,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
 
     // LDS regions of batch buffer `buf`
     const size_t bd_stride = (size_t)2 * K * nwp;                        // uint2 entries per buffer
-    const int cnt_stride = MULTI ? K * G * 3 : K * NWAVE * 4;            // ints per buffer
+    const int cnt_stride = MULTI ? K * G * 3 : K * NWAVE * 2;            // ints per buffer
 
     // ================= phase A: build the bit-vectors of the batch at rows [rbA, rbA+Kc) into buffer buf ===
     // First take the strings fetched while the previous batch was processed and immediately issue the
@@ -866,7 +868,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
                 }
             }
             if (!MULTI && lane == 0)
-                reinterpret_cast<int4*>(lcb)[k * NWAVE + wave] = make_int4((int)(ca - cc), (int)(cb - cc), (int)cc, 0);
+                reinterpret_cast<uint2*>(lcb)[k * NWAVE + wave] = make_uint2((ca - cc) | (cb - cc) << 16, cc);
             if (GT && emit) {
 #pragma unroll
                 for (int q = 0; q < NKEEP; ++q) {
@@ -899,7 +901,10 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
                 if (rb + k >= a.row0) {
                     int32_t v = 0;
 #pragma unroll
-                    for (int w = 0; w < NWAVE; ++w) v += lcb[(k * NWAVE + w) * 4 + comp];
+                    for (int w = 0; w < NWAVE; ++w) {
+                        const uint32_t x = (uint32_t)lcb[(k * NWAVE + w) * 2 + (comp >> 1)];
+                        v += (int32_t)(comp == 0 ? x & 0xffffu : comp == 1 ? x >> 16 : x);
+                    }
                     if (v) atomicAdd(a.raw_counts + (size_t)(rb + k - a.row0) * 3 + comp, v);
                 }
             }

@@ -28,8 +28,8 @@ static const GeomEntry kGeoms[] = {
 
 static int lds_need(int nw, int K, int G, int threads, int nbuf = 1)
 {
-    const int cnt = G > 1 ? K * G * 3 * 4 : K * (threads / 64) * 16;
-    return nbuf * (16 * K * ((nw + 2) & ~1) + cnt + 2 * K * 4) + (threads / 64) * (8 + 16);
+    const int cnt = G > 1 ? K * G * 3 * 4 : K * (threads / 64) * 8;
+    return nbuf * (16 * K * ((nw + 2) & ~1) + cnt + 2 * K * 4) + 64;
 }
 
 // Cost model (cycles per decoded row on one CU; the kernel is VALU-bound at one wave-instruction per
