@@ -126,8 +126,7 @@ def main():
                 host_flags[b].copy_(g_flags[b], non_blocking=True)
                 host_n_pass[b].copy_(n_pass_d[b], non_blocking=True)
                 copied[b].record(side)
-        kernel_ms.append(rd.timing()["scan_ms"])                         # waits for the scan kernel only
-        return b
+        return b                                                         # (nothing here waits: steps are enqueued back to back)
 
     def barrier():
         if world > 1:
@@ -144,6 +143,7 @@ def main():
         last = step()
     barrier()                                                            # includes the side stream: all results on the host
     dt = time.perf_counter() - t0
+    kernel_ms.append(rd.timing()["scan_ms"])                             # HIP events around the scan kernel of the last step
     n_pass = int(host_n_pass[last].item()) if rank == 0 else 0
     if rank == 0:
         host = host[last]
