@@ -734,7 +734,8 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
         a.debug_times = d_times;
     }
     if (timed) HIP_TRY(hipEventRecord(r->ev[0], s), return -1);
-    HIP_TRY(hipMemsetAsync(r->raw.p, 0, (size_t)rows * G * 3 * 4, s), return -1);
+    if (G > 1 || geo.slices > 1)                             // a single-group, single-slice launch stores its counts
+        HIP_TRY(hipMemsetAsync(r->raw.p, 0, (size_t)rows * G * 3 * 4, s), return -1);
     if (timed) HIP_TRY(hipEventRecord(r->ev[1], s), return -1);
     HIP_TRY(launch_scan(a, geo, s), return -1);
     if (timed) HIP_TRY(hipEventRecord(r->ev[2], s), return -1);

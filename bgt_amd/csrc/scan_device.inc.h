@@ -905,7 +905,9 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
                         const uint32_t x = (uint32_t)lcb[(k * NWAVE + w) * 2 + (comp >> 1)];
                         v += (int32_t)(comp == 0 ? x & 0xffffu : comp == 1 ? x >> 16 : x);
                     }
-                    if (v) atomicAdd(a.raw_counts + (size_t)(rb + k - a.row0) * 3 + comp, v);
+                    int32_t *dst = a.raw_counts + (size_t)(rb + k - a.row0) * 3 + comp;
+                    if (a.n_slices == 1) *dst = v;                   // the only writer of this row: no zero-fill, no atomic
+                    else if (v) atomicAdd(dst, v);
                 }
             }
         }
