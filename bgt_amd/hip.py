@@ -307,6 +307,57 @@ class HipReader:
 # ---------------------------------------------------------------------------------------------------
 # synthetic cohorts (include/bgt_synth.h)
 # ---------------------------------------------------------------------------------------------------
+class HipEncoder:
+    """The device writer (bgth_encoder_t): rows of 2-bit codes -> the bytes of a .pbf, identical to what the
+    reference writer produces (pbf_open_w / pbf_write / pbf_close, ref pbwt.c:199-311)."""
+
+    def __init__(self, m, g=2, shift=13, device=0):
+        L = lib()
+        L.bgth_encoder_open.restype = C.c_void_p
+        L.bgth_encoder_open.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int]
+        L.bgth_encoder_write.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.bgth_encoder_finish.restype = C.c_int64
+        L.bgth_encoder_finish.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.bgth_encoder_free_image.argtypes = [C.c_void_p]
+        L.bgth_encoder_close.argtypes = [C.c_void_p]
+        L.bgth_encoder_kernel_ms.restype = C.c_double
+        L.bgth_encoder_kernel_ms.argtypes = [C.c_void_p]
+        L.bgth_encoder_last_error.restype = C.c_char_p
+        self.m = m
+        self.h = L.bgth_encoder_open(m, g, shift, device)
+        if not self.h:
+            raise RuntimeError(L.bgth_encoder_last_error().decode() or "bgth_encoder_open failed")
+
+    def write(self, codes):
+        """codes: (rows, m) uint8, bit k = plane k."""
+        codes = np.ascontiguousarray(codes, np.uint8)
+        assert codes.ndim == 2 and codes.shape[1] == self.m
+        if lib().bgth_encoder_write(self.h, codes.ctypes.data, codes.shape[0]) < 0:
+            raise RuntimeError(lib().bgth_encoder_last_error().decode())
+
+    def finish(self):
+        """The complete image (header, records, footer) as bytes."""
+        out = C.c_void_p()
+        n = lib().bgth_encoder_finish(self.h, C.byref(out))
+        if n < 0:
+            raise RuntimeError(lib().bgth_encoder_last_error().decode())
+        data = C.string_at(out, n)
+        lib().bgth_encoder_free_image(out)
+        return data
+
+    @property
+    def kernel_ms(self):
+        return lib().bgth_encoder_kernel_ms(self.h)
+
+    def close(self):
+        if self.h:
+            lib().bgth_encoder_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
 def synth_rows(m, row0, n_rows, seed, n_threads=0):
     """Draw rows [row0,row0+n_rows) of cohort (seed, m) in the PBWT domain. Returns (rle uint8[], len uint32[2n])."""
     L = lib()

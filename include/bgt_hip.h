@@ -64,6 +64,21 @@ int64_t     bgth_pbf_get_n(const bgth_pbf_t *p);       /* rows                  
 int64_t     bgth_pbf_hbm_bytes(const bgth_pbf_t *p);   /* device footprint                          */
 int64_t     bgth_pbf_rle_bytes(const bgth_pbf_t *p);   /* total RLE payload                         */
 
+/* ---- writer: rows of 2-bit codes -> .pbf  (replaces pbf_open_w / pbf_write / pbf_close, pbwt.h:35,57,49;
+ *      pbwt.c:199-219, :288-311, :264-277; the row encoder pbc_enc_core pbwt.c:57-66 and the run-length bytes of
+ *      pbwt.c:24-36 run on the device) ----
+ * The image is byte for byte the file the reference writer produces from the same rows.  `codes` is a HOST array
+ * [n_rows][m], bit k of a byte = the bit of plane k (what import.c:96-97 hands to pbf_write as g byte arrays).
+ * One workgroup per plane encodes the rows in order; m <= 32768 columns in this version.  No CPU path. */
+typedef struct bgth_encoder_s bgth_encoder_t;
+bgth_encoder_t *bgth_encoder_open(int32_t m, int32_t g, int32_t shift, int device);      /* NULL on failure       */
+int             bgth_encoder_write(bgth_encoder_t *e, const uint8_t *codes, int64_t n_rows);   /* <0 on failure   */
+int64_t         bgth_encoder_finish(bgth_encoder_t *e, uint8_t **image);   /* footer; bytes of the malloc'd image */
+void            bgth_encoder_free_image(uint8_t *image);
+void            bgth_encoder_close(bgth_encoder_t *e);
+double          bgth_encoder_kernel_ms(const bgth_encoder_t *e);           /* device time of the encode kernels   */
+const char     *bgth_encoder_last_error(void);
+
 /* ---- reader ---- */
 bgth_reader_t *bgth_reader_create(bgth_pbf_t *p);
 void           bgth_reader_destroy(bgth_reader_t *r);

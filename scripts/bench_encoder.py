@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Throughput of the device writer (bgth_encoder_*) at a C2-shaped width: the rows come from the synthetic cohort
+(decoded on the device), go through the encoder, and the image is checked against the oracle writer on a prefix and
+by scanning it back.  The CPU oracle writer (a port of pbf_write/pbc_enc) is timed beside it.
+usage: python scripts/bench_encoder.py [--samples 10000] [--rows 65536]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+    sys.path.insert(0, p)
+import bgt_amd  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--samples", type=int, default=10000)
+ap.add_argument("--rows", type=int, default=65536)
+ap.add_argument("--seed", type=int, default=2)
+ap.add_argument("--cpu-rows", type=int, default=2048)
+args = ap.parse_args()
+m, rows, shift = 2 * args.samples, args.rows, 13
+
+rle, lens = bgt_amd.synth_rows(m, 0, rows, args.seed)
+src = bgt_amd.HipPbf.from_rle(m, shift, rle, lens)
+rd = bgt_amd.HipReader(src)
+counts, gt = rd.scan(0, rows, want_gt=True)
+codes = np.empty((rows, m), np.uint8)
+for k in range(4):
+    codes[:, k::4] = ((gt >> (2 * k)) & 3)[:, :(m - k + 3) // 4]
+del gt
+
+enc = bgt_amd.HipEncoder(m, 2, shift)
+t0 = time.time()
+enc.write(codes)
+image = enc.finish()
+wall = time.time() - t0
+kernel_s = enc.kernel_ms / 1e3
+
+back = bgt_amd.HipReader(bgt_amd.HipPbf.from_bytes(image))
+assert np.array_equal(back.scan(0, rows), counts), "the encoded image does not scan back to the same counts"
+
+import orc  # noqa: E402  (checker + CPU baseline)
+n_cpu = min(args.cpu_rows, rows)
+t0 = time.time()
+ref = orc.encode_pbf(codes[:n_cpu], 2, shift)
+cpu_s = time.time() - t0
+enc2 = bgt_amd.HipEncoder(m, 2, shift)
+enc2.write(codes[:n_cpu])
+assert enc2.finish() == ref, "device image differs from the oracle writer"
+
+print(json.dumps({"metric": "rows/sec pbf_write (encode)", "columns": m, "rows": rows, "image_bytes": len(image),
+                  "rows_per_s_kernel": rows / kernel_s, "rows_per_s_wall_incl_upload_and_assembly": rows / wall,
+                  "kernel_us_per_row": 1e6 * kernel_s / rows,
+                  "cpu_oracle_rows_per_s": n_cpu / cpu_s, "cpu_rows": n_cpu,
+                  "parity": "image == oracle writer on the first %d rows; whole image scans back to the input counts" % n_cpu}))

@@ -1,0 +1,133 @@
+"""The device writer (row f-4 of SURVEY.md section 8: pbf_open_w / pbf_write / pbf_close, ref pbwt.c:199-311) against
+the oracle writer, which is pinned to files written by the reference (tests/test_oracle_golden.py): the images must be
+identical byte for byte -- header, 'S' checkpoints, run-length strings, footer."""
+import os
+
+import numpy as np
+import pytest
+
+import orc
+import scenarios
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def decode_all(data):
+    """every row of a .pbf as codes (rows, m), through the oracle reader"""
+    pbf = orc.Pbf(data)
+    rows = np.zeros((pbf.n, pbf.m), np.uint8)
+    for r in range(pbf.n):
+        planes = pbf.read()                       # (g, m) bits
+        for k in range(pbf.g):
+            rows[r] |= planes[k] << k
+    return rows, pbf.m, pbf.g, pbf.shift
+
+
+def test_encoder_symbols_exported():
+    import bgt_amd
+    L = bgt_amd.lib()
+    for name in ("bgth_encoder_open", "bgth_encoder_write", "bgth_encoder_finish", "bgth_encoder_free_image",
+                 "bgth_encoder_close", "bgth_encoder_kernel_ms", "bgth_encoder_last_error"):
+        assert hasattr(L, name)
+
+
+def test_encoder_refuses_what_it_cannot_hold():
+    import bgt_amd
+    with pytest.raises(RuntimeError):
+        bgt_amd.HipEncoder(0)
+    with pytest.raises(RuntimeError):
+        bgt_amd.HipEncoder(40000)                 # more than 32768 columns: not in this version, and no CPU path
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,rows,shift", [(1, 5, 2), (2, 9, 1), (31, 40, 3), (32, 40, 3), (33, 70, 4), (64, 100, 13),
+                                          (1000, 300, 5), (4096, 64, 4), (4097, 64, 4), (5008, 200, 6),
+                                          (8192, 40, 3), (9000, 50, 4), (20000, 300, 7), (20480, 30, 3),
+                                          (20481, 30, 3), (32767, 20, 2), (32768, 20, 2)])
+def test_encoder_matches_oracle_writer(m, rows, shift):
+    import bgt_amd
+    rng = np.random.default_rng(m * 31 + rows)
+    mat = scenarios.ld_matrix(rng, rows, m, n_founders=8, switch=0.02)
+    enc = bgt_amd.HipEncoder(m, 2, shift)
+    enc.write(mat)
+    assert enc.finish() == orc.encode_pbf(mat, 2, shift)
+    enc.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("style", ["zeros", "ones", "alternating", "random", "long_runs", "all_codes"])
+def test_encoder_run_length_edge_cases(style):
+    """constant rows (one run of m), alternating bits (m one-bit runs: the longest output), runs whose length has
+    several non-zero hex digits, and every 2-bit code"""
+    import bgt_amd
+    m, rows = 4500, 24
+    rng = np.random.default_rng(5)
+    if style == "zeros":
+        mat = np.zeros((rows, m), np.uint8)
+    elif style == "ones":
+        mat = np.full((rows, m), 3, np.uint8)
+    elif style == "alternating":
+        mat = np.tile((np.arange(m) & 1).astype(np.uint8) * 3, (rows, 1))
+    elif style == "random":
+        mat = rng.integers(0, 4, (rows, m)).astype(np.uint8)
+    elif style == "long_runs":
+        mat = np.zeros((rows, m), np.uint8)
+        for r in range(rows):
+            cut = np.sort(rng.integers(0, m, 4))
+            mat[r, cut[0]:cut[1]] = 1
+            mat[r, cut[2]:cut[3]] = 2
+    else:
+        mat = (np.arange(rows * m).reshape(rows, m) % 4).astype(np.uint8)
+    enc = bgt_amd.HipEncoder(m, 2, 3)
+    enc.write(mat)
+    assert enc.finish() == orc.encode_pbf(mat, 2, 3)
+
+
+@pytest.mark.gpu
+def test_encoder_rows_in_several_calls_and_one_plane():
+    """pbf_write is called row by row (import.c:100); batches must not show in the file.  g = 1 is the reference's
+    second writer (import.c:74)."""
+    import bgt_amd
+    rng = np.random.default_rng(11)
+    m = 3000
+    mat = scenarios.ld_matrix(rng, 157, m, n_founders=5, switch=0.05)
+    enc = bgt_amd.HipEncoder(m, 2, 4)
+    for lo, hi in ((0, 1), (1, 17), (17, 17), (17, 100), (100, 157)):
+        enc.write(mat[lo:hi])
+    assert enc.finish() == orc.encode_pbf(mat, 2, 4)
+    one = bgt_amd.HipEncoder(m, 1, 4)
+    one.write(mat & 1)
+    assert one.finish() == orc.encode_pbf(mat & 1, 1, 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["ex1.pbf", "bgt/synA.pbf", "bgt/synB.pbf", "bgt/ex2.pbf", "bgt/ex3.pbf"])
+def test_encoder_reproduces_reference_files(name):
+    """decode a file the REFERENCE wrote (bgt import), encode the rows again: the same file"""
+    import bgt_amd
+    path = os.path.join(GOLD, name)
+    if not os.path.exists(path):
+        pytest.skip(name + " not among the goldens")
+    data = open(path, "rb").read()
+    rows, m, g, shift = decode_all(data)
+    enc = bgt_amd.HipEncoder(m, g, shift)
+    enc.write(rows)
+    assert enc.finish() == data
+
+
+@pytest.mark.gpu
+def test_encoder_output_scans_back():
+    """encode -> open the image on the device -> scan: the counts of the matrix that went in"""
+    import bgt_amd
+    rng = np.random.default_rng(3)
+    m, rows = 10000, 600
+    mat = scenarios.ld_matrix(rng, rows, m, n_founders=12, switch=0.01)
+    enc = bgt_amd.HipEncoder(m, 2, 6)
+    enc.write(mat)
+    pbf = bgt_amd.HipPbf.from_bytes(enc.finish())
+    rd = bgt_amd.HipReader(pbf)
+    counts = rd.scan(0, rows)
+    assert np.array_equal(counts[:, 0, 0], (mat != 2).sum(1))
+    assert np.array_equal(counts[:, 0, 1], (mat == 1).sum(1))
+    assert np.array_equal(counts[:, 0, 2], (mat == 3).sum(1))
