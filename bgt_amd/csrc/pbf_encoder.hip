@@ -9,14 +9,22 @@
 //   directory  ones before every 32-bit word (block scan) and the positions where a run starts
 //   emit       every word-thread writes the run-length bytes of the runs that start in its word
 //   step       rank <- bit ? zeros + ones_before(rank) : rank - ones_before(rank)         (the stable partition)
-// Rows are sequential (row r is written in the order rows 0..r-1 left); planes are independent.  DESIGN.md section 7
-// has the plan that removes the sequential pass (block-start orders by a device sort).
+// Rows are sequential only in appearance -- row r is written in the order rows 0..r-1 left -- and planes are
+// independent.  The order at a row is a SORT: columns ordered by their bits read backwards from that row, ties in
+// the order they had before.  A call with many rows is therefore cut into UNITS of 4096 rows and runs as
+//   A  every unit and plane at once, from the identity order and without emitting: the order L the unit's own rows
+//      produce, then which neighbours in L are identical over the whole unit (classes)
+//   B  unit after unit (cheap): order after unit k = sort by (class in L_k, order before unit k)   [rocPRIM radix sort]
+//   C  every unit and plane at once, from its true start order: scatter / directory / emit / step as above.
+// A call with one unit is phase C alone.
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <cstring>
 #include <vector>
+#include <rocprim/rocprim.hpp>
 #include "../../include/bgt_hip.h"
 
 namespace {
@@ -28,12 +36,16 @@ struct EncodeArgs {
     const uint8_t *codes;      // [n_rows][CPT * 1024]  bit k of a byte = plane k, zero beyond column m
     int64_t n_rows, row0;      // row0 = file row of codes[0]
     int32_t m, mask;           // mask = (1 << shift) - 1
-    int32_t *rank;             // [g][m] in/out
-    uint8_t *out;              // [g][cap]
+    int32_t g, unit_rows;      // workgroup (plane, unit) handles rows [unit * unit_rows, ...)
+    const int32_t *rank_in;    // [n_units][g][m] order before each unit, or NULL = identity
+    int32_t *rank_out;         // [n_units][g][m] order after it
+    int32_t *perm_out;         // [n_units][g][m] the same as position -> column (phase A), or NULL
+    uint8_t *out;              // [n_units][g][cap]
     int64_t cap;
-    int64_t *out_len;          // [g]
+    int64_t *out_len;          // [n_units][g]
     int32_t *row_len;          // [g][n_rows]
     int32_t *snap;             // [g][n_snap][m]   permutation before every row with (row & mask) == 0
+    const int32_t *snap_base;  // [n_units] index of the first of them in each unit
     int32_t n_snap;
     int32_t *status;           // != 0: output capacity exceeded
 };
@@ -91,35 +103,38 @@ __device__ __forceinline__ uint32_t put_run(uint8_t *dst, uint32_t len, uint32_t
 
 // CPT columns per thread (a multiple of 4); rows of `codes` are CPT * 1024 bytes apart, zero beyond column m, so a
 // thread fetches its columns as whole words and the padding columns never set a bit.
-template <int CPT>
+template <int CPT, bool EMIT>
 __global__ __launch_bounds__(kThreads) void encode_kernel(EncodeArgs a)
 {
     __shared__ uint32_t bits2[2][kThreads + 1]; // the row's bit-vector in PBWT order, double-buffered over rows
     __shared__ uint32_t before[kThreads];       // ones before each word
     __shared__ uint32_t agg[3][16];             // per wave: ones, end of the last run that ends in it, bytes
-    const int tid = threadIdx.x, lane = tid & 63, plane = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, plane = blockIdx.x, unit = blockIdx.y;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = a.m, nw = (m + 31) >> 5;
     constexpr int stride = CPT * kThreads;
-    int32_t *rank = a.rank + (size_t)plane * m;
-    uint8_t *out = a.out + (size_t)plane * a.cap;
+    const size_t up = (size_t)unit * a.g + plane;
+    const int64_t r_beg = (int64_t)unit * a.unit_rows;
+    const int64_t r_end = r_beg + a.unit_rows < a.n_rows ? r_beg + a.unit_rows : a.n_rows;
+    uint8_t *out = a.out + up * a.cap;
     const int col0 = tid * CPT;                 // this thread's columns: col0 .. col0 + CPT - 1
     int32_t R[CPT];
     uint32_t nxt[CPT / 4];
 #pragma unroll
-    for (int i = 0; i < CPT; ++i) R[i] = col0 + i < m ? rank[col0 + i] : 0;
+    for (int i = 0; i < CPT; ++i) R[i] = col0 + i < m ? (a.rank_in ? a.rank_in[up * m + col0 + i] : col0 + i) : 0;
 #pragma unroll
-    for (int q = 0; q < CPT / 4; ++q) nxt[q] = a.n_rows > 0 ? reinterpret_cast<const uint32_t*>(a.codes + col0)[q] : 0u;
+    for (int q = 0; q < CPT / 4; ++q)
+        nxt[q] = r_beg < r_end ? reinterpret_cast<const uint32_t*>(a.codes + (size_t)r_beg * stride + col0)[q] : 0u;
     bits2[0][tid] = 0u; bits2[1][tid] = 0u;
     if (tid == 0) { bits2[0][kThreads] = 0u; bits2[1][kThreads] = 0u; }
     __syncthreads();
     const uint32_t valid = tid < nw ? ((tid == nw - 1 && (m & 31)) ? (1u << (m & 31)) - 1u : 0xffffffffu) : 0u;
     const uint32_t last_bit = (tid == nw - 1) ? 1u << ((m - 1) & 31) : 0u;      // the row ends here
     int64_t off = 0;
-    int snap_i = 0;
-    for (int64_t r = 0; r < a.n_rows; ++r) {
+    int snap_i = EMIT ? a.snap_base[unit] : 0;
+    for (int64_t r = r_beg; r < r_end; ++r) {
         uint32_t *bits = bits2[r & 1];
-        if (((a.row0 + r) & a.mask) == 0) {                 // the 'S' record: S[rank] = column (ref pbwt.c:292-301)
+        if (EMIT && ((a.row0 + r) & a.mask) == 0) {         // the 'S' record: S[rank] = column (ref pbwt.c:292-301)
             int32_t *S = a.snap + ((size_t)plane * a.n_snap + snap_i) * m;
 #pragma unroll
             for (int i = 0; i < CPT; ++i) if (col0 + i < m) S[R[i]] = col0 + i;
@@ -133,7 +148,7 @@ __global__ __launch_bounds__(kThreads) void encode_kernel(EncodeArgs a)
             mine |= b << i;
             if (b) atomicOr(&bits[R[i] >> 5], 1u << (R[i] & 31));
         }
-        if (r + 1 < a.n_rows) {
+        if (r + 1 < r_end) {
             const uint32_t *src = reinterpret_cast<const uint32_t*>(a.codes + (size_t)(r + 1) * stride + col0);
 #pragma unroll
             for (int q = 0; q < CPT / 4; ++q) nxt[q] = src[q];
@@ -143,24 +158,28 @@ __global__ __launch_bounds__(kThreads) void encode_kernel(EncodeArgs a)
         const uint32_t w = bits[tid];
         const uint32_t wn = bits[tid + 1];
         // a run ends at bit i of this word if the next position holds the other bit, or the row ends there
-        const uint32_t ends = (((w ^ (w >> 1 | wn << 31)) & valid) & ~last_bit) | last_bit;
+        const uint32_t ends = EMIT ? ((((w ^ (w >> 1 | wn << 31)) & valid) & ~last_bit) | last_bit) : 0u;
         const uint32_t pc = (uint32_t)__popc(w);
         const uint32_t incl = wave_incl_add(pc);
         const uint32_t le = ends ? (uint32_t)(tid * 32 + 32 - __builtin_clz(ends)) : 0u;   // position after the last end
-        const uint32_t lmax = wave_incl_max(le);
+        const uint32_t lmax = EMIT ? wave_incl_max(le) : 0u;
         if (lane == 63) { agg[0][wave] = incl; agg[1][wave] = lmax; }
         __syncthreads();                                    // (2)
-        uint32_t ones, wbase, start;
+        uint32_t ones, wbase, start = 0;
         {
-            const uint32_t va = lane < 16 ? agg[0][lane] : 0u, vm = lane < 16 ? agg[1][lane] : 0u;
-            const uint32_t sa = wave_incl_add(va), sx = wave_incl_max(vm);
+            const uint32_t va = lane < 16 ? agg[0][lane] : 0u;
+            const uint32_t sa = wave_incl_add(va);
             ones = lane_value(sa, 15);
             wbase = wave ? lane_value(sa, wave - 1) : 0u;
-            start = umax(wave ? lane_value(sx, wave - 1) : 0u, wave_shr1(lmax));   // where the first run ending here began
+            if (EMIT) {
+                const uint32_t vm = lane < 16 ? agg[1][lane] : 0u;
+                const uint32_t sx = wave_incl_max(vm);
+                start = umax(wave ? lane_value(sx, wave - 1) : 0u, wave_shr1(lmax));   // where the first run ending here began
+            }
         }
         before[tid] = wbase + incl - pc;
         uint32_t nb = 0;
-        {
+        if (EMIT) {
             uint32_t st = start;
             for (uint32_t x = ends; x;) {                   // the runs that end in this word
                 const uint32_t e = (uint32_t)(tid * 32 + __builtin_ctz(x) + 1);
@@ -169,18 +188,18 @@ __global__ __launch_bounds__(kThreads) void encode_kernel(EncodeArgs a)
                 st = e;
             }
         }
-        const uint32_t incl2 = wave_incl_add(nb);
-        if (lane == 63) agg[2][wave] = incl2;
+        const uint32_t incl2 = EMIT ? wave_incl_add(nb) : 0u;
+        if (EMIT && lane == 63) agg[2][wave] = incl2;
         __syncthreads();                                    // (3) `before` and the byte counts are visible
-        uint32_t bbase, total;
-        {
+        uint32_t bbase = 0, total = 0;
+        if (EMIT) {
             const uint32_t vb = lane < 16 ? agg[2][lane] : 0u;
             const uint32_t sb = wave_incl_add(vb);
             total = lane_value(sb, 15);
             bbase = wave ? lane_value(sb, wave - 1) : 0u;
         }
-        if (off + (int64_t)total > a.cap) { if (tid == 0) *a.status = 1; break; }          // uniform
-        {
+        if (EMIT && off + (int64_t)total > a.cap) { if (tid == 0) *a.status = 1; break; }  // uniform
+        if (EMIT) {
             uint8_t *dst = out + off + bbase + incl2 - nb;
             uint32_t st = start;
             for (uint32_t x = ends; x;) {
@@ -191,7 +210,7 @@ __global__ __launch_bounds__(kThreads) void encode_kernel(EncodeArgs a)
                 st = e;
             }
         }
-        if (tid == 0) a.row_len[(size_t)plane * a.n_rows + r] = (int32_t)total;
+        if (EMIT && tid == 0) a.row_len[(size_t)plane * a.n_rows + r] = (int32_t)total;
         off += total;
         // ---- the stable partition, on ranks (ref pbwt.c:57-66 moves S instead)
         const int32_t n0 = m - (int32_t)ones;
@@ -203,8 +222,72 @@ __global__ __launch_bounds__(kThreads) void encode_kernel(EncodeArgs a)
         }
     }
 #pragma unroll
-    for (int i = 0; i < CPT; ++i) if (col0 + i < m) rank[col0 + i] = R[i];
-    if (tid == 0) a.out_len[plane] = off;
+    for (int i = 0; i < CPT; ++i)
+        if (col0 + i < m) {
+            a.rank_out[up * m + col0 + i] = R[i];
+            if (a.perm_out) a.perm_out[up * m + R[i]] = col0 + i;
+        }
+    if (EMIT && tid == 0) a.out_len[up] = off;
+}
+
+// ---- phase B helpers ------------------------------------------------------------------------------------------
+// flag[p] = 1 if the column at position p of a unit's own order differs from its left neighbour in any row of the unit
+__global__ __launch_bounds__(256) void class_flags_kernel(const uint8_t *codes, int stride, int64_t n_rows, int unit_rows,
+                                                          int m, int g, const int32_t *perm, uint8_t *flag)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x, plane = blockIdx.y, unit = blockIdx.z;
+    if (p >= m) return;
+    const size_t up = (size_t)unit * g + plane;
+    uint32_t diff = 1u;
+    if (p > 0) {
+        const int ca = perm[up * m + p], cb = perm[up * m + p - 1];
+        const int64_t r_beg = (int64_t)unit * unit_rows;
+        const int64_t r_end = r_beg + unit_rows < n_rows ? r_beg + unit_rows : n_rows;
+        diff = 0u;
+        for (int64_t r = r_beg; r < r_end && !diff; ++r) {
+            const uint8_t *row = codes + (size_t)r * stride;
+            diff = ((uint32_t)(row[ca] ^ row[cb]) >> plane) & 1u;
+        }
+    }
+    flag[up * m + p] = (uint8_t)diff;
+}
+
+// cid[p] = number of class starts in positions 1..p (one workgroup per unit and plane)
+__global__ __launch_bounds__(kThreads) void class_ids_kernel(int m, const uint8_t *flag, int32_t *cid)
+{
+    __shared__ uint32_t wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t up = blockIdx.x;
+    const int per = (m + kThreads - 1) / kThreads, p0 = tid * per;
+    uint32_t mine = 0;
+    for (int i = 0; i < per; ++i) if (p0 + i < m && p0 + i > 0) mine += flag[up * m + p0 + i];
+    const uint32_t incl = wave_incl_add(mine);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t base = incl - mine;
+    for (int k = 0; k < wave; ++k) base += wsum[k];
+    for (int i = 0; i < per; ++i)
+        if (p0 + i < m) { if (p0 + i > 0) base += flag[up * m + p0 + i]; cid[up * m + p0 + i] = (int32_t)base; }
+}
+
+// key = plane | class in the unit's own order | order before the unit  (m <= 32768: 15 bits each)
+__global__ __launch_bounds__(256) void sort_keys_kernel(int m, int g, const int32_t *cid_u, const int32_t *local_u,
+                                                        const int32_t *before_u, uint32_t *key, int32_t *val)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= g * m) return;
+    const int plane = i / m, col = i - plane * m;
+    key[i] = (uint32_t)plane << 30 | (uint32_t)cid_u[(size_t)plane * m + local_u[(size_t)plane * m + col]] << 15 |
+             (uint32_t)before_u[(size_t)plane * m + col];
+    val[i] = col;
+}
+
+__global__ __launch_bounds__(256) void ranks_from_sorted_kernel(int m, int g, const int32_t *val, int32_t *after_u)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= g * m) return;
+    const int plane = i / m;
+    after_u[(size_t)plane * m + val[i]] = i - plane * m;
 }
 
 thread_local char g_enc_err[256] = "";
@@ -227,28 +310,47 @@ void enc_err(const char *fmt, ...)
 struct bgth_encoder_s {
     int32_t m = 0, g = 0, shift = 0, device = 0;
     int64_t n = 0;                                   // rows written
-    int64_t batch_rows = 0, cap = 0;
     int32_t cpt = 0, stride = 0;                     // device rows of codes are stride = cpt * 1024 bytes apart
-    int32_t max_snap = 0;
+    int32_t unit_rows = 4096;                        // rows per parallel unit (BGTH_ENC_UNIT_SHIFT)
+    int64_t batch_rows = 0;                          // most rows per device pass
+    int64_t rows_cap = 0;                            // what the buffers below hold
+    int32_t units_cap = 0, snap_cap = 0;
     hipStream_t stream = nullptr;
-    uint8_t *d_codes = nullptr, *d_out = nullptr;
-    int32_t *d_rank = nullptr, *d_row_len = nullptr, *d_snap = nullptr, *d_status = nullptr;
+    uint8_t *d_codes = nullptr, *d_out = nullptr, *d_flag = nullptr;
+    int32_t *d_state = nullptr;                      // [g][m] order after the last row written
+    int32_t *d_true = nullptr, *d_local = nullptr, *d_perm = nullptr, *d_cid = nullptr;   // [units(+1)][g][m]
+    int32_t *d_row_len = nullptr, *d_snap = nullptr, *d_snap_base = nullptr, *d_status = nullptr, *d_val[2] = {nullptr, nullptr};
+    uint32_t *d_key[2] = {nullptr, nullptr};
+    void *d_temp = nullptr;
+    size_t temp_bytes = 0;
     int64_t *d_out_len = nullptr;
     std::vector<uint8_t> image;
     std::vector<uint64_t> idx;
     std::vector<uint8_t> h_out;
-    std::vector<int32_t> h_row_len, h_snap;
+    std::vector<int32_t> h_row_len, h_snap, h_snap_base;
+    std::vector<int64_t> h_out_len;
     double kernel_ms = 0.0;
 };
 
 extern "C" const char *bgth_encoder_last_error(void) { return g_enc_err; }
 
+static void free_batch_buffers(bgth_encoder_t *e)
+{
+    hipFree(e->d_codes); hipFree(e->d_out); hipFree(e->d_flag); hipFree(e->d_true); hipFree(e->d_local); hipFree(e->d_perm);
+    hipFree(e->d_cid); hipFree(e->d_row_len); hipFree(e->d_snap); hipFree(e->d_snap_base); hipFree(e->d_out_len);
+    e->d_codes = e->d_out = e->d_flag = nullptr;
+    e->d_true = e->d_local = e->d_perm = e->d_cid = e->d_row_len = e->d_snap = e->d_snap_base = nullptr;
+    e->d_out_len = nullptr;
+    e->rows_cap = 0; e->units_cap = 0; e->snap_cap = 0;
+}
+
 extern "C" void bgth_encoder_close(bgth_encoder_t *e)
 {
     if (!e) return;
     hipSetDevice(e->device);
-    hipFree(e->d_codes); hipFree(e->d_out); hipFree(e->d_rank); hipFree(e->d_row_len); hipFree(e->d_snap);
-    hipFree(e->d_status); hipFree(e->d_out_len);
+    free_batch_buffers(e);
+    hipFree(e->d_state); hipFree(e->d_status); hipFree(e->d_temp);
+    for (int i = 0; i < 2; ++i) { hipFree(e->d_key[i]); hipFree(e->d_val[i]); }
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
 }
@@ -264,27 +366,30 @@ extern "C" bgth_encoder_t *bgth_encoder_open(int32_t m, int32_t g, int32_t shift
     }
     bgth_encoder_t *e = new bgth_encoder_t;
     e->m = m; e->g = g; e->shift = shift; e->device = device;
-    // a batch: at most 8192 rows and about 256 MB of codes; a row of m bits never needs more than m bytes
     e->cpt = m <= 4 * kThreads ? 4 : m <= 8 * kThreads ? 8 : m <= 20 * kThreads ? 20 : 32;
     e->stride = e->cpt * kThreads;
-    e->batch_rows = (int64_t)(256 << 20) / e->stride;
-    if (e->batch_rows > 8192) e->batch_rows = 8192;
-    if (e->batch_rows < 16) e->batch_rows = 16;
-    e->cap = e->batch_rows * (int64_t)m;
-    e->max_snap = (int32_t)((e->batch_rows >> shift) + 2);
+    if (const char *u = getenv("BGTH_ENC_UNIT_SHIFT")) {
+        const int us = atoi(u);
+        if (us >= 1 && us <= 20) e->unit_rows = 1 << us;
+    }
+    // one device pass: up to 12 GB of codes = 150 units of 4096 rows at 10,000 samples, two workgroups each (the
+    // run-length output is sized for the worst case, one byte per bit: 36 GB of the 288 in all)
+    e->batch_rows = ((int64_t)12 << 30) / e->stride / e->unit_rows * e->unit_rows;
+    if (e->batch_rows < e->unit_rows) e->batch_rows = e->unit_rows;
     ENC_TRY(hipSetDevice(device), { delete e; return nullptr; });
     ENC_TRY(hipStreamCreate(&e->stream), { delete e; return nullptr; });
-    ENC_TRY(hipMalloc(&e->d_codes, (size_t)e->batch_rows * e->stride), { bgth_encoder_close(e); return nullptr; });
-    ENC_TRY(hipMemset(e->d_codes, 0, (size_t)e->batch_rows * e->stride), { bgth_encoder_close(e); return nullptr; });   // the padding stays 0
-    ENC_TRY(hipMalloc(&e->d_out, (size_t)g * e->cap), { bgth_encoder_close(e); return nullptr; });
-    ENC_TRY(hipMalloc(&e->d_rank, (size_t)g * m * 4), { bgth_encoder_close(e); return nullptr; });
-    ENC_TRY(hipMalloc(&e->d_row_len, (size_t)g * e->batch_rows * 4), { bgth_encoder_close(e); return nullptr; });
-    ENC_TRY(hipMalloc(&e->d_snap, (size_t)g * e->max_snap * m * 4), { bgth_encoder_close(e); return nullptr; });
+    ENC_TRY(hipMalloc(&e->d_state, (size_t)g * m * 4), { bgth_encoder_close(e); return nullptr; });
     ENC_TRY(hipMalloc(&e->d_status, 4), { bgth_encoder_close(e); return nullptr; });
-    ENC_TRY(hipMalloc(&e->d_out_len, (size_t)g * 8), { bgth_encoder_close(e); return nullptr; });
+    for (int i = 0; i < 2; ++i) {
+        ENC_TRY(hipMalloc(&e->d_key[i], (size_t)g * m * 4), { bgth_encoder_close(e); return nullptr; });
+        ENC_TRY(hipMalloc(&e->d_val[i], (size_t)g * m * 4), { bgth_encoder_close(e); return nullptr; });
+    }
+    ENC_TRY(rocprim::radix_sort_pairs(nullptr, e->temp_bytes, e->d_key[0], e->d_key[1], e->d_val[0], e->d_val[1], (unsigned)(g * m), 0, 32,
+                                      e->stream), { bgth_encoder_close(e); return nullptr; });
+    ENC_TRY(hipMalloc(&e->d_temp, e->temp_bytes ? e->temp_bytes : 16), { bgth_encoder_close(e); return nullptr; });
     std::vector<int32_t> ident((size_t)g * m);
     for (int k = 0; k < g; ++k) for (int j = 0; j < m; ++j) ident[(size_t)k * m + j] = j;     // identity start (ref pbwt.c:92-105)
-    ENC_TRY(hipMemcpy(e->d_rank, ident.data(), ident.size() * 4, hipMemcpyHostToDevice), { bgth_encoder_close(e); return nullptr; });
+    ENC_TRY(hipMemcpy(e->d_state, ident.data(), ident.size() * 4, hipMemcpyHostToDevice), { bgth_encoder_close(e); return nullptr; });
     e->image.reserve(1 << 20);
     const int32_t hdr[3] = {m, g, shift};                                                       // ref pbwt.c:199-219
     e->image.insert(e->image.end(), (const uint8_t*)"PBF\1", (const uint8_t*)"PBF\1" + 4);
@@ -292,36 +397,102 @@ extern "C" bgth_encoder_t *bgth_encoder_open(int32_t m, int32_t g, int32_t shift
     return e;
 }
 
+static int ensure_capacity(bgth_encoder_t *e, int64_t rows, int32_t n_units, int32_t n_snap)
+{
+    // `rows` covers whole units: every (unit, plane) has an output region of unit_rows * m bytes
+    if (rows <= e->rows_cap && n_units <= e->units_cap && n_snap <= e->snap_cap) return 0;
+    const int m = e->m, g = e->g;
+    if (rows < e->rows_cap) rows = e->rows_cap;
+    if (n_units < e->units_cap) n_units = e->units_cap;
+    if (n_snap < e->snap_cap) n_snap = e->snap_cap;
+    free_batch_buffers(e);
+    const size_t ugm = (size_t)n_units * g * m;
+    ENC_TRY(hipMalloc(&e->d_codes, (size_t)rows * e->stride), return -1);
+    ENC_TRY(hipMemset(e->d_codes, 0, (size_t)rows * e->stride), return -1);                     // the padding stays 0
+    ENC_TRY(hipMalloc(&e->d_out, (size_t)g * rows * m), return -1);                             // a row of m bits: at most m bytes
+    ENC_TRY(hipMalloc(&e->d_flag, ugm), return -1);
+    ENC_TRY(hipMalloc(&e->d_true, (ugm + (size_t)g * m) * 4), return -1);
+    ENC_TRY(hipMalloc(&e->d_local, ugm * 4), return -1);
+    ENC_TRY(hipMalloc(&e->d_perm, ugm * 4), return -1);
+    ENC_TRY(hipMalloc(&e->d_cid, ugm * 4), return -1);
+    ENC_TRY(hipMalloc(&e->d_row_len, (size_t)g * rows * 4), return -1);
+    ENC_TRY(hipMalloc(&e->d_snap, ((size_t)g * n_snap * m + 1) * 4), return -1);
+    ENC_TRY(hipMalloc(&e->d_snap_base, (size_t)n_units * 4), return -1);
+    ENC_TRY(hipMalloc(&e->d_out_len, (size_t)n_units * g * 8), return -1);
+    e->rows_cap = rows; e->units_cap = n_units; e->snap_cap = n_snap;
+    return 0;
+}
+
+template <bool EMIT>
+static void launch_encode(const bgth_encoder_t *e, const EncodeArgs &a, int n_units)
+{
+    const dim3 grid((unsigned)e->g, (unsigned)n_units), block(kThreads);
+    if (e->cpt == 4)       hipLaunchKernelGGL((encode_kernel<4, EMIT>),  grid, block, 0, e->stream, a);
+    else if (e->cpt == 8)  hipLaunchKernelGGL((encode_kernel<8, EMIT>),  grid, block, 0, e->stream, a);
+    else if (e->cpt == 20) hipLaunchKernelGGL((encode_kernel<20, EMIT>), grid, block, 0, e->stream, a);
+    else                   hipLaunchKernelGGL((encode_kernel<32, EMIT>), grid, block, 0, e->stream, a);
+}
+
 static int encode_batch(bgth_encoder_t *e, const uint8_t *codes, int64_t rows)
 {
     const int m = e->m, g = e->g;
     const int64_t mask = ((int64_t)1 << e->shift) - 1;
+    // units: a call of few rows, or more than two planes (the sort key holds one plane bit), is one unit
+    const bool parallel = rows > e->unit_rows && g <= 2;
+    const int64_t unit_rows = parallel ? e->unit_rows : rows;
+    const int32_t n_units = (int32_t)((rows + unit_rows - 1) / unit_rows);
+    e->h_snap_base.assign((size_t)n_units, 0);
     int32_t n_snap = 0;
-    for (int64_t r = 0; r < rows; ++r) if (((e->n + r) & mask) == 0) ++n_snap;
+    for (int64_t r = 0; r < rows; ++r) {
+        if (r % unit_rows == 0) e->h_snap_base[(size_t)(r / unit_rows)] = n_snap;
+        if (((e->n + r) & mask) == 0) ++n_snap;
+    }
+    if (ensure_capacity(e, (int64_t)n_units * unit_rows, n_units, n_snap) < 0) return -1;
+    const size_t gm = (size_t)g * m;
     EncodeArgs a;
-    a.codes = e->d_codes; a.n_rows = rows; a.row0 = e->n; a.m = m; a.mask = (int32_t)mask;
-    a.rank = e->d_rank; a.out = e->d_out; a.cap = e->cap; a.out_len = e->d_out_len; a.row_len = e->d_row_len;
-    a.snap = e->d_snap; a.n_snap = n_snap; a.status = e->d_status;
+    a.codes = e->d_codes; a.n_rows = rows; a.row0 = e->n; a.m = m; a.mask = (int32_t)mask; a.g = g; a.unit_rows = (int32_t)unit_rows;
+    a.out = e->d_out; a.cap = unit_rows * (int64_t)m; a.out_len = e->d_out_len; a.row_len = e->d_row_len;
+    a.snap = e->d_snap; a.snap_base = e->d_snap_base; a.n_snap = n_snap; a.status = e->d_status;
     ENC_TRY(hipMemcpy2DAsync(e->d_codes, (size_t)e->stride, codes, (size_t)m, (size_t)m, (size_t)rows, hipMemcpyHostToDevice, e->stream), return -1);
+    ENC_TRY(hipMemcpyAsync(e->d_snap_base, e->h_snap_base.data(), (size_t)n_units * 4, hipMemcpyHostToDevice, e->stream), return -1);
     ENC_TRY(hipMemsetAsync(e->d_status, 0, 4, e->stream), return -1);
     hipEvent_t ev0, ev1;
     ENC_TRY(hipEventCreate(&ev0), return -1);
     ENC_TRY(hipEventCreate(&ev1), return -1);
     hipEventRecord(ev0, e->stream);
-    if (e->cpt == 4)       hipLaunchKernelGGL(encode_kernel<4>,  dim3(g), dim3(kThreads), 0, e->stream, a);
-    else if (e->cpt == 8)  hipLaunchKernelGGL(encode_kernel<8>,  dim3(g), dim3(kThreads), 0, e->stream, a);
-    else if (e->cpt == 20) hipLaunchKernelGGL(encode_kernel<20>, dim3(g), dim3(kThreads), 0, e->stream, a);
-    else                   hipLaunchKernelGGL(encode_kernel<32>, dim3(g), dim3(kThreads), 0, e->stream, a);
+    if (n_units > 1) {
+        // A: every unit from the identity order -> its own order (ranks and permutation), then the classes of identical columns
+        a.rank_in = nullptr; a.rank_out = e->d_local; a.perm_out = e->d_perm;
+        launch_encode<false>(e, a, n_units);
+        hipLaunchKernelGGL(class_flags_kernel, dim3((unsigned)((m + 255) / 256), (unsigned)g, (unsigned)n_units), dim3(256), 0, e->stream,
+                           e->d_codes, e->stride, rows, (int)unit_rows, m, g, e->d_perm, e->d_flag);
+        hipLaunchKernelGGL(class_ids_kernel, dim3((unsigned)(n_units * g)), dim3(kThreads), 0, e->stream, m, e->d_flag, e->d_cid);
+        // B: the true order before every unit, one sort per unit
+        ENC_TRY(hipMemcpyAsync(e->d_true, e->d_state, gm * 4, hipMemcpyDeviceToDevice, e->stream), return -1);
+        const unsigned nk = (unsigned)gm, kb = (nk + 255) / 256;
+        for (int32_t k = 0; k < n_units; ++k) {
+            hipLaunchKernelGGL(sort_keys_kernel, dim3(kb), dim3(256), 0, e->stream, m, g, e->d_cid + (size_t)k * gm, e->d_local + (size_t)k * gm,
+                               e->d_true + (size_t)k * gm, e->d_key[0], e->d_val[0]);
+            ENC_TRY(rocprim::radix_sort_pairs(e->d_temp, e->temp_bytes, e->d_key[0], e->d_key[1], e->d_val[0], e->d_val[1], nk, 0, 32, e->stream),
+                    return -1);
+            hipLaunchKernelGGL(ranks_from_sorted_kernel, dim3(kb), dim3(256), 0, e->stream, m, g, e->d_val[1], e->d_true + (size_t)(k + 1) * gm);
+        }
+        ENC_TRY(hipMemcpyAsync(e->d_state, e->d_true + (size_t)n_units * gm, gm * 4, hipMemcpyDeviceToDevice, e->stream), return -1);
+        // C: every unit from its true start order
+        a.rank_in = e->d_true; a.rank_out = e->d_local; a.perm_out = nullptr;
+        launch_encode<true>(e, a, n_units);
+    } else {
+        a.rank_in = e->d_state; a.rank_out = e->d_state; a.perm_out = nullptr;
+        launch_encode<true>(e, a, 1);
+    }
     hipEventRecord(ev1, e->stream);
     ENC_TRY(hipGetLastError(), return -1);
     int32_t status = 0;
-    std::vector<int64_t> out_len((size_t)g);
+    e->h_out_len.resize((size_t)n_units * g);
     ENC_TRY(hipMemcpyAsync(&status, e->d_status, 4, hipMemcpyDeviceToHost, e->stream), return -1);
-    ENC_TRY(hipMemcpyAsync(out_len.data(), e->d_out_len, (size_t)g * 8, hipMemcpyDeviceToHost, e->stream), return -1);
+    ENC_TRY(hipMemcpyAsync(e->h_out_len.data(), e->d_out_len, e->h_out_len.size() * 8, hipMemcpyDeviceToHost, e->stream), return -1);
     e->h_row_len.resize((size_t)g * rows);
-    for (int k = 0; k < g; ++k)
-        ENC_TRY(hipMemcpyAsync(e->h_row_len.data() + (size_t)k * rows, e->d_row_len + (size_t)k * rows, (size_t)rows * 4,
-                               hipMemcpyDeviceToHost, e->stream), return -1);
+    ENC_TRY(hipMemcpyAsync(e->h_row_len.data(), e->d_row_len, (size_t)g * rows * 4, hipMemcpyDeviceToHost, e->stream), return -1);
     e->h_snap.resize((size_t)g * n_snap * m);
     if (n_snap) ENC_TRY(hipMemcpyAsync(e->h_snap.data(), e->d_snap, e->h_snap.size() * 4, hipMemcpyDeviceToHost, e->stream), return -1);
     ENC_TRY(hipStreamSynchronize(e->stream), return -1);
@@ -330,16 +501,19 @@ static int encode_batch(bgth_encoder_t *e, const uint8_t *codes, int64_t rows)
     e->kernel_ms += ms;
     hipEventDestroy(ev0); hipEventDestroy(ev1);
     if (status != 0) { enc_err("[E::%s] run-length output exceeded its buffer", __func__); return -1; }
-    int64_t worst = 0;
-    for (int k = 0; k < g; ++k) if (out_len[k] > worst) worst = out_len[k];
-    e->h_out.resize((size_t)g * worst);
-    for (int k = 0; k < g; ++k)
-        if (out_len[k]) ENC_TRY(hipMemcpy(e->h_out.data() + (size_t)k * worst, e->d_out + (size_t)k * e->cap, (size_t)out_len[k],
-                                          hipMemcpyDeviceToHost), return -1);
+    // the run-length bytes of every (unit, plane), packed one after the other on the host
+    std::vector<size_t> base((size_t)n_units * g + 1, 0);
+    for (size_t i = 0; i < e->h_out_len.size(); ++i) base[i + 1] = base[i] + (size_t)e->h_out_len[i];
+    e->h_out.resize(base.back() ? base.back() : 1);
+    for (size_t i = 0; i < e->h_out_len.size(); ++i)
+        if (e->h_out_len[i]) ENC_TRY(hipMemcpyAsync(e->h_out.data() + base[i], e->d_out + i * (size_t)a.cap, (size_t)e->h_out_len[i],
+                                                    hipMemcpyDeviceToHost, e->stream), return -1);
+    ENC_TRY(hipStreamSynchronize(e->stream), return -1);
     // ---- records in file order (ref pbwt.c:288-311): ['S' perms]  'B' { int32 len, bytes } per plane
-    std::vector<int64_t> at((size_t)g, 0);
+    std::vector<size_t> at((size_t)g, 0);
     int32_t si = 0;
     for (int64_t r = 0; r < rows; ++r) {
+        if (r % unit_rows == 0) for (int k = 0; k < g; ++k) at[(size_t)k] = base[(size_t)(r / unit_rows) * g + k];
         if (((e->n + r) & mask) == 0) {
             e->idx.push_back((uint64_t)e->image.size());
             e->image.push_back('S');
@@ -352,10 +526,10 @@ static int encode_batch(bgth_encoder_t *e, const uint8_t *codes, int64_t rows)
         e->image.push_back('B');
         for (int k = 0; k < g; ++k) {
             const int32_t l = e->h_row_len[(size_t)k * rows + r];
-            const uint8_t *p = e->h_out.data() + (size_t)k * worst + at[k];
+            const uint8_t *p = e->h_out.data() + at[(size_t)k];
             e->image.insert(e->image.end(), (const uint8_t*)&l, (const uint8_t*)&l + 4);
             e->image.insert(e->image.end(), p, p + l);
-            at[k] += l;
+            at[(size_t)k] += (size_t)l;
         }
     }
     e->n += rows;

@@ -131,3 +131,53 @@ def test_encoder_output_scans_back():
     assert np.array_equal(counts[:, 0, 0], (mat != 2).sum(1))
     assert np.array_equal(counts[:, 0, 1], (mat == 1).sum(1))
     assert np.array_equal(counts[:, 0, 2], (mat == 3).sum(1))
+
+
+@pytest.fixture
+def small_units(monkeypatch):
+    """the encoder cuts a call into units that run in parallel (4096 rows); 16-row units put many of them, and the
+    unit-to-unit order hand-over, into a test the oracle finishes quickly"""
+    monkeypatch.setenv("BGTH_ENC_UNIT_SHIFT", "4")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,rows,shift,founders,switch", [(100, 200, 5, 3, 0.0), (1000, 333, 3, 2, 0.0), (5008, 500, 6, 6, 0.01),
+                                                          (20000, 260, 7, 4, 0.001), (20000, 100, 13, 40, 0.05),
+                                                          (32768, 70, 2, 3, 0.0), (1, 50, 2, 1, 0.0), (2, 64, 3, 2, 0.5)])
+def test_encoder_parallel_units_match_oracle(small_units, m, rows, shift, founders, switch):
+    """few founders and no switching = many identical columns: the classes whose order has to come from the units before"""
+    import bgt_amd
+    rng = np.random.default_rng(m + rows)
+    mat = scenarios.ld_matrix(rng, rows, m, n_founders=founders, switch=switch)
+    enc = bgt_amd.HipEncoder(m, 2, shift)
+    enc.write(mat)
+    assert enc.finish() == orc.encode_pbf(mat, 2, shift)
+
+
+@pytest.mark.gpu
+def test_encoder_parallel_units_over_several_calls(small_units):
+    import bgt_amd
+    rng = np.random.default_rng(77)
+    m = 4000
+    mat = scenarios.ld_matrix(rng, 300, m, n_founders=3, switch=0.002)
+    mat[40:90] = 0                                   # a stretch of constant rows: every column in one class
+    mat[200:210] = 3
+    enc = bgt_amd.HipEncoder(m, 2, 5)
+    for lo, hi in ((0, 50), (50, 53), (53, 201), (201, 300)):
+        enc.write(mat[lo:hi])
+    assert enc.finish() == orc.encode_pbf(mat, 2, 5)
+    one = bgt_amd.HipEncoder(m, 1, 5)
+    one.write(mat >> 1)
+    assert one.finish() == orc.encode_pbf(mat >> 1, 1, 5)
+
+
+@pytest.mark.gpu
+def test_encoder_default_units():
+    """more rows than one default unit (4096)"""
+    import bgt_amd
+    rng = np.random.default_rng(8)
+    m, rows = 1500, 9001
+    mat = scenarios.ld_matrix(rng, rows, m, n_founders=10, switch=0.003)
+    enc = bgt_amd.HipEncoder(m, 2, 13)
+    enc.write(mat)
+    assert enc.finish() == orc.encode_pbf(mat, 2, 13)
