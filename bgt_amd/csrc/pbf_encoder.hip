@@ -80,6 +80,9 @@ __device__ __forceinline__ uint32_t wave_shr1(uint32_t v)      // value of the l
 {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);
 }
+// Workgroup barrier for data exchanged through LDS only: __syncthreads() would also wait for the global loads of the
+// next row (prefetched a row ahead) and for the stores of the run-length bytes.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ uint32_t lane_value(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
 
 // bytes of one run (ref pbwt.c:24-36): one below 16, else one per non-zero hex digit
@@ -94,9 +97,10 @@ __device__ __forceinline__ uint32_t put_run(uint8_t *dst, uint32_t len, uint32_t
 {
     if (len < 16u) { dst[0] = (uint8_t)(len << 1 | bit); return 1u; }
     uint32_t n = 0;
-    for (int digit = 7; digit >= 0; --digit) {
-        const uint32_t d = (len >> (4 * digit)) & 15u;
-        if (d) dst[n++] = (uint8_t)((((uint32_t)digit << 4) | d) << 1 | bit);
+    for (uint32_t nz = (len | len >> 1 | len >> 2 | len >> 3) & 0x11111111u; nz;) {     // non-zero hex digits, top first
+        const uint32_t hb = 31u - (uint32_t)__builtin_clz(nz), digit = hb >> 2;
+        nz &= ~(1u << hb);
+        dst[n++] = (uint8_t)(((digit << 4) | ((len >> (4u * digit)) & 15u)) << 1 | bit);
     }
     return n;
 }
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(kThreads) void encode_kernel(EncodeArgs a)
         nxt[q] = r_beg < r_end ? reinterpret_cast<const uint32_t*>(a.codes + (size_t)r_beg * stride + col0)[q] : 0u;
     bits2[0][tid] = 0u; bits2[1][tid] = 0u;
     if (tid == 0) { bits2[0][kThreads] = 0u; bits2[1][kThreads] = 0u; }
-    __syncthreads();
+    lds_barrier();
     const uint32_t valid = tid < nw ? ((tid == nw - 1 && (m & 31)) ? (1u << (m & 31)) - 1u : 0xffffffffu) : 0u;
     const uint32_t last_bit = (tid == nw - 1) ? 1u << ((m - 1) & 31) : 0u;      // the row ends here
     int64_t off = 0;
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(kThreads) void encode_kernel(EncodeArgs a)
 #pragma unroll
             for (int q = 0; q < CPT / 4; ++q) nxt[q] = src[q];
         }
-        __syncthreads();                                    // (1) the bit-vector is complete
+        lds_barrier();                                    // (1) the bit-vector is complete
         bits2[(r & 1) ^ 1][tid] = 0u;                       // everyone is done with the previous row's
         const uint32_t w = bits[tid];
         const uint32_t wn = bits[tid + 1];
@@ -164,20 +168,19 @@ __global__ __launch_bounds__(kThreads) void encode_kernel(EncodeArgs a)
         const uint32_t le = ends ? (uint32_t)(tid * 32 + 32 - __builtin_clz(ends)) : 0u;   // position after the last end
         const uint32_t lmax = EMIT ? wave_incl_max(le) : 0u;
         if (lane == 63) { agg[0][wave] = incl; agg[1][wave] = lmax; }
-        __syncthreads();                                    // (2)
-        uint32_t ones, wbase, start = 0;
+        lds_barrier();                                    // (2)
+        uint32_t ones, start = 0;
         {
             const uint32_t va = lane < 16 ? agg[0][lane] : 0u;
             const uint32_t sa = wave_incl_add(va);
             ones = lane_value(sa, 15);
-            wbase = wave ? lane_value(sa, wave - 1) : 0u;
+            before[tid] = (wave ? lane_value(sa, wave - 1) : 0u) + incl - pc;
             if (EMIT) {
                 const uint32_t vm = lane < 16 ? agg[1][lane] : 0u;
                 const uint32_t sx = wave_incl_max(vm);
                 start = umax(wave ? lane_value(sx, wave - 1) : 0u, wave_shr1(lmax));   // where the first run ending here began
             }
         }
-        before[tid] = wbase + incl - pc;
         uint32_t nb = 0;
         if (EMIT) {
             uint32_t st = start;
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(kThreads) void encode_kernel(EncodeArgs a)
         }
         const uint32_t incl2 = EMIT ? wave_incl_add(nb) : 0u;
         if (EMIT && lane == 63) agg[2][wave] = incl2;
-        __syncthreads();                                    // (3) `before` and the byte counts are visible
+        lds_barrier();                                    // (3) `before` and the byte counts are visible
         uint32_t bbase = 0, total = 0;
         if (EMIT) {
             const uint32_t vb = lane < 16 ? agg[2][lane] : 0u;
