@@ -110,8 +110,9 @@ __device__ __forceinline__ uint32_t put_run(uint8_t *dst, uint32_t len, uint32_t
 template <int CPT, bool EMIT>
 __global__ __launch_bounds__(kThreads) void encode_kernel(EncodeArgs a)
 {
-    __shared__ uint32_t bits2[2][kThreads + 1]; // the row's bit-vector in PBWT order, double-buffered over rows
-    __shared__ uint32_t before[kThreads];       // ones before each word
+    // the row in PBWT order as a rank directory, double-buffered over rows: {32 bits, ones before them} per entry, so
+    // that one 8-byte read answers a lookup (the layout of the scan kernel)
+    __shared__ uint2 dir2[2][kThreads + 1];
     __shared__ uint32_t agg[3][16];             // per wave: ones, end of the last run that ends in it, bytes
     const int tid = threadIdx.x, lane = tid & 63, plane = blockIdx.x, unit = blockIdx.y;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -122,35 +123,34 @@ __global__ __launch_bounds__(kThreads) void encode_kernel(EncodeArgs a)
     const int64_t r_end = r_beg + a.unit_rows < a.n_rows ? r_beg + a.unit_rows : a.n_rows;
     uint8_t *out = a.out + up * a.cap;
     const int col0 = tid * CPT;                 // this thread's columns: col0 .. col0 + CPT - 1
-    int32_t R[CPT];
+    int32_t Q[CPT];                             // COMPLEMENTED ranks, q = ~r (saves an instruction per lookup, see the scan)
     uint32_t nxt[CPT / 4];
 #pragma unroll
-    for (int i = 0; i < CPT; ++i) R[i] = col0 + i < m ? (a.rank_in ? a.rank_in[up * m + col0 + i] : col0 + i) : 0;
+    for (int i = 0; i < CPT; ++i) Q[i] = ~(col0 + i < m ? (a.rank_in ? a.rank_in[up * m + col0 + i] : col0 + i) : 0);
 #pragma unroll
     for (int q = 0; q < CPT / 4; ++q)
         nxt[q] = r_beg < r_end ? reinterpret_cast<const uint32_t*>(a.codes + (size_t)r_beg * stride + col0)[q] : 0u;
-    bits2[0][tid] = 0u; bits2[1][tid] = 0u;
-    if (tid == 0) { bits2[0][kThreads] = 0u; bits2[1][kThreads] = 0u; }
+    dir2[0][tid] = make_uint2(0u, 0u); dir2[1][tid] = make_uint2(0u, 0u);
+    if (tid == 0) { dir2[0][kThreads] = make_uint2(0u, 0u); dir2[1][kThreads] = make_uint2(0u, 0u); }
     lds_barrier();
     const uint32_t valid = tid < nw ? ((tid == nw - 1 && (m & 31)) ? (1u << (m & 31)) - 1u : 0xffffffffu) : 0u;
     const uint32_t last_bit = (tid == nw - 1) ? 1u << ((m - 1) & 31) : 0u;      // the row ends here
     int64_t off = 0;
     int snap_i = EMIT ? a.snap_base[unit] : 0;
     for (int64_t r = r_beg; r < r_end; ++r) {
-        uint32_t *bits = bits2[r & 1];
+        uint2 *dir = dir2[r & 1];
+        char *dir_m8 = reinterpret_cast<char*>(dir) - 8;   // entry of rank r: dir_m8 - 8 * (q >> 5)
         if (EMIT && ((a.row0 + r) & a.mask) == 0) {         // the 'S' record: S[rank] = column (ref pbwt.c:292-301)
             int32_t *S = a.snap + ((size_t)plane * a.n_snap + snap_i) * m;
 #pragma unroll
-            for (int i = 0; i < CPT; ++i) if (col0 + i < m) S[R[i]] = col0 + i;
+            for (int i = 0; i < CPT; ++i) if (col0 + i < m) S[~Q[i]] = col0 + i;
             ++snap_i;
         }
         // ---- scatter this row, fetch the next one
-        uint32_t mine = 0;
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
             const uint32_t b = (nxt[i >> 2] >> (8 * (i & 3) + plane)) & 1u;
-            mine |= b << i;
-            if (b) atomicOr(&bits[R[i] >> 5], 1u << (R[i] & 31));
+            if (b) atomicOr(reinterpret_cast<uint32_t*>(dir_m8 - 8 * (Q[i] >> 5)), 0x80000000u >> (Q[i] & 31));   // bit r & 31
         }
         if (r + 1 < r_end) {
             const uint32_t *src = reinterpret_cast<const uint32_t*>(a.codes + (size_t)(r + 1) * stride + col0);
@@ -158,9 +158,9 @@ __global__ __launch_bounds__(kThreads) void encode_kernel(EncodeArgs a)
             for (int q = 0; q < CPT / 4; ++q) nxt[q] = src[q];
         }
         lds_barrier();                                    // (1) the bit-vector is complete
-        bits2[(r & 1) ^ 1][tid] = 0u;                       // everyone is done with the previous row's
-        const uint32_t w = bits[tid];
-        const uint32_t wn = bits[tid + 1];
+        dir2[(r & 1) ^ 1][tid].x = 0u;                      // everyone is done with the previous row's
+        const uint32_t w = dir[tid].x;
+        const uint32_t wn = dir[tid + 1].x;
         // a run ends at bit i of this word if the next position holds the other bit, or the row ends there
         const uint32_t ends = EMIT ? ((((w ^ (w >> 1 | wn << 31)) & valid) & ~last_bit) | last_bit) : 0u;
         const uint32_t pc = (uint32_t)__popc(w);
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(kThreads) void encode_kernel(EncodeArgs a)
             const uint32_t va = lane < 16 ? agg[0][lane] : 0u;
             const uint32_t sa = wave_incl_add(va);
             ones = lane_value(sa, 15);
-            before[tid] = (wave ? lane_value(sa, wave - 1) : 0u) + incl - pc;
+            dir[tid].y = (wave ? lane_value(sa, wave - 1) : 0u) + incl - pc;
             if (EMIT) {
                 const uint32_t vm = lane < 16 ? agg[1][lane] : 0u;
                 const uint32_t sx = wave_incl_max(vm);
@@ -216,19 +216,22 @@ __global__ __launch_bounds__(kThreads) void encode_kernel(EncodeArgs a)
         if (EMIT && tid == 0) a.row_len[(size_t)plane * a.n_rows + r] = (int32_t)total;
         off += total;
         // ---- the stable partition, on ranks (ref pbwt.c:57-66 moves S instead)
-        const int32_t n0 = m - (int32_t)ones;
+        // t = word << (q & 31): bit r & 31 in the sign, the bits above it gone; oi = ones up to and including r;
+        // bit ? r = n0 + oi - 1 : r = r - oi, i.e. q = bit ? -n0 - oi : q + oi
+        const int32_t neg_n0 = (int32_t)ones - m;
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
-            const int wd = R[i] >> 5;
-            const int32_t r1 = (int32_t)(before[wd] + (uint32_t)__popc(bits[wd] & ((1u << (R[i] & 31)) - 1u)));
-            R[i] = ((mine >> i) & 1u) ? n0 + r1 : R[i] - r1;
+            const uint2 e = *reinterpret_cast<const uint2*>(dir_m8 - 8 * (Q[i] >> 5));
+            const uint32_t t = e.x << (Q[i] & 31);
+            const int32_t oi = (int32_t)(e.y + (uint32_t)__popc(t));
+            Q[i] = (int32_t)t < 0 ? neg_n0 - oi : Q[i] + oi;
         }
     }
 #pragma unroll
     for (int i = 0; i < CPT; ++i)
         if (col0 + i < m) {
-            a.rank_out[up * m + col0 + i] = R[i];
-            if (a.perm_out) a.perm_out[up * m + R[i]] = col0 + i;
+            a.rank_out[up * m + col0 + i] = ~Q[i];
+            if (a.perm_out) a.perm_out[up * m + ~Q[i]] = col0 + i;
         }
     if (EMIT && tid == 0) a.out_len[up] = off;
 }
