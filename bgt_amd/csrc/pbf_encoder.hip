@@ -30,7 +30,8 @@
 namespace {
 
 constexpr int kThreads = 1024;                 // one word of the bit-vector per thread: m <= 32768
-constexpr int kMaxM = kThreads * 32;
+constexpr int kMaxM = kThreads * 32;             // registers hold the ranks up to here
+constexpr int kMaxWideM = kThreads * 32 * 8;     // beyond: ranks in memory, up to 8 directory words per thread
 
 struct EncodeArgs {
     const uint8_t *codes;      // [n_rows][CPT * 1024]  bit k of a byte = plane k, zero beyond column m
@@ -236,6 +237,129 @@ __global__ __launch_bounds__(kThreads) void encode_kernel(EncodeArgs a)
     if (EMIT && tid == 0) a.out_len[up] = off;
 }
 
+// ---- wide cohorts (more than 32768 columns): the ranks do not fit the registers of one workgroup, so they live in
+// memory (800 KB per plane at 100,000 samples: L2) and every thread owns WPT words of the directory.  Same phases,
+// same barriers; `stride` of the codes is m.
+template <int WPT, bool EMIT>
+__global__ __launch_bounds__(kThreads) void encode_wide_kernel(EncodeArgs a)
+{
+    extern __shared__ uint2 wide_dir[];         // [2][kThreads * WPT + 1]
+    __shared__ uint32_t agg[3][16];
+    constexpr int NWP = kThreads * WPT + 1;
+    const int tid = threadIdx.x, lane = tid & 63, plane = blockIdx.x, unit = blockIdx.y;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = a.m, nw = (m + 31) >> 5;
+    const size_t up = (size_t)unit * a.g + plane;
+    const int64_t r_beg = (int64_t)unit * a.unit_rows;
+    const int64_t r_end = r_beg + a.unit_rows < a.n_rows ? r_beg + a.unit_rows : a.n_rows;
+    uint8_t *out = a.out + up * a.cap;
+    int32_t *Qg = a.rank_out + up * m;          // complemented ranks; column c belongs to thread c % 1024 throughout
+    for (int c = tid; c < m; c += kThreads) Qg[c] = ~(a.rank_in ? a.rank_in[up * m + c] : c);
+    for (int i = tid; i < 2 * NWP; i += kThreads) wide_dir[i] = make_uint2(0u, 0u);
+    lds_barrier();
+    const int w0 = tid * WPT;
+    int64_t off = 0;
+    int snap_i = EMIT ? a.snap_base[unit] : 0;
+    for (int64_t r = r_beg; r < r_end; ++r) {
+        uint2 *dir = wide_dir + (r & 1) * NWP, *other = wide_dir + ((r & 1) ^ 1) * NWP;
+        char *dir_m8 = reinterpret_cast<char*>(dir) - 8;
+        if (EMIT && ((a.row0 + r) & a.mask) == 0) {
+            int32_t *S = a.snap + ((size_t)plane * a.n_snap + snap_i) * m;
+            for (int c = tid; c < m; c += kThreads) S[~Qg[c]] = c;
+            ++snap_i;
+        }
+        const uint8_t *src = a.codes + (size_t)r * m;
+#pragma unroll 4
+        for (int c = tid; c < m; c += kThreads) {
+            const int32_t q = Qg[c];
+            if ((src[c] >> plane) & 1) atomicOr(reinterpret_cast<uint32_t*>(dir_m8 - 8 * (q >> 5)), 0x80000000u >> (q & 31));
+        }
+        lds_barrier();                                      // (1)
+        uint32_t w[WPT], ends[WPT], pc = 0, le = 0;
+#pragma unroll
+        for (int k = 0; k < WPT; ++k) {
+            const int wi = w0 + k;
+            other[wi].x = 0u;
+            w[k] = dir[wi].x;
+            const uint32_t wn = dir[wi + 1].x;
+            const uint32_t valid = wi < nw ? ((wi == nw - 1 && (m & 31)) ? (1u << (m & 31)) - 1u : 0xffffffffu) : 0u;
+            const uint32_t last_bit = wi == nw - 1 ? 1u << ((m - 1) & 31) : 0u;
+            ends[k] = EMIT ? ((((w[k] ^ (w[k] >> 1 | wn << 31)) & valid) & ~last_bit) | last_bit) : 0u;
+            pc += (uint32_t)__popc(w[k]);
+            if (ends[k]) le = (uint32_t)(wi * 32 + 32 - __builtin_clz(ends[k]));
+        }
+        const uint32_t incl = wave_incl_add(pc);
+        const uint32_t lmax = EMIT ? wave_incl_max(le) : 0u;
+        if (lane == 63) { agg[0][wave] = incl; agg[1][wave] = lmax; }
+        lds_barrier();                                      // (2)
+        uint32_t ones, start = 0;
+        {
+            const uint32_t va = lane < 16 ? agg[0][lane] : 0u;
+            const uint32_t sa = wave_incl_add(va);
+            ones = lane_value(sa, 15);
+            uint32_t base = (wave ? lane_value(sa, wave - 1) : 0u) + incl - pc;
+#pragma unroll
+            for (int k = 0; k < WPT; ++k) { dir[w0 + k].y = base; base += (uint32_t)__popc(w[k]); }
+            if (EMIT) {
+                const uint32_t vm = lane < 16 ? agg[1][lane] : 0u;
+                const uint32_t sx = wave_incl_max(vm);
+                start = umax(wave ? lane_value(sx, wave - 1) : 0u, wave_shr1(lmax));
+            }
+        }
+        uint32_t nb = 0;
+        if (EMIT) {
+            uint32_t st = start;
+#pragma unroll
+            for (int k = 0; k < WPT; ++k)
+                for (uint32_t x = ends[k]; x;) {
+                    const uint32_t e = (uint32_t)((w0 + k) * 32 + __builtin_ctz(x) + 1);
+                    x &= x - 1u;
+                    nb += run_bytes(e - st);
+                    st = e;
+                }
+        }
+        const uint32_t incl2 = EMIT ? wave_incl_add(nb) : 0u;
+        if (EMIT && lane == 63) agg[2][wave] = incl2;
+        lds_barrier();                                      // (3)
+        uint32_t total = 0;
+        if (EMIT) {
+            const uint32_t vb = lane < 16 ? agg[2][lane] : 0u;
+            const uint32_t sb = wave_incl_add(vb);
+            total = lane_value(sb, 15);
+            const uint32_t bbase = wave ? lane_value(sb, wave - 1) : 0u;
+            if (off + (int64_t)total > a.cap) { if (tid == 0) *a.status = 1; break; }      // uniform
+            uint8_t *dst = out + off + bbase + incl2 - nb;
+            uint32_t st = start;
+#pragma unroll
+            for (int k = 0; k < WPT; ++k)
+                for (uint32_t x = ends[k]; x;) {
+                    const uint32_t i = (uint32_t)__builtin_ctz(x);
+                    const uint32_t e = (uint32_t)((w0 + k) * 32) + i + 1u;
+                    x &= x - 1u;
+                    dst += put_run(dst, e - st, (w[k] >> i) & 1u);
+                    st = e;
+                }
+            if (tid == 0) a.row_len[(size_t)plane * a.n_rows + r] = (int32_t)total;
+            off += total;
+        }
+        const int32_t neg_n0 = (int32_t)ones - m;
+#pragma unroll 4
+        for (int c = tid; c < m; c += kThreads) {
+            const int32_t q = Qg[c];
+            const uint2 e = *reinterpret_cast<const uint2*>(dir_m8 - 8 * (q >> 5));
+            const uint32_t t = e.x << (q & 31);
+            const int32_t oi = (int32_t)(e.y + (uint32_t)__popc(t));
+            Qg[c] = (int32_t)t < 0 ? neg_n0 - oi : q + oi;
+        }
+    }
+    for (int c = tid; c < m; c += kThreads) {
+        const int32_t rk = ~Qg[c];
+        Qg[c] = rk;
+        if (a.perm_out) a.perm_out[up * m + rk] = c;
+    }
+    if (EMIT && tid == 0) a.out_len[up] = off;
+}
+
 // ---- phase B helpers ------------------------------------------------------------------------------------------
 // flag[p] = 1 if the column at position p of a unit's own order differs from its left neighbour in any row of the unit
 __global__ __launch_bounds__(256) void class_flags_kernel(const uint8_t *codes, int stride, int64_t n_rows, int unit_rows,
@@ -276,15 +400,16 @@ __global__ __launch_bounds__(kThreads) void class_ids_kernel(int m, const uint8_
         if (p0 + i < m) { if (p0 + i > 0) base += flag[up * m + p0 + i]; cid[up * m + p0 + i] = (int32_t)base; }
 }
 
-// key = plane | class in the unit's own order | order before the unit  (m <= 32768: 15 bits each)
+// key = plane | class in the unit's own order | order before the unit  (BITS bits each: 15 up to 32768 columns, 18 beyond)
+template <typename Key, int BITS>
 __global__ __launch_bounds__(256) void sort_keys_kernel(int m, int g, const int32_t *cid_u, const int32_t *local_u,
-                                                        const int32_t *before_u, uint32_t *key, int32_t *val)
+                                                        const int32_t *before_u, Key *key, int32_t *val)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= g * m) return;
     const int plane = i / m, col = i - plane * m;
-    key[i] = (uint32_t)plane << 30 | (uint32_t)cid_u[(size_t)plane * m + local_u[(size_t)plane * m + col]] << 15 |
-             (uint32_t)before_u[(size_t)plane * m + col];
+    key[i] = (Key)plane << (2 * BITS) | (Key)cid_u[(size_t)plane * m + local_u[(size_t)plane * m + col]] << BITS |
+             (Key)before_u[(size_t)plane * m + col];
     val[i] = col;
 }
 
@@ -326,7 +451,8 @@ struct bgth_encoder_s {
     int32_t *d_state = nullptr;                      // [g][m] order after the last row written
     int32_t *d_true = nullptr, *d_local = nullptr, *d_perm = nullptr, *d_cid = nullptr;   // [units(+1)][g][m]
     int32_t *d_row_len = nullptr, *d_snap = nullptr, *d_snap_base = nullptr, *d_status = nullptr, *d_val[2] = {nullptr, nullptr};
-    uint32_t *d_key[2] = {nullptr, nullptr};
+    void *d_key[2] = {nullptr, nullptr};             // uint32 keys up to 32768 columns, uint64 beyond
+    int32_t wpt = 0;                                 // > 0: the wide kernel with this many directory words per thread
     void *d_temp = nullptr;
     size_t temp_bytes = 0;
     int64_t *d_out_len = nullptr;
@@ -363,7 +489,7 @@ extern "C" void bgth_encoder_close(bgth_encoder_t *e)
 
 extern "C" bgth_encoder_t *bgth_encoder_open(int32_t m, int32_t g, int32_t shift, int device)
 {
-    if (m < 1 || m > kMaxM) { enc_err("[E::%s] %d columns: this encoder holds 1..%d", __func__, m, kMaxM); return nullptr; }
+    if (m < 1 || m > kMaxWideM) { enc_err("[E::%s] %d columns: this encoder holds 1..%d", __func__, m, kMaxWideM); return nullptr; }
     if (g < 1 || g > 8 || shift < 0 || shift > 30) { enc_err("[E::%s] bad plane count or checkpoint shift", __func__); return nullptr; }
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) {
@@ -374,6 +500,12 @@ extern "C" bgth_encoder_t *bgth_encoder_open(int32_t m, int32_t g, int32_t shift
     e->m = m; e->g = g; e->shift = shift; e->device = device;
     e->cpt = m <= 4 * kThreads ? 4 : m <= 8 * kThreads ? 8 : m <= 20 * kThreads ? 20 : 32;
     e->stride = e->cpt * kThreads;
+    if (m > kMaxM) {
+        const int nw = (m + 31) / 32;
+        e->wpt = nw <= 2 * kThreads ? 2 : nw <= 4 * kThreads ? 4 : 8;
+        e->stride = m;
+    }
+    if (e->wpt) e->unit_rows = 1024;                 // wide rows are slow and large: smaller units, more of them at once
     if (const char *u = getenv("BGTH_ENC_UNIT_SHIFT")) {
         const int us = atoi(u);
         if (us >= 1 && us <= 20) e->unit_rows = 1 << us;
@@ -387,11 +519,13 @@ extern "C" bgth_encoder_t *bgth_encoder_open(int32_t m, int32_t g, int32_t shift
     ENC_TRY(hipMalloc(&e->d_state, (size_t)g * m * 4), { bgth_encoder_close(e); return nullptr; });
     ENC_TRY(hipMalloc(&e->d_status, 4), { bgth_encoder_close(e); return nullptr; });
     for (int i = 0; i < 2; ++i) {
-        ENC_TRY(hipMalloc(&e->d_key[i], (size_t)g * m * 4), { bgth_encoder_close(e); return nullptr; });
+        ENC_TRY(hipMalloc(&e->d_key[i], (size_t)g * m * 8), { bgth_encoder_close(e); return nullptr; });
         ENC_TRY(hipMalloc(&e->d_val[i], (size_t)g * m * 4), { bgth_encoder_close(e); return nullptr; });
     }
-    ENC_TRY(rocprim::radix_sort_pairs(nullptr, e->temp_bytes, e->d_key[0], e->d_key[1], e->d_val[0], e->d_val[1], (unsigned)(g * m), 0, 32,
-                                      e->stream), { bgth_encoder_close(e); return nullptr; });
+    if (e->wpt) ENC_TRY(rocprim::radix_sort_pairs(nullptr, e->temp_bytes, (uint64_t*)e->d_key[0], (uint64_t*)e->d_key[1], e->d_val[0], e->d_val[1],
+                                                  (unsigned)(g * m), 0, 37, e->stream), { bgth_encoder_close(e); return nullptr; });
+    else        ENC_TRY(rocprim::radix_sort_pairs(nullptr, e->temp_bytes, (uint32_t*)e->d_key[0], (uint32_t*)e->d_key[1], e->d_val[0], e->d_val[1],
+                                                  (unsigned)(g * m), 0, 32, e->stream), { bgth_encoder_close(e); return nullptr; });
     ENC_TRY(hipMalloc(&e->d_temp, e->temp_bytes ? e->temp_bytes : 16), { bgth_encoder_close(e); return nullptr; });
     std::vector<int32_t> ident((size_t)g * m);
     for (int k = 0; k < g; ++k) for (int j = 0; j < m; ++j) ident[(size_t)k * m + j] = j;     // identity start (ref pbwt.c:92-105)
@@ -433,6 +567,20 @@ template <bool EMIT>
 static void launch_encode(const bgth_encoder_t *e, const EncodeArgs &a, int n_units)
 {
     const dim3 grid((unsigned)e->g, (unsigned)n_units), block(kThreads);
+    if (e->wpt) {
+        const size_t lds = (size_t)2 * (kThreads * e->wpt + 1) * sizeof(uint2);
+        if (e->wpt == 2) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_wide_kernel<2, EMIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((encode_wide_kernel<2, EMIT>), grid, block, lds, e->stream, a);
+        } else if (e->wpt == 4) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_wide_kernel<4, EMIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((encode_wide_kernel<4, EMIT>), grid, block, lds, e->stream, a);
+        } else {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_wide_kernel<8, EMIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((encode_wide_kernel<8, EMIT>), grid, block, lds, e->stream, a);
+        }
+        return;
+    }
     if (e->cpt == 4)       hipLaunchKernelGGL((encode_kernel<4, EMIT>),  grid, block, 0, e->stream, a);
     else if (e->cpt == 8)  hipLaunchKernelGGL((encode_kernel<8, EMIT>),  grid, block, 0, e->stream, a);
     else if (e->cpt == 20) hipLaunchKernelGGL((encode_kernel<20, EMIT>), grid, block, 0, e->stream, a);
@@ -477,10 +625,17 @@ static int encode_batch(bgth_encoder_t *e, const uint8_t *codes, int64_t rows)
         ENC_TRY(hipMemcpyAsync(e->d_true, e->d_state, gm * 4, hipMemcpyDeviceToDevice, e->stream), return -1);
         const unsigned nk = (unsigned)gm, kb = (nk + 255) / 256;
         for (int32_t k = 0; k < n_units; ++k) {
-            hipLaunchKernelGGL(sort_keys_kernel, dim3(kb), dim3(256), 0, e->stream, m, g, e->d_cid + (size_t)k * gm, e->d_local + (size_t)k * gm,
-                               e->d_true + (size_t)k * gm, e->d_key[0], e->d_val[0]);
-            ENC_TRY(rocprim::radix_sort_pairs(e->d_temp, e->temp_bytes, e->d_key[0], e->d_key[1], e->d_val[0], e->d_val[1], nk, 0, 32, e->stream),
-                    return -1);
+            if (e->wpt) {
+                hipLaunchKernelGGL((sort_keys_kernel<uint64_t, 18>), dim3(kb), dim3(256), 0, e->stream, m, g, e->d_cid + (size_t)k * gm,
+                                   e->d_local + (size_t)k * gm, e->d_true + (size_t)k * gm, (uint64_t*)e->d_key[0], e->d_val[0]);
+                ENC_TRY(rocprim::radix_sort_pairs(e->d_temp, e->temp_bytes, (uint64_t*)e->d_key[0], (uint64_t*)e->d_key[1], e->d_val[0], e->d_val[1],
+                                                  nk, 0, 37, e->stream), return -1);
+            } else {
+                hipLaunchKernelGGL((sort_keys_kernel<uint32_t, 15>), dim3(kb), dim3(256), 0, e->stream, m, g, e->d_cid + (size_t)k * gm,
+                                   e->d_local + (size_t)k * gm, e->d_true + (size_t)k * gm, (uint32_t*)e->d_key[0], e->d_val[0]);
+                ENC_TRY(rocprim::radix_sort_pairs(e->d_temp, e->temp_bytes, (uint32_t*)e->d_key[0], (uint32_t*)e->d_key[1], e->d_val[0], e->d_val[1],
+                                                  nk, 0, 32, e->stream), return -1);
+            }
             hipLaunchKernelGGL(ranks_from_sorted_kernel, dim3(kb), dim3(256), 0, e->stream, m, g, e->d_val[1], e->d_true + (size_t)(k + 1) * gm);
         }
         ENC_TRY(hipMemcpyAsync(e->d_state, e->d_true + (size_t)n_units * gm, gm * 4, hipMemcpyDeviceToDevice, e->stream), return -1);

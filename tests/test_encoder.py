@@ -37,7 +37,7 @@ def test_encoder_refuses_what_it_cannot_hold():
     with pytest.raises(RuntimeError):
         bgt_amd.HipEncoder(0)
     with pytest.raises(RuntimeError):
-        bgt_amd.HipEncoder(40000)                 # more than 32768 columns: not in this version, and no CPU path
+        bgt_amd.HipEncoder(300000)                # more than 262144 columns: not in this version, and no CPU path
 
 
 @pytest.mark.gpu
@@ -181,3 +181,19 @@ def test_encoder_default_units():
     enc = bgt_amd.HipEncoder(m, 2, 13)
     enc.write(mat)
     assert enc.finish() == orc.encode_pbf(mat, 2, 13)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,rows,unit", [(32769, 40, 0), (40000, 90, 4), (65536, 30, 3), (65537, 30, 0), (70002, 60, 4),
+                                         (131072, 24, 3), (131073, 24, 3), (200000, 50, 4), (262144, 12, 2)])
+def test_encoder_wide_cohorts(monkeypatch, m, rows, unit):
+    """more than 32768 columns: ranks in memory, several directory words per thread, 64-bit sort keys"""
+    import bgt_amd
+    if unit:
+        monkeypatch.setenv("BGTH_ENC_UNIT_SHIFT", str(unit))
+    rng = np.random.default_rng(m + rows)
+    mat = scenarios.ld_matrix(rng, rows, m, n_founders=5, switch=0.0005)
+    enc = bgt_amd.HipEncoder(m, 2, 3)
+    enc.write(mat[:rows // 2])
+    enc.write(mat[rows // 2:])
+    assert enc.finish() == orc.encode_pbf(mat, 2, 3)
