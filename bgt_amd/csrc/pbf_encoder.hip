@@ -38,6 +38,7 @@ struct EncodeArgs {
     int64_t n_rows, row0;      // row0 = file row of codes[0]
     int32_t m, mask;           // mask = (1 << shift) - 1
     int32_t g, unit_rows;      // workgroup (plane, unit) handles rows [unit * unit_rows, ...)
+    int32_t stride;            // bytes between rows of codes (a multiple of 4)
     const int32_t *rank_in;    // [n_units][g][m] order before each unit, or NULL = identity
     int32_t *rank_out;         // [n_units][g][m] order after it
     int32_t *perm_out;         // [n_units][g][m] the same as position -> column (phase A), or NULL
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(kThreads) void encode_kernel(EncodeArgs a)
 
 // ---- wide cohorts (more than 32768 columns): the ranks do not fit the registers of one workgroup, so they live in
 // memory (800 KB per plane at 100,000 samples: L2) and every thread owns WPT words of the directory.  Same phases,
-// same barriers; `stride` of the codes is m.
+// same barriers.
 template <int WPT, bool EMIT>
 __global__ __launch_bounds__(kThreads) void encode_wide_kernel(EncodeArgs a)
 {
@@ -260,6 +261,14 @@ __global__ __launch_bounds__(kThreads) void encode_wide_kernel(EncodeArgs a)
     const int w0 = tid * WPT;
     int64_t off = 0;
     int snap_i = EMIT ? a.snap_base[unit] : 0;
+    if (r_beg < r_end) {                                    // the first row's bits; later rows are scattered by the step before them
+        const uint8_t *src = a.codes + (size_t)r_beg * a.stride;
+        char *dir_m8 = reinterpret_cast<char*>(wide_dir + (r_beg & 1) * NWP) - 8;
+        for (int c = tid; c < m; c += kThreads) {
+            const int32_t q = Qg[c];
+            if ((src[c] >> plane) & 1) atomicOr(reinterpret_cast<uint32_t*>(dir_m8 - 8 * (q >> 5)), 0x80000000u >> (q & 31));
+        }
+    }
     for (int64_t r = r_beg; r < r_end; ++r) {
         uint2 *dir = wide_dir + (r & 1) * NWP, *other = wide_dir + ((r & 1) ^ 1) * NWP;
         char *dir_m8 = reinterpret_cast<char*>(dir) - 8;
@@ -268,13 +277,7 @@ __global__ __launch_bounds__(kThreads) void encode_wide_kernel(EncodeArgs a)
             for (int c = tid; c < m; c += kThreads) S[~Qg[c]] = c;
             ++snap_i;
         }
-        const uint8_t *src = a.codes + (size_t)r * m;
-#pragma unroll 4
-        for (int c = tid; c < m; c += kThreads) {
-            const int32_t q = Qg[c];
-            if ((src[c] >> plane) & 1) atomicOr(reinterpret_cast<uint32_t*>(dir_m8 - 8 * (q >> 5)), 0x80000000u >> (q & 31));
-        }
-        lds_barrier();                                      // (1)
+        lds_barrier();                                      // (1) the bit-vector of this row is complete
         uint32_t w[WPT], ends[WPT], pc = 0, le = 0;
 #pragma unroll
         for (int k = 0; k < WPT; ++k) {
@@ -342,14 +345,33 @@ __global__ __launch_bounds__(kThreads) void encode_wide_kernel(EncodeArgs a)
             if (tid == 0) a.row_len[(size_t)plane * a.n_rows + r] = (int32_t)total;
             off += total;
         }
+        // the step of this row fused with the scatter of the next one (one pass over the ranks per row), eight
+        // columns at a time so that their loads are in flight together
         const int32_t neg_n0 = (int32_t)ones - m;
-#pragma unroll 4
-        for (int c = tid; c < m; c += kThreads) {
-            const int32_t q = Qg[c];
-            const uint2 e = *reinterpret_cast<const uint2*>(dir_m8 - 8 * (q >> 5));
-            const uint32_t t = e.x << (q & 31);
-            const int32_t oi = (int32_t)(e.y + (uint32_t)__popc(t));
-            Qg[c] = (int32_t)t < 0 ? neg_n0 - oi : q + oi;
+        const bool more = r + 1 < r_end;
+        const uint8_t *nsrc = a.codes + (size_t)(more ? r + 1 : r) * a.stride;
+        char *other_m8 = reinterpret_cast<char*>(other) - 8;
+        for (int c0 = tid; c0 < m; c0 += 8 * kThreads) {
+            int32_t q[8];
+            uint32_t nb8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = c0 + j * kThreads;
+                q[j] = c < m ? Qg[c] : -1;
+                nb8[j] = (c < m && more) ? nsrc[c] : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = c0 + j * kThreads;
+                const uint2 e = *reinterpret_cast<const uint2*>(dir_m8 - 8 * (q[j] >> 5));
+                const uint32_t t = e.x << (q[j] & 31);
+                const int32_t oi = (int32_t)(e.y + (uint32_t)__popc(t));
+                const int32_t qn = (int32_t)t < 0 ? neg_n0 - oi : q[j] + oi;
+                if (c < m) {
+                    Qg[c] = qn;
+                    if ((nb8[j] >> plane) & 1u) atomicOr(reinterpret_cast<uint32_t*>(other_m8 - 8 * (qn >> 5)), 0x80000000u >> (qn & 31));
+                }
+            }
         }
     }
     for (int c = tid; c < m; c += kThreads) {
@@ -361,9 +383,35 @@ __global__ __launch_bounds__(kThreads) void encode_wide_kernel(EncodeArgs a)
 }
 
 // ---- phase B helpers ------------------------------------------------------------------------------------------
+// The columns of a unit as bits: colbits[(unit * wpu + j) * 2 + plane][col] = bits of the column in rows 32j..32j+31 of the
+// unit (row-block major, so that both this kernel's loads and stores are coalesced).  Planes 0 and 1 only (the parallel
+// path is used for g <= 2).
+__global__ __launch_bounds__(256) void column_bits_kernel(const uint8_t *codes, int stride, int64_t n_rows, int unit_rows, int wpu,
+                                                          int m, uint32_t *colbits)
+{
+    const int col = 4 * (blockIdx.x * 256 + threadIdx.x), blk = blockIdx.y;   // four columns per thread; blk = unit * wpu + j
+    if (col >= m) return;
+    const int unit = blk / wpu, j = blk - unit * wpu;
+    const int64_t u_end = (int64_t)(unit + 1) * unit_rows < n_rows ? (int64_t)(unit + 1) * unit_rows : n_rows;
+    const int64_t r0 = (int64_t)unit * unit_rows + 32 * j;
+    uint32_t w0[4] = {0, 0, 0, 0}, w1[4] = {0, 0, 0, 0};
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i)
+        if (r0 + i < u_end) {
+            const uint32_t c4 = *reinterpret_cast<const uint32_t*>(codes + (size_t)(r0 + i) * stride + col);   // stride % 4 == 0
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                w0[k] |= ((c4 >> (8 * k)) & 1u) << i;
+                w1[k] |= ((c4 >> (8 * k + 1)) & 1u) << i;
+            }
+        }
+    uint32_t *d0 = colbits + ((size_t)blk * 2 + 0) * m + col, *d1 = colbits + ((size_t)blk * 2 + 1) * m + col;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (col + k < m) { d0[k] = w0[k]; d1[k] = w1[k]; }
+}
+
 // flag[p] = 1 if the column at position p of a unit's own order differs from its left neighbour in any row of the unit
-__global__ __launch_bounds__(256) void class_flags_kernel(const uint8_t *codes, int stride, int64_t n_rows, int unit_rows,
-                                                          int m, int g, const int32_t *perm, uint8_t *flag)
+__global__ __launch_bounds__(256) void class_flags_kernel(const uint32_t *colbits, int wpu, int m, int g, const int32_t *perm, uint8_t *flag)
 {
     const int p = blockIdx.x * 256 + threadIdx.x, plane = blockIdx.y, unit = blockIdx.z;
     if (p >= m) return;
@@ -371,15 +419,13 @@ __global__ __launch_bounds__(256) void class_flags_kernel(const uint8_t *codes, 
     uint32_t diff = 1u;
     if (p > 0) {
         const int ca = perm[up * m + p], cb = perm[up * m + p - 1];
-        const int64_t r_beg = (int64_t)unit * unit_rows;
-        const int64_t r_end = r_beg + unit_rows < n_rows ? r_beg + unit_rows : n_rows;
         diff = 0u;
-        for (int64_t r = r_beg; r < r_end && !diff; ++r) {
-            const uint8_t *row = codes + (size_t)r * stride;
-            diff = ((uint32_t)(row[ca] ^ row[cb]) >> plane) & 1u;
+        for (int j = 0; j < wpu && !diff; ++j) {
+            const uint32_t *w = colbits + (((size_t)unit * wpu + j) * 2 + plane) * m;
+            diff = w[ca] ^ w[cb];
         }
     }
-    flag[up * m + p] = (uint8_t)diff;
+    flag[up * m + p] = diff ? 1 : 0;
 }
 
 // cid[p] = number of class starts in positions 1..p (one workgroup per unit and plane)
@@ -448,6 +494,8 @@ struct bgth_encoder_s {
     int32_t units_cap = 0, snap_cap = 0;
     hipStream_t stream = nullptr;
     uint8_t *d_codes = nullptr, *d_out = nullptr, *d_flag = nullptr;
+    uint32_t *d_colbits = nullptr;                   // [units * ceil(unit_rows / 32)][2][m] the columns of every unit as bits
+    size_t colbits_cap = 0;
     int32_t *d_state = nullptr;                      // [g][m] order after the last row written
     int32_t *d_true = nullptr, *d_local = nullptr, *d_perm = nullptr, *d_cid = nullptr;   // [units(+1)][g][m]
     int32_t *d_row_len = nullptr, *d_snap = nullptr, *d_snap_base = nullptr, *d_status = nullptr, *d_val[2] = {nullptr, nullptr};
@@ -481,7 +529,7 @@ extern "C" void bgth_encoder_close(bgth_encoder_t *e)
     if (!e) return;
     hipSetDevice(e->device);
     free_batch_buffers(e);
-    hipFree(e->d_state); hipFree(e->d_status); hipFree(e->d_temp);
+    hipFree(e->d_state); hipFree(e->d_status); hipFree(e->d_temp); hipFree(e->d_colbits);
     for (int i = 0; i < 2; ++i) { hipFree(e->d_key[i]); hipFree(e->d_val[i]); }
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
@@ -503,7 +551,7 @@ extern "C" bgth_encoder_t *bgth_encoder_open(int32_t m, int32_t g, int32_t shift
     if (m > kMaxM) {
         const int nw = (m + 31) / 32;
         e->wpt = nw <= 2 * kThreads ? 2 : nw <= 4 * kThreads ? 4 : 8;
-        e->stride = m;
+        e->stride = (m + 3) & ~3;
     }
     if (e->wpt) e->unit_rows = 1024;                 // wide rows are slow and large: smaller units, more of them at once
     if (const char *u = getenv("BGTH_ENC_UNIT_SHIFT")) {
@@ -604,7 +652,7 @@ static int encode_batch(bgth_encoder_t *e, const uint8_t *codes, int64_t rows)
     if (ensure_capacity(e, (int64_t)n_units * unit_rows, n_units, n_snap) < 0) return -1;
     const size_t gm = (size_t)g * m;
     EncodeArgs a;
-    a.codes = e->d_codes; a.n_rows = rows; a.row0 = e->n; a.m = m; a.mask = (int32_t)mask; a.g = g; a.unit_rows = (int32_t)unit_rows;
+    a.codes = e->d_codes; a.n_rows = rows; a.row0 = e->n; a.m = m; a.mask = (int32_t)mask; a.g = g; a.unit_rows = (int32_t)unit_rows; a.stride = e->stride;
     a.out = e->d_out; a.cap = unit_rows * (int64_t)m; a.out_len = e->d_out_len; a.row_len = e->d_row_len;
     a.snap = e->d_snap; a.snap_base = e->d_snap_base; a.n_snap = n_snap; a.status = e->d_status;
     ENC_TRY(hipMemcpy2DAsync(e->d_codes, (size_t)e->stride, codes, (size_t)m, (size_t)m, (size_t)rows, hipMemcpyHostToDevice, e->stream), return -1);
@@ -618,8 +666,17 @@ static int encode_batch(bgth_encoder_t *e, const uint8_t *codes, int64_t rows)
         // A: every unit from the identity order -> its own order (ranks and permutation), then the classes of identical columns
         a.rank_in = nullptr; a.rank_out = e->d_local; a.perm_out = e->d_perm;
         launch_encode<false>(e, a, n_units);
+        const int wpu = (int)((unit_rows + 31) / 32);
+        const size_t cb_words = (size_t)n_units * wpu * 2 * m;
+        if (cb_words > e->colbits_cap) {
+            hipFree(e->d_colbits); e->d_colbits = nullptr; e->colbits_cap = 0;
+            ENC_TRY(hipMalloc(&e->d_colbits, cb_words * 4), return -1);
+            e->colbits_cap = cb_words;
+        }
+        hipLaunchKernelGGL(column_bits_kernel, dim3((unsigned)((m + 1023) / 1024), (unsigned)(n_units * wpu)), dim3(256), 0, e->stream,
+                           e->d_codes, e->stride, rows, (int)unit_rows, wpu, m, e->d_colbits);
         hipLaunchKernelGGL(class_flags_kernel, dim3((unsigned)((m + 255) / 256), (unsigned)g, (unsigned)n_units), dim3(256), 0, e->stream,
-                           e->d_codes, e->stride, rows, (int)unit_rows, m, g, e->d_perm, e->d_flag);
+                           e->d_colbits, wpu, m, g, e->d_perm, e->d_flag);
         hipLaunchKernelGGL(class_ids_kernel, dim3((unsigned)(n_units * g)), dim3(kThreads), 0, e->stream, m, e->d_flag, e->d_cid);
         // B: the true order before every unit, one sort per unit
         ENC_TRY(hipMemcpyAsync(e->d_true, e->d_state, gm * 4, hipMemcpyDeviceToDevice, e->stream), return -1);
