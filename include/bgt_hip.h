@@ -69,7 +69,8 @@ int64_t     bgth_pbf_rle_bytes(const bgth_pbf_t *p);   /* total RLE payload     
  *      pbwt.c:24-36 run on the device) ----
  * The image is byte for byte the file the reference writer produces from the same rows.  `codes` is a HOST array
  * [n_rows][m], bit k of a byte = the bit of plane k (what import.c:96-97 hands to pbf_write as g byte arrays).
- * One workgroup per plane encodes the rows in order; m <= 32768 columns in this version.  No CPU path. */
+ * A call is cut into units of 4096 rows (1024 above 32768 columns) that are encoded in parallel, so hand over rows in
+ * bulk; m <= 262144 columns in this version.  No CPU path. */
 typedef struct bgth_encoder_s bgth_encoder_t;
 bgth_encoder_t *bgth_encoder_open(int32_t m, int32_t g, int32_t shift, int device);      /* NULL on failure       */
 int             bgth_encoder_write(bgth_encoder_t *e, const uint8_t *codes, int64_t n_rows);   /* <0 on failure   */
