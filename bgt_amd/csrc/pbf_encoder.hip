@@ -50,6 +50,7 @@ struct EncodeArgs {
     const int32_t *snap_base;  // [n_units] index of the first of them in each unit
     int32_t n_snap;
     int32_t *status;           // != 0: output capacity exceeded
+    int32_t debug;             // BGTH_ENC_DEBUG: ablation switches for timing (1 no byte stores, 2 no run passes, 4 no run list)
 };
 
 // inclusive prefix sum / prefix maximum over the 64 lanes in the VALU (DPP row shifts + the two row broadcasts);
@@ -115,7 +116,8 @@ __global__ __launch_bounds__(kThreads) void encode_kernel(EncodeArgs a)
     // the row in PBWT order as a rank directory, double-buffered over rows: {32 bits, ones before them} per entry, so
     // that one 8-byte read answers a lookup (the layout of the scan kernel)
     __shared__ uint2 dir2[2][kThreads + 1];
-    __shared__ uint32_t agg[3][16];             // per wave: ones, end of the last run that ends in it, bytes
+    __shared__ uint32_t agg[4][16];             // per wave: ones, runs that end in it, bytes; [3][0]: the row's first bit
+    __shared__ uint16_t run_end[EMIT ? kMaxM : 2];   // last position of every run of the row
     const int tid = threadIdx.x, lane = tid & 63, plane = blockIdx.x, unit = blockIdx.y;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = a.m, nw = (m + 31) >> 5;
@@ -154,69 +156,64 @@ __global__ __launch_bounds__(kThreads) void encode_kernel(EncodeArgs a)
             const uint32_t b = (nxt[i >> 2] >> (8 * (i & 3) + plane)) & 1u;
             if (b) atomicOr(reinterpret_cast<uint32_t*>(dir_m8 - 8 * (Q[i] >> 5)), 0x80000000u >> (Q[i] & 31));   // bit r & 31
         }
-        if (r + 1 < r_end) {
-            const uint32_t *src = reinterpret_cast<const uint32_t*>(a.codes + (size_t)(r + 1) * stride + col0);
-#pragma unroll
-            for (int q = 0; q < CPT / 4; ++q) nxt[q] = src[q];
-        }
         lds_barrier();                                    // (1) the bit-vector is complete
         dir2[(r & 1) ^ 1][tid].x = 0u;                      // everyone is done with the previous row's
         const uint32_t w = dir[tid].x;
         const uint32_t wn = dir[tid + 1].x;
         // a run ends at bit i of this word if the next position holds the other bit, or the row ends there
         const uint32_t ends = EMIT ? ((((w ^ (w >> 1 | wn << 31)) & valid) & ~last_bit) | last_bit) : 0u;
-        const uint32_t pc = (uint32_t)__popc(w);
+        const uint32_t pc = (uint32_t)__popc(w), ne = (uint32_t)__popc(ends);
         const uint32_t incl = wave_incl_add(pc);
-        const uint32_t le = ends ? (uint32_t)(tid * 32 + 32 - __builtin_clz(ends)) : 0u;   // position after the last end
-        const uint32_t lmax = EMIT ? wave_incl_max(le) : 0u;
-        if (lane == 63) { agg[0][wave] = incl; agg[1][wave] = lmax; }
+        const uint32_t incl_e = EMIT ? wave_incl_add(ne) : 0u;
+        if (lane == 63) { agg[0][wave] = incl; agg[1][wave] = incl_e; }
+        if (EMIT && tid == 0) agg[3][0] = w & 1u;           // runs alternate: the bit of run k is this one ^ (k & 1)
         lds_barrier();                                    // (2)
-        uint32_t ones, start = 0;
+        uint32_t ones, n_runs = 0, first_bit = 0;
         {
             const uint32_t va = lane < 16 ? agg[0][lane] : 0u;
             const uint32_t sa = wave_incl_add(va);
             ones = lane_value(sa, 15);
             dir[tid].y = (wave ? lane_value(sa, wave - 1) : 0u) + incl - pc;
-            if (EMIT) {
-                const uint32_t vm = lane < 16 ? agg[1][lane] : 0u;
-                const uint32_t sx = wave_incl_max(vm);
-                start = umax(wave ? lane_value(sx, wave - 1) : 0u, wave_shr1(lmax));   // where the first run ending here began
+            if (EMIT) {                                     // the last position of every run, in order, one list for the row
+                const uint32_t ve = lane < 16 ? agg[1][lane] : 0u;
+                const uint32_t se = wave_incl_add(ve);
+                n_runs = lane_value(se, 15);
+                uint32_t k = (wave ? lane_value(se, wave - 1) : 0u) + incl_e - ne;
+                if (!(a.debug & 4)) for (uint32_t x = ends; x; x &= x - 1u) run_end[k++] = (uint16_t)(tid * 32 + __builtin_ctz(x));
+                first_bit = agg[3][0];
             }
         }
+        lds_barrier();                                    // (3) `before` and the run list are visible
+        // the runs dealt evenly to the threads (a row of C2 has ~165: three waves emit, thirteen only take part in the scan)
+        const uint32_t rpt = (n_runs + kThreads - 1) >> 10, k0 = (uint32_t)tid * rpt, k1 = k0 + rpt < n_runs ? k0 + rpt : n_runs;
         uint32_t nb = 0;
+        if (EMIT && !(a.debug & 2))
+            for (uint32_t k = k0; k < k1; ++k) nb += run_bytes((uint32_t)run_end[k] - (k ? (uint32_t)run_end[k - 1] : 0xffffffffu));
+        uint32_t bbase = 0, total = 0, incl2 = 0;
         if (EMIT) {
-            uint32_t st = start;
-            for (uint32_t x = ends; x;) {                   // the runs that end in this word
-                const uint32_t e = (uint32_t)(tid * 32 + __builtin_ctz(x) + 1);
-                x &= x - 1u;
-                nb += run_bytes(e - st);
-                st = e;
-            }
-        }
-        const uint32_t incl2 = EMIT ? wave_incl_add(nb) : 0u;
-        if (EMIT && lane == 63) agg[2][wave] = incl2;
-        lds_barrier();                                    // (3) `before` and the byte counts are visible
-        uint32_t bbase = 0, total = 0;
-        if (EMIT) {
+            incl2 = wave_incl_add(nb);
+            if (lane == 63) agg[2][wave] = incl2;
+            lds_barrier();                                // (4)
             const uint32_t vb = lane < 16 ? agg[2][lane] : 0u;
             const uint32_t sb = wave_incl_add(vb);
             total = lane_value(sb, 15);
             bbase = wave ? lane_value(sb, wave - 1) : 0u;
         }
         if (EMIT && off + (int64_t)total > a.cap) { if (tid == 0) *a.status = 1; break; }  // uniform
-        if (EMIT) {
+        if (EMIT && !(a.debug & 3)) {
             uint8_t *dst = out + off + bbase + incl2 - nb;
-            uint32_t st = start;
-            for (uint32_t x = ends; x;) {
-                const uint32_t i = (uint32_t)__builtin_ctz(x);
-                const uint32_t e = (uint32_t)(tid * 32) + i + 1u;
-                x &= x - 1u;
-                dst += put_run(dst, e - st, (w >> i) & 1u);
-                st = e;
-            }
+            for (uint32_t k = k0; k < k1; ++k)
+                dst += put_run(dst, (uint32_t)run_end[k] - (k ? (uint32_t)run_end[k - 1] : 0xffffffffu), first_bit ^ (k & 1u));
         }
         if (EMIT && tid == 0) a.row_len[(size_t)plane * a.n_rows + r] = (int32_t)total;
         off += total;
+        // the next row's codes, fetched behind the stores of this row's bytes (the memory counter retires in order: a
+        // fetch issued before them would make the next scatter wait for the stores as well) and under the rank step
+        if (r + 1 < r_end) {
+            const uint32_t *src = reinterpret_cast<const uint32_t*>(a.codes + (size_t)(r + 1) * stride + col0);
+#pragma unroll
+            for (int q = 0; q < CPT / 4; ++q) nxt[q] = src[q];
+        }
         // ---- the stable partition, on ranks (ref pbwt.c:57-66 moves S instead)
         // t = word << (q & 31): bit r & 31 in the sign, the bits above it gone; oi = ones up to and including r;
         // bit ? r = n0 + oi - 1 : r = r - oi, i.e. q = bit ? -n0 - oi : q + oi
@@ -446,25 +443,25 @@ __global__ __launch_bounds__(kThreads) void class_ids_kernel(int m, const uint8_
         if (p0 + i < m) { if (p0 + i > 0) base += flag[up * m + p0 + i]; cid[up * m + p0 + i] = (int32_t)base; }
 }
 
-// key = plane | class in the unit's own order | order before the unit  (BITS bits each: 15 up to 32768 columns, 18 beyond)
-template <typename Key, int BITS>
-__global__ __launch_bounds__(256) void sort_keys_kernel(int m, int g, const int32_t *cid_u, const int32_t *local_u,
-                                                        const int32_t *before_u, Key *key, int32_t *val)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= g * m) return;
-    const int plane = i / m, col = i - plane * m;
-    key[i] = (Key)plane << (2 * BITS) | (Key)cid_u[(size_t)plane * m + local_u[(size_t)plane * m + col]] << BITS |
-             (Key)before_u[(size_t)plane * m + col];
-    val[i] = col;
-}
-
-__global__ __launch_bounds__(256) void ranks_from_sorted_kernel(int m, int g, const int32_t *val, int32_t *after_u)
+// Phase B walks the columns IN THE ORDER BEFORE THE UNIT (perm) and sorts them stably by the class they have in the
+// unit's own order: key = plane | class.  The sorted columns are the order after the unit; ties keep the order before.
+__global__ __launch_bounds__(256) void class_keys_kernel(int m, int g, int bits, const int32_t *cid_u, const int32_t *local_u,
+                                                         const int32_t *perm_u, uint32_t *key)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= g * m) return;
     const int plane = i / m;
-    after_u[(size_t)plane * m + val[i]] = i - plane * m;
+    const int col = perm_u[i];
+    key[i] = (uint32_t)plane << bits | (uint32_t)cid_u[(size_t)plane * m + local_u[(size_t)plane * m + col]];
+}
+
+// position -> column  <->  column -> position, for n consecutive (unit, plane) arrays of m entries
+__global__ __launch_bounds__(256) void invert_kernel(int m, int64_t n_total, const int32_t *src, int32_t *dst)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_total) return;
+    const int64_t base = i / m * m;
+    dst[base + src[i]] = (int32_t)(i - base);
 }
 
 thread_local char g_enc_err[256] = "";
@@ -487,6 +484,7 @@ void enc_err(const char *fmt, ...)
 struct bgth_encoder_s {
     int32_t m = 0, g = 0, shift = 0, device = 0;
     int64_t n = 0;                                   // rows written
+    bool finished = false;
     int32_t cpt = 0, stride = 0;                     // device rows of codes are stride = cpt * 1024 bytes apart
     int32_t unit_rows = 4096;                        // rows per parallel unit (BGTH_ENC_UNIT_SHIFT)
     int64_t batch_rows = 0;                          // most rows per device pass
@@ -498,8 +496,9 @@ struct bgth_encoder_s {
     size_t colbits_cap = 0;
     int32_t *d_state = nullptr;                      // [g][m] order after the last row written
     int32_t *d_true = nullptr, *d_local = nullptr, *d_perm = nullptr, *d_cid = nullptr;   // [units(+1)][g][m]
-    int32_t *d_row_len = nullptr, *d_snap = nullptr, *d_snap_base = nullptr, *d_status = nullptr, *d_val[2] = {nullptr, nullptr};
-    void *d_key[2] = {nullptr, nullptr};             // uint32 keys up to 32768 columns, uint64 beyond
+    int32_t *d_row_len = nullptr, *d_snap = nullptr, *d_snap_base = nullptr, *d_status = nullptr;
+    int32_t *d_perms = nullptr;                      // [units + 1][g][m] true order before every unit as position -> column
+    uint32_t *d_key[2] = {nullptr, nullptr};
     int32_t wpt = 0;                                 // > 0: the wide kernel with this many directory words per thread
     void *d_temp = nullptr;
     size_t temp_bytes = 0;
@@ -516,9 +515,10 @@ extern "C" const char *bgth_encoder_last_error(void) { return g_enc_err; }
 
 static void free_batch_buffers(bgth_encoder_t *e)
 {
-    hipFree(e->d_codes); hipFree(e->d_out); hipFree(e->d_flag); hipFree(e->d_true); hipFree(e->d_local); hipFree(e->d_perm);
+    hipFree(e->d_codes); hipFree(e->d_out); hipFree(e->d_flag); hipFree(e->d_true); hipFree(e->d_perms); hipFree(e->d_local); hipFree(e->d_perm);
     hipFree(e->d_cid); hipFree(e->d_row_len); hipFree(e->d_snap); hipFree(e->d_snap_base); hipFree(e->d_out_len);
     e->d_codes = e->d_out = e->d_flag = nullptr;
+    e->d_perms = nullptr;
     e->d_true = e->d_local = e->d_perm = e->d_cid = e->d_row_len = e->d_snap = e->d_snap_base = nullptr;
     e->d_out_len = nullptr;
     e->rows_cap = 0; e->units_cap = 0; e->snap_cap = 0;
@@ -530,7 +530,7 @@ extern "C" void bgth_encoder_close(bgth_encoder_t *e)
     hipSetDevice(e->device);
     free_batch_buffers(e);
     hipFree(e->d_state); hipFree(e->d_status); hipFree(e->d_temp); hipFree(e->d_colbits);
-    for (int i = 0; i < 2; ++i) { hipFree(e->d_key[i]); hipFree(e->d_val[i]); }
+    for (int i = 0; i < 2; ++i) hipFree(e->d_key[i]);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
 }
@@ -567,13 +567,10 @@ extern "C" bgth_encoder_t *bgth_encoder_open(int32_t m, int32_t g, int32_t shift
     ENC_TRY(hipMalloc(&e->d_state, (size_t)g * m * 4), { bgth_encoder_close(e); return nullptr; });
     ENC_TRY(hipMalloc(&e->d_status, 4), { bgth_encoder_close(e); return nullptr; });
     for (int i = 0; i < 2; ++i) {
-        ENC_TRY(hipMalloc(&e->d_key[i], (size_t)g * m * 8), { bgth_encoder_close(e); return nullptr; });
-        ENC_TRY(hipMalloc(&e->d_val[i], (size_t)g * m * 4), { bgth_encoder_close(e); return nullptr; });
+        ENC_TRY(hipMalloc(&e->d_key[i], (size_t)g * m * 4), { bgth_encoder_close(e); return nullptr; });
     }
-    if (e->wpt) ENC_TRY(rocprim::radix_sort_pairs(nullptr, e->temp_bytes, (uint64_t*)e->d_key[0], (uint64_t*)e->d_key[1], e->d_val[0], e->d_val[1],
-                                                  (unsigned)(g * m), 0, 37, e->stream), { bgth_encoder_close(e); return nullptr; });
-    else        ENC_TRY(rocprim::radix_sort_pairs(nullptr, e->temp_bytes, (uint32_t*)e->d_key[0], (uint32_t*)e->d_key[1], e->d_val[0], e->d_val[1],
-                                                  (unsigned)(g * m), 0, 32, e->stream), { bgth_encoder_close(e); return nullptr; });
+    ENC_TRY(rocprim::radix_sort_pairs(nullptr, e->temp_bytes, e->d_key[0], e->d_key[1], (int32_t*)nullptr, (int32_t*)nullptr, (unsigned)(g * m), 0, 20,
+                                      e->stream), { bgth_encoder_close(e); return nullptr; });
     ENC_TRY(hipMalloc(&e->d_temp, e->temp_bytes ? e->temp_bytes : 16), { bgth_encoder_close(e); return nullptr; });
     std::vector<int32_t> ident((size_t)g * m);
     for (int k = 0; k < g; ++k) for (int j = 0; j < m; ++j) ident[(size_t)k * m + j] = j;     // identity start (ref pbwt.c:92-105)
@@ -600,6 +597,7 @@ static int ensure_capacity(bgth_encoder_t *e, int64_t rows, int32_t n_units, int
     ENC_TRY(hipMalloc(&e->d_out, (size_t)g * rows * m), return -1);                             // a row of m bits: at most m bytes
     ENC_TRY(hipMalloc(&e->d_flag, ugm), return -1);
     ENC_TRY(hipMalloc(&e->d_true, (ugm + (size_t)g * m) * 4), return -1);
+    ENC_TRY(hipMalloc(&e->d_perms, (ugm + (size_t)g * m) * 4), return -1);
     ENC_TRY(hipMalloc(&e->d_local, ugm * 4), return -1);
     ENC_TRY(hipMalloc(&e->d_perm, ugm * 4), return -1);
     ENC_TRY(hipMalloc(&e->d_cid, ugm * 4), return -1);
@@ -653,6 +651,7 @@ static int encode_batch(bgth_encoder_t *e, const uint8_t *codes, int64_t rows)
     const size_t gm = (size_t)g * m;
     EncodeArgs a;
     a.codes = e->d_codes; a.n_rows = rows; a.row0 = e->n; a.m = m; a.mask = (int32_t)mask; a.g = g; a.unit_rows = (int32_t)unit_rows; a.stride = e->stride;
+    a.debug = getenv("BGTH_ENC_DEBUG") ? atoi(getenv("BGTH_ENC_DEBUG")) : 0;
     a.out = e->d_out; a.cap = unit_rows * (int64_t)m; a.out_len = e->d_out_len; a.row_len = e->d_row_len;
     a.snap = e->d_snap; a.snap_base = e->d_snap_base; a.n_snap = n_snap; a.status = e->d_status;
     ENC_TRY(hipMemcpy2DAsync(e->d_codes, (size_t)e->stride, codes, (size_t)m, (size_t)m, (size_t)rows, hipMemcpyHostToDevice, e->stream), return -1);
@@ -678,22 +677,19 @@ static int encode_batch(bgth_encoder_t *e, const uint8_t *codes, int64_t rows)
         hipLaunchKernelGGL(class_flags_kernel, dim3((unsigned)((m + 255) / 256), (unsigned)g, (unsigned)n_units), dim3(256), 0, e->stream,
                            e->d_colbits, wpu, m, g, e->d_perm, e->d_flag);
         hipLaunchKernelGGL(class_ids_kernel, dim3((unsigned)(n_units * g)), dim3(kThreads), 0, e->stream, m, e->d_flag, e->d_cid);
-        // B: the true order before every unit, one sort per unit
-        ENC_TRY(hipMemcpyAsync(e->d_true, e->d_state, gm * 4, hipMemcpyDeviceToDevice, e->stream), return -1);
+        // B: the true order before every unit: one stable sort by class per unit, then all orders turned into ranks
         const unsigned nk = (unsigned)gm, kb = (nk + 255) / 256;
+        const int cbits = e->wpt ? 18 : 15;                 // bits of a class number
+        hipLaunchKernelGGL(invert_kernel, dim3(kb), dim3(256), 0, e->stream, m, (int64_t)gm, e->d_state, e->d_perms);
         for (int32_t k = 0; k < n_units; ++k) {
-            if (e->wpt) {
-                hipLaunchKernelGGL((sort_keys_kernel<uint64_t, 18>), dim3(kb), dim3(256), 0, e->stream, m, g, e->d_cid + (size_t)k * gm,
-                                   e->d_local + (size_t)k * gm, e->d_true + (size_t)k * gm, (uint64_t*)e->d_key[0], e->d_val[0]);
-                ENC_TRY(rocprim::radix_sort_pairs(e->d_temp, e->temp_bytes, (uint64_t*)e->d_key[0], (uint64_t*)e->d_key[1], e->d_val[0], e->d_val[1],
-                                                  nk, 0, 37, e->stream), return -1);
-            } else {
-                hipLaunchKernelGGL((sort_keys_kernel<uint32_t, 15>), dim3(kb), dim3(256), 0, e->stream, m, g, e->d_cid + (size_t)k * gm,
-                                   e->d_local + (size_t)k * gm, e->d_true + (size_t)k * gm, (uint32_t*)e->d_key[0], e->d_val[0]);
-                ENC_TRY(rocprim::radix_sort_pairs(e->d_temp, e->temp_bytes, (uint32_t*)e->d_key[0], (uint32_t*)e->d_key[1], e->d_val[0], e->d_val[1],
-                                                  nk, 0, 32, e->stream), return -1);
-            }
-            hipLaunchKernelGGL(ranks_from_sorted_kernel, dim3(kb), dim3(256), 0, e->stream, m, g, e->d_val[1], e->d_true + (size_t)(k + 1) * gm);
+            hipLaunchKernelGGL(class_keys_kernel, dim3(kb), dim3(256), 0, e->stream, m, g, cbits, e->d_cid + (size_t)k * gm,
+                               e->d_local + (size_t)k * gm, e->d_perms + (size_t)k * gm, e->d_key[0]);
+            ENC_TRY(rocprim::radix_sort_pairs(e->d_temp, e->temp_bytes, e->d_key[0], e->d_key[1], e->d_perms + (size_t)k * gm,
+                                              e->d_perms + (size_t)(k + 1) * gm, nk, 0, (unsigned)(cbits + (g > 1 ? 1 : 0)), e->stream), return -1);
+        }
+        {
+            const int64_t n_total = (int64_t)(n_units + 1) * (int64_t)gm;
+            hipLaunchKernelGGL(invert_kernel, dim3((unsigned)((n_total + 255) / 256)), dim3(256), 0, e->stream, m, n_total, e->d_perms, e->d_true);
         }
         ENC_TRY(hipMemcpyAsync(e->d_state, e->d_true + (size_t)n_units * gm, gm * 4, hipMemcpyDeviceToDevice, e->stream), return -1);
         // C: every unit from its true start order
@@ -757,6 +753,7 @@ static int encode_batch(bgth_encoder_t *e, const uint8_t *codes, int64_t rows)
 extern "C" int bgth_encoder_write(bgth_encoder_t *e, const uint8_t *codes, int64_t n_rows)
 {
     if (!e || (!codes && n_rows > 0) || n_rows < 0) { enc_err("[E::%s] bad argument", __func__); return -1; }
+    if (e->finished) { enc_err("[E::%s] the image is finished", __func__); return -1; }
     ENC_TRY(hipSetDevice(e->device), return -1);
     for (int64_t done = 0; done < n_rows;) {
         int64_t rows = n_rows - done;
@@ -770,6 +767,8 @@ extern "C" int bgth_encoder_write(bgth_encoder_t *e, const uint8_t *codes, int64
 extern "C" int64_t bgth_encoder_finish(bgth_encoder_t *e, uint8_t **image)
 {
     if (!e || !image) { enc_err("[E::%s] bad argument", __func__); return -1; }
+    if (e->finished) { enc_err("[E::%s] the image is finished", __func__); return -1; }
+    e->finished = true;
     const uint64_t off = (uint64_t)e->image.size();                                             // ref pbwt.c:264-277
     const int64_t n = e->n;
     const int32_t n_idx = (int32_t)e->idx.size();

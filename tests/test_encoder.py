@@ -197,3 +197,16 @@ def test_encoder_wide_cohorts(monkeypatch, m, rows, unit):
     enc.write(mat[:rows // 2])
     enc.write(mat[rows // 2:])
     assert enc.finish() == orc.encode_pbf(mat, 2, 3)
+
+
+@pytest.mark.gpu
+def test_encoder_empty_and_finished():
+    """no rows: header + footer, as pbf_open_w followed by pbf_close; nothing can follow the footer"""
+    import bgt_amd
+    enc = bgt_amd.HipEncoder(10, 2, 13)
+    enc.write(np.zeros((0, 10), np.uint8))
+    assert enc.finish() == orc.encode_pbf(np.zeros((0, 10), np.uint8), 2, 13)
+    with pytest.raises(RuntimeError):
+        enc.write(np.zeros((1, 10), np.uint8))
+    with pytest.raises(RuntimeError):
+        enc.finish()
