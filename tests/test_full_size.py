@@ -64,3 +64,31 @@ def test_plane_popcounts_match_counts_everywhere(n_samples, sites, seed):
         data = open(path, "rb").read()
     oc = orc.Pbf(data).scan(w0, w1).astype(np.int64)
     assert np.array_equal(oc, counts[w0:w1])
+
+
+@pytest.mark.parametrize("n_samples,sites,seed", [(10000, 131072, 2), (2504, 100000, 1), (100000, 6000, 3)])
+def test_decode_encode_round_trip_at_scale(n_samples, sites, seed, tmp_path):
+    """decode -> encode -> decode: the synthetic cohort's run-length strings come from the CPU generator; scanning them
+    gives the genotype matrix, the device WRITER turns the matrix back into a .pbf, and (1) that image scans back to the
+    same counts and genotypes, (2) its run-length strings are the generator's, byte for byte -- two independent encoders,
+    one on each side of the PCIe bus, agreeing on every row."""
+    import bgt_amd
+    m = 2 * n_samples
+    rle, lens = bgt_amd.synth_rows(m, 0, sites, seed)
+    src = bgt_amd.HipPbf.from_rle(m, 13, rle, lens)
+    counts, gt = bgt_amd.HipReader(src).scan(0, sites, want_gt=True)
+    codes = np.empty((sites, m), np.uint8)
+    for k in range(4):
+        codes[:, k::4] = ((gt >> (2 * k)) & 3)[:, :(m - k + 3) // 4]
+    enc = bgt_amd.HipEncoder(m, 2, 13)
+    half = sites // 2 + 7
+    enc.write(codes[:half])
+    enc.write(codes[half:])
+    image = enc.finish()
+    enc.close()
+    back = bgt_amd.HipPbf.from_bytes(image)
+    counts2, gt2 = bgt_amd.HipReader(back).scan(0, sites, want_gt=True)
+    assert np.array_equal(counts2, counts) and np.array_equal(gt2, gt)
+    path = str(tmp_path / "src.pbf")
+    src.save(path)
+    assert open(path, "rb").read() == image
