@@ -4,19 +4,22 @@
 // pbwt.c:57-66; run-length bytes pbwt.c:24-36).
 //
 // The encoder is the mirror image of the scan kernel.  One workgroup per bit plane keeps the RANK of every column
-// in registers (the reference moves the permutation array instead).  Per row:
-//   scatter    every column drops its bit at its rank into an LDS bit-vector              (a[S[j]] read backwards)
-//   directory  ones before every 32-bit word (block scan) and the positions where a run starts
-//   emit       every word-thread writes the run-length bytes of the runs that start in its word
-//   step       rank <- bit ? zeros + ones_before(rank) : rank - ones_before(rank)         (the stable partition)
+// in registers, complemented as in the scan (the reference moves the permutation array instead).  Per row:
+//   scatter    every column with a 1 drops it at its rank into an LDS rank directory {32 bits, ones before}  (ds_or)
+//   directory  ones before every 32-bit word (block scan); where runs end (w ^ (w >> 1 | next << 31))
+//   emit       the last position of every run goes into one list for the row (index: block scan of the run counts);
+//              thread k encodes run k -- its bit is the row's first bit ^ (k & 1) -- at the offset a third scan gives
+//   step       rank <- bit ? zeros + ones_before(rank) : rank - ones_before(rank)   (the stable partition; the scan's
+//              8-instruction step on the same directory layout)
 // Rows are sequential only in appearance -- row r is written in the order rows 0..r-1 left -- and planes are
 // independent.  The order at a row is a SORT: columns ordered by their bits read backwards from that row, ties in
 // the order they had before.  A call with many rows is therefore cut into UNITS of 4096 rows and runs as
 //   A  every unit and plane at once, from the identity order and without emitting: the order L the unit's own rows
-//      produce, then which neighbours in L are identical over the whole unit (classes)
-//   B  unit after unit (cheap): order after unit k = sort by (class in L_k, order before unit k)   [rocPRIM radix sort]
+//      produce; then which neighbours in L are identical over the whole unit (classes), on a bit-transposed copy
+//   B  unit after unit (cheap): the columns in the order before unit k, sorted stably by their class in L_k, are the
+//      order after it   [rocPRIM radix sort, 16-bit keys]; all orders turned into ranks by one kernel at the end
 //   C  every unit and plane at once, from its true start order: scatter / directory / emit / step as above.
-// A call with one unit is phase C alone.
+// A call with one unit is phase C alone.  Above 32768 columns (encode_wide_kernel) the ranks live in memory.
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
