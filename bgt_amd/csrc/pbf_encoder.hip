@@ -489,7 +489,8 @@ struct bgth_encoder_s {
     int64_t n = 0;                                   // rows written
     bool finished = false;
     int32_t cpt = 0, stride = 0;                     // device rows of codes are stride = cpt * 1024 bytes apart
-    int32_t unit_rows = 4096;                        // rows per parallel unit (BGTH_ENC_UNIT_SHIFT)
+    int32_t unit_rows = 4096;                        // most rows per parallel unit (BGTH_ENC_UNIT_SHIFT fixes the size)
+    bool unit_fixed = false;
     int64_t batch_rows = 0;                          // most rows per device pass
     int64_t rows_cap = 0;                            // what the buffers below hold
     int32_t units_cap = 0, snap_cap = 0;
@@ -559,7 +560,7 @@ extern "C" bgth_encoder_t *bgth_encoder_open(int32_t m, int32_t g, int32_t shift
     if (e->wpt) e->unit_rows = 1024;                 // wide rows are slow and large: smaller units, more of them at once
     if (const char *u = getenv("BGTH_ENC_UNIT_SHIFT")) {
         const int us = atoi(u);
-        if (us >= 1 && us <= 20) e->unit_rows = 1 << us;
+        if (us >= 1 && us <= 20) { e->unit_rows = 1 << us; e->unit_fixed = true; }
     }
     // one device pass: up to 12 GB of codes = 150 units of 4096 rows at 10,000 samples, two workgroups each (the
     // run-length output is sized for the worst case, one byte per bit: 36 GB of the 288 in all)
@@ -641,8 +642,12 @@ static int encode_batch(bgth_encoder_t *e, const uint8_t *codes, int64_t rows)
     const int m = e->m, g = e->g;
     const int64_t mask = ((int64_t)1 << e->shift) - 1;
     // units: a call of few rows, or more than two planes (the sort key holds one plane bit), is one unit
-    const bool parallel = rows > e->unit_rows && g <= 2;
-    const int64_t unit_rows = parallel ? e->unit_rows : rows;
+    // The time of a pass is the time of ONE workgroup over its unit (they all run at once), so a call that does not
+    // fill the chip with full-size units gets smaller ones: about one workgroup per CU, not below 512 rows.
+    int64_t want = e->unit_rows;
+    if (!e->unit_fixed) while (want > 512 && (rows + want - 1) / want * g < 256) want >>= 1;
+    const bool parallel = rows > want && g <= 2;
+    const int64_t unit_rows = parallel ? want : rows;
     const int32_t n_units = (int32_t)((rows + unit_rows - 1) / unit_rows);
     e->h_snap_base.assign((size_t)n_units, 0);
     int32_t n_snap = 0;
