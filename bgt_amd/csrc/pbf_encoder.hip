@@ -643,9 +643,11 @@ static int encode_batch(bgth_encoder_t *e, const uint8_t *codes, int64_t rows)
     const int64_t mask = ((int64_t)1 << e->shift) - 1;
     // units: a call of few rows, or more than two planes (the sort key holds one plane bit), is one unit
     // The time of a pass is the time of ONE workgroup over its unit (they all run at once), so a call that does not
-    // fill the chip with full-size units gets smaller ones: about one workgroup per CU, not below 512 rows.
+    // fill the chip with full-size units gets smaller ones: about one workgroup per CU.
     int64_t want = e->unit_rows;
-    if (!e->unit_fixed) while (want > 512 && (rows + want - 1) / want * g < 256) want >>= 1;
+    // (the chain of phase B grows with the number of units: below ~sqrt(9 rows) narrow / sqrt(1.4 rows) wide it costs more than it saves)
+    const int64_t least = e->wpt ? 256 : 512;
+    if (!e->unit_fixed) while (want > least && (rows + want - 1) / want * g < 256) want >>= 1;
     const bool parallel = rows > want && g <= 2;
     const int64_t unit_rows = parallel ? want : rows;
     const int32_t n_units = (int32_t)((rows + unit_rows - 1) / unit_rows);
