@@ -45,9 +45,23 @@ assert np.array_equal(back.scan(0, rows), counts), "the encoded image does not s
 
 import orc  # noqa: E402  (checker + CPU baseline)
 n_cpu = min(args.cpu_rows, rows)
-t0 = time.time()
 ref = orc.encode_pbf(codes[:n_cpu], 2, shift)
+# the CPU baseline: the oracle writer alone, its g byte arrays per row prepared beforehand (what import.c hands over)
+import ctypes as C  # noqa: E402
+p0 = np.ascontiguousarray(codes[:n_cpu] & 1)
+p1 = np.ascontiguousarray(codes[:n_cpu] >> 1)
+w = orc.lib.orc_pbw_new(m, 2, shift)
+planes = (orc.u8p * 2)()
+a0, a1 = p0.ctypes.data, p1.ctypes.data
+t0 = time.time()
+for r in range(n_cpu):
+    planes[0] = C.cast(a0 + r * m, orc.u8p)
+    planes[1] = C.cast(a1 + r * m, orc.u8p)
+    orc.lib.orc_pbw_row(w, planes)
 cpu_s = time.time() - t0
+out = orc.u8p()
+n_out = orc.lib.orc_pbw_finish(w, C.byref(out))
+assert C.string_at(out, n_out) == ref
 enc2 = bgt_amd.HipEncoder(m, 2, shift)
 enc2.write(codes[:n_cpu])
 assert enc2.finish() == ref, "device image differs from the oracle writer"
