@@ -26,6 +26,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <cstring>
+#include <chrono>
 #include <vector>
 #include <rocprim/rocprim.hpp>
 #include "../../include/bgt_hip.h"
@@ -467,6 +468,14 @@ __global__ __launch_bounds__(256) void invert_kernel(int m, int64_t n_total, con
     dst[base + src[i]] = (int32_t)(i - base);
 }
 
+// the used part of every (unit, plane) output region, one after the other: one download instead of hundreds
+__global__ __launch_bounds__(kThreads) void compact_kernel(const uint8_t *out, int64_t cap, const int64_t *base, uint8_t *packed)
+{
+    const int64_t b0 = base[blockIdx.x], n = base[blockIdx.x + 1] - b0;
+    const uint8_t *src = out + (size_t)blockIdx.x * cap;
+    for (int64_t i = threadIdx.x; i < n; i += kThreads) packed[b0 + i] = src[i];
+}
+
 thread_local char g_enc_err[256] = "";
 void enc_err(const char *fmt, ...)
 {
@@ -496,6 +505,9 @@ struct bgth_encoder_s {
     int32_t units_cap = 0, snap_cap = 0;
     hipStream_t stream = nullptr;
     uint8_t *d_codes = nullptr, *d_out = nullptr, *d_flag = nullptr;
+    uint8_t *d_packed = nullptr;                     // the run-length bytes of a pass, regions closed up
+    int64_t *d_base = nullptr;
+    size_t packed_cap = 0, base_cap = 0;
     uint32_t *d_colbits = nullptr;                   // [units * ceil(unit_rows / 32)][2][m] the columns of every unit as bits
     size_t colbits_cap = 0;
     int32_t *d_state = nullptr;                      // [g][m] order after the last row written
@@ -509,7 +521,8 @@ struct bgth_encoder_s {
     int64_t *d_out_len = nullptr;
     std::vector<uint8_t> image;
     std::vector<uint64_t> idx;
-    std::vector<uint8_t> h_out;
+    uint8_t *h_out = nullptr;                        // pinned: the packed run-length bytes of a pass
+    size_t h_out_cap = 0;
     std::vector<int32_t> h_row_len, h_snap, h_snap_base;
     std::vector<int64_t> h_out_len;
     double kernel_ms = 0.0;
@@ -533,7 +546,7 @@ extern "C" void bgth_encoder_close(bgth_encoder_t *e)
     if (!e) return;
     hipSetDevice(e->device);
     free_batch_buffers(e);
-    hipFree(e->d_state); hipFree(e->d_status); hipFree(e->d_temp); hipFree(e->d_colbits);
+    hipFree(e->d_state); hipFree(e->d_status); hipFree(e->d_temp); hipFree(e->d_colbits); hipFree(e->d_packed); hipFree(e->d_base); hipHostFree(e->h_out);
     for (int i = 0; i < 2; ++i) hipFree(e->d_key[i]);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
@@ -637,8 +650,12 @@ static void launch_encode(const bgth_encoder_t *e, const EncodeArgs &a, int n_un
     else                   hipLaunchKernelGGL((encode_kernel<32, EMIT>), grid, block, 0, e->stream, a);
 }
 
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 static int encode_batch(bgth_encoder_t *e, const uint8_t *codes, int64_t rows)
 {
+    const bool trace = getenv("BGTH_TRACE") != nullptr;
+    const double t_begin = now_ms();
     const int m = e->m, g = e->g;
     const int64_t mask = ((int64_t)1 << e->shift) - 1;
     // units: a call of few rows, or more than two planes (the sort key holds one plane bit), is one unit
@@ -658,6 +675,7 @@ static int encode_batch(bgth_encoder_t *e, const uint8_t *codes, int64_t rows)
         if (((e->n + r) & mask) == 0) ++n_snap;
     }
     if (ensure_capacity(e, (int64_t)n_units * unit_rows, n_units, n_snap) < 0) return -1;
+    const double t_alloc = now_ms();
     const size_t gm = (size_t)g * m;
     EncodeArgs a;
     a.codes = e->d_codes; a.n_rows = rows; a.row0 = e->n; a.m = m; a.mask = (int32_t)mask; a.g = g; a.unit_rows = (int32_t)unit_rows; a.stride = e->stride;
@@ -667,6 +685,8 @@ static int encode_batch(bgth_encoder_t *e, const uint8_t *codes, int64_t rows)
     ENC_TRY(hipMemcpy2DAsync(e->d_codes, (size_t)e->stride, codes, (size_t)m, (size_t)m, (size_t)rows, hipMemcpyHostToDevice, e->stream), return -1);
     ENC_TRY(hipMemcpyAsync(e->d_snap_base, e->h_snap_base.data(), (size_t)n_units * 4, hipMemcpyHostToDevice, e->stream), return -1);
     ENC_TRY(hipMemsetAsync(e->d_status, 0, 4, e->stream), return -1);
+    if (trace) hipStreamSynchronize(e->stream);
+    const double t_up = now_ms();
     hipEvent_t ev0, ev1;
     ENC_TRY(hipEventCreate(&ev0), return -1);
     ENC_TRY(hipEventCreate(&ev1), return -1);
@@ -725,38 +745,63 @@ static int encode_batch(bgth_encoder_t *e, const uint8_t *codes, int64_t rows)
     e->kernel_ms += ms;
     hipEventDestroy(ev0); hipEventDestroy(ev1);
     if (status != 0) { enc_err("[E::%s] run-length output exceeded its buffer", __func__); return -1; }
-    // the run-length bytes of every (unit, plane), packed one after the other on the host
-    std::vector<size_t> base((size_t)n_units * g + 1, 0);
-    for (size_t i = 0; i < e->h_out_len.size(); ++i) base[i + 1] = base[i] + (size_t)e->h_out_len[i];
-    e->h_out.resize(base.back() ? base.back() : 1);
-    for (size_t i = 0; i < e->h_out_len.size(); ++i)
-        if (e->h_out_len[i]) ENC_TRY(hipMemcpyAsync(e->h_out.data() + base[i], e->d_out + i * (size_t)a.cap, (size_t)e->h_out_len[i],
-                                                    hipMemcpyDeviceToHost, e->stream), return -1);
-    ENC_TRY(hipStreamSynchronize(e->stream), return -1);
+    // the run-length bytes of every (unit, plane), packed one after the other
+    std::vector<int64_t> base((size_t)n_units * g + 1, 0);
+    for (size_t i = 0; i < e->h_out_len.size(); ++i) base[i + 1] = base[i] + e->h_out_len[i];
+    if (base.back() > 0) {
+        if ((size_t)base.back() > e->h_out_cap) {
+            hipHostFree(e->h_out); e->h_out = nullptr; e->h_out_cap = 0;
+            ENC_TRY(hipHostMalloc(&e->h_out, (size_t)base.back(), hipHostMallocDefault), return -1);
+            e->h_out_cap = (size_t)base.back();
+        }
+        if ((size_t)base.back() > e->packed_cap) {
+            hipFree(e->d_packed); e->d_packed = nullptr; e->packed_cap = 0;
+            ENC_TRY(hipMalloc(&e->d_packed, (size_t)base.back()), return -1);
+            e->packed_cap = (size_t)base.back();
+        }
+        if (base.size() > e->base_cap) {
+            hipFree(e->d_base); e->d_base = nullptr; e->base_cap = 0;
+            ENC_TRY(hipMalloc(&e->d_base, base.size() * 8), return -1);
+            e->base_cap = base.size();
+        }
+        ENC_TRY(hipMemcpyAsync(e->d_base, base.data(), base.size() * 8, hipMemcpyHostToDevice, e->stream), return -1);
+        hipLaunchKernelGGL(compact_kernel, dim3((unsigned)(n_units * g)), dim3(kThreads), 0, e->stream, e->d_out, a.cap, e->d_base, e->d_packed);
+        ENC_TRY(hipMemcpyAsync(e->h_out, e->d_packed, (size_t)base.back(), hipMemcpyDeviceToHost, e->stream), return -1);
+        ENC_TRY(hipStreamSynchronize(e->stream), return -1);
+    }
+    const double t_down = now_ms();
     // ---- records in file order (ref pbwt.c:288-311): ['S' perms]  'B' { int32 len, bytes } per plane
+    size_t grow = (size_t)rows * (1 + 4 * (size_t)g) + (size_t)base.back() + (size_t)n_snap * (1 + (size_t)g * m * 4);
+    const size_t old_size = e->image.size();
+    e->image.resize(old_size + grow);
+    uint8_t *wp = e->image.data() + old_size;
     std::vector<size_t> at((size_t)g, 0);
     int32_t si = 0;
     for (int64_t r = 0; r < rows; ++r) {
-        if (r % unit_rows == 0) for (int k = 0; k < g; ++k) at[(size_t)k] = base[(size_t)(r / unit_rows) * g + k];
+        if (r % unit_rows == 0) for (int k = 0; k < g; ++k) at[(size_t)k] = (size_t)base[(size_t)(r / unit_rows) * g + k];
         if (((e->n + r) & mask) == 0) {
-            e->idx.push_back((uint64_t)e->image.size());
-            e->image.push_back('S');
+            e->idx.push_back((uint64_t)(wp - e->image.data()));
+            *wp++ = 'S';
             for (int k = 0; k < g; ++k) {
-                const uint8_t *p = (const uint8_t*)(e->h_snap.data() + ((size_t)k * n_snap + si) * m);
-                e->image.insert(e->image.end(), p, p + (size_t)m * 4);
+                memcpy(wp, e->h_snap.data() + ((size_t)k * n_snap + si) * m, (size_t)m * 4);
+                wp += (size_t)m * 4;
             }
             ++si;
         }
-        e->image.push_back('B');
+        *wp++ = 'B';
         for (int k = 0; k < g; ++k) {
             const int32_t l = e->h_row_len[(size_t)k * rows + r];
-            const uint8_t *p = e->h_out.data() + at[(size_t)k];
-            e->image.insert(e->image.end(), (const uint8_t*)&l, (const uint8_t*)&l + 4);
-            e->image.insert(e->image.end(), p, p + l);
+            memcpy(wp, &l, 4);
+            memcpy(wp + 4, e->h_out + at[(size_t)k], (size_t)l);
+            wp += 4 + (size_t)l;
             at[(size_t)k] += (size_t)l;
         }
     }
+    if (wp != e->image.data() + e->image.size()) { enc_err("[E::%s] record sizes do not add up", __func__); return -1; }
     e->n += rows;
+    if (trace)
+        fprintf(stderr, "[bgth_encoder] %lld rows, %d units of %lld: buffers %.1f ms, upload %.1f, device + download %.1f (kernels %.1f), records %.1f\n",
+                (long long)rows, n_units, (long long)unit_rows, t_alloc - t_begin, t_up - t_alloc, t_down - t_up, (double)ms, now_ms() - t_down);
     return 0;
 }
 
