@@ -468,6 +468,22 @@ __global__ __launch_bounds__(256) void invert_kernel(int m, int64_t n_total, con
     dst[base + src[i]] = (int32_t)(i - base);
 }
 
+// rows of 2-bit codes, four columns to a byte (column c in bits 2 (c & 3) of byte c >> 2: the layout the reader's
+// genotype rows have), spread to one byte per column with zero padding
+__global__ __launch_bounds__(256) void unpack_codes_kernel(const uint8_t *packed, int64_t n_rows, int m, int stride, uint8_t *codes)
+{
+    const int pb = (m + 3) >> 2;
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= pb) return;
+    const int left = m - 4 * b;                              // columns of this byte that exist
+    const uint32_t keep = left < 4 ? (1u << (8 * left)) - 1u : 0xffffffffu;
+    for (int64_t r = blockIdx.y; r < n_rows; r += gridDim.y) {
+        const uint32_t x = packed[(size_t)r * pb + b];
+        const uint32_t w = (x & 3u) | ((x >> 2) & 3u) << 8 | ((x >> 4) & 3u) << 16 | ((x >> 6) & 3u) << 24;
+        *reinterpret_cast<uint32_t*>(codes + (size_t)r * stride + 4 * b) = w & keep;
+    }
+}
+
 // the used part of every (unit, plane) output region, one after the other: one download instead of hundreds
 __global__ __launch_bounds__(kThreads) void compact_kernel(const uint8_t *out, int64_t cap, const int64_t *base, uint8_t *packed)
 {
@@ -505,6 +521,8 @@ struct bgth_encoder_s {
     int32_t units_cap = 0, snap_cap = 0;
     hipStream_t stream = nullptr;
     uint8_t *d_codes = nullptr, *d_out = nullptr, *d_flag = nullptr;
+    uint8_t *d_packed_in = nullptr;                  // bgth_encoder_write_packed: the rows as they came
+    size_t packed_in_cap = 0;
     uint8_t *d_packed = nullptr;                     // the run-length bytes of a pass, regions closed up
     int64_t *d_base = nullptr;
     size_t packed_cap = 0, base_cap = 0;
@@ -546,7 +564,7 @@ extern "C" void bgth_encoder_close(bgth_encoder_t *e)
     if (!e) return;
     hipSetDevice(e->device);
     free_batch_buffers(e);
-    hipFree(e->d_state); hipFree(e->d_status); hipFree(e->d_temp); hipFree(e->d_colbits); hipFree(e->d_packed); hipFree(e->d_base); hipHostFree(e->h_out);
+    hipFree(e->d_state); hipFree(e->d_status); hipFree(e->d_temp); hipFree(e->d_colbits); hipFree(e->d_packed); hipFree(e->d_packed_in); hipFree(e->d_base); hipHostFree(e->h_out);
     for (int i = 0; i < 2; ++i) hipFree(e->d_key[i]);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
@@ -652,7 +670,7 @@ static void launch_encode(const bgth_encoder_t *e, const EncodeArgs &a, int n_un
 
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-static int encode_batch(bgth_encoder_t *e, const uint8_t *codes, int64_t rows)
+static int encode_batch(bgth_encoder_t *e, const uint8_t *codes, int64_t rows, bool packed)
 {
     const bool trace = getenv("BGTH_TRACE") != nullptr;
     const double t_begin = now_ms();
@@ -682,7 +700,18 @@ static int encode_batch(bgth_encoder_t *e, const uint8_t *codes, int64_t rows)
     a.debug = getenv("BGTH_ENC_DEBUG") ? atoi(getenv("BGTH_ENC_DEBUG")) : 0;
     a.out = e->d_out; a.cap = unit_rows * (int64_t)m; a.out_len = e->d_out_len; a.row_len = e->d_row_len;
     a.snap = e->d_snap; a.snap_base = e->d_snap_base; a.n_snap = n_snap; a.status = e->d_status;
-    ENC_TRY(hipMemcpy2DAsync(e->d_codes, (size_t)e->stride, codes, (size_t)m, (size_t)m, (size_t)rows, hipMemcpyHostToDevice, e->stream), return -1);
+    if (packed) {                                           // a quarter of the bytes over PCIe, spread on the device
+        const size_t nb = (size_t)rows * ((m + 3) >> 2);
+        if (nb > e->packed_in_cap) {
+            hipFree(e->d_packed_in); e->d_packed_in = nullptr; e->packed_in_cap = 0;
+            ENC_TRY(hipMalloc(&e->d_packed_in, nb), return -1);
+            e->packed_in_cap = nb;
+        }
+        ENC_TRY(hipMemcpyAsync(e->d_packed_in, codes, nb, hipMemcpyHostToDevice, e->stream), return -1);
+        hipLaunchKernelGGL(unpack_codes_kernel, dim3((unsigned)((((m + 3) >> 2) + 255) / 256), (unsigned)(rows < 16384 ? rows : 16384)), dim3(256), 0, e->stream,
+                           e->d_packed_in, rows, m, e->stride, e->d_codes);
+    } else
+        ENC_TRY(hipMemcpy2DAsync(e->d_codes, (size_t)e->stride, codes, (size_t)m, (size_t)m, (size_t)rows, hipMemcpyHostToDevice, e->stream), return -1);
     ENC_TRY(hipMemcpyAsync(e->d_snap_base, e->h_snap_base.data(), (size_t)n_units * 4, hipMemcpyHostToDevice, e->stream), return -1);
     ENC_TRY(hipMemsetAsync(e->d_status, 0, 4, e->stream), return -1);
     if (trace) hipStreamSynchronize(e->stream);
@@ -805,19 +834,23 @@ static int encode_batch(bgth_encoder_t *e, const uint8_t *codes, int64_t rows)
     return 0;
 }
 
-extern "C" int bgth_encoder_write(bgth_encoder_t *e, const uint8_t *codes, int64_t n_rows)
+static int write_rows(bgth_encoder_t *e, const uint8_t *codes, int64_t n_rows, bool packed, const char *who)
 {
-    if (!e || (!codes && n_rows > 0) || n_rows < 0) { enc_err("[E::%s] bad argument", __func__); return -1; }
-    if (e->finished) { enc_err("[E::%s] the image is finished", __func__); return -1; }
+    if (!e || (!codes && n_rows > 0) || n_rows < 0) { enc_err("[E::%s] bad argument", who); return -1; }
+    if (e->finished) { enc_err("[E::%s] the image is finished", who); return -1; }
     ENC_TRY(hipSetDevice(e->device), return -1);
+    const size_t row_bytes = packed ? (size_t)((e->m + 3) >> 2) : (size_t)e->m;
     for (int64_t done = 0; done < n_rows;) {
         int64_t rows = n_rows - done;
         if (rows > e->batch_rows) rows = e->batch_rows;
-        if (encode_batch(e, codes + (size_t)done * e->m, rows) < 0) return -1;
+        if (encode_batch(e, codes + (size_t)done * row_bytes, rows, packed) < 0) return -1;
         done += rows;
     }
     return 0;
 }
+
+extern "C" int bgth_encoder_write(bgth_encoder_t *e, const uint8_t *codes, int64_t n_rows) { return write_rows(e, codes, n_rows, false, __func__); }
+extern "C" int bgth_encoder_write_packed(bgth_encoder_t *e, const uint8_t *packed, int64_t n_rows) { return write_rows(e, packed, n_rows, true, __func__); }
 
 extern "C" int64_t bgth_encoder_finish(bgth_encoder_t *e, uint8_t **image)
 {

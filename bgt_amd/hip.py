@@ -316,6 +316,7 @@ class HipEncoder:
         L.bgth_encoder_open.restype = C.c_void_p
         L.bgth_encoder_open.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int]
         L.bgth_encoder_write.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.bgth_encoder_write_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.bgth_encoder_finish.restype = C.c_int64
         L.bgth_encoder_finish.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.bgth_encoder_free_image.argtypes = [C.c_void_p]
@@ -333,6 +334,13 @@ class HipEncoder:
         codes = np.ascontiguousarray(codes, np.uint8)
         assert codes.ndim == 2 and codes.shape[1] == self.m
         if lib().bgth_encoder_write(self.h, codes.ctypes.data, codes.shape[0]) < 0:
+            raise RuntimeError(lib().bgth_encoder_last_error().decode())
+
+    def write_packed(self, packed):
+        """packed: (rows, (m + 3) // 4) uint8, four 2-bit codes per byte -- the genotype rows HipReader.scan(want_gt=True) returns."""
+        packed = np.ascontiguousarray(packed, np.uint8)
+        assert packed.ndim == 2 and packed.shape[1] == (self.m + 3) // 4
+        if lib().bgth_encoder_write_packed(self.h, packed.ctypes.data, packed.shape[0]) < 0:
             raise RuntimeError(lib().bgth_encoder_last_error().decode())
 
     def finish(self):

@@ -74,6 +74,9 @@ int64_t     bgth_pbf_rle_bytes(const bgth_pbf_t *p);   /* total RLE payload     
 typedef struct bgth_encoder_s bgth_encoder_t;
 bgth_encoder_t *bgth_encoder_open(int32_t m, int32_t g, int32_t shift, int device);      /* NULL on failure       */
 int             bgth_encoder_write(bgth_encoder_t *e, const uint8_t *codes, int64_t n_rows);   /* <0 on failure   */
+/* the same rows with four columns to a byte (column c in bits 2 (c & 3) of byte c >> 2, (m + 3) / 4 bytes per row):
+ * the 2-bit rows bgth_reader_scan hands out; a quarter of the bytes cross PCIe (g <= 2) */
+int             bgth_encoder_write_packed(bgth_encoder_t *e, const uint8_t *packed, int64_t n_rows);
 int64_t         bgth_encoder_finish(bgth_encoder_t *e, uint8_t **image);   /* footer; bytes of the malloc'd image */
 void            bgth_encoder_free_image(uint8_t *image);
 void            bgth_encoder_close(bgth_encoder_t *e);

@@ -27,7 +27,7 @@ def decode_all(data):
 def test_encoder_symbols_exported():
     import bgt_amd
     L = bgt_amd.lib()
-    for name in ("bgth_encoder_open", "bgth_encoder_write", "bgth_encoder_finish", "bgth_encoder_free_image",
+    for name in ("bgth_encoder_open", "bgth_encoder_write", "bgth_encoder_write_packed", "bgth_encoder_finish", "bgth_encoder_free_image",
                  "bgth_encoder_close", "bgth_encoder_kernel_ms", "bgth_encoder_last_error"):
         assert hasattr(L, name)
 
@@ -210,3 +210,21 @@ def test_encoder_empty_and_finished():
         enc.write(np.zeros((1, 10), np.uint8))
     with pytest.raises(RuntimeError):
         enc.finish()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,rows", [(1, 9), (5, 40), (4096, 100), (5007, 150), (20001, 120), (70002, 40)])
+def test_encoder_packed_rows(m, rows):
+    """four columns to a byte, the layout of the reader's genotype rows: same image; bits beyond column m are ignored"""
+    import bgt_amd
+    rng = np.random.default_rng(m)
+    mat = scenarios.ld_matrix(rng, rows, m, n_founders=6, switch=0.01)
+    pad = np.zeros((rows, (m + 3) // 4 * 4), np.uint8)
+    pad[:, :m] = mat
+    pad[:, m:] = 3                                            # garbage in the padding bits
+    packed = (pad[:, 0::4] | pad[:, 1::4] << 2 | pad[:, 2::4] << 4 | pad[:, 3::4] << 6).astype(np.uint8)
+    enc = bgt_amd.HipEncoder(m, 2, 4)
+    enc.write_packed(packed[:rows // 3])
+    enc.write(mat[rows // 3:rows // 2])                       # the two forms may alternate
+    enc.write_packed(packed[rows // 2:])
+    assert enc.finish() == orc.encode_pbf(mat, 2, 4)

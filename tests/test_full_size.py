@@ -83,7 +83,7 @@ def test_decode_encode_round_trip_at_scale(n_samples, sites, seed, tmp_path):
     enc = bgt_amd.HipEncoder(m, 2, 13)
     half = sites // 2 + 7
     enc.write(codes[:half])
-    enc.write(codes[half:])
+    enc.write_packed(gt[half:])                               # the reader's 2-bit rows go straight back in
     image = enc.finish()
     enc.close()
     back = bgt_amd.HipPbf.from_bytes(image)
