@@ -228,3 +228,18 @@ def test_encoder_packed_rows(m, rows):
     enc.write(mat[rows // 3:rows // 2])                       # the two forms may alternate
     enc.write_packed(packed[rows // 2:])
     assert enc.finish() == orc.encode_pbf(mat, 2, 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("g", [3, 8])
+def test_encoder_more_than_two_planes(small_units, g):
+    """the container allows any number of planes (pbwt.c:199-219); beyond two the rows of a call are one unit"""
+    import bgt_amd
+    rng = np.random.default_rng(g)
+    m, rows = 700, 150
+    mat = rng.integers(0, 1 << g, (rows, m)).astype(np.uint8)
+    mat[20:60] &= 5
+    enc = bgt_amd.HipEncoder(m, g, 4)
+    enc.write(mat[:90])
+    enc.write(mat[90:])
+    assert enc.finish() == orc.encode_pbf(mat, g, 4)
