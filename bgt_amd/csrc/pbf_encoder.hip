@@ -513,6 +513,7 @@ struct bgth_encoder_s {
     int32_t m = 0, g = 0, shift = 0, device = 0;
     int64_t n = 0;                                   // rows written
     bool finished = false;
+    bool broken = false;                             // a pass failed half way: the order on the device is ahead of the image
     int32_t cpt = 0, stride = 0;                     // device rows of codes are stride = cpt * 1024 bytes apart
     int32_t unit_rows = 4096;                        // most rows per parallel unit (BGTH_ENC_UNIT_SHIFT fixes the size)
     bool unit_fixed = false;
@@ -838,12 +839,13 @@ static int write_rows(bgth_encoder_t *e, const uint8_t *codes, int64_t n_rows, b
 {
     if (!e || (!codes && n_rows > 0) || n_rows < 0) { enc_err("[E::%s] bad argument", who); return -1; }
     if (e->finished) { enc_err("[E::%s] the image is finished", who); return -1; }
+    if (e->broken) { enc_err("[E::%s] an earlier write failed; close this encoder", who); return -1; }
     ENC_TRY(hipSetDevice(e->device), return -1);
     const size_t row_bytes = packed ? (size_t)((e->m + 3) >> 2) : (size_t)e->m;
     for (int64_t done = 0; done < n_rows;) {
         int64_t rows = n_rows - done;
         if (rows > e->batch_rows) rows = e->batch_rows;
-        if (encode_batch(e, codes + (size_t)done * row_bytes, rows, packed) < 0) return -1;
+        if (encode_batch(e, codes + (size_t)done * row_bytes, rows, packed) < 0) { e->broken = true; return -1; }
         done += rows;
     }
     return 0;
@@ -856,6 +858,7 @@ extern "C" int64_t bgth_encoder_finish(bgth_encoder_t *e, uint8_t **image)
 {
     if (!e || !image) { enc_err("[E::%s] bad argument", __func__); return -1; }
     if (e->finished) { enc_err("[E::%s] the image is finished", __func__); return -1; }
+    if (e->broken) { enc_err("[E::%s] an earlier write failed; there is no complete image", __func__); return -1; }
     e->finished = true;
     const uint64_t off = (uint64_t)e->image.size();                                             // ref pbwt.c:264-277
     const int64_t n = e->n;
