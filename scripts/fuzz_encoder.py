@@ -45,7 +45,12 @@ while time.time() < t_end:
     enc = bgt_amd.HipEncoder(m, g, shift)
     cuts = np.unique(np.concatenate([[0, rows], rng.integers(0, rows + 1, int(rng.integers(0, 4)))]))
     for lo, hi in zip(cuts[:-1], cuts[1:]):
-        enc.write(mat[lo:hi])
+        if rng.random() < 0.4:                                # the same rows four columns to a byte
+            pad = np.zeros((hi - lo, (m + 3) // 4 * 4), np.uint8)
+            pad[:, :m] = mat[lo:hi]
+            enc.write_packed((pad[:, 0::4] | pad[:, 1::4] << 2 | pad[:, 2::4] << 4 | pad[:, 3::4] << 6).astype(np.uint8))
+        else:
+            enc.write(mat[lo:hi])
     got = enc.finish()
     enc.close()
     want = orc.encode_pbf(mat, g, shift)
