@@ -243,3 +243,20 @@ def test_encoder_more_than_two_planes(small_units, g):
     enc.write(mat[:90])
     enc.write(mat[90:])
     assert enc.finish() == orc.encode_pbf(mat, g, 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["bgt/synA.pbf", "bgt/synB.pbf"])
+def test_reader_rows_feed_the_writer(name, tmp_path):
+    """scripts/subset_pbf.py: a sub-cohort through reader -> packed rows -> writer equals the oracle's encoding of the same
+    columns of the reference-written file"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("subset_pbf", os.path.join(ROOT, "scripts", "subset_pbf.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    data = open(os.path.join(GOLD, name), "rb").read()
+    rows, m, g, shift = decode_all(data)
+    cols = np.arange(4, m - 6)                                # drop two samples in front, three at the end
+    out = str(tmp_path / "sub.pbf")
+    mod.subset_pbf(os.path.join(GOLD, name), out, cols, chunk=11)
+    assert open(out, "rb").read() == orc.encode_pbf(rows[:, cols], g, shift)
