@@ -513,6 +513,7 @@ struct bgth_encoder_s {
     int32_t m = 0, g = 0, shift = 0, device = 0;
     int64_t n = 0;                                   // rows written
     bool finished = false;
+    uint64_t taken = 0;                              // bytes of the file already handed out by bgth_encoder_take
     bool broken = false;                             // a pass failed half way: the order on the device is ahead of the image
     int32_t cpt = 0, stride = 0;                     // device rows of codes are stride = cpt * 1024 bytes apart
     int32_t unit_rows = 4096;                        // most rows per parallel unit (BGTH_ENC_UNIT_SHIFT fixes the size)
@@ -810,7 +811,7 @@ static int encode_batch(bgth_encoder_t *e, const uint8_t *codes, int64_t rows, b
     for (int64_t r = 0; r < rows; ++r) {
         if (r % unit_rows == 0) for (int k = 0; k < g; ++k) at[(size_t)k] = (size_t)base[(size_t)(r / unit_rows) * g + k];
         if (((e->n + r) & mask) == 0) {
-            e->idx.push_back((uint64_t)(wp - e->image.data()));
+            e->idx.push_back(e->taken + (uint64_t)(wp - e->image.data()));
             *wp++ = 'S';
             for (int k = 0; k < g; ++k) {
                 memcpy(wp, e->h_snap.data() + ((size_t)k * n_snap + si) * m, (size_t)m * 4);
@@ -860,7 +861,7 @@ extern "C" int64_t bgth_encoder_finish(bgth_encoder_t *e, uint8_t **image)
     if (e->finished) { enc_err("[E::%s] the image is finished", __func__); return -1; }
     if (e->broken) { enc_err("[E::%s] an earlier write failed; there is no complete image", __func__); return -1; }
     e->finished = true;
-    const uint64_t off = (uint64_t)e->image.size();                                             // ref pbwt.c:264-277
+    const uint64_t off = e->taken + (uint64_t)e->image.size();                                  // ref pbwt.c:264-277
     const int64_t n = e->n;
     const int32_t n_idx = (int32_t)e->idx.size();
     e->image.push_back('I');
@@ -873,6 +874,20 @@ extern "C" int64_t bgth_encoder_finish(bgth_encoder_t *e, uint8_t **image)
     memcpy(p, e->image.data(), e->image.size());
     *image = p;
     return (int64_t)e->image.size();
+}
+
+extern "C" int64_t bgth_encoder_take(bgth_encoder_t *e, uint8_t **chunk)
+{
+    if (!e || !chunk) { enc_err("[E::%s] bad argument", __func__); return -1; }
+    if (e->finished || e->broken) { enc_err("[E::%s] nothing to take from a finished or failed encoder", __func__); return -1; }
+    const size_t n = e->image.size();
+    uint8_t *p = (uint8_t*)malloc(n ? n : 1);
+    if (!p) { enc_err("[E::%s] out of memory", __func__); return -1; }
+    memcpy(p, e->image.data(), n);
+    e->taken += n;
+    e->image.clear();
+    *chunk = p;
+    return (int64_t)n;
 }
 
 extern "C" void bgth_encoder_free_image(uint8_t *image) { free(image); }

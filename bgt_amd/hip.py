@@ -317,6 +317,8 @@ class HipEncoder:
         L.bgth_encoder_open.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int]
         L.bgth_encoder_write.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.bgth_encoder_write_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.bgth_encoder_take.restype = C.c_int64
+        L.bgth_encoder_take.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.bgth_encoder_finish.restype = C.c_int64
         L.bgth_encoder_finish.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.bgth_encoder_free_image.argtypes = [C.c_void_p]
@@ -343,8 +345,18 @@ class HipEncoder:
         if lib().bgth_encoder_write_packed(self.h, packed.ctypes.data, packed.shape[0]) < 0:
             raise RuntimeError(lib().bgth_encoder_last_error().decode())
 
+    def take(self):
+        """The bytes of the file produced so far; the encoder forgets them (stream them to the file)."""
+        out = C.c_void_p()
+        n = lib().bgth_encoder_take(self.h, C.byref(out))
+        if n < 0:
+            raise RuntimeError(lib().bgth_encoder_last_error().decode())
+        data = C.string_at(out, n)
+        lib().bgth_encoder_free_image(out)
+        return data
+
     def finish(self):
-        """The complete image (header, records, footer) as bytes."""
+        """The rest of the image (everything not taken yet, and the footer) as bytes."""
         out = C.c_void_p()
         n = lib().bgth_encoder_finish(self.h, C.byref(out))
         if n < 0:

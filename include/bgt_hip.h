@@ -77,6 +77,9 @@ int             bgth_encoder_write(bgth_encoder_t *e, const uint8_t *codes, int6
 /* the same rows with four columns to a byte (column c in bits 2 (c & 3) of byte c >> 2, (m + 3) / 4 bytes per row):
  * the 2-bit rows bgth_reader_scan hands out; a quarter of the bytes cross PCIe (g <= 2) */
 int             bgth_encoder_write_packed(bgth_encoder_t *e, const uint8_t *packed, int64_t n_rows);
+/* Streaming: the bytes of the file produced so far (header, records), malloc'd, and forgotten by the encoder -- write
+ * them out and the image never has to fit the host memory; bgth_encoder_finish then returns the rest and the footer. */
+int64_t         bgth_encoder_take(bgth_encoder_t *e, uint8_t **chunk);
 int64_t         bgth_encoder_finish(bgth_encoder_t *e, uint8_t **image);   /* footer; bytes of the malloc'd image */
 void            bgth_encoder_free_image(uint8_t *image);
 void            bgth_encoder_close(bgth_encoder_t *e);

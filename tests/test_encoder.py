@@ -27,7 +27,7 @@ def decode_all(data):
 def test_encoder_symbols_exported():
     import bgt_amd
     L = bgt_amd.lib()
-    for name in ("bgth_encoder_open", "bgth_encoder_write", "bgth_encoder_write_packed", "bgth_encoder_finish", "bgth_encoder_free_image",
+    for name in ("bgth_encoder_open", "bgth_encoder_write", "bgth_encoder_write_packed", "bgth_encoder_take", "bgth_encoder_finish", "bgth_encoder_free_image",
                  "bgth_encoder_close", "bgth_encoder_kernel_ms", "bgth_encoder_last_error"):
         assert hasattr(L, name)
 
@@ -260,3 +260,20 @@ def test_reader_rows_feed_the_writer(name, tmp_path):
     out = str(tmp_path / "sub.pbf")
     mod.subset_pbf(os.path.join(GOLD, name), out, cols, chunk=11)
     assert open(out, "rb").read() == orc.encode_pbf(rows[:, cols], g, shift)
+
+
+@pytest.mark.gpu
+def test_encoder_streams_the_file_out():
+    """take() after every write: the pieces concatenate to the same file (checkpoint offsets in the footer stay absolute)"""
+    import bgt_amd
+    rng = np.random.default_rng(21)
+    m, rows = 900, 260
+    mat = scenarios.ld_matrix(rng, rows, m, n_founders=7, switch=0.01)
+    enc = bgt_amd.HipEncoder(m, 2, 4)
+    pieces = [enc.take()]                                      # just the header
+    for lo, hi in ((0, 33), (33, 34), (34, 200), (200, 260)):
+        enc.write(mat[lo:hi])
+        pieces.append(enc.take())
+    pieces.append(enc.take())                                  # nothing new
+    pieces.append(enc.finish())                                # the footer
+    assert pieces[-2] == b"" and b"".join(pieces) == orc.encode_pbf(mat, 2, 4)
