@@ -19,14 +19,15 @@ def subset_pbf(src_path, dst_path, cols, chunk=65536):
     rd = bgt_amd.HipReader(pbf)
     rd.select(cols=np.asarray(cols, np.int32))
     enc = bgt_amd.HipEncoder(len(cols), pbf.g, pbf.shift)
-    for r0 in range(0, pbf.n, chunk):
-        _, gt = rd.scan(r0, min(pbf.n, r0 + chunk), want_gt=True)
-        enc.write_packed(gt)
-    image = enc.finish()
-    enc.close()
+    total = 0
     with open(dst_path, "wb") as fp:
-        fp.write(image)
-    return len(image)
+        for r0 in range(0, pbf.n, chunk):
+            _, gt = rd.scan(r0, min(pbf.n, r0 + chunk), want_gt=True)
+            enc.write_packed(gt)
+            total += fp.write(enc.take())                     # streamed: the image is never held whole
+        total += fp.write(enc.finish())
+    enc.close()
+    return total
 
 
 if __name__ == "__main__":
