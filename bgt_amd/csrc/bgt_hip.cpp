@@ -11,6 +11,8 @@
 #include <cstring>
 #include <chrono>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -39,6 +41,19 @@ static void set_err(const char *fmt, ...)
     } while (0)
 
 extern "C" const char *bgth_last_error(void) { return g_err; }
+
+// Nothing C++ may cross the C ABI: entry points that build host-side vectors run under this guard.  An image under
+// construction is registered in t_building so that an exception does not leak its device memory.
+static thread_local bgth_pbf_t *t_building = nullptr;
+template <class F, class R>
+static R guarded(const char *who, R on_fail, F body)
+{
+    try { return body(); }
+    catch (const std::bad_alloc &) { set_err("[E::%s] out of host memory", who); }
+    catch (const std::exception &e) { set_err("[E::%s] %s", who, e.what()); }
+    if (t_building) { bgth_pbf_t *p = t_building; t_building = nullptr; bgth_pbf_close(p); }
+    return on_fail;
+}
 extern "C" const char *bgth_version(void) { return "bgt-hip 0.1 (gfx950)"; }
 
 extern "C" int bgth_device_count(void)
@@ -91,9 +106,11 @@ struct bgth_pbf_s {
     std::mutex rowindex_lock;         // an image is shared by readers on different threads
 };
 
-// profiling / test knob: bits of the environment variable BGTH_DEBUG_SKIP (0x200 = team mode without the separate
-// toggle array, i.e. the code path of cohorts too wide for it)
-static bool debug_flag(int bit) { const char *d = getenv("BGTH_DEBUG_SKIP"); return d && (atoi(d) & bit); }
+// Test / tuning knob BGTH_VARIANT: picks between kernel variants that all give the SAME results (like bgth_reader_tune):
+//   1 = team mode without the separate toggle array (the code path of cohorts too wide for it)
+//   2 / 4 = never / always the kernels with the all-zero-plane-1 shortcut
+enum { kVariantNoTog = 1, kVariantNeverZP = 2, kVariantAlwaysZP = 4 };
+static bool variant_flag(int bit) { const char *d = getenv("BGTH_VARIANT"); return d && (atoi(d) & bit); }
 
 // Builds the row index once per image; later calls only return it.  The build is enqueued on `s`, the
 // stream of the scan that needs it, and waited for, so that other streams may use the index afterwards.
@@ -161,6 +178,7 @@ struct bgth_reader_s {
     int ring_has = 0;                 // BGTH_WANT_* bits the ring was filled with
     int want = BGTH_WANT_PLANES;      // pull interface: what a refill materialises besides the counts
     int64_t max_ahead = 0;            // rows per refill (0 = automatic)
+    int64_t ahead = 0;                // automatic look-ahead of the next refill (grows on sequential reads)
     const uint8_t *ret[2] = {nullptr, nullptr};
     const int32_t *last_counts = nullptr;
     const int8_t *last_gt8 = nullptr;
@@ -291,7 +309,13 @@ struct Trace {
 
 // Walks the record stream of an image (format: SURVEY.md App. A; ref pbwt.c:288-311 writer,
 // :313-337 reader) and splits it into packed RLE bytes, row descriptors and checkpoint permutations.
+static bgth_pbf_t *open_mem_impl(const void *image, size_t len, int device);
 extern "C" bgth_pbf_t *bgth_pbf_open_mem(const void *image, size_t len, int device)
+{
+    return guarded("bgth_pbf_open", (bgth_pbf_t*)nullptr, [&] { return open_mem_impl(image, len, device); });
+}
+
+static bgth_pbf_t *open_mem_impl(const void *image, size_t len, int device)
 {
     const uint8_t *buf = (const uint8_t*)image;
     if (len < 16 || memcmp(buf, "PBF\1", 4) != 0) { set_err("[E::bgth_pbf_open] not a PBF image"); return nullptr; }
@@ -312,6 +336,7 @@ extern "C" bgth_pbf_t *bgth_pbf_open_mem(const void *image, size_t len, int devi
     tr.lap("device init");
     bgth_pbf_t *p = pbf_alloc(device, m, g, shift, 0);
     if (!p) return nullptr;
+    t_building = p;
 
     std::vector<uint8_t> rle;
     std::vector<uint64_t> desc;
@@ -368,20 +393,30 @@ extern "C" bgth_pbf_t *bgth_pbf_open_mem(const void *image, size_t len, int devi
         if (np) {
             const int d = p->shift - p->sub_shift;
             int32_t *d_perm = nullptr;
+            int *d_bad = nullptr, bad = 0;
             HIP_TRY(hipMalloc((void**)&d_perm, np * 4), goto fail);
-            HIP_TRY(hipMalloc((void**)&p->d_rank0, std::max<int64_t>(p->n_sub, 1) * per * 4), { hipFree(d_perm); goto fail; });
-            HIP_TRY(hipMemcpy(d_perm, perms.data(), np * 4, hipMemcpyHostToDevice), { hipFree(d_perm); goto fail; });
-            for (size_t b = 0; b < np / per; ++b)
-                HIP_TRY(launch_invert(d_perm + b * per, p->d_rank0 + ((size_t)b << d) * per, m, 2, nullptr), { hipFree(d_perm); goto fail; });
-            HIP_TRY(hipDeviceSynchronize(), { hipFree(d_perm); goto fail; });
-            hipFree(d_perm);
+            HIP_TRY(hipMalloc((void**)&d_bad, 4), { hipFree(d_perm); goto fail; });
+            HIP_TRY(hipMemset(d_bad, 0, 4), { hipFree(d_perm); hipFree(d_bad); goto fail; });
+            HIP_TRY(hipMalloc((void**)&p->d_rank0, std::max<int64_t>(p->n_sub, 1) * per * 4), { hipFree(d_perm); hipFree(d_bad); goto fail; });
+            HIP_TRY(hipMemcpy(d_perm, perms.data(), np * 4, hipMemcpyHostToDevice), { hipFree(d_perm); hipFree(d_bad); goto fail; });
+            for (size_t b = 0; b < np / per; ++b)                 // validated: the records come from a file
+                HIP_TRY(launch_invert(d_perm + b * per, p->d_rank0 + ((size_t)b << d) * per, m, 2, nullptr, d_bad), { hipFree(d_perm); hipFree(d_bad); goto fail; });
+            HIP_TRY(hipDeviceSynchronize(), { hipFree(d_perm); hipFree(d_bad); goto fail; });
+            HIP_TRY(hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost), { hipFree(d_perm); hipFree(d_bad); goto fail; });
+            hipFree(d_perm); hipFree(d_bad);
+            if (bad) {
+                set_err("[E::bgth_pbf_open] corrupt 'S' record: %s", (bad & 1) ? "an entry is outside 0..m-1" : "not a permutation of the columns");
+                goto fail;
+            }
             tr.lap("checkpoints -> rank form");
             if (!derive_sub_checkpoints(p)) goto fail;
             tr.lap("sub-checkpoint pass");
         }
     }
+    t_building = nullptr;
     return p;
 fail:
+    t_building = nullptr;
     bgth_pbf_close(p);
     return nullptr;
 }
@@ -390,13 +425,19 @@ extern "C" bgth_pbf_t *bgth_pbf_open(const char *path, int device)
 {
     FILE *fp = fopen(path, "rb");
     if (!fp) { set_err("[E::bgth_pbf_open] cannot open '%s'", path); return nullptr; }
-    fseek(fp, 0, SEEK_END);
-    const long sz = ftell(fp);
-    fseek(fp, 0, SEEK_SET);
-    std::vector<uint8_t> buf((size_t)sz);
-    if (sz > 0 && fread(buf.data(), 1, (size_t)sz, fp) != (size_t)sz) { fclose(fp); set_err("[E::bgth_pbf_open] short read on '%s'", path); return nullptr; }
-    fclose(fp);
-    return bgth_pbf_open_mem(buf.data(), buf.size(), device);
+    long sz = -1;
+    if (fseek(fp, 0, SEEK_END) == 0) sz = ftell(fp);
+    if (sz < 0 || fseek(fp, 0, SEEK_SET) != 0) { fclose(fp); set_err("[E::bgth_pbf_open] '%s' is not a seekable file", path); return nullptr; }
+    try {
+        std::vector<uint8_t> buf((size_t)sz);
+        if (sz > 0 && fread(buf.data(), 1, (size_t)sz, fp) != (size_t)sz) { fclose(fp); set_err("[E::bgth_pbf_open] short read on '%s'", path); return nullptr; }
+        fclose(fp);
+        return bgth_pbf_open_mem(buf.data(), buf.size(), device);
+    } catch (const std::bad_alloc &) {                          // nothing C++ may cross the C ABI
+        fclose(fp);
+        set_err("[E::bgth_pbf_open] out of host memory for the %ld bytes of '%s'", sz, path);
+        return nullptr;
+    }
 }
 
 // A string without a byte of bit 1 describes an all-zero row (the row starts at 0 and nothing toggles it).
@@ -412,8 +453,8 @@ static bool string_is_all_zero(const uint8_t *q, size_t l)
 // the lookups (1.5x on a fully called panel): use them when at least one row in eight qualifies.
 static bool use_zp(const bgth_pbf_t *p)
 {
-    if (debug_flag(0x800)) return false;
-    if (debug_flag(0x1000)) return true;
+    if (variant_flag(kVariantNeverZP)) return false;
+    if (variant_flag(kVariantAlwaysZP)) return true;
     return p->n_empty1 * 8 >= std::max<int64_t>(p->n, 1);
 }
 
@@ -451,7 +492,7 @@ static bool common_scan_args(ScanArgs &a, bgth_pbf_t *p, const Selection &sel, c
 static bool run_block_pass(bgth_pbf_t *p, Selection &all, int64_t blk, int64_t n_blk, int32_t *d_final, hipStream_t s)
 {
     Geometry geo;
-    if (!choose_geometry(p->m, all.n_chunks, 1, (int)n_blk, 0, 0, 0, &geo, !debug_flag(0x200))) { set_err("[E::bgth] geometry"); return false; }
+    if (!choose_geometry(p->m, all.n_chunks, 1, (int)n_blk, 0, 0, 0, &geo, !variant_flag(kVariantNoTog))) { set_err("[E::bgth] geometry"); return false; }
     ScanArgs a;
     if (!common_scan_args(a, p, all, geo, s)) return false;
     a.shift = p->shift;                                                                   // units = file blocks,
@@ -468,7 +509,13 @@ static bool run_block_pass(bgth_pbf_t *p, Selection &all, int64_t blk, int64_t n
 
 // Partial image: only the file blocks that cover rows [row0, row1) are read (through the footer's block index,
 // pbwt.c:268-276), parsed and uploaded -- what a region query needs instead of the whole file.
+static bgth_pbf_t *open_rows_impl(const char *path, int64_t row0, int64_t row1, int device);
 extern "C" bgth_pbf_t *bgth_pbf_open_rows(const char *path, int64_t row0, int64_t row1, int device)
+{
+    return guarded("bgth_pbf_open_rows", (bgth_pbf_t*)nullptr, [&] { return open_rows_impl(path, row0, row1, device); });
+}
+
+static bgth_pbf_t *open_rows_impl(const char *path, int64_t row0, int64_t row1, int device)
 {
     FILE *fp = fopen(path, "rb");
     if (!fp) { set_err("[E::bgth_pbf_open_rows] cannot open '%s'", path); return nullptr; }
@@ -527,12 +574,19 @@ static bool derive_sub_checkpoints(bgth_pbf_t *p)
     return ok;
 }
 
+static bgth_pbf_t *from_rle_impl(int m, int g, int shift, int64_t n_rows, const uint8_t *rle, const uint32_t *len, int device);
 extern "C" bgth_pbf_t *bgth_pbf_from_rle(int m, int g, int shift, int64_t n_rows, const uint8_t *rle,
                                          const uint32_t *len, int device)
+{
+    return guarded("bgth_pbf_from_rle", (bgth_pbf_t*)nullptr, [&] { return from_rle_impl(m, g, shift, n_rows, rle, len, device); });
+}
+
+static bgth_pbf_t *from_rle_impl(int m, int g, int shift, int64_t n_rows, const uint8_t *rle, const uint32_t *len, int device)
 {
     if (!use_device(device)) return nullptr;
     bgth_pbf_t *p = pbf_alloc(device, m, g, shift, n_rows);
     if (!p) return nullptr;
+    t_building = p;
     p->n_total = n_rows;
     std::vector<uint64_t> desc((size_t)n_rows * g);
     std::vector<uint8_t> packed;
@@ -543,7 +597,7 @@ extern "C" bgth_pbf_t *bgth_pbf_from_rle(int m, int g, int shift, int64_t n_rows
         packed.resize(total);
     }
     for (size_t i = 0; i < desc.size(); ++i) {
-        if (len[i] >= (1u << 24)) { set_err("[E::bgth_pbf_from_rle] string %zu too long", i); bgth_pbf_close(p); return nullptr; }
+        if (len[i] >= (1u << 24)) { set_err("[E::bgth_pbf_from_rle] string %zu too long", i); t_building = nullptr; bgth_pbf_close(p); return nullptr; }
         desc[i] = off | (uint64_t)len[i] << kDescLenShift;
         memcpy(packed.data() + off, rle + src, len[i]);
         if ((i & 1) && string_is_all_zero(rle + src, len[i])) ++p->n_empty1;
@@ -574,14 +628,22 @@ extern "C" bgth_pbf_t *bgth_pbf_from_rle(int m, int g, int shift, int64_t n_rows
         HIP_TRY(hipDeviceSynchronize(), goto fail);
     }
     all.release();
+    t_building = nullptr;
     return p;
 fail:
     all.release();
+    t_building = nullptr;
     bgth_pbf_close(p);
     return nullptr;
 }
 
+static int64_t save_impl(const bgth_pbf_t *p, const char *path);
 extern "C" int64_t bgth_pbf_save(const bgth_pbf_t *p, const char *path)
+{
+    return guarded("bgth_pbf_save", (int64_t)-1, [&] { return save_impl(p, path); });
+}
+
+static int64_t save_impl(const bgth_pbf_t *p, const char *path)
 {
     if (!p) return -1;
     if (p->row_off != 0 || p->n != p->n_total) { set_err("[E::bgth_pbf_save] a partial image cannot be saved"); return -1; }
@@ -677,7 +739,7 @@ extern "C" int bgth_reader_select(bgth_reader_t *r, int n_sub, const int32_t *su
     if (!r) return -1;
     if (!use_device(r->pbf->device)) return -1;
     hipStreamSynchronize(r->stream);
-    if (!build_selection(r->sel, r->pbf->m, n_sub, sub, group, n_groups)) return -1;
+    if (!guarded("bgth_reader_select", false, [&] { return build_selection(r->sel, r->pbf->m, n_sub, sub, group, n_groups); })) return -1;
     r->ring0 = r->ring1 = 0;          // invalidate the pull ring
     return 0;
 }
@@ -709,7 +771,7 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
     const int G = r->sel.G;
     const int64_t blk0 = row0 >> p->sub_shift, blk1 = (row1 - 1) >> p->sub_shift;      // sub-blocks
     Geometry geo;
-    if (!choose_geometry(p->m, r->sel.n_chunks, G, (int)(blk1 - blk0 + 1), r->tune_threads, r->tune_cpt, r->tune_K, &geo, !debug_flag(0x200))) {
+    if (!choose_geometry(p->m, r->sel.n_chunks, G, (int)(blk1 - blk0 + 1), r->tune_threads, r->tune_cpt, r->tune_K, &geo, !variant_flag(kVariantNoTog))) {
         set_err("[E::bgth_reader_scan] no launch geometry for m=%d (threads=%d cpt=%d)", p->m, r->tune_threads, r->tune_cpt);
         return -1;
     }
@@ -726,13 +788,15 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
     a.n_blk = (int32_t)(blk1 - blk0 + 1);
     a.row0 = row0;
     a.row1 = row1;
-    { const char *dbg = getenv("BGTH_DEBUG_SKIP"); a.debug_skip = dbg ? atoi(dbg) : 0; }
     unsigned long long *d_times = nullptr;
-    if (getenv("BGTH_DEBUG_TIMES")) {                    // profiling aid: per-phase cycle sums over all waves
+#ifdef BGTH_ABLATE
+    { const char *dbg = getenv("BGTH_DEBUG_SKIP"); a.debug_skip = dbg ? atoi(dbg) : 0; }
+    if (getenv("BGTH_DEBUG_TIMES")) {                    // per-phase cycle sums over all waves
         HIP_TRY(hipMalloc((void**)&d_times, 64), return -1);
         HIP_TRY(hipMemsetAsync(d_times, 0, 64, s), return -1);
         a.debug_times = d_times;
     }
+#endif
     if (timed) HIP_TRY(hipEventRecord(r->ev[0], s), return -1);
     if (G > 1 || geo.slices > 1)                             // a single-group, single-slice launch stores its counts
         HIP_TRY(hipMemsetAsync(r->raw.p, 0, (size_t)rows * G * 3 * 4, s), return -1);
@@ -878,6 +942,14 @@ static bool refill(bgth_reader_t *r)
     if (r->max_ahead > 0) max_rows = std::min(max_rows, r->max_ahead);
     max_rows = std::max<int64_t>(blk_rows, max_rows / blk_rows * blk_rows);
     const int64_t row0 = r->next;
+    // Adaptive look-ahead: a refill that continues where the last window ended is a sequential walk and gets four times
+    // the previous window (up to max_rows); one that lands elsewhere (sparse access: BED / allele sets, merges with gaps)
+    // starts again at one sub-block, so a visited site costs a pre-roll of at most one sub-block, not a 256 MiB window.
+    if (r->max_ahead <= 0) {
+        const bool sequential = r->ring1 > r->ring0 && row0 == r->ring1 && r->ring_has == want;
+        r->ahead = sequential ? std::min(max_rows, std::max<int64_t>(blk_rows, r->ahead * 4)) : blk_rows;
+        max_rows = std::min(max_rows, r->ahead);
+    }
     int64_t row1 = std::min<int64_t>(p->n, ((row0 >> p->sub_shift) << p->sub_shift) + max_rows);
     const int64_t rows = row1 - row0;
     const size_t pl = (size_t)rows * r->sel.n_chunks * 8, by = (size_t)rows * width;
@@ -1001,3 +1073,12 @@ extern "C" int bgth_debug_stream_read(int device, size_t bytes, int width, int r
     hipFree(buf); hipFree(sink);
     return 0;
 }
+
+// Issue-rate calibration behind the roofline of the scan kernel: see microbench.hip.
+extern "C" int bgth_debug_issue_rate(int device, int mix, int waves_per_simd, int iters, double out[4])
+{
+    if (!use_device(device)) return -1;
+    HIP_TRY(run_issue_rate(mix, waves_per_simd, iters, out), return -1);
+    return 0;
+}
+extern "C" const char *bgth_debug_issue_rate_name(int mix) { return issue_rate_mix_name(mix); }

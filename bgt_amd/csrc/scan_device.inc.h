@@ -525,7 +525,7 @@ __device__ __forceinline__ void chunk_toggles(const ScanArgs &a, uint32_t *words
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const uint32_t start = lane_start + d.before[i];
-        if (d.valid[i] && d.bit[i] != pb && start < m && !(a.debug_skip & 64))
+        if (d.valid[i] && d.bit[i] != pb && start < m && !(BGTH_SKIP(a, 64)))
             atomicXor(words + (size_t)(start >> 5) * stride, 0xffffffffu << (start & 31));
         if (d.valid[i]) pb = d.bit[i];
     }
@@ -539,10 +539,10 @@ __device__ __forceinline__ void build_plane_row(const ScanArgs &a, const uint8_t
     const int nw = a.nw;
     for (int i = lane; i < nw; i += 64) bd[i] = make_uint2(0u, 0u);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    if (!(a.debug_skip & 2)) rle_toggles(a, rle, bd, desc, pre0, pre1, 0u, 0u, 2, lane);
+    if (!(BGTH_SKIP(a, 2))) rle_toggles(a, rle, bd, desc, pre0, pre1, 0u, 0u, 2, lane);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     uint32_t carry_x = 0, carry_c = 0;
-    if (!(a.debug_skip & 4)) directory_pass(bd, 0, nw, nw, tail_mask, carry_x, carry_c, lane);
+    if (!(BGTH_SKIP(a, 4))) directory_pass(bd, 0, nw, nw, tail_mask, carry_x, carry_c, lane);
     if (lane == 0) *n0_out = (uint32_t)a.m - carry_c;
 }
 
@@ -551,7 +551,7 @@ __device__ __forceinline__ void build_plane_row(const ScanArgs &a, const uint8_t
 // ZP = with the shortcut for rows whose plane 1 is all zero (chosen per image: worth a taken branch per statement
 // only if such rows exist);  TEAM = wide cohort: few rows fit the LDS, every plane-row is built by a team of waves (single batch
 // buffer); otherwise a wave builds its plane-rows alone and batches are pipelined over two buffers.
-#define BGTH_TICK(slot) do { if (a.debug_times) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+#define BGTH_TICK(slot) do { if (BGTH_TIMES(a)) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
     tsum[slot] += now_ - tlast; tlast = now_; } } while (0)
 
 template <int NT, int CPT, bool MULTI, bool GT, bool TEAM, bool ZP>
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
             const int c = chunk0 + j;
-            const int col = (c < a.n_chunks && !(a.debug_skip & 8)) ? a.slot_col[c * 64 + lane] : -1;
+            const int col = (c < a.n_chunks && !(BGTH_SKIP(a, 8))) ? a.slot_col[c * 64 + lane] : -1;
             r0[j] = ~(col >= 0 ? (uint32_t)rk[col] : pad_rank);             // complemented ranks (see the row step)
             r1[j] = ~(col >= 0 ? (uint32_t)rk[m + col] : pad_rank);
         }
@@ -667,7 +667,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
         dsc_next[i] = fetch_desc(blk_beg + K, i);
     }
     fetch_pre(blk_beg);
-    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = a.debug_times ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = BGTH_TIMES(a) ? __builtin_amdgcn_s_memtime() : 0ull;
 
     // LDS regions of batch buffer `buf`
     const size_t bd_stride = (size_t)2 * K * nwp;                        // uint2 entries per buffer
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
         for (int i = 0; i < 2; ++i) dsc_next[i] = fetch_desc(rbA + 2 * K, i);
         BGTH_TICK(0);
         if constexpr (!TEAM) {
-            if (!(a.debug_skip & 0x4000)) set_wave_priority(3);          // the build is a latency chain of few instructions: let it through
+            if (!(BGTH_SKIP(a, 0x4000))) set_wave_priority(3);          // the build is a latency chain of few instructions: let it through
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int p = build_slot + i * NWAVE;
@@ -725,7 +725,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
             BGTH_TICK(1);
             lds_barrier();
             BGTH_TICK(2);
-            if (active && !(a.debug_skip & 2)) {
+            if (active && !(BGTH_SKIP(a, 2))) {
                 int i = 0;
                 for (int c = tw; (uint32_t)c * 256u < slen; c += wpp, ++i) {
                     uint32_t w, ci;
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
             BGTH_TICK(3);
             lds_barrier();
             BGTH_TICK(4);
-            if (active && !(a.debug_skip & 4)) {
+            if (active && !(BGTH_SKIP(a, 4))) {
                 int u = 0;
                 for (int t = tw; t < ntrip; t += wpp, ++u) {
                     const uint32_t cy = (uint32_t)__builtin_amdgcn_readlane((int)cyl, u);
@@ -780,7 +780,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
             keep_cyl = t < ntrip ? sc[t] : 0u;
             keep_tot = sc[a.S8];
         }
-        if (active && !(a.debug_skip & 2)) {
+        if (active && !(BGTH_SKIP(a, 2))) {
             uint32_t *trow = TOG + (size_t)team * nwt;
             int i = 0;
             for (int c = tw; (uint32_t)c * 256u < slen; c += wpp, ++i) {
@@ -797,7 +797,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
     };
     auto team_directory = [&](int64_t rbA) {
         const int Kc = (int)((blk_end - rbA) < K ? (blk_end - rbA) : K);
-        if (team < 2 * Kc && !(a.debug_skip & 4)) {
+        if (team < 2 * Kc && !(BGTH_SKIP(a, 4))) {
             directory_trips_tog<(CPT > 88 ? 1 : 2)>(TOG + (size_t)team * nwt, BD + (size_t)team * nwp, tw, wpp, (nw + 255) >> 8, nw, tail_mask,
                                 keep_cyl, lane);
             if (tw == 0 && lane == 0) n0s[team] = (uint32_t)m - keep_tot;
@@ -810,7 +810,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
         const uint32_t *n0b = n0s + buf * 2 * K;
         int32_t *lcb = lcnt + buf * cnt_stride;
         const uint32_t bufbase = lds0 + (uint32_t)(buf * bd_stride) * 8u;
-        if (!(a.debug_skip & 1))
+        if (!(BGTH_SKIP(a, 1)))
         for (int k = 0; k < Kc; ++k) {
             // operands of the row step: (LDS byte address of the plane-row) - 8 and -n0 (see BGTH_TAIL)
             const uint32_t base0 = bufbase + (uint32_t)(2 * k) * (uint32_t)nwp * 8u - 8u;
@@ -821,7 +821,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
             // The SIMD arbiter prefers its oldest wave: left alone, waves 0-3 race through a batch and idle at the
             // barrier while waves 12-15 finish it nearly alone (measured: walk 96 vs 189 ticks).  Rotating the user
             // priority over the rows of a batch gives the four waves of a SIMD equal progress.
-            if (!TEAM && !(a.debug_skip & 0x2000)) set_wave_priority(((wave >> 2) + k) & 3);   // (team mode: one row per barrier, no gain)
+            if (!TEAM && !(BGTH_SKIP(a, 0x2000))) set_wave_priority(((wave >> 2) + k) & 3);   // (team mode: one row per barrier, no gain)
             if (ZP && n01 == 0u - (uint32_t)m) base1 = 0u;       // plane 1 all zero: its lookups are skipped (see step2)
             if (a.snap && rb + k > blk_beg && ((rb + k) & (((int64_t)1 << a.snap_shift) - 1)) == 0) {
                 // sub-checkpoint: the ranks before this row (image-open pass only)
@@ -954,9 +954,11 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
         }
     }
 
-    if (a.debug_times && lane == 0 && (!(a.debug_skip & 0x100) || wave == ((a.debug_skip >> 16) & 15))) {   // 0x100: one wave only (bits 16..19)
+#ifdef BGTH_ABLATE
+    if (BGTH_TIMES(a) && lane == 0 && (!(BGTH_SKIP(a, 0x100)) || wave == ((a.debug_skip >> 16) & 15))) {   // 0x100: one wave only (bits 16..19)
         for (int i = 0; i < 8; ++i) atomicAdd(a.debug_times + i, tsum[i]);
     }
+#endif
     if (a.final_rank) {
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {

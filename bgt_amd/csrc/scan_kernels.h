@@ -43,12 +43,22 @@ struct ScanArgs {
     int32_t  tog_off;            // team mode: byte offset in LDS of the separate toggle array [2K][(nw+4)&~3], 0 = toggles in place
     int32_t  blk0, n_blk, n_slices;
     int64_t  row0, row1;         // rows whose results are emitted; decoding starts at blk0<<shift
-    unsigned long long *debug_times;   // optional [workgroups][8] cycle sums per phase (env BGTH_DEBUG_TIMES)
-    int32_t  debug_skip;         // ablation bits (env BGTH_DEBUG_SKIP): 1 no walk, 2 no RLE read / toggles, 4 no directory build,
+    // Profiling builds only (make ABLATE=1 -> libbgt_hip_ablate.so, used by scripts/profile.sh): the shipped library
+    // compiles every one of these switches out (BGTH_SKIP / BGTH_TIMES below are constant 0) and never reads the
+    // environment variables that set them -- an ablation switch makes the kernels return wrong numbers faster.
+    unsigned long long *debug_times;   // [8] cycle sums per phase
+    int32_t  debug_skip;         // ablation bits: 1 no walk, 2 no RLE read / toggles, 4 no directory build,
                                  //   8 every lookup reads the sentinel word (no LDS conflicts), 64 no toggle atomics, 0x100 timing
-                                 //   of wave 0 only, 0x200 team mode without the separate toggle array (host-side switch), 0x800 / 0x1000 never / always the ZP
-                                 //   kernels (host-side), 0x2000 no priority rotation in the walk, 0x4000 no raised priority for the build
+                                 //   of one wave only, 0x2000 no priority rotation in the walk, 0x4000 no raised priority for the build
 };
+
+#ifdef BGTH_ABLATE
+#define BGTH_SKIP(a, bit) ((a).debug_skip & (bit))
+#define BGTH_TIMES(a)     ((a).debug_times != nullptr)
+#else
+#define BGTH_SKIP(a, bit) 0
+#define BGTH_TIMES(a)     false
+#endif
 
 // columns per thread instantiated for each workgroup size (keep in sync with kGeoms in scan_kernels.hip)
 #define BGTH_CPT_256(X)  X(2) X(4) X(8) X(12) X(16) X(20)
@@ -72,8 +82,9 @@ hipError_t launch_rowindex(const uint64_t *rowdesc, const uint8_t *rle, int64_t 
 // raw {c1,c2,c3} per group -> {AN,AC,AC<M>} for total (+ per group when G>1)
 hipError_t launch_finalize(const int32_t *raw, int32_t *out, const int32_t *group_haps, int64_t n_rows,
                            int G, hipStream_t s);
-// inv[perm[j]] = j for n_perm permutations of m entries each
-hipError_t launch_invert(const int32_t *perm, int32_t *inv, int m, int64_t n_perm, hipStream_t s);
+// inv[perm[j]] = j for n_perm permutations of m entries each.  bad != NULL (untrusted input): entries outside
+// 0..m-1 are not stored and every record is checked to be a permutation; *bad (device int) becomes non-zero otherwise
+hipError_t launch_invert(const int32_t *perm, int32_t *inv, int m, int64_t n_perm, hipStream_t s, int *bad = nullptr);
 // slot-ordered bit planes -> 2-bit codes in output-column order (4 per byte)
 hipError_t launch_pack2(const uint64_t *h0, const uint64_t *h1, const int32_t *slot_of_out, uint8_t *gt,
                         int64_t n_rows, int n_chunks, int width, hipStream_t s);
@@ -94,5 +105,8 @@ struct FilterProgram { int32_t n; int32_t op[kFilterMaxItems]; int32_t slot[kFil
 hipError_t launch_filter(const FilterProgram &prog, const int32_t *counts, int64_t n_rows, int ints_per_row,
                          uint8_t *flags, unsigned long long *n_pass, hipStream_t s);
 hipError_t launch_stream_read(const void *src, size_t bytes, int width, uint32_t *sink, hipStream_t s);
+// issue-rate calibration (microbench.hip): out = {cycles of the slowest wave, ms, VALU wave-instr per wave, LDS wave-instr per wave}
+hipError_t run_issue_rate(int mix, int waves_per_simd, int iters, double out[4]);
+const char *issue_rate_mix_name(int mix);
 
 }  // namespace bgth

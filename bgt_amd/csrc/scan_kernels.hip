@@ -171,21 +171,41 @@ hipError_t launch_finalize(const int32_t *raw, int32_t *out, const int32_t *grou
     return hipGetLastError();
 }
 
-// reference pbwt.c:343: invS[S[i]] = i
-__global__ void invert_kernel(const int32_t *perm, int32_t *inv, int m, int64_t total)
+// reference pbwt.c:343: invS[S[i]] = i.  The permutations come from a file: an entry outside 0..m-1 must not become a
+// store outside the image (HBM is shared with every other image and reader of the process), so it is dropped and
+// reported; verify_inverse_kernel then proves the record was a permutation (inv was pre-filled with -1).
+__global__ void invert_kernel(const int32_t *perm, int32_t *inv, int m, int64_t total, int *bad)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int64_t base = i / m * m;
-    inv[base + perm[i]] = (int32_t)(i - base);
+    const int32_t p = perm[i];
+    if (p < 0 || p >= m) { if (bad) atomicOr(bad, 1); return; }
+    inv[base + p] = (int32_t)(i - base);
 }
 
-hipError_t launch_invert(const int32_t *perm, int32_t *inv, int m, int64_t n_perm, hipStream_t s)
+__global__ void verify_inverse_kernel(const int32_t *perm, const int32_t *inv, int m, int64_t total, int *bad)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= total) return;
+    const int64_t base = j / m * m;
+    const int32_t i = inv[j];
+    if (i < 0 || i >= m || perm[base + i] != (int32_t)(j - base)) atomicOr(bad, 2);
+}
+
+hipError_t launch_invert(const int32_t *perm, int32_t *inv, int m, int64_t n_perm, hipStream_t s, int *bad)
 {
     const int64_t total = n_perm * m;
     if (total <= 0) return hipSuccess;
+    if (bad) {
+        hipError_t e = hipMemsetAsync(inv, 0xff, (size_t)total * 4, s);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(invert_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
-                       perm, inv, m, total);
+                       perm, inv, m, total, bad);
+    if (bad)
+        hipLaunchKernelGGL(verify_inverse_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                           perm, inv, m, total, bad);
     return hipGetLastError();
 }
 

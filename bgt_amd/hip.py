@@ -6,7 +6,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "lib", "libbgt_hip.so")
+_LIB_PATH = os.environ.get("BGT_AMD_LIB") or os.path.join(_HERE, "lib", "libbgt_hip.so")   # (profiling builds: see csrc/Makefile)
 
 i32p = C.POINTER(C.c_int32)
 u32p = C.POINTER(C.c_uint32)

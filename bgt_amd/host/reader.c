@@ -25,8 +25,9 @@ int bgt_no_file = 0;
 typedef struct {
     int64_t n;
     int32_t *rid, *pos, *rlen, *row, *n_allele;
-    uint32_t *ref_off, *alt_off;
-    uint16_t *ref_len, *alt_len;
+    uint32_t *ref_off, *alt_off, *raw_off;                       /* raw: the record's `shared` block as in the file (bgt_read) */
+    uint32_t *ref_len, *alt_len, *raw_len;
+    uint16_t *n_info; float *qual;
     char *pool; size_t pool_len, pool_cap;
     int32_t max_rlen;
 } sitetab_t;
@@ -35,7 +36,8 @@ static void st_free(sitetab_t *t)
 {
     if (!t) return;
     free(t->rid); free(t->pos); free(t->rlen); free(t->row); free(t->n_allele);
-    free(t->ref_off); free(t->alt_off); free(t->ref_len); free(t->alt_len); free(t->pool); free(t);
+    free(t->ref_off); free(t->alt_off); free(t->ref_len); free(t->alt_len); free(t->raw_off); free(t->raw_len);
+    free(t->n_info); free(t->qual); free(t->pool); free(t);
 }
 
 static uint32_t st_intern(sitetab_t *t, const uint8_t *s, int n)
@@ -79,14 +81,16 @@ static int st_append(sitetab_t *t, int64_t *cap, const bcf1_t *b, int row_key)
         t->rlen = (int32_t*)realloc(t->rlen, (size_t)c * 4); t->row = (int32_t*)realloc(t->row, (size_t)c * 4);
         t->n_allele = (int32_t*)realloc(t->n_allele, (size_t)c * 4);
         t->ref_off = (uint32_t*)realloc(t->ref_off, (size_t)c * 4); t->alt_off = (uint32_t*)realloc(t->alt_off, (size_t)c * 4);
-        t->ref_len = (uint16_t*)realloc(t->ref_len, (size_t)c * 2); t->alt_len = (uint16_t*)realloc(t->alt_len, (size_t)c * 2);
+        t->ref_len = (uint32_t*)realloc(t->ref_len, (size_t)c * 4); t->alt_len = (uint32_t*)realloc(t->alt_len, (size_t)c * 4);
+        t->raw_off = (uint32_t*)realloc(t->raw_off, (size_t)c * 4); t->raw_len = (uint32_t*)realloc(t->raw_len, (size_t)c * 4);
+        t->n_info = (uint16_t*)realloc(t->n_info, (size_t)c * 2); t->qual = (float*)realloc(t->qual, (size_t)c * 4);
     }
     if (b->n_sample != 0 || b->n_allele < 2) return -3;
     n = tv_size(p, &q, &type); p = q + n;                                   /* ID */
     n = tv_size(p, &q, &type);                                              /* REF */
-    t->ref_off[t->n] = st_intern(t, q, n); t->ref_len[t->n] = (uint16_t)n; p = q + n;
+    t->ref_off[t->n] = st_intern(t, q, n); t->ref_len[t->n] = (uint32_t)n; p = q + n;
     n = tv_size(p, &q, &type);                                              /* first ALT */
-    t->alt_off[t->n] = st_intern(t, q, n); t->alt_len[t->n] = (uint16_t)n; p = q + n;
+    t->alt_off[t->n] = st_intern(t, q, n); t->alt_len[t->n] = (uint32_t)n; p = q + n;
     for (i = 2; i < (int)b->n_allele; ++i) { n = tv_size(p, &q, &type); p = q + n; }
     n = tv_size(p, &q, &type); p = q + (size_t)n * tv_bytes(type);          /* FILTER */
     for (i = 0; i < (int)b->n_info; ++i) {
@@ -99,6 +103,8 @@ static int st_append(sitetab_t *t, int64_t *cap, const bcf1_t *b, int row_key)
     if (row < 0) return -3;
     t->rid[t->n] = b->rid; t->pos[t->n] = b->pos; t->rlen[t->n] = b->rlen;
     t->row[t->n] = row; t->n_allele[t->n] = b->n_allele;
+    t->raw_off[t->n] = st_intern(t, (const uint8_t*)b->shared.s, (int)b->shared.l); t->raw_len[t->n] = (uint32_t)b->shared.l;
+    t->n_info[t->n] = (uint16_t)b->n_info; t->qual[t->n] = b->qual;
     if (b->rlen > t->max_rlen) t->max_rlen = b->rlen;
     ++t->n;
     return 0;
@@ -746,9 +752,15 @@ int bgt_read(bgt_t *bgt, bcf1_t *b)                           /* ref bgt.c:347-3
         bcf_hdr_parse(bgt->h_out);
     }
     if ((ret = read_rec(bgt, &r)) < 0) return ret;
-    b->rid = r.b0->rid; b->pos = r.b0->pos; b->rlen = r.b0->rlen; b->qual = r.b0->qual;
-    b->n_info = 0; b->n_allele = r.b0->n_allele; b->n_fmt = 0; b->n_sample = 0;
-    b->shared.l = 0; ks_putn(&b->shared, r.b0->shared.s, r.b0->shared.l);
+    {   /* bcfcpy(b, r.b0) of the reference: the site record exactly as the file holds it (ID, every allele, FILTER,
+         * INFO with _row), then the genotypes */
+        const sitetab_t *t = sites_of(bgt);
+        const int64_t i = ((devrd_t*)bgt->pb)->site;
+        b->rid = t->rid[i]; b->pos = t->pos[i]; b->rlen = t->rlen[i]; b->qual = t->qual[i];
+        b->n_info = t->n_info[i]; b->n_allele = (uint32_t)t->n_allele[i]; b->n_fmt = 0; b->n_sample = 0;
+        b->shared.l = 0; ks_putn(&b->shared, t->pool + t->raw_off[i], t->raw_len[i]);
+        b->unpacked = 0;
+    }
     gen_gt(bgt->h_out, b, bgt->n_out, r.a, NULL);
     return ret;
 }
@@ -1410,7 +1422,8 @@ static void fill_info(const bcf_hdr_t *h, const bgt_info_t *ss, bcf1_t *b)   /* 
     }
 }
 
-/* one merged site.  Returns 0 = emitted, 1 = filtered out, -1 = no more sites (ref bgt.c:797-878).
+/* one merged site.  Returns 0 = emitted, 1 = filtered out, -1 = no more sites (ref bgt.c:797-878), -2 = a database
+ * could not deliver its row (device failure, row outside the .pbf): the caller must not take that for the end.
  * AC/AN of the merged site = sum over the databases that carry the site of the counts the device
  * reduced for that database's row (ref bgt.c:735-757 over the concatenated planes; a database
  * without the site contributes code 2 = missing, which adds to no count, ref :837-840,755-756). */
@@ -1421,7 +1434,8 @@ static int read_core(bgtm_t *bm, bcf1_t *b)
     int64_t bs = -1;
     bgt_info_t ss;
     for (i = 0; i < bm->n_bgt; ++i) {
-        if (bm->r[i].b0 == NULL) read_rec(bm->bgt[i], &bm->r[i]);
+        if (bm->r[i].b0 == NULL && read_rec(bm->bgt[i], &bm->r[i]) < -1) return -2;   /* device / seek failure: an
+                                                                * error, not the end of this database's sites */
         n_rest += bm->r[i].b0 != NULL;
         if (bm->r[i].b0) bm->n_gt_read += (uint64_t)bm->bgt[i]->n_out;
     }
@@ -1507,7 +1521,7 @@ static int read_core(bgtm_t *bm, bcf1_t *b)
 int bgtm_read(bgtm_t *bm, bcf1_t *b)                          /* ref bgt.c:880-888 */
 {
     int ret;
-    if (bm->h_out == NULL) bgtm_prepare(bm);
+    if (bm->h_out == NULL && bgtm_prepare(bm) < 0) return -2;
     while ((ret = read_core(bm, b)) > 0) {}
     if (ret >= 0 && (bm->flag & BGT_F_NO_GT) == 0) {
         if (bm->n_bgt > 0 && (((devrd_t*)bm->bgt[0]->pb)->want & BGTH_WANT_GT8)) gen_gt8(bm->h_out, b, bm->n_out, bm->a[0]);
@@ -1528,7 +1542,7 @@ void bgtm_want_vcf_text(bgtm_t *bm)      /* call before bgtm_prepare: the caller
 int bgtm_read_vcf(bgtm_t *bm, bcf1_t *b, kstring_t *s)
 {
     int ret;
-    if (bm->h_out == NULL) { bgtm_want_vcf_text(bm); bgtm_prepare(bm); }
+    if (bm->h_out == NULL) { bgtm_want_vcf_text(bm); if (bgtm_prepare(bm) < 0) return -2; }
     if (bm->n_bgt == 0 || !(((devrd_t*)bm->bgt[0]->pb)->want & BGTH_WANT_GTTEXT) || bm->n_out == 0) {
         if ((ret = bgtm_read(bm, b)) >= 0) vcf_format1(bm->h_out, b, s);
         return ret;

@@ -30,6 +30,7 @@ int main_view(int argc, char *argv[])
     fmf_t *vardb = NULL;
     void *bed = NULL;
     long seekn = -1, n_rec = LONG_MAX, n_read = 0;
+    int rd_ret = -1;
     char *reg = NULL, *site_flt = NULL, *fmt = NULL, *aexpr = NULL, *dbfn = NULL, *gexpr[BGT_MAX_GROUPS];
     bgt_file_t **files;
     bgtm_t *bm;
@@ -66,6 +67,10 @@ int main_view(int argc, char *argv[])
     if (u_set) { clevel = 0; out_bcf = 1; }
     if (n_groups > 1) flag |= BGT_F_SET_AC;
     if (argc - optind < 1) return usage(argv[0]);
+    if ((flag & (BGT_F_CNT_AL | BGT_F_CNT_HAP)) && aexpr == NULL) {  /* ref view.c:93-96 */
+        fprintf(stderr, "[E::%s] -a must be specified when -S/-H is in use.\n", __func__);
+        return 1;
+    }
 
     n_files = argc - optind;
     files = (bgt_file_t**)calloc((size_t)n_files, sizeof(bgt_file_t*));
@@ -117,7 +122,7 @@ int main_view(int argc, char *argv[])
     else vcf_hdr_write_text(stdout, bm->h_out);
 
     b = bcf_init1();
-    while (((bz || not_vcf) ? bgtm_read(bm, b) : bgtm_read_vcf(bm, b, &line)) >= 0 && n_read < n_rec) {
+    while ((rd_ret = (bz || not_vcf) ? bgtm_read(bm, b) : bgtm_read_vcf(bm, b, &line)) >= 0 && n_read < n_rec) {
         if (bz) bcf_write1_stream(bz, b);
         else if (!not_vcf) { fwrite(line.s, 1, line.l, stdout); fputc('\n', stdout); }
         if (fmt && bm->n_fields > 0) puts(bm->tbl_line.s);
@@ -146,5 +151,9 @@ int main_view(int argc, char *argv[])
     if (vardb) fmf_destroy(vardb);
     for (i = 0; i < n_files; ++i) bgt_close(files[i]);
     free(files);
+    if (rd_ret < -1) {                                              /* -1 is the end of the data; anything below is a failure */
+        fprintf(stderr, "[E::%s] reading stopped on an error (%d): the output is incomplete.\n", __func__, rd_ret);
+        return 1;
+    }
     return 0;
 }

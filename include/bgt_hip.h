@@ -170,6 +170,12 @@ int  bgth_filter_apply_device(const bgth_filter_t *f, const void *d_counts, int6
 /* Diagnostics: stream `bytes` of HBM `repeats` times with `width`-byte loads per lane (4 or 16); used under
  * rocprofv3 to calibrate the FETCH_SIZE counter against a known byte count. */
 int bgth_debug_stream_read(int device, size_t bytes, int width, int repeats);
+/* Issue-rate calibration for the roofline of the scan kernel (which is bound by VALU issue and LDS gathers, not by
+ * HBM): runs `iters` iterations of instruction mix `mix` (bgth_debug_issue_rate_name(mix) describes it; NULL past the
+ * last one) on every CU with `waves_per_simd` (1..4) waves per SIMD.  out[0] = shader cycles of the slowest wave,
+ * out[1] = milliseconds of the launch, out[2] / out[3] = VALU / LDS wave-instructions issued per wave. */
+int         bgth_debug_issue_rate(int device, int mix, int waves_per_simd, int iters, double out[4]);
+const char *bgth_debug_issue_rate_name(int mix);
 
 #ifdef __cplusplus
 }

@@ -33,10 +33,10 @@ while time.time() < t_end:
     elif style == 3 and rows > 3:
         mat[rng.integers(0, rows)] = rng.integers(0, 4); mat[rng.integers(0, rows)] = 3
     data = orc.encode_pbf(mat, 2, shift)
-    os.environ.pop("BGTH_DEBUG_SKIP", None)
-    flag = int(rng.choice([0, 0, 512, 2048, 4096, 4096 | 512]))
+    os.environ.pop("BGTH_VARIANT", None)
+    flag = int(rng.choice([0, 0, 1, 2, 4, 4 | 1]))
     if flag:
-        os.environ["BGTH_DEBUG_SKIP"] = str(flag)
+        os.environ["BGTH_VARIANT"] = str(flag)
     os.environ["BGTH_SUB_SHIFT"] = str(int(rng.integers(1, 12)))
     pbf = bgt_amd.HipPbf.from_bytes(data)
     for _ in range(3):

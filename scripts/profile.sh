@@ -1,6 +1,8 @@
 #!/bin/bash
 # rocprofv3 evidence for the round: kernel-trace stats + separate PMC passes (never combined with
 # tracing domains). Run on the GPU box from the repo root: bash scripts/profile.sh <tag> [bench args...]
+# BGTH_DEBUG_SKIP / BGTH_DEBUG_TIMES only act on the profiling build: make -C bgt_amd/csrc ABLATE=1 and
+# BGT_AMD_LIB=$R/bgt_amd/lib/libbgt_hip_ablate.so
 set -u
 TAG=${1:-r01}; shift || true
 R=${GRAFT_REPO_ROOT:-$(pwd)}

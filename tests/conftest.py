@@ -11,3 +11,19 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+REF_DIR = os.path.join(ROOT, "oracle", "_ref")
+
+
+def require_ref(name="bgt"):
+    """Path of a compiled-reference artefact (oracle/_ref/<name>, built by `make -C oracle ref` in the build container and
+    shipped with the snapshot).  Its absence FAILS the test: a parity test that silently disappears is not a pass."""
+    path = os.path.join(REF_DIR, name)
+    if not os.path.exists(path) and os.path.exists("/root/reference/pbwt.c"):      # build container: build the checker
+        import subprocess
+        subprocess.call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    if not os.path.exists(path):
+        pytest.fail("oracle/_ref/%s is missing: build it with `make -C oracle ref` where /root/reference exists "
+                    "(it is git-ignored but travels to the GPU box with the snapshot)" % name)
+    return path

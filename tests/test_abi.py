@@ -48,6 +48,16 @@ def test_library_does_not_link_the_oracle(libpath):
     assert "orc_" not in syms
 
 
+def test_shipped_library_has_no_ablation_switches(libpath):
+    """The ablation switches (skip the walk / the RLE read / the directory build ...) and the per-phase cycle counters
+    exist only in the profiling build (make -C bgt_amd/csrc ABLATE=1): the shipped kernels cannot be told through the
+    environment to return wrong numbers faster."""
+    blob = open(libpath, "rb").read()
+    assert b"BGTH_DEBUG_SKIP" not in blob and b"BGTH_DEBUG_TIMES" not in blob
+    host = open(os.path.join(ROOT, "bgt_amd", "lib", "libbgt.so"), "rb").read() if os.path.exists(os.path.join(ROOT, "bgt_amd", "lib", "libbgt.so")) else b""
+    assert b"BGTH_DEBUG_SKIP" not in host
+
+
 def test_fails_loudly_without_a_device(libpath):
     import bgt_amd
     if bgt_amd.device_count() > 0:

@@ -14,6 +14,13 @@ REF = os.path.join(ROOT, "oracle", "_ref", "bgt")
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(scope="module", autouse=True)
+def reference_binary_present():
+    from conftest import require_ref
+    require_ref("bgt")
+    require_ref("pbfview")
+
+
 @pytest.fixture(scope="module")
 def c1(tmp_path_factory):
     import bgt_amd
@@ -32,7 +39,6 @@ def md5_of(cmd):
     return p.returncode, hashlib.md5(p.stdout).hexdigest(), len(p.stdout), p.stderr.decode()[-300:]
 
 
-@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref not present")
 @pytest.mark.parametrize("args", [["-C", "-G"], ["-G", "-f", "AC>0"], ["-G", "-f", "AC>0", "-r", "11:20000-300000"],
                                   ["-C", "-G", "-i", "40000", "-n", "5000"],
                                   ["-G", "-s", "pop==\"A\"", "-s", "pop==\"B\"", "-f", "AC1>0&&AC2==0"],
@@ -48,7 +54,6 @@ def test_same_bytes_as_reference_binary(c1, args):
     assert mine[2] > 0 and mine[1:3] == ref[1:3], (args, mine, ref)
 
 
-@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref not present")
 def test_generated_pbf_is_what_the_reference_encoder_writes(c1, tmp_path):
     """decode the synthetic .pbf with the reference (pbfview) and re-encode it with the reference: same bytes,
     i.e. the PBWT-domain generator + GPU checkpoints produce a canonical file."""
@@ -64,7 +69,6 @@ def test_generated_pbf_is_what_the_reference_encoder_writes(c1, tmp_path):
     assert open(re, "rb").read() == open(small + ".pbf", "rb").read()
 
 
-@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref not present")
 def test_two_database_group_join_like_config5(tmp_path):
     """Shape of BASELINE.json configs[4]: two databases over the same positions with independent alleles, two
     sample groups, `-f'AC1>0&&AC2==0'`; plus the variants with genotypes and with three groups."""
@@ -83,7 +87,6 @@ def test_two_database_group_join_like_config5(tmp_path):
         assert mine[2] > 0 and mine[1:3] == ref[1:3], (args, mine, ref)
 
 
-@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref not present")
 def test_tables_bed_and_allele_sets_like_reference(c1, tmp_path):
     """-t tables, -B/-e BED filters and -a/-S allele sets on the C1-shaped database; the allele strings are taken
     from sites the reference itself reports (every 997th site with AC > 20), in REF:ALT and in rlen:ALT form."""
@@ -113,7 +116,6 @@ def test_tables_bed_and_allele_sets_like_reference(c1, tmp_path):
         assert mine[1:3] == ref[1:3], (args, mine, ref)
 
 
-@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref not present")
 def test_wide_cohort_subset_like_config3(tmp_path):
     """Shape of BASELINE.json configs[2] at reduced length: 100,000 samples (m = 200,000: the team-mode kernels, row
     index, sub-checkpoints), `-s` picks every 20th sample (5,000 of 100,000), AC/AN; plus a region with genotypes of

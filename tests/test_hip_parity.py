@@ -196,7 +196,7 @@ def test_wide_cohort_team_mode(hip, threads, cpt, K, in_place, monkeypatch):
     whose string stops short of m -- whole cohort, a sparse subset and two groups.  in_place: the variant for
     cohorts too wide for a separate toggle array in LDS (forced here through the debug knob)."""
     if in_place:
-        monkeypatch.setenv("BGTH_DEBUG_SKIP", "512")
+        monkeypatch.setenv("BGTH_VARIANT", "1")
     rng = np.random.default_rng(77)
     m, rows, shift = 41000, 24, 3
     mat = scenarios.ld_matrix(rng, rows, m, n_founders=40, switch=0.2)
@@ -288,14 +288,14 @@ def test_sub_checkpoints(hip, tmp_path, monkeypatch, sub):
         assert open(out, "rb").read() == data
 
 
-@pytest.mark.parametrize("force", [None, "2048", "4096"])
+@pytest.mark.parametrize("force", [None, "2", "4"])
 @pytest.mark.parametrize("threads,cpt,K", [(0, 0, 0), (1024, 20, 0), (512, 10, 3), (256, 8, 2), (512, 80, 1), (512, 98, 1), (1024, 8, 1)])
 def test_rows_with_an_empty_plane(hip, monkeypatch, force, threads, cpt, K):
     """Rows whose plane 1 (missing / <M>) is all zero take the shortcut of the ZP kernels (reference pbwt.c:135-138);
     a cohort that mixes such rows with ordinary ones, rows of one repeated code, and a plane-0-empty row, through both
-    kernel families (BGTH_DEBUG_SKIP 2048 = never, 4096 = always use the ZP kernels), whole cohort, groups, genotypes."""
+    kernel families (BGTH_VARIANT 2 = never, 4 = always use the ZP kernels), whole cohort, groups, genotypes."""
     if force:
-        monkeypatch.setenv("BGTH_DEBUG_SKIP", force)
+        monkeypatch.setenv("BGTH_VARIANT", force)
     rng = np.random.default_rng(123)
     m, rows, shift = 9000, 160, 5
     mat = scenarios.ld_matrix(rng, rows, m, n_founders=12, switch=0.03)

@@ -89,7 +89,6 @@ def test_cli_genotype_independent_goldens(name):
     assert res.stdout == open(os.path.join(GOLD, "expected", name + ".out"), "rb").read()
 
 
-@pytest.mark.skipif(not os.path.exists(REF_BGT), reason="oracle/_ref not built")
 @pytest.mark.parametrize("args,prefixes", [(["-G"], ["synA", "synB"]), (["-G", "-r", "11:1000-1100"], ["synA"]),
                                            (["-G", "-r", "11:1,035-1,120"], ["synB", "synA"]), (["-G", "-r", "12"], ["synA"]),
                                            (["-G", "-r", "11:1101"], ["synA"]), (["-G", "-i", "5", "-n", "7"], ["synA"]),
@@ -101,6 +100,8 @@ def test_cli_genotype_independent_goldens(name):
                                            (["-G", "-B", "regions.bed", "-r", "11:1000-1200"], ["synA"]),
                                            (["-G", "-B", "nosuchfile.bed"], ["synA"])])
 def test_cli_live_against_reference_without_genotypes(args, prefixes):
+    from conftest import require_ref
+    require_ref("bgt")
     mine, ref = run_view(args, prefixes), run_view(args, prefixes, exe=REF_BGT)
     assert mine.returncode == ref.returncode
     assert mine.stdout == ref.stdout, (args, prefixes)
@@ -108,8 +109,8 @@ def test_cli_live_against_reference_without_genotypes(args, prefixes):
 
 def test_metadata_selection_matches_reference_counts():
     """-s expressions / lists / files resolve to the same samples (checked through the VCF header)."""
-    if not os.path.exists(REF_BGT):
-        pytest.skip("oracle/_ref not built")
+    from conftest import require_ref
+    require_ref("bgt")
     for sel in (["-s", "idx%5==0"], ["-s", ",A003,A010,A011,A049"], ["-s", ":A001"], ["-s", "pop==\"X\"||idx>45"],
                 ["-s", "pop!=\"Y\"&&idx<30"], ["-s", "nosuchkey==1"], ["-s", "_ROW_==\"A007\""]):
         mine, ref = run_view(["-G"] + sel, ["synA"]), run_view(["-G"] + sel, ["synA"], exe=REF_BGT)

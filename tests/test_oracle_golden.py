@@ -114,10 +114,11 @@ def test_scan_counts_equal_matrix_histogram():
 # ---------------------------------------------------------------------------------------------------
 # live comparison with the compiled reference (present in the build container and on the GPU box)
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref not built")
 @pytest.mark.parametrize("seed,m,rows,shift", [(1, 64, 40, 3), (2, 129, 300, 5), (3, 1000, 50, 13),
                                                (4, 7, 100, 2), (5, 2504 * 2, 30, 13)])
 def test_live_against_reference(tmp_path, seed, m, rows, shift):
+    from conftest import require_ref
+    require_ref("libbgt_ref.so")
     import make_golden_lib as mg
     rng = np.random.default_rng(seed)
     mat = scenarios.ld_matrix(rng, rows, m, n_founders=int(rng.integers(2, 12)), switch=float(rng.random() * 0.2))
