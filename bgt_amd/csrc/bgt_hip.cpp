@@ -1082,3 +1082,10 @@ extern "C" int bgth_debug_issue_rate(int device, int mix, int waves_per_simd, in
     return 0;
 }
 extern "C" const char *bgth_debug_issue_rate_name(int mix) { return issue_rate_mix_name(mix); }
+extern "C" int bgth_debug_op_rate(int device, int op, int waves_per_simd, int iters, double out[3])
+{
+    if (!use_device(device)) return -1;
+    HIP_TRY(run_op_rate(op, waves_per_simd, iters, out), return -1);
+    return 0;
+}
+extern "C" const char *bgth_debug_op_rate_name(int op) { return op_rate_name(op); }

@@ -127,6 +127,134 @@ __global__ void issue_rate_kernel(int iters, unsigned long long *cycles, uint32_
     if (acc == 0x9e3779b9u) *sink = acc;
 }
 
+// ---- instruction classes: which VALU opcodes issue in 2 cycles per wave64 and which in 4 (or more) ----
+// ONE instruction, 8 independent instances (destinations v40..v47; 64-bit forms v[40:41]..v[54:55]) x 8 per loop
+// iteration; second / third sources v48 / v49 (v[56:59] for the 64-bit forms), condition / carry operands vcc, s[20:23].
+template <int OP>
+__device__ __forceinline__ void op_block()
+{
+    if constexpr (OP == 0) asm volatile("v_mov_b32 v40, v48\n\tv_mov_b32 v41, v48\n\tv_mov_b32 v42, v48\n\tv_mov_b32 v43, v48\n\tv_mov_b32 v44, v48\n\tv_mov_b32 v45, v48\n\tv_mov_b32 v46, v48\n\tv_mov_b32 v47, v48\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 1) asm volatile("v_and_b32 v40, v48, v40\n\tv_and_b32 v41, v48, v41\n\tv_and_b32 v42, v48, v42\n\tv_and_b32 v43, v48, v43\n\tv_and_b32 v44, v48, v44\n\tv_and_b32 v45, v48, v45\n\tv_and_b32 v46, v48, v46\n\tv_and_b32 v47, v48, v47\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 2) asm volatile("v_or_b32 v40, v48, v40\n\tv_or_b32 v41, v48, v41\n\tv_or_b32 v42, v48, v42\n\tv_or_b32 v43, v48, v43\n\tv_or_b32 v44, v48, v44\n\tv_or_b32 v45, v48, v45\n\tv_or_b32 v46, v48, v46\n\tv_or_b32 v47, v48, v47\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 3) asm volatile("v_xor_b32 v40, v48, v40\n\tv_xor_b32 v41, v48, v41\n\tv_xor_b32 v42, v48, v42\n\tv_xor_b32 v43, v48, v43\n\tv_xor_b32 v44, v48, v44\n\tv_xor_b32 v45, v48, v45\n\tv_xor_b32 v46, v48, v46\n\tv_xor_b32 v47, v48, v47\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 4) asm volatile("v_sub_u32 v40, v48, v40\n\tv_sub_u32 v41, v48, v41\n\tv_sub_u32 v42, v48, v42\n\tv_sub_u32 v43, v48, v43\n\tv_sub_u32 v44, v48, v44\n\tv_sub_u32 v45, v48, v45\n\tv_sub_u32 v46, v48, v46\n\tv_sub_u32 v47, v48, v47\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 5) asm volatile("v_lshrrev_b32 v40, 5, v40\n\tv_lshrrev_b32 v41, 5, v41\n\tv_lshrrev_b32 v42, 5, v42\n\tv_lshrrev_b32 v43, 5, v43\n\tv_lshrrev_b32 v44, 5, v44\n\tv_lshrrev_b32 v45, 5, v45\n\tv_lshrrev_b32 v46, 5, v46\n\tv_lshrrev_b32 v47, 5, v47\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 6) asm volatile("v_ashrrev_i32 v40, 5, v40\n\tv_ashrrev_i32 v41, 5, v41\n\tv_ashrrev_i32 v42, 5, v42\n\tv_ashrrev_i32 v43, 5, v43\n\tv_ashrrev_i32 v44, 5, v44\n\tv_ashrrev_i32 v45, 5, v45\n\tv_ashrrev_i32 v46, 5, v46\n\tv_ashrrev_i32 v47, 5, v47\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 7) asm volatile("v_lshlrev_b32 v40, 3, v40\n\tv_lshlrev_b32 v41, 3, v41\n\tv_lshlrev_b32 v42, 3, v42\n\tv_lshlrev_b32 v43, 3, v43\n\tv_lshlrev_b32 v44, 3, v44\n\tv_lshlrev_b32 v45, 3, v45\n\tv_lshlrev_b32 v46, 3, v46\n\tv_lshlrev_b32 v47, 3, v47\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 8) asm volatile("v_lshlrev_b32 v40, v48, v40\n\tv_lshlrev_b32 v41, v48, v41\n\tv_lshlrev_b32 v42, v48, v42\n\tv_lshlrev_b32 v43, v48, v43\n\tv_lshlrev_b32 v44, v48, v44\n\tv_lshlrev_b32 v45, v48, v45\n\tv_lshlrev_b32 v46, v48, v46\n\tv_lshlrev_b32 v47, v48, v47\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 9) asm volatile("v_lshl_add_u32 v40, v40, 3, v48\n\tv_lshl_add_u32 v41, v41, 3, v48\n\tv_lshl_add_u32 v42, v42, 3, v48\n\tv_lshl_add_u32 v43, v43, 3, v48\n\tv_lshl_add_u32 v44, v44, 3, v48\n\tv_lshl_add_u32 v45, v45, 3, v48\n\tv_lshl_add_u32 v46, v46, 3, v48\n\tv_lshl_add_u32 v47, v47, 3, v48\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 10) asm volatile("v_add_lshl_u32 v40, v40, v48, 3\n\tv_add_lshl_u32 v41, v41, v48, 3\n\tv_add_lshl_u32 v42, v42, v48, 3\n\tv_add_lshl_u32 v43, v43, v48, 3\n\tv_add_lshl_u32 v44, v44, v48, 3\n\tv_add_lshl_u32 v45, v45, v48, 3\n\tv_add_lshl_u32 v46, v46, v48, 3\n\tv_add_lshl_u32 v47, v47, v48, 3\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 11) asm volatile("v_and_or_b32 v40, v40, v48, v49\n\tv_and_or_b32 v41, v41, v48, v49\n\tv_and_or_b32 v42, v42, v48, v49\n\tv_and_or_b32 v43, v43, v48, v49\n\tv_and_or_b32 v44, v44, v48, v49\n\tv_and_or_b32 v45, v45, v48, v49\n\tv_and_or_b32 v46, v46, v48, v49\n\tv_and_or_b32 v47, v47, v48, v49\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 12) asm volatile("v_lshl_or_b32 v40, v40, 3, v48\n\tv_lshl_or_b32 v41, v41, 3, v48\n\tv_lshl_or_b32 v42, v42, 3, v48\n\tv_lshl_or_b32 v43, v43, 3, v48\n\tv_lshl_or_b32 v44, v44, 3, v48\n\tv_lshl_or_b32 v45, v45, 3, v48\n\tv_lshl_or_b32 v46, v46, 3, v48\n\tv_lshl_or_b32 v47, v47, 3, v48\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 13) asm volatile("v_or3_b32 v40, v40, v48, v49\n\tv_or3_b32 v41, v41, v48, v49\n\tv_or3_b32 v42, v42, v48, v49\n\tv_or3_b32 v43, v43, v48, v49\n\tv_or3_b32 v44, v44, v48, v49\n\tv_or3_b32 v45, v45, v48, v49\n\tv_or3_b32 v46, v46, v48, v49\n\tv_or3_b32 v47, v47, v48, v49\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 14) asm volatile("v_add3_u32 v40, v40, v48, v49\n\tv_add3_u32 v41, v41, v48, v49\n\tv_add3_u32 v42, v42, v48, v49\n\tv_add3_u32 v43, v43, v48, v49\n\tv_add3_u32 v44, v44, v48, v49\n\tv_add3_u32 v45, v45, v48, v49\n\tv_add3_u32 v46, v46, v48, v49\n\tv_add3_u32 v47, v47, v48, v49\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 15) asm volatile("v_bfe_u32 v40, v40, 5, 20\n\tv_bfe_u32 v41, v41, 5, 20\n\tv_bfe_u32 v42, v42, 5, 20\n\tv_bfe_u32 v43, v43, 5, 20\n\tv_bfe_u32 v44, v44, 5, 20\n\tv_bfe_u32 v45, v45, 5, 20\n\tv_bfe_u32 v46, v46, 5, 20\n\tv_bfe_u32 v47, v47, 5, 20\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 16) asm volatile("v_bfe_i32 v40, v40, 5, 20\n\tv_bfe_i32 v41, v41, 5, 20\n\tv_bfe_i32 v42, v42, 5, 20\n\tv_bfe_i32 v43, v43, 5, 20\n\tv_bfe_i32 v44, v44, 5, 20\n\tv_bfe_i32 v45, v45, 5, 20\n\tv_bfe_i32 v46, v46, 5, 20\n\tv_bfe_i32 v47, v47, 5, 20\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 17) asm volatile("v_bfi_b32 v40, v48, v40, v49\n\tv_bfi_b32 v41, v48, v41, v49\n\tv_bfi_b32 v42, v48, v42, v49\n\tv_bfi_b32 v43, v48, v43, v49\n\tv_bfi_b32 v44, v48, v44, v49\n\tv_bfi_b32 v45, v48, v45, v49\n\tv_bfi_b32 v46, v48, v46, v49\n\tv_bfi_b32 v47, v48, v47, v49\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 18) asm volatile("v_alignbit_b32 v40, v48, v40, 5\n\tv_alignbit_b32 v41, v48, v41, 5\n\tv_alignbit_b32 v42, v48, v42, 5\n\tv_alignbit_b32 v43, v48, v43, 5\n\tv_alignbit_b32 v44, v48, v44, 5\n\tv_alignbit_b32 v45, v48, v45, 5\n\tv_alignbit_b32 v46, v48, v46, 5\n\tv_alignbit_b32 v47, v48, v47, 5\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 19) asm volatile("v_perm_b32 v40, v40, v48, v49\n\tv_perm_b32 v41, v41, v48, v49\n\tv_perm_b32 v42, v42, v48, v49\n\tv_perm_b32 v43, v43, v48, v49\n\tv_perm_b32 v44, v44, v48, v49\n\tv_perm_b32 v45, v45, v48, v49\n\tv_perm_b32 v46, v46, v48, v49\n\tv_perm_b32 v47, v47, v48, v49\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 20) asm volatile("v_bitop3_b32 v40, v40, v48, v49 bitop3:0x36\n\tv_bitop3_b32 v41, v41, v48, v49 bitop3:0x36\n\tv_bitop3_b32 v42, v42, v48, v49 bitop3:0x36\n\tv_bitop3_b32 v43, v43, v48, v49 bitop3:0x36\n\tv_bitop3_b32 v44, v44, v48, v49 bitop3:0x36\n\tv_bitop3_b32 v45, v45, v48, v49 bitop3:0x36\n\tv_bitop3_b32 v46, v46, v48, v49 bitop3:0x36\n\tv_bitop3_b32 v47, v47, v48, v49 bitop3:0x36\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 21) asm volatile("v_cndmask_b32 v40, v48, v40, vcc\n\tv_cndmask_b32 v41, v48, v41, vcc\n\tv_cndmask_b32 v42, v48, v42, vcc\n\tv_cndmask_b32 v43, v48, v43, vcc\n\tv_cndmask_b32 v44, v48, v44, vcc\n\tv_cndmask_b32 v45, v48, v45, vcc\n\tv_cndmask_b32 v46, v48, v46, vcc\n\tv_cndmask_b32 v47, v48, v47, vcc\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 22) asm volatile("v_cndmask_b32_e64 v40, v48, v40, s[20:21]\n\tv_cndmask_b32_e64 v41, v48, v41, s[20:21]\n\tv_cndmask_b32_e64 v42, v48, v42, s[20:21]\n\tv_cndmask_b32_e64 v43, v48, v43, s[20:21]\n\tv_cndmask_b32_e64 v44, v48, v44, s[20:21]\n\tv_cndmask_b32_e64 v45, v48, v45, s[20:21]\n\tv_cndmask_b32_e64 v46, v48, v46, s[20:21]\n\tv_cndmask_b32_e64 v47, v48, v47, s[20:21]\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 23) asm volatile("v_cmp_gt_i32 vcc, 0, v40\n\tv_cmp_gt_i32 vcc, 0, v41\n\tv_cmp_gt_i32 vcc, 0, v42\n\tv_cmp_gt_i32 vcc, 0, v43\n\tv_cmp_gt_i32 vcc, 0, v44\n\tv_cmp_gt_i32 vcc, 0, v45\n\tv_cmp_gt_i32 vcc, 0, v46\n\tv_cmp_gt_i32 vcc, 0, v47\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 24) asm volatile("v_cmp_gt_i32_e64 s[22:23], 0, v40\n\tv_cmp_gt_i32_e64 s[22:23], 0, v41\n\tv_cmp_gt_i32_e64 s[22:23], 0, v42\n\tv_cmp_gt_i32_e64 s[22:23], 0, v43\n\tv_cmp_gt_i32_e64 s[22:23], 0, v44\n\tv_cmp_gt_i32_e64 s[22:23], 0, v45\n\tv_cmp_gt_i32_e64 s[22:23], 0, v46\n\tv_cmp_gt_i32_e64 s[22:23], 0, v47\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 25) asm volatile("v_mul_u32_u24 v40, v48, v40\n\tv_mul_u32_u24 v41, v48, v41\n\tv_mul_u32_u24 v42, v48, v42\n\tv_mul_u32_u24 v43, v48, v43\n\tv_mul_u32_u24 v44, v48, v44\n\tv_mul_u32_u24 v45, v48, v45\n\tv_mul_u32_u24 v46, v48, v46\n\tv_mul_u32_u24 v47, v48, v47\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 26) asm volatile("v_mad_u32_u24 v40, v40, 8, v48\n\tv_mad_u32_u24 v41, v41, 8, v48\n\tv_mad_u32_u24 v42, v42, 8, v48\n\tv_mad_u32_u24 v43, v43, 8, v48\n\tv_mad_u32_u24 v44, v44, 8, v48\n\tv_mad_u32_u24 v45, v45, 8, v48\n\tv_mad_u32_u24 v46, v46, 8, v48\n\tv_mad_u32_u24 v47, v47, 8, v48\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 27) asm volatile("v_mad_i32_i24 v40, v40, -8, v48\n\tv_mad_i32_i24 v41, v41, -8, v48\n\tv_mad_i32_i24 v42, v42, -8, v48\n\tv_mad_i32_i24 v43, v43, -8, v48\n\tv_mad_i32_i24 v44, v44, -8, v48\n\tv_mad_i32_i24 v45, v45, -8, v48\n\tv_mad_i32_i24 v46, v46, -8, v48\n\tv_mad_i32_i24 v47, v47, -8, v48\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 28) asm volatile("v_mul_lo_u32 v40, v40, v48\n\tv_mul_lo_u32 v41, v41, v48\n\tv_mul_lo_u32 v42, v42, v48\n\tv_mul_lo_u32 v43, v43, v48\n\tv_mul_lo_u32 v44, v44, v48\n\tv_mul_lo_u32 v45, v45, v48\n\tv_mul_lo_u32 v46, v46, v48\n\tv_mul_lo_u32 v47, v47, v48\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 29) asm volatile("v_mul_hi_u32 v40, v40, v48\n\tv_mul_hi_u32 v41, v41, v48\n\tv_mul_hi_u32 v42, v42, v48\n\tv_mul_hi_u32 v43, v43, v48\n\tv_mul_hi_u32 v44, v44, v48\n\tv_mul_hi_u32 v45, v45, v48\n\tv_mul_hi_u32 v46, v46, v48\n\tv_mul_hi_u32 v47, v47, v48\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 30) asm volatile("v_min_u32 v40, v48, v40\n\tv_min_u32 v41, v48, v41\n\tv_min_u32 v42, v48, v42\n\tv_min_u32 v43, v48, v43\n\tv_min_u32 v44, v48, v44\n\tv_min_u32 v45, v48, v45\n\tv_min_u32 v46, v48, v46\n\tv_min_u32 v47, v48, v47\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 31) asm volatile("v_mbcnt_lo_u32_b32 v40, v48, v40\n\tv_mbcnt_lo_u32_b32 v41, v48, v41\n\tv_mbcnt_lo_u32_b32 v42, v48, v42\n\tv_mbcnt_lo_u32_b32 v43, v48, v43\n\tv_mbcnt_lo_u32_b32 v44, v48, v44\n\tv_mbcnt_lo_u32_b32 v45, v48, v45\n\tv_mbcnt_lo_u32_b32 v46, v48, v46\n\tv_mbcnt_lo_u32_b32 v47, v48, v47\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 32) asm volatile("v_ffbh_u32 v40, v40\n\tv_ffbh_u32 v41, v41\n\tv_ffbh_u32 v42, v42\n\tv_ffbh_u32 v43, v43\n\tv_ffbh_u32 v44, v44\n\tv_ffbh_u32 v45, v45\n\tv_ffbh_u32 v46, v46\n\tv_ffbh_u32 v47, v47\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 33) asm volatile("v_bcnt_u32_b32 v40, v48, v40\n\tv_bcnt_u32_b32 v41, v48, v41\n\tv_bcnt_u32_b32 v42, v48, v42\n\tv_bcnt_u32_b32 v43, v48, v43\n\tv_bcnt_u32_b32 v44, v48, v44\n\tv_bcnt_u32_b32 v45, v48, v45\n\tv_bcnt_u32_b32 v46, v48, v46\n\tv_bcnt_u32_b32 v47, v48, v47\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 34) asm volatile("v_add_co_u32 v40, vcc, v48, v40\n\tv_add_co_u32 v41, vcc, v48, v41\n\tv_add_co_u32 v42, vcc, v48, v42\n\tv_add_co_u32 v43, vcc, v48, v43\n\tv_add_co_u32 v44, vcc, v48, v44\n\tv_add_co_u32 v45, vcc, v48, v45\n\tv_add_co_u32 v46, vcc, v48, v46\n\tv_add_co_u32 v47, vcc, v48, v47\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 35) asm volatile("v_xad_u32 v40, v40, v48, v49\n\tv_xad_u32 v41, v41, v48, v49\n\tv_xad_u32 v42, v42, v48, v49\n\tv_xad_u32 v43, v43, v48, v49\n\tv_xad_u32 v44, v44, v48, v49\n\tv_xad_u32 v45, v45, v48, v49\n\tv_xad_u32 v46, v46, v48, v49\n\tv_xad_u32 v47, v47, v48, v49\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 36) asm volatile("v_sad_u32 v40, v40, v48, v49\n\tv_sad_u32 v41, v41, v48, v49\n\tv_sad_u32 v42, v42, v48, v49\n\tv_sad_u32 v43, v43, v48, v49\n\tv_sad_u32 v44, v44, v48, v49\n\tv_sad_u32 v45, v45, v48, v49\n\tv_sad_u32 v46, v46, v48, v49\n\tv_sad_u32 v47, v47, v48, v49\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 37) asm volatile("v_add_u32_dpp v40, v48, v40 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_u32_dpp v41, v48, v41 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_u32_dpp v42, v48, v42 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_u32_dpp v43, v48, v43 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_u32_dpp v44, v48, v44 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_u32_dpp v45, v48, v45 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_u32_dpp v46, v48, v46 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_u32_dpp v47, v48, v47 row_shr:1 row_mask:0xf bank_mask:0xf\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 38) asm volatile("v_mov_b32_dpp v40, v48 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp v41, v48 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp v42, v48 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp v43, v48 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp v44, v48 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp v45, v48 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp v46, v48 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp v47, v48 row_shr:1 row_mask:0xf bank_mask:0xf\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 39) asm volatile("v_pk_add_u16 v40, v40, v48\n\tv_pk_add_u16 v41, v41, v48\n\tv_pk_add_u16 v42, v42, v48\n\tv_pk_add_u16 v43, v43, v48\n\tv_pk_add_u16 v44, v44, v48\n\tv_pk_add_u16 v45, v45, v48\n\tv_pk_add_u16 v46, v46, v48\n\tv_pk_add_u16 v47, v47, v48\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 40) asm volatile("v_cvt_f32_u32 v40, v40\n\tv_cvt_f32_u32 v41, v41\n\tv_cvt_f32_u32 v42, v42\n\tv_cvt_f32_u32 v43, v43\n\tv_cvt_f32_u32 v44, v44\n\tv_cvt_f32_u32 v45, v45\n\tv_cvt_f32_u32 v46, v46\n\tv_cvt_f32_u32 v47, v47\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 41) asm volatile("v_subrev_u32 v40, s20, v40\n\tv_subrev_u32 v41, s20, v41\n\tv_subrev_u32 v42, s20, v42\n\tv_subrev_u32 v43, s20, v43\n\tv_subrev_u32 v44, s20, v44\n\tv_subrev_u32 v45, s20, v45\n\tv_subrev_u32 v46, s20, v46\n\tv_subrev_u32 v47, s20, v47\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 42) asm volatile("v_and_b32 v40, 0xffffffe0, v40\n\tv_and_b32 v41, 0xffffffe0, v41\n\tv_and_b32 v42, 0xffffffe0, v42\n\tv_and_b32 v43, 0xffffffe0, v43\n\tv_and_b32 v44, 0xffffffe0, v44\n\tv_and_b32 v45, 0xffffffe0, v45\n\tv_and_b32 v46, 0xffffffe0, v46\n\tv_and_b32 v47, 0xffffffe0, v47\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 43) asm volatile("v_add_u32 v40, v48, v40\n\tv_add_u32 v41, v48, v41\n\tv_add_u32 v42, v48, v42\n\tv_add_u32 v43, v48, v43\n\tv_add_u32 v44, v48, v44\n\tv_add_u32 v45, v48, v45\n\tv_add_u32 v46, v48, v46\n\tv_add_u32 v47, v48, v47\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 44) asm volatile("v_fma_f32 v40, v40, v48, v49\n\tv_fma_f32 v41, v41, v48, v49\n\tv_fma_f32 v42, v42, v48, v49\n\tv_fma_f32 v43, v43, v48, v49\n\tv_fma_f32 v44, v44, v48, v49\n\tv_fma_f32 v45, v45, v48, v49\n\tv_fma_f32 v46, v46, v48, v49\n\tv_fma_f32 v47, v47, v48, v49\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 45) asm volatile("v_pk_fma_f32 v[40:41], v[40:41], v[56:57], v[58:59]\n\tv_pk_fma_f32 v[42:43], v[42:43], v[56:57], v[58:59]\n\tv_pk_fma_f32 v[44:45], v[44:45], v[56:57], v[58:59]\n\tv_pk_fma_f32 v[46:47], v[46:47], v[56:57], v[58:59]\n\tv_pk_fma_f32 v[56:57], v[56:57], v[56:57], v[58:59]\n\tv_pk_fma_f32 v[58:59], v[58:59], v[56:57], v[58:59]\n\tv_pk_fma_f32 v[52:53], v[52:53], v[56:57], v[58:59]\n\tv_pk_fma_f32 v[54:55], v[54:55], v[56:57], v[58:59]\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 46) asm volatile("v_lshlrev_b64 v[40:41], 3, v[40:41]\n\tv_lshlrev_b64 v[42:43], 3, v[42:43]\n\tv_lshlrev_b64 v[44:45], 3, v[44:45]\n\tv_lshlrev_b64 v[46:47], 3, v[46:47]\n\tv_lshlrev_b64 v[56:57], 3, v[56:57]\n\tv_lshlrev_b64 v[58:59], 3, v[58:59]\n\tv_lshlrev_b64 v[52:53], 3, v[52:53]\n\tv_lshlrev_b64 v[54:55], 3, v[54:55]\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 47) asm volatile("v_readlane_b32 s24, v40, 3\n\tv_readlane_b32 s24, v41, 3\n\tv_readlane_b32 s24, v42, 3\n\tv_readlane_b32 s24, v43, 3\n\tv_readlane_b32 s24, v44, 3\n\tv_readlane_b32 s24, v45, 3\n\tv_readlane_b32 s24, v46, 3\n\tv_readlane_b32 s24, v47, 3\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+    if constexpr (OP == 48) asm volatile("v_mad_u64_u32 v[40:41], vcc, v40, v56, v[40:41]\n\tv_mad_u64_u32 v[42:43], vcc, v42, v56, v[42:43]\n\tv_mad_u64_u32 v[44:45], vcc, v44, v56, v[44:45]\n\tv_mad_u64_u32 v[46:47], vcc, v46, v56, v[46:47]\n\tv_mad_u64_u32 v[56:57], vcc, v56, v56, v[56:57]\n\tv_mad_u64_u32 v[58:59], vcc, v50, v56, v[58:59]\n\tv_mad_u64_u32 v[52:53], vcc, v52, v56, v[52:53]\n\tv_mad_u64_u32 v[54:55], vcc, v54, v56, v[54:55]\n\t" ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21","s22","s23","s24");
+}
+static const char *const kOpName[] = {"v_mov_b32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_sub_u32", "v_lshrrev_b32 imm", "v_ashrrev_i32 imm", "v_lshlrev_b32 imm", "v_lshlrev_b32 vgpr", "v_lshl_add_u32", "v_add_lshl_u32", "v_and_or_b32", "v_lshl_or_b32", "v_or3_b32", "v_add3_u32", "v_bfe_u32", "v_bfe_i32", "v_bfi_b32", "v_alignbit_b32", "v_perm_b32", "v_bitop3_b32", "v_cndmask_b32 vcc", "v_cndmask_b32_e64 sgpr", "v_cmp_gt_i32 vcc", "v_cmp_gt_i32_e64 sgpr", "v_mul_u32_u24", "v_mad_u32_u24", "v_mad_i32_i24", "v_mul_lo_u32", "v_mul_hi_u32", "v_min_u32", "v_mbcnt_lo_u32_b32", "v_ffbh_u32", "v_bcnt_u32_b32", "v_add_co_u32", "v_xad_u32", "v_sad_u32", "v_add_u32 dpp row_shr", "v_mov_b32 dpp row_shr", "v_pk_add_u16", "v_cvt_f32_u32", "v_subrev_u32 sgpr", "v_and_b32 literal", "v_add_u32", "v_fma_f32", "v_pk_fma_f32", "v_lshlrev_b64", "v_readlane_b32", "v_mad_u64_u32"};
+constexpr int kNumOps = 49;
+
+template <int OP>
+__global__ void op_rate_kernel(int iters, unsigned long long *cycles, uint32_t *sink)
+{
+    uint32_t acc;
+    asm volatile("v_mov_b32 v48, 3\n\tv_mov_b32 v49, 1.0\n\tv_mov_b32 v56, 3\n\tv_mov_b32 v57, 0\n\tv_mov_b32 v58, 0\n\tv_mov_b32 v59, 0\n\t"
+                 "v_mov_b32 v40, 0\n\tv_mov_b32 v41, 1\n\tv_mov_b32 v42, 2\n\tv_mov_b32 v43, 3\n\tv_mov_b32 v44, 4\n\tv_mov_b32 v45, 5\n\t"
+                 "v_mov_b32 v46, 6\n\tv_mov_b32 v47, 7\n\tv_mov_b32 v50, 0\n\tv_mov_b32 v51, 0\n\tv_mov_b32 v52, 0\n\tv_mov_b32 v53, 0\n\t"
+                 "v_mov_b32 v54, 0\n\tv_mov_b32 v55, 0\n\ts_mov_b64 s[20:21], 0x55\n\ts_mov_b64 vcc, 0x33\n\t"
+                 ::: "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","vcc","s20","s21");
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        op_block<OP>(); op_block<OP>(); op_block<OP>(); op_block<OP>(); op_block<OP>(); op_block<OP>(); op_block<OP>(); op_block<OP>();
+    }
+    asm volatile("v_xor_b32 %0, v40, v47" : "=v"(acc) :: "v40", "v47");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) atomicMax(cycles, t1 - t0);
+    if (acc == 0x9e3779b9u) *sink = acc;
+}
+
+template <int OP>
+static hipError_t launch_op(int threads, int iters, unsigned long long *cyc, uint32_t *sink)
+{
+    auto fn = op_rate_kernel<OP>;
+    const int lds = 96 * 1024;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fn, dim3(256), dim3(threads), lds, nullptr, iters, cyc, sink);
+    return hipGetLastError();
+}
+
+template <int OP>
+static hipError_t dispatch_op(int op, int threads, int iters, unsigned long long *cyc, uint32_t *sink)
+{
+    if constexpr (OP >= kNumOps) return hipErrorInvalidValue;
+    else {
+        if (op == OP) return launch_op<OP>(threads, iters, cyc, sink);
+        return dispatch_op<OP + 1>(op, threads, iters, cyc, sink);
+    }
+}
+
+// out[0] = cycles of the slowest wave, out[1] = ms, out[2] = instructions per wave
+hipError_t run_op_rate(int op, int waves_per_simd, int iters, double out[3])
+{
+    if (op < 0 || op >= kNumOps || waves_per_simd < 1 || waves_per_simd > 4) return hipErrorInvalidValue;
+    unsigned long long *cyc = nullptr; uint32_t *sink = nullptr;
+    hipEvent_t e0, e1;
+    hipError_t e;
+    if ((e = hipMalloc((void**)&cyc, 8)) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&sink, 4)) != hipSuccess) return e;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        hipMemset(cyc, 0, 8);
+        hipEventRecord(e0, nullptr);
+        e = dispatch_op<0>(op, 256 * waves_per_simd, iters, cyc, sink);
+        hipEventRecord(e1, nullptr);
+        if (e != hipSuccess) break;
+        if ((e = hipEventSynchronize(e1)) != hipSuccess) break;
+        hipEventElapsedTime(&ms, e0, e1);
+    }
+    unsigned long long h = 0;
+    if (e == hipSuccess) e = hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
+    out[0] = (double)h; out[1] = ms; out[2] = 64.0 * iters;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(cyc); hipFree(sink);
+    return e;
+}
+const char *op_rate_name(int op) { return op >= 0 && op < kNumOps ? kOpName[op] : nullptr; }
+
 struct MixInfo { const char *name; int valu_per_iter; int lds_per_iter; };
 static const MixInfo kMix[MIX_N] = {
     {"v_fma_f32", 64, 0}, {"v_add_u32", 64, 0}, {"row step (8 VALU), no LDS", 4 * 8 * 8, 0}, {"v_bcnt_u32_b32", 64, 0},

@@ -108,5 +108,7 @@ hipError_t launch_stream_read(const void *src, size_t bytes, int width, uint32_t
 // issue-rate calibration (microbench.hip): out = {cycles of the slowest wave, ms, VALU wave-instr per wave, LDS wave-instr per wave}
 hipError_t run_issue_rate(int mix, int waves_per_simd, int iters, double out[4]);
 const char *issue_rate_mix_name(int mix);
+hipError_t run_op_rate(int op, int waves_per_simd, int iters, double out[3]);
+const char *op_rate_name(int op);
 
 }  // namespace bgth

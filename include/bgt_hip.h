@@ -176,6 +176,10 @@ int bgth_debug_stream_read(int device, size_t bytes, int width, int repeats);
  * out[1] = milliseconds of the launch, out[2] / out[3] = VALU / LDS wave-instructions issued per wave. */
 int         bgth_debug_issue_rate(int device, int mix, int waves_per_simd, int iters, double out[4]);
 const char *bgth_debug_issue_rate_name(int mix);
+/* The same for single VALU opcodes (instruction classes: which issue in 2 cycles per wave64, which in 4 or more):
+ * out[0] = cycles, out[1] = ms, out[2] = instructions per wave. */
+int         bgth_debug_op_rate(int device, int op, int waves_per_simd, int iters, double out[3]);
+const char *bgth_debug_op_rate_name(int op);
 
 #ifdef __cplusplus
 }

@@ -43,9 +43,30 @@ def main():
                 "%.2f" % rec["cycles_per_valu"] if valu else " - ",
                 "%.2f" % rec["lds_cycles_per_instr_per_cu"] if lds else " - "), flush=True)
         mix += 1
+    # instruction classes
+    L.bgth_debug_op_rate.restype = C.c_int
+    L.bgth_debug_op_rate.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    L.bgth_debug_op_rate_name.restype = C.c_char_p
+    L.bgth_debug_op_rate_name.argtypes = [C.c_int]
+    ops = []
+    op = 0
+    while True:
+        name = L.bgth_debug_op_rate_name(op)
+        if not name:
+            break
+        rec = {"op": name.decode()}
+        for w in (2, 4):
+            out = (C.c_double * 3)()
+            if L.bgth_debug_op_rate(0, op, w, iters, out) != 0:
+                raise SystemExit(bgt_amd.last_error())
+            rec["cycles_per_instr_w%d" % w] = out[0] / (w * out[2])
+        ops.append(rec)
+        print("%-28s cycles per wave-instruction and SIMD: %.2f (2 waves/SIMD)  %.2f (4 waves/SIMD)" %
+              (rec["op"], rec["cycles_per_instr_w2"], rec["cycles_per_instr_w4"]), flush=True)
+        op += 1
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump({"device": "MI355X (gfx950)", "note": "one workgroup per CU, 256 CUs; cycles = s_memtime of the slowest wave",
-               "runs": rows}, open(os.path.join(ROOT, "gpurun_out", "valu_calibration.json"), "w"), indent=1)
+               "runs": rows, "instruction_classes": ops}, open(os.path.join(ROOT, "gpurun_out", "valu_calibration.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
