@@ -6,19 +6,31 @@ planes of every site, rank-tracking column reconstruction, AC/AN reduction (all 
 C ABI of libbgt_hip.so), the site filter AC>0 on the device, counts + pass flags delivered to the host.  Inputs (RLE
 strings, row directory, checkpoints) are resident in HBM before the timed region starts.
 
-  N = 1   workload C2 of BASELINE.json: synthetic 10,000 samples (m = 20,000 haplotypes) x 1,000,000 sites.
-  N > 1   weak scaling: rank r scans sites [r*1M, (r+1)*1M) of the same cohort (site-range sharding, no
-          data-path collective), then an all_gather over RCCL/xGMI of the per-shard allele counts and pass flags.
+  N = 1   headline: workload C2 of BASELINE.json, synthetic 10,000 samples (m = 20,000 haplotypes) x 1,000,000 sites;
+          then `secondary` records at 100,000 samples (the north-star width): C3 (1,000,000 sites, every 20th sample =
+          10,000 tracked columns) and one C4 shard (153 file blocks = 1,253,376 sites, whole cohort), each with its own
+          roofline and a CPU baseline from the compiled reference on the first sites of the same database.
+  N > 1   weak scaling (--workload c2, default): rank r scans sites [r*1M, (r+1)*1M) of the same cohort (site-range
+          sharding, no data-path collective), then an all_gather over RCCL/xGMI of the per-shard counts and flags.
+          --workload c4: BASELINE configs[3] itself, strong scaling: the 1,221 file blocks of 100,000 samples x
+          10,000,000 sites split over the N ranks (153 blocks per rank at N = 8), gather of the per-shard counts.
 
-Prints one JSON line (rank 0).  `roofline.achieved` prices the decode kernel with the reference's
-ALGORITHMIC bytes (16*T + r + 12 per site); the kernel keeps that permutation state in
-registers, so its real HBM traffic (`traffic`, from rocprofv3 PMC counters when profiles/ holds them) is
-~3 orders of magnitude lower -- see DESIGN.md.  `cpu_baseline` times the CPU oracle (a port of the
-reference path; the reference itself is not on the GPU box) on a bounded sample of the same workload.
+Prints one JSON line (rank 0).
+
+roofline: the scan kernel keeps the permutation in registers, so it moves ~0.1 % of the reference algorithm's bytes and
+its bound is the issue side, not HBM.  `bound` = "valu_issue"; `unit` = rank lookups per second (one lookup = one tracked
+column x one bit plane x one site: the LF-mapping step); `peak` is MEASURED LIVE in this run by bgth_debug_issue_rate():
+the product's own row-step statement (8 VALU + 1 ds_read_b64 per lookup, random LDS entries) alone on every SIMD at 4
+waves per SIMD -- what the chip sustains if nothing but lookups ran; `achieved` = algorithmic lookups of the launch /
+its duration (HIP events).  `algorithmic_equiv_gbs` keeps SURVEY 8d's figure (reference-algorithm bytes / kernel time) and
+`hbm_traffic` / `valu` / `lds` the rocprofv3 PMC numbers of the same kernel, replayed from profiles/ (marked so).
+`cpu_baseline` = the compiled reference (oracle/_ref/bgt) timed on this box's host cores on a bounded sample.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import tempfile
 import time
@@ -26,8 +38,261 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-SAMPLES = {"c2": 10000, "c3": 100000, "small": 2504}
+SAMPLES = {"c2": 10000, "c3": 100000, "c4": 100000, "small": 2504}
 HBM_PEAK_GBS = 8000.0                      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "bgt")
+MY_BIN = os.path.join(ROOT, "bgt_amd", "bin", "bgt")
+
+
+def lookup_peak(bgt_amd, device):
+    """G rank-lookups/s the chip sustains running only the product's row step (live microbenchmark, ~40 ms)."""
+    import ctypes as C
+    L = bgt_amd.lib()
+    L.bgth_debug_issue_rate.restype = C.c_int
+    L.bgth_debug_issue_rate.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    out = (C.c_double * 4)()
+    iters, waves = 20000, 4
+    if L.bgth_debug_issue_rate(device, 7, waves, iters, out) != 0:            # mix 7: step4 + ds_read_b64, random entries
+        raise RuntimeError(bgt_amd.last_error())
+    cycles, ms, valu = out[0], out[1], out[2]
+    lookups = 256.0 * (4 * waves) * 64 * (valu / 8.0)                           # CUs x waves x lanes x lookups per wave
+    return {"g_lookups_per_s": lookups / (ms * 1e-3) / 1e9, "cycles_per_valu_instr": cycles / (waves * valu),
+            "valu_instr_per_cycle_per_simd": waves * valu / cycles, "clock_ghz": cycles / (ms * 1e6), "ms": ms,
+            "source": "live: bgth_debug_issue_rate(mix 7 = the scan kernel's own 8-lookup statement incl. ds_read_b64 on "
+                      "random entries and SALU counts, 256 CUs x 4 waves/SIMD, %d iterations)" % iters}
+
+
+def replayed_counters(workload, sites, kernel_name):
+    """rocprofv3 PMC numbers of the same kernel on the same workload, collected by scripts/profile.sh and committed under
+    profiles/ -- NOT measured in this run."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for tag in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        tp, pp = os.path.join(pdir, tag, "traffic.json"), os.path.join(pdir, tag, "pmc_summary.json")
+        if not (os.path.exists(tp) and os.path.exists(pp)):
+            continue
+        try:
+            tj, pj = json.load(open(tp)), json.load(open(pp))
+        except Exception:
+            continue
+        if tj.get("workload") == workload and tj.get("sites") == sites and kernel_name in pj.get("kernel", ""):
+            best = (tag, tj, pj)                                                   # latest tag wins (sorted)
+    if best is None:
+        return None
+    tag, tj, pj = best
+    c = {k: v["mean_per_launch"] for k, v in pj.get("counters", {}).items()}
+    out = {"replayed_from": "profiles/%s (rocprofv3 --pmc passes of scripts/profile.sh on this workload; not measured in this run)" % tag,
+           "profiled_kernel_ms": pj.get("avg_ms"), "hbm_bytes_per_launch": tj.get("hbm_bytes_per_launch"),
+           "valu_instr_per_launch": c.get("SQ_INSTS_VALU")}
+    if c.get("GRBM_GUI_ACTIVE") and c.get("SQ_INSTS_VALU"):
+        cyc = c["GRBM_GUI_ACTIVE"] / 8.0                                           # summed over the 8 XCDs
+        out["valu_instr_per_cycle_per_simd"] = c["SQ_INSTS_VALU"] / (1024.0 * cyc)
+        if c.get("SQ_LDS_IDX_ACTIVE"):
+            out["lds_busy"] = c["SQ_LDS_IDX_ACTIVE"] / (256.0 * cyc)
+    if c.get("SQ_LDS_IDX_ACTIVE") and c.get("SQ_LDS_BANK_CONFLICT"):
+        out["lds_conflict_frac"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]
+    return out
+
+
+def make_roofline(peak, T, sites, k_ms, rle_bytes_per_site, geo, workload, counters_sites):
+    lookups = 2.0 * T * sites                                                      # tracked columns x 2 planes x sites
+    achieved = lookups / (k_ms * 1e-3) / 1e9
+    alg_bytes_per_site = 16.0 * T + rle_bytes_per_site + 12.0
+    kname = "scan_kernel<%d, %d" % (geo["threads"], geo["cols_per_thread"])
+    r = {"bound": "valu_issue", "achieved": achieved, "peak": peak["g_lookups_per_s"], "unit": "G rank-lookups/s",
+         "frac": achieved / peak["g_lookups_per_s"], "traffic": None,
+         "kernel": kname + ", ...>", "kernel_ms": k_ms, "lookups_per_launch": lookups,
+         "peak_source": peak["source"], "peak_cycles_per_valu_instr": peak["cycles_per_valu_instr"],
+         "peak_clock_ghz": peak["clock_ghz"],
+         "algorithmic_bytes_per_site": alg_bytes_per_site,
+         "algorithmic_equiv_gbs": alg_bytes_per_site * sites / (k_ms * 1e-3) / 1e9,
+         "hbm_peak_gbs": HBM_PEAK_GBS,
+         "note": "the permutation stays in registers: HBM carries only RLE strings, row descriptors and checkpoints, so the "
+                 "16*T-bytes-per-site figure of SURVEY 8d (algorithmic_equiv_gbs) exceeds the HBM peak and bounds nothing; the "
+                 "bound is VALU issue (calibration: profiles/r02a_calibration)"}
+    rc = replayed_counters(workload, counters_sites, kname)
+    if rc:
+        r["counters"] = rc
+        r["traffic"] = rc.get("hbm_bytes_per_launch")
+        r["traffic_replayed_from"] = rc["replayed_from"]
+        if rc.get("valu_instr_per_cycle_per_simd"):
+            r["valu_issue_frac_profiled"] = rc["valu_instr_per_cycle_per_simd"] / peak["valu_instr_per_cycle_per_simd"]
+    return r
+
+
+def reference_cli_baseline(n_samples, ns, seed, view_args, tmp, what, all_cores=False):
+    """The compiled reference's `bgt view` on a database of the first `ns` sites of the cohort; also this repo's CLI on
+    the same command (stdout compared)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bgt_amd", "host")])
+    prefix = os.path.join(tmp, "db_%d_%d" % (n_samples, ns))
+    if not os.path.exists(prefix + ".pbf"):
+        subprocess.check_call([MY_BIN, "synth", prefix, str(n_samples), str(ns), str(seed)])
+    cmd = ["view"] + view_args + [prefix]
+    t0 = time.perf_counter()
+    ref_out = subprocess.run([REF_BIN] + cmd, stdout=subprocess.PIPE, check=True).stdout
+    t_ref = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    my_out = subprocess.run([MY_BIN] + cmd, stdout=subprocess.PIPE, check=True).stdout
+    t_mine = time.perf_counter() - t0
+    same = hashlib.md5(ref_out).hexdigest() == hashlib.md5(my_out).hexdigest()
+    out = {"value": ns / t_ref, "unit": "sites/s", "cores": 1, "kind": "reference",
+           "sample": "reference `bgt view %s` (oracle/_ref/bgt, gcc -O2, one thread, %.1f s wall incl. open) on a %d-sample x "
+                     "%d-site database = first sites of %s" % (" ".join(view_args), t_ref, n_samples, ns, what),
+           "cli_stdout_identical_to_reference": same, "cli_stdout_bytes": len(ref_out),
+           "this_repo_cli_same_command_s": round(t_mine, 2)}
+    if all_cores:
+        # the reference is single-threaded; the whole box = one process per 8192-site block range (disjoint -r
+        # ranges, SURVEY 8d), as many at a time as there are cores
+        try:
+            n_blk = (ns + 8191) // 8192
+            procs = min(n_blk, os.cpu_count() or 1)
+            t0 = time.perf_counter()
+            running = []
+            for k in range(n_blk):
+                reg = "11:%d-%d" % (1000 + 10 * k * 8192, 1000 + 10 * min(ns, (k + 1) * 8192) - 1)
+                running.append(subprocess.Popen([REF_BIN, "view"] + view_args + ["-r", reg, prefix], stdout=subprocess.DEVNULL))
+                if len(running) >= procs:
+                    running.pop(0).wait()
+            for pr in running:
+                pr.wait()
+            t_all = time.perf_counter() - t0
+            out["all_cores"] = {"value": ns / t_all, "unit": "sites/s", "processes": procs,
+                                "sample": "%d reference processes over disjoint 8192-site regions, %.1f s wall" % (n_blk, t_all)}
+        except Exception as e:
+            out["all_cores"] = {"error": repr(e)[:120]}
+    return out, same
+
+
+class Pipeline:
+    """scan -> device filter -> (all_gather) -> pinned host copy, double buffered: the copy of step i overlaps step i+1."""
+
+    def __init__(self, torch, bgt_amd, rd, row0, row1, dev, local, world, rank, dist):
+        self.torch, self.rd, self.row0, self.row1, self.world, self.rank, self.dist = torch, rd, row0, row1, world, rank, dist
+        n = self.n = row1 - row0
+        self.flt = bgt_amd.HipFilter("AC>0", n_groups=1, device=local)            # -f'AC>0', evaluated on the device
+        self.main = torch.cuda.current_stream()
+        self.side = torch.cuda.Stream(device=dev)
+        self.counts = [torch.empty((n, 1, 3), dtype=torch.int32, device=dev) for _ in range(2)]
+        self.flags = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.n_pass_d = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(2)]
+        if world > 1:
+            self.g_counts = [torch.empty((world * n, 1, 3), dtype=torch.int32, device=dev) for _ in range(2)]
+            self.g_flags = [torch.empty(world * n, dtype=torch.uint8, device=dev) for _ in range(2)]
+        else:
+            self.g_counts, self.g_flags = self.counts, self.flags
+        if rank == 0:
+            self.host = [torch.empty((world * n, 1, 3), dtype=torch.int32).pin_memory() for _ in range(2)]
+            self.host_flags = [torch.empty(world * n, dtype=torch.uint8).pin_memory() for _ in range(2)]
+            self.host_n_pass = [torch.zeros(1, dtype=torch.int64).pin_memory() for _ in range(2)]
+        self.ready = [torch.cuda.Event() for _ in range(2)]
+        self.copied = [torch.cuda.Event() for _ in range(2)]
+        for e in self.copied:
+            e.record(self.main)
+        self.done = 0
+
+    def step(self):
+        torch = self.torch
+        b = self.done & 1
+        self.done += 1
+        self.main.wait_event(self.copied[b])                                     # buffer b has left the device
+        self.rd.scan_device(self.row0, self.row1, self.counts[b].data_ptr(), stream=self.main.cuda_stream)
+        self.n_pass_d[b].zero_()
+        self.flt.apply_device(self.counts[b].data_ptr(), self.n, 3, self.flags[b].data_ptr(), self.n_pass_d[b].data_ptr(),
+                              self.main.cuda_stream)
+        if self.world > 1:                                                       # per-shard AN/AC + flags over xGMI
+            self.dist.all_gather_into_tensor(self.g_counts[b], self.counts[b])
+            self.dist.all_gather_into_tensor(self.g_flags[b], self.flags[b])
+            self.dist.all_reduce(self.n_pass_d[b])
+        self.ready[b].record(self.main)
+        if self.rank == 0:
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(self.ready[b])
+                self.host[b].copy_(self.g_counts[b], non_blocking=True)
+                self.host_flags[b].copy_(self.g_flags[b], non_blocking=True)
+                self.host_n_pass[b].copy_(self.n_pass_d[b], non_blocking=True)
+                self.copied[b].record(self.side)
+        return b                                                                 # (nothing here waits: steps are enqueued back to back)
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def run(self, steps, warmup):
+        for _ in range(warmup):
+            self.step()
+        self.barrier()
+        t0 = time.perf_counter()
+        last = 0
+        for _ in range(steps):
+            last = self.step()
+        self.barrier()                                                           # includes the side stream: all results on the host
+        dt = time.perf_counter() - t0
+        k_ms = self.rd.timing()["scan_ms"]                                       # HIP events around the scan kernel of the last step
+        return dt, k_ms, last
+
+
+def secondary_record(torch, bgt_amd, np, peak, name, what, n_samples, sites, seed, every, steps, warmup, dev, local, tmp,
+                     cpu_sites, counters_workload):
+    m = 2 * n_samples
+    t0 = time.time()
+    rle, lens = bgt_amd.synth_rows(m, 0, sites, seed)
+    t_gen = time.time() - t0
+    t0 = time.time()
+    pbf = bgt_amd.HipPbf.from_rle(m, 13, rle, lens, device=local)
+    t_load = time.time() - t0
+    rle_bytes_per_site = rle.size / sites
+    n_chk, chk = min(sites, 1024), None
+    try:                                                          # a small image of the first sites for the oracle check
+        nb = int(lens[:2 * n_chk].sum(dtype=np.int64))
+        small = bgt_amd.HipPbf.from_rle(m, 13, rle[:nb], lens[:2 * n_chk], device=local)
+        small.save(os.path.join(tmp, "chk.pbf"))
+        small.close()
+        chk = open(os.path.join(tmp, "chk.pbf"), "rb").read()
+    except Exception:
+        chk = None
+    del rle
+    rd = bgt_amd.HipReader(pbf)
+    view_args = ["-G", "-f", "AC>0"]
+    if every > 1:
+        sel = np.arange(0, n_samples, every)
+        rd.select(np.stack([2 * sel, 2 * sel + 1], 1).reshape(-1))
+        view_args = ["-G", "-f", "AC>0", "-s", "idx%%%d==0" % every]
+    T = rd.width
+    pipe = Pipeline(torch, bgt_amd, rd, 0, sites, dev, local, 1, 0, None)
+    dt, k_ms, last = pipe.run(steps, warmup)
+    geo = rd.geometry()
+    rec = {"workload": what, "haplotypes": m, "tracked_columns": T, "sites": sites,
+           "sites_per_s": sites / (dt / steps), "ms_per_step": dt / steps * 1e3, "kernel_ms": k_ms, "steps": steps,
+           "sites_passing_filter": int(pipe.host_n_pass[last].item()), "launch": geo,
+           "rle_bytes_per_site": round(rle_bytes_per_site, 1), "hbm_resident_bytes": pbf.hbm_bytes,
+           "setup": {"generate_s": round(t_gen, 1), "upload_and_checkpoints_s": round(t_load, 1)},
+           "roofline": make_roofline(peak, T, sites, k_ms, rle_bytes_per_site, geo, counters_workload, sites)}
+    # the timed step's output against the CPU oracle (port of the reference path) on the first sites
+    if chk is not None:
+        import orc                                                # checker only
+        ora = orc.Pbf(chk)
+        if every > 1:
+            ora.subset(np.stack([2 * sel, 2 * sel + 1], 1).reshape(-1))
+        oc = ora.scan(0, n_chk)
+        rec["gpu_matches_cpu_oracle_on_first_sites"] = bool(np.array_equal(oc.reshape(n_chk, 1, 3), pipe.host[last].numpy()[:n_chk]))
+        rec["oracle_sites_checked"] = n_chk
+        if not rec["gpu_matches_cpu_oracle_on_first_sites"]:
+            rec["parity_error"] = "GPU counts differ from the CPU oracle on the first %d sites" % n_chk
+    if os.path.exists(REF_BIN) and cpu_sites > 0:
+        try:
+            base, same = reference_cli_baseline(n_samples, cpu_sites, seed, view_args, tmp, what)
+            # the timed GPU output against the reference's stdout on those sites: passing sites = data lines
+            rec["cpu_baseline"] = base
+            rec["speedup_vs_reference_1core"] = rec["sites_per_s"] / base["value"]
+            if not same:
+                rec["parity_error"] = "`bgt view` stdout differs from the reference binary"
+        except Exception as e:
+            rec["cpu_baseline"] = {"error": repr(e)[:200]}
+    del pipe
+    rd.close()
+    pbf.close()
+    return rec
 
 
 def main():
@@ -36,10 +301,12 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=sorted(SAMPLES))
-    ap.add_argument("--sites", type=int, default=1000000, help="sites per GPU")
+    ap.add_argument("--sites", type=int, default=0, help="sites per GPU (default 1,000,000; c4: all 10,000,000 split over the GPUs)")
     ap.add_argument("--every", type=int, default=0, help="select every N-th sample only (C3: --workload c3 --every 20)")
-    ap.add_argument("--seed", type=int, default=2)
+    ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=262144, help="sites for the CPU baseline (0 = skip)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the 100,000-sample secondary records (N = 1)")
+    ap.add_argument("--secondary-steps", type=int, default=3)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--cpt", type=int, default=0)
     ap.add_argument("--batch", type=int, default=0)
@@ -55,6 +322,7 @@ def main():
     import numpy as np
     import torch
     import bgt_amd
+    from bgt_amd.shard import block_shards
 
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -65,17 +333,30 @@ def main():
 
     n_samples = SAMPLES[args.workload]
     m = 2 * n_samples
-    sites = args.sites
     shift = 13
+    seed = args.seed or {"c2": 2, "c3": 3, "c4": 4, "small": 1}[args.workload]
+    strong = args.workload == "c4"
+    if strong:                                                # configs[3]: one database, block-aligned shards
+        total = args.sites or 10000000
+        shards = block_shards(total, shift, world)
+        row_lo, row_hi = shards[rank]
+        sites = shards[0][1] - shards[0][0]                   # every rank's buffers are sized for the longest shard
+    else:
+        sites = args.sites or 1000000
+        total = world * sites
+        row_lo, row_hi = rank * sites, (rank + 1) * sites
 
-    # ---- synthetic shard: rows [rank*sites, (rank+1)*sites) of cohort (seed, m), drawn on the host cores
+    # ---- synthetic shard: file rows [row_lo, row_hi) of cohort (seed, m), drawn on the host cores
     t0 = time.time()
-    rle, lens = bgt_amd.synth_rows(m, rank * sites, sites, args.seed)
+    my_rows = row_hi - row_lo
+    if strong and my_rows < sites:                            # the last shard is shorter: pad with the cohort's next rows so
+        my_rows = sites                                       # that all_gather sees equal sizes (they are cut off below)
+    rle, lens = bgt_amd.synth_rows(m, row_lo, my_rows, seed)
     t_gen = time.time() - t0
     t0 = time.time()
     pbf = bgt_amd.HipPbf.from_rle(m, shift, rle, lens, device=local)   # upload + checkpoints on the GPU
     t_load = time.time() - t0
-    rle_bytes_per_site = rle.size / sites
+    rle_bytes_per_site = rle.size / my_rows
     rd = bgt_amd.HipReader(pbf)
     if args.every > 1:                                          # sample subset (-s): fewer tracked columns, same rows
         sel = np.arange(0, n_samples, args.every)
@@ -83,134 +364,65 @@ def main():
     rd.tune(args.threads, args.cpt, args.batch)
     T = rd.width
 
-    # Two result buffers: the D2H copy of step i (rank 0, side stream) overlaps the scan of step i+1.
-    flt = bgt_amd.HipFilter("AC>0", n_groups=1, device=local)            # -f'AC>0', evaluated on the device
-    main = torch.cuda.current_stream()
-    side = torch.cuda.Stream(device=dev)
-    counts = [torch.empty((sites, 1, 3), dtype=torch.int32, device=dev) for _ in range(2)]
-    flags = [torch.empty(sites, dtype=torch.uint8, device=dev) for _ in range(2)]
-    n_pass_d = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(2)]
-    if world > 1:
-        g_counts = [torch.empty((world * sites, 1, 3), dtype=torch.int32, device=dev) for _ in range(2)]
-        g_flags = [torch.empty(world * sites, dtype=torch.uint8, device=dev) for _ in range(2)]
-    else:
-        g_counts, g_flags = counts, flags
+    peak = lookup_peak(bgt_amd, local) if rank == 0 else None
+    pipe = Pipeline(torch, bgt_amd, rd, 0, sites, dev, local, world, rank, dist)
+    dt, k_ms, last = pipe.run(args.steps, args.warmup)
+    n_pass = int(pipe.host_n_pass[last].item()) if rank == 0 else 0
     if rank == 0:
-        host = [torch.empty((world * sites, 1, 3), dtype=torch.int32).pin_memory() for _ in range(2)]
-        host_flags = [torch.empty(world * sites, dtype=torch.uint8).pin_memory() for _ in range(2)]
-        host_n_pass = [torch.zeros(1, dtype=torch.int64).pin_memory() for _ in range(2)]
-    ready = [torch.cuda.Event() for _ in range(2)]
-    copied = [torch.cuda.Event() for _ in range(2)]
-    for e in copied:
-        e.record(main)
-    kernel_ms = []
-    n_steps_done = [0]
-
-    def step():
-        b = n_steps_done[0] & 1
-        n_steps_done[0] += 1
-        main.wait_event(copied[b])                                       # buffer b has left the device
-        rd.scan_device(0, sites, counts[b].data_ptr(), stream=main.cuda_stream)
-        n_pass_d[b].zero_()
-        flt.apply_device(counts[b].data_ptr(), sites, 3, flags[b].data_ptr(), n_pass_d[b].data_ptr(),
-                         main.cuda_stream)
-        if world > 1:                                                    # per-shard AN/AC + flags over xGMI
-            dist.all_gather_into_tensor(g_counts[b], counts[b])
-            dist.all_gather_into_tensor(g_flags[b], flags[b])
-            dist.all_reduce(n_pass_d[b])
-        ready[b].record(main)
-        if rank == 0:
-            with torch.cuda.stream(side):
-                side.wait_event(ready[b])
-                host[b].copy_(g_counts[b], non_blocking=True)
-                host_flags[b].copy_(g_flags[b], non_blocking=True)
-                host_n_pass[b].copy_(n_pass_d[b], non_blocking=True)
-                copied[b].record(side)
-        return b                                                         # (nothing here waits: steps are enqueued back to back)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    kernel_ms.clear()
-    barrier()
-    t0 = time.perf_counter()
-    last = 0
-    for _ in range(args.steps):
-        last = step()
-    barrier()                                                            # includes the side stream: all results on the host
-    dt = time.perf_counter() - t0
-    kernel_ms.append(rd.timing()["scan_ms"])                             # HIP events around the scan kernel of the last step
-    n_pass = int(host_n_pass[last].item()) if rank == 0 else 0
-    if rank == 0:
-        host = host[last]
-        assert n_pass == int(host_flags[last].numpy().sum())
+        host = pipe.host[last]
+        host_flags = pipe.host_flags[last]
+        if not strong:
+            assert n_pass == int(host_flags.numpy().sum())
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
     ms_per_step = dt / args.steps * 1e3
-    value = world * sites / (dt / args.steps)
-    k_ms = sum(kernel_ms) / len(kernel_ms)
-    alg_bytes_per_site = 16.0 * T + rle_bytes_per_site + 12.0
-    achieved = alg_bytes_per_site * sites / (k_ms * 1e-3) / 1e9
+    value = total / (dt / args.steps)
     geo = rd.geometry()
 
     out = None
     if rank == 0:
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("workload") == args.workload and tj.get("sites") == sites:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        if args.workload == "c2":
+            wl = "C2: synthetic %d samples x %d sites per GPU, whole cohort, -G -f'AC>0'" % (n_samples, sites)
+        elif strong:
+            wl = "C4: synthetic %d samples x %d sites, whole cohort, -G -f'AC>0', %d file blocks sharded over %d GPU(s)" % (
+                n_samples, total, (total + 8191) // 8192, world)
+        else:
+            wl = "%s: %d samples x %d sites per GPU%s" % (args.workload, n_samples, sites,
+                                                          ", every %d-th sample selected" % args.every if args.every > 1 else "")
         out = {
             "metric": "sites/sec `bgt view -G -f'AC>0'` whole-cohort scan",
             "value": value, "unit": "sites/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "C2: synthetic %d samples x %d sites per GPU, whole cohort, -G -f'AC>0'"
-                                   % (n_samples, sites) if args.workload == "c2" else
-                                   "%s: %d samples x %d sites per GPU%s" % (args.workload, n_samples, sites,
-                                   ", every %d-th sample selected" % args.every if args.every > 1 else ""),
-                       "haplotypes": m, "tracked_columns": T, "sites_per_gpu": sites,
-                       "sharding": "site-range x%d + all_gather(counts)" % world if world > 1 else "single GPU",
+            "config": {"workload": wl,
+                       "haplotypes": m, "tracked_columns": T, "sites_per_gpu": sites, "sites_total": total,
+                       "sharding": ("block-aligned site ranges x%d (bgt_amd.shard.block_shards) + all_gather(counts)" % world if strong else
+                                    "site-range x%d + all_gather(counts)" % world) if world > 1 else "single GPU",
                        "rle_bytes_per_site": round(rle_bytes_per_site, 1), "sites_passing_filter": n_pass,
                        "filter": "AC>0 evaluated on the device (bgth_filter_apply_device); counts + flags copied "
                                  "to pinned host memory, the copy of step i overlapping the scan of step i+1",
                        "launch": geo},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "scan_kernel<%d,%d>" % (geo["threads"], geo["cols_per_thread"]),
-                         "kernel_ms": k_ms, "algorithmic_bytes_per_site": alg_bytes_per_site,
-                         "note": "achieved = reference-algorithm bytes / kernel time; the kernel keeps the "
-                                 "permutation in registers, real HBM traffic is `traffic` (see DESIGN.md)"},
+            "roofline": make_roofline(peak, T, sites, k_ms, rle_bytes_per_site, geo, args.workload, sites),
             "setup": {"generate_s": round(t_gen, 2), "upload_and_checkpoints_s": round(t_load, 2),
                       "hbm_resident_bytes": pbf.hbm_bytes},
         }
 
     # ---- CPU baseline + on-box parity check (rank 0, N=1 only) on a bounded sample of the same cohort:
-    # the first `cpu_sample` sites.  Preferred: the COMPILED REFERENCE (oracle/_ref/bgt, built from
-    # /root/reference in the build container and shipped with the repo) running the metric's own command
-    # line on a database this repo writes; its stdout is also compared with this repo's `bgt view`.
-    # Always: the CPU oracle (port) on the same rows, compared with the counts the GPU delivered.
-    if rank == 0 and world == 1 and args.cpu_sample > 0 and args.every <= 1:
-        import hashlib
-        import subprocess
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import orc                                            # CPU oracle: checker / baseline only
-        ns = min(sites, args.cpu_sample)
-        nstr = 2 * ns
-        nbytes = int(lens[:nstr].sum(dtype=np.int64))
-        sample = bgt_amd.HipPbf.from_rle(m, shift, rle[:nbytes], lens[:nstr], device=local)
-        with tempfile.TemporaryDirectory() as tmp:
+    # the first `cpu_sample` sites.  The COMPILED REFERENCE (oracle/_ref/bgt, built from /root/reference in the build
+    # container and shipped with the repo) runs the metric's own command line on a database this repo writes; its
+    # stdout is also compared with this repo's `bgt view`.  Always: the CPU oracle (port) on the same rows, compared
+    # with the counts the GPU delivered in the last timed step.
+    with tempfile.TemporaryDirectory() as tmp:
+        if rank == 0 and world == 1 and args.cpu_sample > 0 and args.every <= 1:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import orc                                            # CPU oracle: checker / baseline only
+            ns = min(sites, args.cpu_sample if m <= 20000 else 4096)
+            nstr = 2 * ns
+            nbytes = int(lens[:nstr].sum(dtype=np.int64))
+            sample = bgt_amd.HipPbf.from_rle(m, shift, rle[:nbytes], lens[:nstr], device=local)
             path = os.path.join(tmp, "sample.pbf")
             sample.save(path)
             data = open(path, "rb").read()
@@ -221,7 +433,7 @@ def main():
             n_pass_cpu = int((oc[:, 1] > 0).sum())
             t_cpu = time.perf_counter() - t0
             same = bool(np.array_equal(oc.reshape(ns, 1, 3), host.numpy()[:ns])) and \
-                bool(np.array_equal(oc[:, 1] > 0, host_flags[last].numpy()[:ns] != 0))
+                bool(np.array_equal(oc[:, 1] > 0, host_flags.numpy()[:ns] != 0))
             port = {"value": ns / t_cpu, "unit": "sites/s", "cores": 1, "kind": "port",
                     "sample": "first %d sites of the same cohort (oracle/liborc.so: decode both planes + AC/AN + "
                               "AC>0, one thread, %.1f s)" % (ns, t_cpu),
@@ -229,53 +441,40 @@ def main():
             out["cpu_baseline"] = port
             if not same:
                 out["parity_error"] = "GPU counts differ from the CPU oracle on the sample"
-            ref_bin = os.path.join(ROOT, "oracle", "_ref", "bgt")
-            my_bin = os.path.join(ROOT, "bgt_amd", "bin", "bgt")
-            if os.path.exists(ref_bin) and args.workload == "c2":
+            if os.path.exists(REF_BIN):
                 try:
-                    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bgt_amd", "host")])
-                    prefix = os.path.join(tmp, "db")
-                    subprocess.check_call([my_bin, "synth", prefix, str(n_samples), str(ns), str(args.seed)])
-                    cmd = ["view", "-G", "-f", "AC>0", prefix]
-                    t0 = time.perf_counter()
-                    ref_out = subprocess.run([ref_bin] + cmd, stdout=subprocess.PIPE, check=True).stdout
-                    t_ref = time.perf_counter() - t0
-                    t0 = time.perf_counter()
-                    my_out = subprocess.run([my_bin] + cmd, stdout=subprocess.PIPE, check=True).stdout
-                    t_mine = time.perf_counter() - t0
-                    cli_same = hashlib.md5(ref_out).hexdigest() == hashlib.md5(my_out).hexdigest()
-                    out["cpu_baseline"] = {
-                        "value": ns / t_ref, "unit": "sites/s", "cores": 1, "kind": "reference",
-                        "sample": "reference `bgt view -G -f'AC>0'` (oracle/_ref/bgt, gcc -O2, one thread, %.1f s wall incl. "
-                                  "open) on a %d-sample x %d-site database = first sites of the same cohort"
-                                  % (t_ref, n_samples, ns),
-                        "cli_stdout_identical_to_reference": cli_same, "cli_stdout_bytes": len(ref_out),
-                        "this_repo_cli_same_command_s": round(t_mine, 2),
-                        "gpu_matches_cpu_on_sample": same, "port": port}
-                    # the reference is single-threaded; the whole box = one process per 8192-site block range
-                    # (disjoint -r ranges), as many at a time as there are cores
-                    try:
-                        n_blk = (ns + 8191) // 8192
-                        procs = min(n_blk, os.cpu_count() or 1)
-                        t0 = time.perf_counter()
-                        running = []
-                        for k in range(n_blk):
-                            reg = "11:%d-%d" % (1000 + 10 * k * 8192, 1000 + 10 * min(ns, (k + 1) * 8192) - 1)
-                            running.append(subprocess.Popen([ref_bin, "view", "-G", "-f", "AC>0", "-r", reg, prefix],
-                                                            stdout=subprocess.DEVNULL))
-                            if len(running) >= procs:
-                                running.pop(0).wait()
-                        for pr in running:
-                            pr.wait()
-                        t_all = time.perf_counter() - t0
-                        out["cpu_baseline"]["all_cores"] = {"value": ns / t_all, "unit": "sites/s", "processes": procs,
-                                                            "sample": "%d reference processes over disjoint 8192-site regions, %.1f s wall" % (n_blk, t_all)}
-                    except Exception as e:
-                        out["cpu_baseline"]["all_cores"] = {"error": repr(e)[:120]}
+                    base, cli_same = reference_cli_baseline(n_samples, ns, seed, ["-G", "-f", "AC>0"], tmp,
+                                                            "the same cohort", all_cores=True)
+                    base["gpu_matches_cpu_on_sample"] = same
+                    base["port"] = port
+                    out["cpu_baseline"] = base
                     if not cli_same:
                         out["parity_error"] = "`bgt view` stdout differs from the reference binary"
                 except Exception as e:                        # keep the port numbers, say why
                     out["cpu_baseline"]["reference_leg_error"] = repr(e)[:200]
+        # ---- secondary records at the north-star width (100,000 samples), N = 1 only
+        if rank == 0 and world == 1 and args.workload == "c2" and not args.no_secondary and not args.every:
+            del pipe
+            rd.close()
+            pbf.close()
+            del rle, lens
+            out["secondary"] = []
+            if os.path.join(ROOT, "tests") not in sys.path:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+            for name, what, s_sites, s_seed, s_every, cw in (
+                    ("C3", "C3: synthetic 100000 samples x 1000000 sites, every 20th sample (5,000 samples, 10,000 tracked columns), -G -f'AC>0'",
+                     1000000, 3, 20, "c3"),
+                    ("C4-shard", "C4 shard: synthetic 100000 samples x 1253376 sites (153 file blocks = one GPU's share of the 10,000,000-site "
+                                 "configuration), whole cohort, -G -f'AC>0'", 153 * 8192, 4, 0, "c4shard")):
+                try:
+                    rec = secondary_record(torch, bgt_amd, np, peak, name, what, 100000, s_sites, s_seed, s_every,
+                                           args.secondary_steps, 1, dev, local, tmp, 4096, cw)
+                    rec["name"] = name
+                    out["secondary"].append(rec)
+                    if rec.get("parity_error"):
+                        out["parity_error"] = name + ": " + rec["parity_error"]
+                except Exception as e:
+                    out["secondary"].append({"name": name, "error": repr(e)[:300]})
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
