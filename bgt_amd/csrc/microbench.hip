@@ -8,12 +8,14 @@
 // BGTH_TAIL of scan_device.inc.h, with and without its ds_read_b64), at a chosen number of waves per SIMD.
 // Every wave brackets its loop with s_memtime (shader cycles); the host also times the launch with HIP events.
 #include "scan_device.inc.h"     // step4<>: the product's own row step, and its instruction macros
+#include "scan_step_variants.inc.h"
 
 namespace bgth {
 
 // one workgroup per CU (the launch asks for more than half the LDS), NT / 256 waves per SIMD
 enum { MIX_FMA = 0, MIX_ADD = 1, MIX_STEP = 2, MIX_BCNT = 3, MIX_CMPSEL = 4, MIX_MAD24 = 5, MIX_STEP_LDS_FLAT = 6,
-       MIX_STEP_LDS_RANDOM = 7, MIX_LSHL = 8, MIX_LDS_ONLY_FLAT = 9, MIX_LDS_ONLY_RANDOM = 10, MIX_N = 11 };
+       MIX_STEP_LDS_RANDOM = 7, MIX_LSHL = 8, MIX_LDS_ONLY_FLAT = 9, MIX_LDS_ONLY_RANDOM = 10,
+       MIX_IL2 = 11, MIX_IL4 = 12, MIX_IL8 = 13, MIX_N = 14 };
 
 // eight independent instances of one instruction, registers v40..v47 (+ v48..v55 as second operands)
 #define R8(OP) OP(40) OP(41) OP(42) OP(43) OP(44) OP(45) OP(46) OP(47)
@@ -30,8 +32,9 @@ __global__ void issue_rate_kernel(int iters, unsigned long long *cycles, uint32_
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint2 *tab = reinterpret_cast<uint2*>(smem);
     constexpr int NE = 4096;                                  // 32 KB of {bits, before} entries: a row of m = 131072 columns
-    constexpr bool RANDOM = MIX == MIX_STEP_LDS_RANDOM || MIX == MIX_LDS_ONLY_RANDOM;
-    if (MIX == MIX_STEP_LDS_FLAT || MIX == MIX_STEP_LDS_RANDOM || MIX == MIX_LDS_ONLY_FLAT || MIX == MIX_LDS_ONLY_RANDOM) {
+    constexpr bool IL = MIX == MIX_IL2 || MIX == MIX_IL4 || MIX == MIX_IL8;
+    constexpr bool RANDOM = MIX == MIX_STEP_LDS_RANDOM || MIX == MIX_LDS_ONLY_RANDOM || IL;
+    if (MIX == MIX_STEP_LDS_FLAT || MIX == MIX_STEP_LDS_RANDOM || MIX == MIX_LDS_ONLY_FLAT || MIX == MIX_LDS_ONLY_RANDOM || IL) {
         // a VALID directory, so that the row step is a true LF-mapping and the ranks stay inside the row for any number
         // of steps: RANDOM = pseudo-random bits with their prefix popcounts; FLAT = the all-zero row (ranks never move)
         for (int i = threadIdx.x; i < NE; i += blockDim.x) tab[i] = make_uint2(RANDOM ? 0x9e3779b9u * (uint32_t)(i + 1) * (uint32_t)(i + 7) : 0u, 0u);
@@ -85,7 +88,7 @@ __global__ void issue_rate_kernel(int iters, unsigned long long *cycles, uint32_
         uint32_t r0[4] = {q[0], q[2], q[4], q[6]}, r1[4] = {q[1], q[3], q[5], q[7]};
         uint64_t m0[4], m1[4];
         uint32_t ca = 0, cb = 0, cc = 0;
-        const uint32_t nn0 = (LDS || ONLY) ? 0u - (uint32_t)__builtin_amdgcn_readfirstlane((int)tab[NE].x) : 0u - 77u;
+        const uint32_t nn0 = (LDS || ONLY || IL) ? 0u - (uint32_t)__builtin_amdgcn_readfirstlane((int)tab[NE].x) : 0u - 77u;
         const uint32_t base0 = base, base1 = base, n00 = nn0, n01 = nn0;     // operand names of BGTH_STEP4_OPERANDS
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -101,6 +104,12 @@ __global__ void issue_rate_kernel(int iters, unsigned long long *cycles, uint32_
                                  : "s"(base), "v"(0)
                                  : "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115",
                                    "v116", "v117", "v118", "v119", "memory");
+                } else if constexpr (MIX == MIX_IL2) {
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\t" BGTH_STEP4_IL2 BGTH_STEP4_OPERANDS);
+                } else if constexpr (MIX == MIX_IL4) {
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\t" BGTH_STEP4_IL4 BGTH_STEP4_OPERANDS);
+                } else if constexpr (MIX == MIX_IL8) {
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\t" BGTH_STEP4_IL8 BGTH_STEP4_OPERANDS);
                 } else if constexpr (LDS) {
                     step4<false>(r0, r1, m0, m1, ca, cb, cc, base, base, nn0, nn0);
                 } else {
@@ -261,6 +270,8 @@ static const MixInfo kMix[MIX_N] = {
     {"v_cmp_gt_i32_e64 + v_cndmask_b32_e64", 64, 0}, {"v_mad_i32_i24", 64, 0},
     {"row step + ds_read_b64, conflict-free", 4 * 8 * 8, 4 * 8}, {"row step + ds_read_b64, random entries", 4 * 8 * 8, 4 * 8},
     {"v_lshlrev_b32", 64, 0}, {"ds_read_b64 + its 2 address VALU, conflict-free", 4 * 16, 4 * 8}, {"ds_read_b64 + its 2 address VALU, random entries", 4 * 16, 4 * 8},
+    {"row step, tails of 2 lookups interleaved, random entries", 4 * 8 * 8, 4 * 8}, {"row step, tails of 4 lookups interleaved, random entries", 4 * 8 * 8, 4 * 8},
+    {"row step, tails of 8 lookups interleaved, random entries", 4 * 8 * 8, 4 * 8},
 };
 
 template <int MIX>
@@ -292,7 +303,7 @@ hipError_t run_issue_rate(int mix, int waves_per_simd, int iters, double out[4])
         hipEventRecord(e0, nullptr);
         switch (mix) {
 #define X(M) case M: e = launch_mix<M>(threads, iters, cyc, sink, nullptr); break;
-        X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
+        X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13)
 #undef X
         }
         hipEventRecord(e1, nullptr);

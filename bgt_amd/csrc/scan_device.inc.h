@@ -112,6 +112,25 @@ __device__ __forceinline__ uint32_t rle_len(uint32_t byte)
     "v_ashrrev_i32 " T ", 5, " Q "\n\t"                \
     "v_mad_i32_i24 " T ", " T ", -8, " BASE "\n\t"
 
+// Two lookups with their dependent chains interleaved: a wave that shares its SIMD with only one other (the wide-cohort
+// kernels: 2 waves per SIMD) issues 8 % more lookups per cycle this way, four waves per SIMD are indifferent
+// (profiles/r02a_calibration: 4.56 vs 4.94 cycles per instruction at 2 waves, 3.99 vs 4.02 at 4).
+#define BGTH_TAIL2(QA, ELA, EHA, MA, N0A, QB, ELB, EHB, MB, N0B)  \
+    "v_lshlrev_b32 " ELA ", " QA ", " ELA "\n\t"                  \
+    "v_lshlrev_b32 " ELB ", " QB ", " ELB "\n\t"                  \
+    "v_bcnt_u32_b32 " EHA ", " ELA ", " EHA "\n\t"                \
+    "v_bcnt_u32_b32 " EHB ", " ELB ", " EHB "\n\t"                \
+    "v_cmp_gt_i32_e64 " MA ", 0, " ELA "\n\t"                     \
+    "v_cmp_gt_i32_e64 " MB ", 0, " ELB "\n\t"                     \
+    "v_sub_u32 " ELA ", " N0A ", " EHA "\n\t"                     \
+    "v_sub_u32 " ELB ", " N0B ", " EHB "\n\t"                     \
+    "v_add_u32 " EHA ", " QA ", " EHA "\n\t"                      \
+    "v_add_u32 " EHB ", " QB ", " EHB "\n\t"                      \
+    "v_cndmask_b32_e64 " QA ", " EHA ", " ELA ", " MA "\n\t"      \
+    "v_cndmask_b32_e64 " QB ", " EHB ", " ELB ", " MB "\n\t"
+#define BGTH_ASHR(T, Q)        "v_ashrrev_i32 " T ", 5, " Q "\n\t"
+#define BGTH_MAD(T, BASE)      "v_mad_i32_i24 " T ", " T ", -8, " BASE "\n\t"
+
 // per column, on the scalar unit (keeps the VALU for the lookups): ones of plane 0, ones of plane 1,
 // ones in both.  M0/M1 are the ballots the v_cmp of the two lookups produced.
 #define BGTH_COUNT(M0, M1, CA, CB, CC)                 \
@@ -132,21 +151,17 @@ __device__ __forceinline__ uint32_t rle_len(uint32_t byte)
     "s_add_u32 " CA ", " CA ", vcc_lo\n\t"
 
 #define BGTH_STEP2_BOTH                                                                  \
-        BGTH_ADDR("v104", "%0", "%11") BGTH_ADDR("v106", "%1", "%12")                    \
-        BGTH_ADDR("v108", "%2", "%11") BGTH_ADDR("v110", "%3", "%12")                    \
+        BGTH_ASHR("v104", "%0") BGTH_ASHR("v106", "%1") BGTH_ASHR("v108", "%2") BGTH_ASHR("v110", "%3")  \
+        BGTH_MAD("v104", "%11") BGTH_MAD("v106", "%12") BGTH_MAD("v108", "%11") BGTH_MAD("v110", "%12")  \
         "ds_read_b64 v[104:105], v104\n\t"                                               \
         "ds_read_b64 v[106:107], v106\n\t"                                               \
         "ds_read_b64 v[108:109], v108\n\t"                                               \
         "ds_read_b64 v[110:111], v110\n\t"                                               \
-        "s_waitcnt lgkmcnt(3)\n\t"                                                       \
-        BGTH_TAIL("%0", "v104", "v105", "v104", "%4", "%13")                             \
         "s_waitcnt lgkmcnt(2)\n\t"                                                       \
-        BGTH_TAIL("%1", "v106", "v107", "v106", "%5", "%14")                             \
+        BGTH_TAIL2("%0", "v104", "v105", "%4", "%13", "%1", "v106", "v107", "%5", "%14")  \
         BGTH_COUNT("%4", "%5", "%8", "%9", "%10")                                        \
-        "s_waitcnt lgkmcnt(1)\n\t"                                                       \
-        BGTH_TAIL("%2", "v108", "v109", "v108", "%6", "%13")                             \
         "s_waitcnt lgkmcnt(0)\n\t"                                                       \
-        BGTH_TAIL("%3", "v110", "v111", "v110", "%7", "%14")                             \
+        BGTH_TAIL2("%2", "v108", "v109", "%6", "%13", "%3", "v110", "v111", "%7", "%14")  \
         BGTH_COUNT("%6", "%7", "%8", "%9", "%10")
 #define BGTH_STEP2_PLANE0                                                                \
         BGTH_ADDR("v104", "%0", "%11") BGTH_ADDR("v108", "%2", "%11")                    \
@@ -194,10 +209,10 @@ __device__ __forceinline__ void step2(uint32_t &ra0, uint32_t &ra1, uint32_t &rb
 }
 
 #define BGTH_STEP4_BOTH                                                                  \
-        BGTH_ADDR("v104", "%0", "%19") BGTH_ADDR("v106", "%1", "%20")                    \
-        BGTH_ADDR("v108", "%2", "%19") BGTH_ADDR("v110", "%3", "%20")                    \
-        BGTH_ADDR("v112", "%4", "%19") BGTH_ADDR("v114", "%5", "%20")                    \
-        BGTH_ADDR("v116", "%6", "%19") BGTH_ADDR("v118", "%7", "%20")                    \
+        BGTH_ASHR("v104", "%0") BGTH_ASHR("v106", "%1") BGTH_ASHR("v108", "%2") BGTH_ASHR("v110", "%3")  \
+        BGTH_ASHR("v112", "%4") BGTH_ASHR("v114", "%5") BGTH_ASHR("v116", "%6") BGTH_ASHR("v118", "%7")  \
+        BGTH_MAD("v104", "%19") BGTH_MAD("v106", "%20") BGTH_MAD("v108", "%19") BGTH_MAD("v110", "%20")  \
+        BGTH_MAD("v112", "%19") BGTH_MAD("v114", "%20") BGTH_MAD("v116", "%19") BGTH_MAD("v118", "%20")  \
         "ds_read_b64 v[104:105], v104\n\t"                                               \
         "ds_read_b64 v[106:107], v106\n\t"                                               \
         "ds_read_b64 v[108:109], v108\n\t"                                               \
@@ -206,25 +221,17 @@ __device__ __forceinline__ void step2(uint32_t &ra0, uint32_t &ra1, uint32_t &rb
         "ds_read_b64 v[114:115], v114\n\t"                                               \
         "ds_read_b64 v[116:117], v116\n\t"                                               \
         "ds_read_b64 v[118:119], v118\n\t"                                               \
-        "s_waitcnt lgkmcnt(7)\n\t"                                                       \
-        BGTH_TAIL("%0", "v104", "v105", "v104", "%8", "%21")                             \
         "s_waitcnt lgkmcnt(6)\n\t"                                                       \
-        BGTH_TAIL("%1", "v106", "v107", "v106", "%9", "%22")                             \
+        BGTH_TAIL2("%0", "v104", "v105", "%8", "%21", "%1", "v106", "v107", "%9", "%22")  \
         BGTH_COUNT("%8", "%9", "%16", "%17", "%18")                                      \
-        "s_waitcnt lgkmcnt(5)\n\t"                                                       \
-        BGTH_TAIL("%2", "v108", "v109", "v108", "%10", "%21")                            \
         "s_waitcnt lgkmcnt(4)\n\t"                                                       \
-        BGTH_TAIL("%3", "v110", "v111", "v110", "%11", "%22")                            \
+        BGTH_TAIL2("%2", "v108", "v109", "%10", "%21", "%3", "v110", "v111", "%11", "%22") \
         BGTH_COUNT("%10", "%11", "%16", "%17", "%18")                                    \
-        "s_waitcnt lgkmcnt(3)\n\t"                                                       \
-        BGTH_TAIL("%4", "v112", "v113", "v112", "%12", "%21")                            \
         "s_waitcnt lgkmcnt(2)\n\t"                                                       \
-        BGTH_TAIL("%5", "v114", "v115", "v114", "%13", "%22")                            \
+        BGTH_TAIL2("%4", "v112", "v113", "%12", "%21", "%5", "v114", "v115", "%13", "%22") \
         BGTH_COUNT("%12", "%13", "%16", "%17", "%18")                                    \
-        "s_waitcnt lgkmcnt(1)\n\t"                                                       \
-        BGTH_TAIL("%6", "v116", "v117", "v116", "%14", "%21")                            \
         "s_waitcnt lgkmcnt(0)\n\t"                                                       \
-        BGTH_TAIL("%7", "v118", "v119", "v118", "%15", "%22")                            \
+        BGTH_TAIL2("%6", "v116", "v117", "%14", "%21", "%7", "v118", "v119", "%15", "%22") \
         BGTH_COUNT("%14", "%15", "%16", "%17", "%18")
 #define BGTH_STEP4_PLANE0                                                                \
         BGTH_ADDR("v104", "%0", "%19") BGTH_ADDR("v108", "%2", "%19")                    \
