@@ -14,6 +14,7 @@
 #include <new>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace bgth;
@@ -104,6 +105,9 @@ struct bgth_pbf_s {
     int32_t   S8 = 0;
     int64_t   rowindex_bytes = 0;
     std::mutex rowindex_lock;         // an image is shared by readers on different threads
+    // A SHARDED image (bgth_pbf_open_sharded): the file's blocks dealt out as contiguous block ranges, one partial image
+    // per shard, each on its own device.  The parent holds no device data; n = n_total, row_off = 0.
+    std::vector<bgth_pbf_t*> shards;
 };
 
 // Test / tuning knob BGTH_VARIANT: picks between kernel variants that all give the SAME results (like bgth_reader_tune):
@@ -155,7 +159,7 @@ struct HostBuf {   // pinned
         if (n <= cap) return true;
         if (p) hipHostFree(p);
         p = nullptr; cap = 0;
-        if (hipHostMalloc(&p, n, hipHostMallocDefault) != hipSuccess) return false;
+        if (hipHostMalloc(&p, n, hipHostMallocPortable) != hipSuccess) return false;   // (pinned for every device: shards)
         cap = n;
         return true;
     }
@@ -183,6 +187,7 @@ struct bgth_reader_s {
     const int32_t *last_counts = nullptr;
     const int8_t *last_gt8 = nullptr;
     const char *last_gttext = nullptr;
+    std::vector<bgth_reader_t*> subs; // reader of a sharded image: one reader per shard (own device, stream, buffers)
 };
 
 static bool use_device(int device)
@@ -283,6 +288,7 @@ static bgth_pbf_t *pbf_alloc(int device, int m, int g, int shift, int64_t n)
 extern "C" void bgth_pbf_close(bgth_pbf_t *p)
 {
     if (!p) return;
+    for (bgth_pbf_t *sh : p->shards) bgth_pbf_close(sh);
     hipSetDevice(p->device);
     if (p->d_rle) hipFree(p->d_rle);
     if (p->d_rowdesc) hipFree(p->d_rowdesc);
@@ -561,6 +567,64 @@ static bgth_pbf_t *open_rows_impl(const char *path, int64_t row0, int64_t row1, 
     return p;
 }
 
+// Block-aligned site-range shards: ceil(B / P) file blocks each, the last ones may be shorter or empty.
+extern "C" void bgth_shard_ranges(int64_t n_rows, int shift, int n_shards, int64_t *ranges)
+{
+    const int64_t n_blk = (n_rows + ((int64_t)1 << shift) - 1) >> shift, per = (n_blk + n_shards - 1) / std::max(n_shards, 1);
+    for (int i = 0; i < n_shards; ++i) {
+        const int64_t b0 = std::min(n_blk, i * per), b1 = std::min(n_blk, (i + 1) * per);
+        ranges[2 * i] = std::min(n_rows, b0 << shift); ranges[2 * i + 1] = std::min(n_rows, b1 << shift);
+    }
+}
+
+static bool read_pbf_geometry(const char *path, int32_t hdr[3], int64_t *n_total)
+{
+    FILE *fp = fopen(path, "rb");
+    uint8_t h[16], tail[8], rec[9];
+    uint64_t off = 0;
+    bool ok = fp && fread(h, 1, 16, fp) == 16 && memcmp(h, "PBF\1", 4) == 0 && fseek(fp, -8, SEEK_END) == 0 && fread(tail, 1, 8, fp) == 8;
+    if (ok) { memcpy(&off, tail, 8); ok = off >= 16 && fseek(fp, (long)off, SEEK_SET) == 0 && fread(rec, 1, 9, fp) == 9 && rec[0] == 'I'; }
+    if (fp) fclose(fp);
+    if (!ok) return false;
+    memcpy(hdr, h + 4, 12); memcpy(n_total, rec + 1, 8);
+    return true;
+}
+
+extern "C" bgth_pbf_t *bgth_pbf_open_sharded(const char *path, int n_shards, const int *devices)
+{
+    return guarded("bgth_pbf_open_sharded", (bgth_pbf_t*)nullptr, [&]() -> bgth_pbf_t* {
+        int32_t hdr[3]; int64_t n_total = 0;
+        if (n_shards < 1 || n_shards > 64 || !devices) { set_err("[E::bgth_pbf_open_sharded] 1..64 shards, one device each"); return nullptr; }
+        if (!read_pbf_geometry(path, hdr, &n_total) || n_total < 0 || hdr[2] < 0 || hdr[2] > 30) { set_err("[E::bgth_pbf_open_sharded] '%s': no PBF header / index footer", path); return nullptr; }
+        if (!use_device(devices[0])) return nullptr;
+        bgth_pbf_t *p = pbf_alloc(devices[0], hdr[0], hdr[1], hdr[2], n_total);
+        if (!p) return nullptr;
+        p->n_total = n_total;
+        std::vector<int64_t> rg((size_t)2 * n_shards);
+        bgth_shard_ranges(n_total, hdr[2], n_shards, rg.data());
+        // every shard reads, uploads and checkpoints its own blocks, concurrently (different devices, or one device's queue)
+        std::vector<bgth_pbf_t*> parts((size_t)n_shards, nullptr);
+        std::vector<std::string> errs((size_t)n_shards);
+        std::vector<std::thread> th;
+        for (int i = 0; i < n_shards; ++i) {
+            if (rg[2 * i] >= rg[2 * i + 1]) continue;
+            th.emplace_back([&, i] {
+                parts[i] = bgth_pbf_open_rows(path, rg[2 * i], rg[2 * i + 1], devices[i]);
+                if (!parts[i]) errs[i] = g_err[0] ? g_err : "shard open failed";
+            });
+        }
+        for (std::thread &t : th) t.join();
+        bool ok = true;
+        for (int i = 0; i < n_shards; ++i) {
+            if (!errs[i].empty()) { set_err("%s", errs[i].c_str()); ok = false; }
+            if (parts[i]) p->shards.push_back(parts[i]);
+        }
+        if (!ok || (p->shards.empty() && n_total > 0)) { bgth_pbf_close(p); return nullptr; }
+        return p;
+    });
+}
+extern "C" int bgth_pbf_n_shards(const bgth_pbf_t *p) { return (int)p->shards.size(); }
+
 extern "C" int64_t bgth_pbf_first_row(const bgth_pbf_t *p) { return p->row_off; }
 extern "C" int64_t bgth_pbf_loaded_rows(const bgth_pbf_t *p) { return p->n; }
 
@@ -646,7 +710,7 @@ extern "C" int64_t bgth_pbf_save(const bgth_pbf_t *p, const char *path)
 static int64_t save_impl(const bgth_pbf_t *p, const char *path)
 {
     if (!p) return -1;
-    if (p->row_off != 0 || p->n != p->n_total) { set_err("[E::bgth_pbf_save] a partial image cannot be saved"); return -1; }
+    if (p->row_off != 0 || p->n != p->n_total || !p->shards.empty()) { set_err("[E::bgth_pbf_save] a partial or sharded image cannot be saved"); return -1; }
     if (!use_device(p->device)) return -1;
     const int m = p->m;
     const size_t per = (size_t)2 * m;
@@ -701,6 +765,7 @@ extern "C" int64_t bgth_pbf_get_n(const bgth_pbf_t *p) { return p->n_total; }
 extern "C" int64_t bgth_pbf_rle_bytes(const bgth_pbf_t *p) { return p->rle_bytes; }
 extern "C" int64_t bgth_pbf_hbm_bytes(const bgth_pbf_t *p)
 {
+    if (!p->shards.empty()) { int64_t t = 0; for (const bgth_pbf_t *sh : p->shards) t += bgth_pbf_hbm_bytes(sh); return t; }
     return p->packed_bytes + 256 + p->n * 2 * 8 + p->n_sub * 2 * (int64_t)p->m * 4 + p->rowindex_bytes;
 }
 
@@ -716,12 +781,18 @@ extern "C" bgth_reader_t *bgth_reader_create(bgth_pbf_t *p)
     HIP_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking), { delete r; return nullptr; });
     for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&r->ev[i]), { delete r; return nullptr; });
     if (!build_selection(r->sel, p->m, 0, nullptr, nullptr, 1)) { bgth_reader_destroy(r); return nullptr; }
+    for (bgth_pbf_t *sh : p->shards) {
+        bgth_reader_t *sub = bgth_reader_create(sh);
+        if (!sub) { bgth_reader_destroy(r); return nullptr; }
+        r->subs.push_back(sub);
+    }
     return r;
 }
 
 extern "C" void bgth_reader_destroy(bgth_reader_t *r)
 {
     if (!r) return;
+    for (bgth_reader_t *sub : r->subs) bgth_reader_destroy(sub);
     hipSetDevice(r->pbf->device);
     if (r->stream) hipStreamSynchronize(r->stream);
     r->sel.release();
@@ -741,6 +812,7 @@ extern "C" int bgth_reader_select(bgth_reader_t *r, int n_sub, const int32_t *su
     hipStreamSynchronize(r->stream);
     if (!guarded("bgth_reader_select", false, [&] { return build_selection(r->sel, r->pbf->m, n_sub, sub, group, n_groups); })) return -1;
     r->ring0 = r->ring1 = 0;          // invalidate the pull ring
+    for (bgth_reader_t *sr : r->subs) if (bgth_reader_select(sr, n_sub, sub, group, n_groups) < 0) return -1;
     return 0;
 }
 
@@ -755,6 +827,7 @@ extern "C" int bgth_reader_slot_map(const bgth_reader_t *r, int32_t *out)
 extern "C" int bgth_reader_tune(bgth_reader_t *r, int threads, int cpt, int K)
 {
     r->tune_threads = threads; r->tune_cpt = cpt; r->tune_K = K;
+    for (bgth_reader_t *sub : r->subs) bgth_reader_tune(sub, threads, cpt, K);
     return 0;
 }
 
@@ -765,6 +838,7 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
                             uint64_t *d_h1, hipStream_t s, bool timed)
 {
     bgth_pbf_t *p = r->pbf;
+    if (!p->shards.empty()) { set_err("[E::bgth_reader_scan_device] a sharded image spans several devices: use bgth_reader_scan or the pull interface"); return -1; }
     if (row0 < 0 || row1 > p->n || row0 > row1) { set_err("[E::bgth_reader_scan] rows [%lld,%lld) outside 0..%lld", (long long)row0, (long long)row1, (long long)p->n); return -1; }
     const int64_t rows = row1 - row0;
     if (rows == 0) return 0;
@@ -866,6 +940,24 @@ extern "C" int64_t bgth_reader_scan(bgth_reader_t *r, int64_t row0, int64_t row1
     const int G = r->sel.G, gx = gx_of(G);
     const size_t cstride = (size_t)(1 + gx) * 3;
     const int nb = (r->sel.width + 3) / 4;
+    if (!r->subs.empty()) {
+        // every shard scans its part of the range on its own device, concurrently (one host thread each), straight into
+        // the caller's arrays at the shard's offset: the "gather in shard order" of SURVEY 8e is the address arithmetic
+        std::vector<std::thread> th;
+        std::vector<std::string> errs(r->subs.size());
+        for (size_t i = 0; i < r->subs.size(); ++i) {
+            bgth_reader_t *sr = r->subs[i];
+            const int64_t a0 = std::max(row0, sr->pbf->row_off), a1 = std::min(row1, sr->pbf->row_off + sr->pbf->n);
+            if (a0 >= a1) continue;
+            th.emplace_back([=, &errs] {
+                if (bgth_reader_scan(sr, a0, a1, counts ? counts + (size_t)(a0 - row0) * cstride : nullptr,
+                                     gt ? gt + (size_t)(a0 - row0) * nb : nullptr) < 0) errs[i] = g_err;
+            });
+        }
+        for (std::thread &t : th) t.join();
+        for (const std::string &e : errs) if (!e.empty()) { set_err("%s", e.c_str()); return -1; }
+        return row1 - row0;
+    }
     // with genotypes the planes are large: walk the range in pieces of whole blocks
     int64_t piece = row1 - row0;
     if (gt) {
@@ -901,6 +993,11 @@ extern "C" int64_t bgth_reader_scan(bgth_reader_t *r, int64_t row0, int64_t row1
 extern "C" int bgth_reader_last_timing(const bgth_reader_t *rc, float out[3])
 {
     bgth_reader_t *r = const_cast<bgth_reader_t*>(rc);
+    if (!r->subs.empty()) {                                      // shards run concurrently: the slowest one
+        out[0] = out[1] = out[2] = 0;
+        for (bgth_reader_t *sr : r->subs) { float t[3]; bgth_reader_last_timing(sr, t); for (int k = 0; k < 3; ++k) out[k] = std::max(out[k], t[k]); }
+        return 0;
+    }
     if (r->t_pending) { hipSetDevice(r->pbf->device); collect_timing(r); }
     out[0] = r->t_ms[0]; out[1] = r->t_ms[1]; out[2] = r->t_ms[2];
     return 0;
@@ -908,6 +1005,7 @@ extern "C" int bgth_reader_last_timing(const bgth_reader_t *rc, float out[3])
 
 extern "C" int bgth_reader_last_geometry(const bgth_reader_t *r, int out[6])
 {
+    if (!r->subs.empty()) return bgth_reader_last_geometry(r->subs[0], out);
     out[0] = r->geom.threads; out[1] = r->geom.cpt; out[2] = r->geom.slices;
     out[3] = r->geom.K; out[4] = r->geom.lds_bytes; out[5] = r->geom.workgroups;
     return 0;
@@ -923,6 +1021,45 @@ extern "C" int bgth_reader_seek(bgth_reader_t *r, int64_t row)
     if (!to_image_rows(r->pbf, row, row1, "bgth_reader_seek")) return -1;                 // ref pbwt.c:359
     r->next = row;
     return 0;
+}
+
+// Host destinations of one piece of a refill window (already offset to the piece's first row)
+struct PieceDst { int32_t *counts; uint8_t *a0, *a1, *gt8, *gttext; };
+
+// Decode image rows [row0,row1) of a single-device reader into its device buffers and copy what `want` asks for to the
+// host destinations; returns when the copies have landed.
+static bool decode_piece(bgth_reader_t *r, int want, int64_t row0, int64_t row1, const PieceDst &d)
+{
+    const int width = r->sel.width;
+    const size_t cstride = (size_t)(1 + gx_of(r->sel.G)) * 3;
+    const bool need_bits = want != 0;                            // any genotype output needs the bit planes H0/H1
+    const int64_t rows = row1 - row0;
+    const size_t pl = (size_t)rows * r->sel.n_chunks * 8, by = (size_t)rows * width;
+    if (!r->fin.reserve((size_t)rows * cstride * 4) || (need_bits && (!r->h0.reserve(pl) || !r->h1.reserve(pl))) ||
+        ((want & BGTH_WANT_PLANES) && !r->planes.reserve(2 * by)) || ((want & BGTH_WANT_GT8) && !r->gt8.reserve(by)) ||
+        ((want & BGTH_WANT_GTTEXT) && !r->gttext.reserve(2 * by))) {
+        set_err("[E::bgth_reader_read] out of HBM for a %lld-row batch", (long long)rows);
+        return false;
+    }
+    uint64_t *d_h0 = need_bits ? (uint64_t*)r->h0.p : nullptr, *d_h1 = need_bits ? (uint64_t*)r->h1.p : nullptr;
+    if (enqueue_scan(r, row0, row1, (int32_t*)r->fin.p, d_h0, d_h1, r->stream, true) < 0) return false;
+    if (want & BGTH_WANT_PLANES) {
+        uint8_t *d_a0 = (uint8_t*)r->planes.p, *d_a1 = d_a0 + by;
+        HIP_TRY(launch_unpack_bytes(d_h0, d_h1, r->sel.d_slot_of_out, d_a0, d_a1, rows, r->sel.n_chunks, width, r->stream), return false);
+        HIP_TRY(hipMemcpyAsync(d.a0, d_a0, by, hipMemcpyDeviceToHost, r->stream), return false);
+        HIP_TRY(hipMemcpyAsync(d.a1, d_a1, by, hipMemcpyDeviceToHost, r->stream), return false);
+    }
+    if (want & (BGTH_WANT_GT8 | BGTH_WANT_GTTEXT)) {
+        uint8_t *d_gt8 = (want & BGTH_WANT_GT8) ? (uint8_t*)r->gt8.p : nullptr;
+        uint32_t *d_txt = (want & BGTH_WANT_GTTEXT) ? (uint32_t*)r->gttext.p : nullptr;
+        HIP_TRY(launch_emit_gt(d_h0, d_h1, r->sel.d_slot_of_out, d_gt8, d_txt, rows, r->sel.n_chunks, width, r->stream), return false);
+        if (d_gt8) HIP_TRY(hipMemcpyAsync(d.gt8, d_gt8, by, hipMemcpyDeviceToHost, r->stream), return false);
+        if (d_txt) HIP_TRY(hipMemcpyAsync(d.gttext, d_txt, 2 * by, hipMemcpyDeviceToHost, r->stream), return false);
+    }
+    HIP_TRY(hipMemcpyAsync(d.counts, r->fin.p, (size_t)rows * cstride * 4, hipMemcpyDeviceToHost, r->stream), return false);
+    HIP_TRY(hipStreamSynchronize(r->stream), return false);
+    collect_timing(r);
+    return true;
 }
 
 static bool refill(bgth_reader_t *r)
@@ -952,8 +1089,8 @@ static bool refill(bgth_reader_t *r)
     }
     int64_t row1 = std::min<int64_t>(p->n, ((row0 >> p->sub_shift) << p->sub_shift) + max_rows);
     const int64_t rows = row1 - row0;
-    const size_t pl = (size_t)rows * r->sel.n_chunks * 8, by = (size_t)rows * width;
-    if (!r->fin.reserve((size_t)rows * cstride * 4) || !r->h_counts.reserve((size_t)rows * cstride * 4)) {
+    const size_t by = (size_t)rows * width;
+    if (!r->h_counts.reserve((size_t)rows * cstride * 4)) {
         set_err("[E::bgth_reader_read] out of memory for a %lld-row batch", (long long)rows);
         return false;
     }
@@ -961,32 +1098,37 @@ static bool refill(bgth_reader_t *r)
         set_err("[E::bgth_reader_read] genotype vectors need whole samples (an even number of columns), have %d", width);
         return false;
     }
-    if ((need_bits && (!r->h0.reserve(pl) || !r->h1.reserve(pl))) ||
-        ((want & BGTH_WANT_PLANES) && (!r->planes.reserve(2 * by) || !r->h_planes.reserve(2 * by))) ||
-        ((want & BGTH_WANT_GT8) && (!r->gt8.reserve(by) || !r->h_gt8.reserve(by))) ||
-        ((want & BGTH_WANT_GTTEXT) && (!r->gttext.reserve(2 * by) || !r->h_gttext.reserve(2 * by)))) {
+    if (((want & BGTH_WANT_PLANES) && !r->h_planes.reserve(2 * by)) ||
+        ((want & BGTH_WANT_GT8) && !r->h_gt8.reserve(by)) ||
+        ((want & BGTH_WANT_GTTEXT) && !r->h_gttext.reserve(2 * by))) {
         set_err("[E::bgth_reader_read] out of memory for a %lld-row batch", (long long)rows);
         return false;
     }
     tr.lap("refill: buffers");
-    uint64_t *d_h0 = need_bits ? (uint64_t*)r->h0.p : nullptr, *d_h1 = need_bits ? (uint64_t*)r->h1.p : nullptr;
-    if (enqueue_scan(r, row0, row1, (int32_t*)r->fin.p, d_h0, d_h1, r->stream, true) < 0) return false;
-    if (want & BGTH_WANT_PLANES) {
-        uint8_t *d_a0 = (uint8_t*)r->planes.p, *d_a1 = d_a0 + by;
-        HIP_TRY(launch_unpack_bytes(d_h0, d_h1, r->sel.d_slot_of_out, d_a0, d_a1, rows, r->sel.n_chunks, width, r->stream), return false);
-        HIP_TRY(hipMemcpyAsync(r->h_planes.p, r->planes.p, 2 * by, hipMemcpyDeviceToHost, r->stream), return false);
+    PieceDst base = {(int32_t*)r->h_counts.p, (uint8_t*)r->h_planes.p, (uint8_t*)r->h_planes.p + by, (uint8_t*)r->h_gt8.p, (uint8_t*)r->h_gttext.p};
+    if (r->subs.empty()) {
+        if (!decode_piece(r, want, row0, row1, base)) return false;
+    } else {
+        // the window is cut at the shard boundaries; every shard decodes its piece on its own device, concurrently, and
+        // copies it to its place in the (portable, pinned) host ring
+        std::vector<std::thread> th;
+        std::vector<std::string> errs(r->subs.size());
+        for (size_t i = 0; i < r->subs.size(); ++i) {
+            bgth_reader_t *sr = r->subs[i];
+            const int64_t a0 = std::max(row0, sr->pbf->row_off), a1 = std::min(row1, sr->pbf->row_off + sr->pbf->n);
+            if (a0 >= a1) continue;
+            const size_t k = (size_t)(a0 - row0);
+            PieceDst d = {base.counts + k * cstride, base.a0 ? base.a0 + k * width : nullptr, base.a1 ? base.a1 + k * width : nullptr,
+                          base.gt8 ? base.gt8 + k * width : nullptr, base.gttext ? base.gttext + 2 * k * width : nullptr};
+            th.emplace_back([=, &errs] {
+                if (hipSetDevice(sr->pbf->device) != hipSuccess || !decode_piece(sr, want, a0 - sr->pbf->row_off, a1 - sr->pbf->row_off, d))
+                    errs[i] = g_err[0] ? g_err : "shard failed";
+            });
+        }
+        for (std::thread &t : th) t.join();
+        for (const std::string &e : errs) if (!e.empty()) { set_err("%s", e.c_str()); return false; }
     }
-    if (want & (BGTH_WANT_GT8 | BGTH_WANT_GTTEXT)) {
-        uint8_t *d_gt8 = (want & BGTH_WANT_GT8) ? (uint8_t*)r->gt8.p : nullptr;
-        uint32_t *d_txt = (want & BGTH_WANT_GTTEXT) ? (uint32_t*)r->gttext.p : nullptr;
-        HIP_TRY(launch_emit_gt(d_h0, d_h1, r->sel.d_slot_of_out, d_gt8, d_txt, rows, r->sel.n_chunks, width, r->stream), return false);
-        if (d_gt8) HIP_TRY(hipMemcpyAsync(r->h_gt8.p, d_gt8, by, hipMemcpyDeviceToHost, r->stream), return false);
-        if (d_txt) HIP_TRY(hipMemcpyAsync(r->h_gttext.p, d_txt, 2 * by, hipMemcpyDeviceToHost, r->stream), return false);
-    }
-    HIP_TRY(hipMemcpyAsync(r->h_counts.p, r->fin.p, (size_t)rows * cstride * 4, hipMemcpyDeviceToHost, r->stream), return false);
-    HIP_TRY(hipStreamSynchronize(r->stream), return false);
     tr.lap("refill: scan + copies");
-    collect_timing(r);
     r->ring0 = row0; r->ring1 = row1; r->ring_has = want;
     return true;
 }

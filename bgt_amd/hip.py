@@ -142,6 +142,15 @@ class HipPbf:
         return cls(L.bgth_pbf_open_rows(path.encode(), row0, row1, device))
 
     @classmethod
+    def open_sharded(cls, path, devices):
+        """One database over several devices (or several shards on one): block-aligned site ranges, one partial image each."""
+        L = lib()
+        L.bgth_pbf_open_sharded.restype = C.c_void_p
+        L.bgth_pbf_open_sharded.argtypes = [C.c_char_p, C.c_int, C.c_void_p]
+        d = np.ascontiguousarray(devices, np.int32)
+        return cls(L.bgth_pbf_open_sharded(os.fsencode(path), d.size, d.ctypes.data))
+
+    @classmethod
     def from_bytes(cls, data, device=0):
         buf = np.frombuffer(data, np.uint8)
         return cls(lib().bgth_pbf_open_mem(buf.ctypes.data, buf.size, device))
@@ -376,6 +385,15 @@ class HipEncoder:
 
     def __del__(self):
         self.close()
+
+
+def shard_ranges(n_rows, shift, n_shards):
+    """[(row0, row1)] per shard as the C ABI deals them out (bgth_shard_ranges); needs no device."""
+    L = lib()
+    L.bgth_shard_ranges.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_void_p]
+    out = np.zeros(2 * n_shards, np.int64)
+    L.bgth_shard_ranges(n_rows, shift, n_shards, out.ctypes.data)
+    return [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(n_shards)]
 
 
 def synth_rows(m, row0, n_rows, seed, n_threads=0):

@@ -247,6 +247,25 @@ typedef struct {                                              /* bgt_t::pb */
     int n_groups_total;        /* as passed to the last selection, to re-apply it on another image */
 } devrd_t;
 
+/* The whole-file image of a database.  BGT_GPUS spreads it over several devices (site-range shards behind the codec
+ * seam, SURVEY.md 8e: `bgt view` then uses every listed GPU, two-database merges included, with no change above this
+ * line): "N" = devices 0..N-1, "all" = every visible device, or an explicit list "0,1,2,3" (a device may repeat:
+ * several shards on one GPU).  Unset: device 0. */
+static bgth_pbf_t *open_whole_image(const char *fn)
+{
+    const char *e = getenv("BGT_GPUS");
+    int dev[64], n = 0;
+    if (e && *e) {
+        if (strcmp(e, "all") == 0) { n = bgth_device_count(); if (n > 64) n = 64; for (int i = 0; i < n; ++i) dev[i] = i; }
+        else if (strchr(e, ',')) {
+            const char *q = e;
+            while (*q && n < 64) { dev[n++] = atoi(q); q = strchr(q, ','); if (!q) break; ++q; }
+        } else { n = atoi(e); if (n > 64) n = 64; for (int i = 0; i < n; ++i) dev[i] = i; }
+    }
+    if (n > 1) return bgth_pbf_open_sharded(fn, n, dev);
+    return bgth_pbf_open(fn, n == 1 ? dev[0] : 0);
+}
+
 /* ------------------------------------------------------------------------------------------------
  * files
  * ------------------------------------------------------------------------------------------------ */
@@ -563,7 +582,7 @@ static int ensure_device(bgt_t *bgt)
         dv->own_img = bgth_pbf_open_rows(fn, r0, r1, 0);         /* private to this reader */
         if (dv->own_img) dv->rd = bgth_reader_create(dv->own_img);
     } else {
-        if (wf->gpu == NULL) wf->gpu = bgth_pbf_open(fn, 0);     /* the whole file, shared by every reader of it */
+        if (wf->gpu == NULL) wf->gpu = open_whole_image(fn);     /* the whole file, shared by every reader of it */
         pthread_mutex_unlock(&g_open_lock);
         if (wf->gpu) dv->rd = bgth_reader_create((bgth_pbf_t*)wf->gpu);
     }
@@ -602,7 +621,7 @@ static int promote_to_full(bgt_t *bgt)
     if (wf->gpu == NULL) {
         char *fn = (char*)malloc(strlen(wf->prefix) + 8);
         sprintf(fn, "%s.pbf", wf->prefix);
-        wf->gpu = bgth_pbf_open(fn, 0);
+        wf->gpu = open_whole_image(fn);
         free(fn);
     }
     pthread_mutex_unlock(&g_open_lock);

@@ -45,6 +45,17 @@ bgth_pbf_t *bgth_pbf_open_mem(const void *image, size_t len, int device);
  * pbf_read, pbwt.c:349-372) needs of a large file.  Row arguments of the reader stay FILE rows; rows outside the
  * loaded blocks fail loudly.  bgth_pbf_get_n() still reports the rows of the file. */
 bgth_pbf_t *bgth_pbf_open_rows(const char *path, int64_t row0, int64_t row1, int device);
+/* ONE database over SEVERAL devices (the site-range sharding of SURVEY.md 8e behind this boundary): the file's 1<<shift-row
+ * blocks are dealt out as n_shards contiguous block ranges (bgth_shard_ranges), shard i is a partial image on HIP device
+ * devices[i] (a device may be listed more than once: several shards on one GPU).  Readers of a sharded image run every
+ * bgth_reader_scan / refill of the pull interface on all shards concurrently -- one host thread and stream per shard --
+ * and deliver rows in file order; the per-shard results meet in the caller's host arrays (each device copies its rows to
+ * their place: no device-to-device hop).  bgth_reader_scan_device is refused: its output lives on one device.
+ * The multi-process form (one rank per GPU, RCCL all-gather of the counts) is bench.py --gpus N. */
+bgth_pbf_t *bgth_pbf_open_sharded(const char *path, int n_shards, const int *devices);
+int         bgth_pbf_n_shards(const bgth_pbf_t *p);      /* 0 for a single-device image                    */
+/* ranges[2 i], ranges[2 i + 1] = rows [row0,row1) of shard i: ceil(blocks / n_shards) whole blocks each          */
+void        bgth_shard_ranges(int64_t n_rows, int shift, int n_shards, int64_t *ranges);
 int64_t     bgth_pbf_first_row(const bgth_pbf_t *p);     /* first loaded row (0 for a full image)        */
 int64_t     bgth_pbf_loaded_rows(const bgth_pbf_t *p);   /* number of loaded rows                         */
 /* Build an image from bare RLE strings (row-major, plane-minor: row0/plane0,row0/plane1,row1/plane0..)

@@ -1,0 +1,94 @@
+"""Site-range sharding BEHIND the C ABI (bgth_pbf_open_sharded): one database dealt out as block-aligned
+shards, each a partial image with its own reader, stream and host thread.  The box has one GPU, so the shards of the GPU
+tests all live on device 0 ("virtual shards"): what is pinned is everything but the device numbers -- the dealing of
+blocks, row offsets of the partial images, concurrent scans into one host array, pull-interface windows that straddle
+shard boundaries, the selection replicated per shard -- and, through `BGT_GPUS`, the whole `bgt view` on top of it,
+two-database merge included (configs[3] and [4] of BASELINE.json in their product form)."""
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import orc
+import scenarios
+from bgt_amd.shard import block_shards
+from conftest import require_ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BGT = os.path.join(ROOT, "bgt_amd", "bin", "bgt")
+
+
+def test_shard_ranges_of_the_c_abi_match_the_python_sharding():
+    import bgt_amd
+    for n_rows, shift, world in [(1000000, 13, 8), (10000000, 13, 8), (50000, 13, 8), (8192, 13, 2), (8193, 13, 2),
+                                 (1, 13, 4), (150, 4, 3), (0, 13, 2), (128072, 13, 8)]:
+        assert bgt_amd.shard_ranges(n_rows, shift, world) == block_shards(n_rows, shift, world)
+    sh = bgt_amd.shard_ranges(10000000, 13, 8)                       # configs[3]: 153 blocks per GPU, the last shorter
+    assert [(b - a) // 8192 for a, b in sh[:7]] == [153] * 7 and sh[7] == (7 * 153 * 8192, 10000000)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_shards", [2, 3, 8])
+def test_sharded_image_equals_the_single_image(tmp_path, n_shards):
+    import bgt_amd
+    rng = np.random.default_rng(11)
+    m, rows, shift = 700, 150, 4                                      # 10 blocks of 16 rows (the last one ragged)
+    mat = scenarios.ld_matrix(rng, rows, m, n_founders=9, switch=0.05)
+    data = orc.encode_pbf(mat, 2, shift)
+    path = str(tmp_path / "x.pbf")
+    open(path, "wb").write(data)
+    one = bgt_amd.HipReader(bgt_amd.HipPbf.from_bytes(data))
+    pbf = bgt_amd.HipPbf.open_sharded(path, [0] * n_shards)
+    assert pbf.n == rows and bgt_amd.lib().bgth_pbf_n_shards(pbf.h) == min(n_shards, len([r for r in block_shards(rows, shift, n_shards) if r[1] > r[0]]))
+    rd = bgt_amd.HipReader(pbf)
+    c1, g1 = one.scan(0, rows, want_gt=True)
+    c2, g2 = rd.scan(0, rows, want_gt=True)
+    assert np.array_equal(c1, c2) and np.array_equal(g1, g2)
+    assert np.array_equal(rd.scan(7, 131), c1[7:131])                 # starts and ends inside shards
+    # a subset with groups, replicated on every shard
+    pick = np.sort(rng.choice(m // 2, 90, replace=False))
+    cols = np.stack([2 * pick, 2 * pick + 1], 1).reshape(-1)
+    grp = (1 + np.arange(90) % 3).astype(np.uint32)
+    for r in (one, rd):
+        r.select(cols, group=grp, n_groups=3)
+    assert np.array_equal(one.scan(0, rows), rd.scan(0, rows))
+    # the pull interface: windows straddle shard boundaries; planes, genotype vector and counts per row
+    for r in (one, rd):
+        r.config(r.WANT_PLANES | r.WANT_GT8, 0)
+    for start in (0, 15, 16, 77, 149):
+        one.seek(start); rd.seek(start)
+        for _ in range(min(40, rows - start)):
+            a, b = one.read(), rd.read()
+            assert np.array_equal(a, b) and np.array_equal(one.last_gt8(), rd.last_gt8())
+            assert np.array_equal(one.last_counts(), rd.last_counts())
+    rd.seek(rows - 1); assert rd.read() is not None and rd.read() is None
+    import torch
+    with pytest.raises(RuntimeError):                                 # a device pointer belongs to one device
+        rd.scan_device(0, rows, torch.empty((rows, 4, 3), dtype=torch.int32, device="cuda").data_ptr())
+
+
+def md5_of(cmd, env=None):
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+    return p.returncode, hashlib.md5(p.stdout).hexdigest(), len(p.stdout), p.stderr.decode()[-300:]
+
+
+@pytest.mark.gpu
+def test_bgt_view_over_shards_like_configs_3_and_4(tmp_path):
+    """`bgt view` with BGT_GPUS: one database over 4 shards (configs[3] in its product form) and the two-database,
+    two-group merge over 3 shards each (configs[4]); byte-identical to the compiled reference on the same files."""
+    import bgt_amd
+    ref = require_ref("bgt")
+    bgt_amd.build_library()
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bgt_amd", "host")])
+    a, b = str(tmp_path / "dba"), str(tmp_path / "dbb")
+    subprocess.check_call([BGT, "synth", a, "3000", "40000", "5"])       # 5 file blocks
+    subprocess.check_call([BGT, "synth", b, "2000", "40000", "6"])
+    for gpus, args, dbs in (("0,0,0,0", ["-G", "-f", "AC>0"], [a]), ("0,0,0", ["-G", "-s", "pop==\"A\"", "-s", "pop==\"B\"", "-f", "AC1>0&&AC2==0"], [a, b]),
+                            ("0,0", ["-C", "-s", "idx%500==1", "-i", "8000", "-n", "9000"], [a]), ("0,0,0,0,0,0,0,0", ["-G", "-C", "-r", "11:90000-330000"], [b, a])):
+        env = dict(os.environ, BGT_GPUS=gpus)
+        mine = md5_of([BGT, "view"] + args + dbs, env=env)
+        want = md5_of([ref, "view"] + args + dbs)
+        assert mine[0] == want[0] == 0, (gpus, args, mine, want)
+        assert mine[2] > 0 and mine[1:3] == want[1:3], (gpus, args, mine, want)
