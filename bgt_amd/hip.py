@@ -170,6 +170,13 @@ class HipPbf:
         return n
 
     @property
+    def n_shards(self):
+        L = lib()
+        L.bgth_pbf_n_shards.restype = C.c_int
+        L.bgth_pbf_n_shards.argtypes = [C.c_void_p]
+        return L.bgth_pbf_n_shards(self.h)
+
+    @property
     def hbm_bytes(self):
         return lib().bgth_pbf_hbm_bytes(self.h)
 

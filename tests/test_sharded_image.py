@@ -41,7 +41,7 @@ def test_sharded_image_equals_the_single_image(tmp_path, n_shards):
     open(path, "wb").write(data)
     one = bgt_amd.HipReader(bgt_amd.HipPbf.from_bytes(data))
     pbf = bgt_amd.HipPbf.open_sharded(path, [0] * n_shards)
-    assert pbf.n == rows and bgt_amd.lib().bgth_pbf_n_shards(pbf.h) == min(n_shards, len([r for r in block_shards(rows, shift, n_shards) if r[1] > r[0]]))
+    assert pbf.n == rows and pbf.n_shards == min(n_shards, len([r for r in block_shards(rows, shift, n_shards) if r[1] > r[0]]))
     rd = bgt_amd.HipReader(pbf)
     c1, g1 = one.scan(0, rows, want_gt=True)
     c2, g2 = rd.scan(0, rows, want_gt=True)
