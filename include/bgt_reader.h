@@ -168,8 +168,9 @@ void *bed_read(const char *fn);
 int   bed_overlap(const void *bed, const char *chr, int beg, int end);
 void  bed_destroy(void *bed);
 
-/* ---- command line front end: `bgt view` (reference view.c:14-183) ---- */
+/* ---- command line front ends: `bgt view` (reference view.c:14-183), `bgt import` (import.c:8-120) ---- */
 int main_view(int argc, char *argv[]);
+int main_import(int argc, char *argv[]);
 
 #ifdef __cplusplus
 }
