@@ -470,17 +470,21 @@ static bcf_hdr_t *site_header(const bcf_hdr_t *h0)
     kstring_t s = {0, 0, 0};
     const char *chrom = NULL, *p;
     bcf_hdr_t *h;
-    int i;
+    int i, n_added = 1;
     for (p = h0->text; (p = strstr(p, "#CHROM\t")) != NULL; ++p) if (p == h0->text || p[-1] == '\n') { chrom = p; break; }
     if (chrom == NULL) return NULL;
     for (p = chrom, i = 0; i < 8 && (p = strchr(p, '\t')) != NULL; ++i) ++p;      /* p: behind the tab after INFO, or NULL */
     ks_putn(&s, h0->text, (size_t)(chrom - h0->text));
-    if (bcf_id2int(h0, BCF_DT_ID, "GT") < 0) ks_puts(&s, "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n");
+    if (bcf_id2int(h0, BCF_DT_ID, "GT") < 0) { ks_puts(&s, "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n"); ++n_added; }
     ks_puts(&s, "##INFO=<ID=_row,Number=1,Type=Integer,Description=\"row number\">\n");
     if (p) ks_putn(&s, chrom, (size_t)(p - 1 - chrom)); else ks_puts(&s, chrom);
     h = bcf_hdr_init();
     h->text = s.s; h->l_text = (int32_t)s.l + 1; h->m_text = (int32_t)s.m;
     bcf_hdr_parse(h);
+    /* The reference's bcf_hdr_append (vcf.c:210-231) grows the text by the line and its newline but l_text by the line
+     * only, so the length it writes into the BCF is one short per appended line: no terminating NUL after one line, the
+     * last character of "#CHROM ... INFO" cut after two.  Readers cope; the bytes must match. */
+    h->l_text = (int32_t)s.l + 1 - n_added;
     return h;
 }
 
