@@ -5,10 +5,15 @@
 #include "scan_kernels.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <chrono>
 #include <mutex>
 #include <new>
@@ -315,6 +320,144 @@ struct Trace {
 
 // Walks the record stream of an image (format: SURVEY.md App. A; ref pbwt.c:288-311 writer,
 // :313-337 reader) and splits it into packed RLE bytes, row descriptors and checkpoint permutations.
+// What parsing a .pbf image yields: the strings packed 4-byte aligned, a descriptor per string, the checkpoint permutations.
+struct Parsed {
+    uint8_t *rle = nullptr; size_t rle_n = 0;
+    uint64_t *desc = nullptr; size_t n_desc = 0;
+    int32_t *perms = nullptr; size_t n_perm = 0;
+    int64_t payload = 0, n_empty1 = 0, rows = 0;
+    ~Parsed() { free(rle); free(desc); free(perms); }
+    void take(const std::vector<uint8_t> &r, const std::vector<uint64_t> &d, const std::vector<int32_t> &pm, int64_t pay, int64_t e1, int64_t n)
+    {
+        rle_n = r.size(); n_desc = d.size(); n_perm = pm.size(); payload = pay; n_empty1 = e1; rows = n;
+        rle = (uint8_t*)malloc(std::max<size_t>(rle_n, 1)); desc = (uint64_t*)malloc(std::max<size_t>(n_desc, 1) * 8); perms = (int32_t*)malloc(std::max<size_t>(n_perm, 1) * 4);
+        if (rle_n) memcpy(rle, r.data(), rle_n);
+        if (n_desc) memcpy(desc, d.data(), n_desc * 8);
+        if (n_perm) memcpy(perms, pm.data(), n_perm * 4);
+    }
+};
+
+static bool string_is_all_zero(const uint8_t *q, size_t l);
+
+// One file block ('S' record + up to 1 << shift 'B' records) at buf[beg,end).  dst_rle == nullptr: count only.
+struct BlockScan { int64_t rows = 0, payload = 0, empty1 = 0; size_t packed = 0; bool ok = false; };
+static BlockScan scan_block(const uint8_t *buf, size_t beg, size_t end, int m, int g, uint8_t *dst_rle, uint64_t *dst_desc,
+                            uint64_t base_off, int32_t *dst_perm)
+{
+    BlockScan r;
+    size_t pos = beg;
+    const size_t sbytes = (size_t)g * m * 4;
+    if (pos >= end || buf[pos] != 'S' || pos + 1 + sbytes > end) return r;
+    if (dst_perm) memcpy(dst_perm, buf + pos + 1, sbytes);
+    pos += 1 + sbytes;
+    while (pos < end) {
+        if (buf[pos] != 'B') return r;
+        ++pos;
+        for (int k = 0; k < g; ++k) {
+            int32_t l;
+            if (pos + 4 > end) return r;
+            memcpy(&l, buf + pos, 4);
+            pos += 4;
+            if (l < 0 || l >= (1 << 24) || pos + (size_t)l > end) return r;
+            const size_t pad = ((size_t)l + 3) & ~(size_t)3;
+            if (dst_rle) {
+                dst_desc[r.rows * g + k] = (base_off + r.packed) | (uint64_t)l << kDescLenShift;
+                memcpy(dst_rle + r.packed, buf + pos, (size_t)l);
+                for (size_t z = (size_t)l; z < pad; ++z) dst_rle[r.packed + z] = 0;
+            } else if (k == 1 && string_is_all_zero(buf + pos, (size_t)l)) ++r.empty1;
+            r.packed += pad; r.payload += l;
+            pos += (size_t)l;
+        }
+        ++r.rows;
+    }
+    r.ok = pos == end;
+    return r;
+}
+
+// The footer's block index makes the blocks of a file independent: sizes first, then every block copied to its place, on
+// several host threads.  false = no usable index (the caller then walks the records in order and reports what is wrong).
+static bool parse_blocks_parallel(const uint8_t *buf, size_t end, size_t len, int m, int g, int shift, int64_t n_rows, Parsed &out)
+{
+    if (end + 13 > len || n_rows <= 0 || m <= 0 || g != 2) return false;
+    int32_t n_idx;
+    memcpy(&n_idx, buf + end + 9, 4);
+    const int64_t blk_rows = (int64_t)1 << shift;
+    if (n_idx <= 0 || (int64_t)n_idx != (n_rows + blk_rows - 1) / blk_rows || end + 13 + (size_t)n_idx * 8 + 8 > len) return false;
+    std::vector<uint64_t> idx((size_t)n_idx + 1);
+    memcpy(idx.data(), buf + end + 13, (size_t)n_idx * 8);
+    idx[n_idx] = end;
+    if (idx[0] != 16) return false;
+    for (int i = 0; i < n_idx; ++i) if (idx[i] >= idx[i + 1]) return false;
+    const int nt = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<BlockScan> info((size_t)n_idx);
+    auto run = [&](auto fn) {
+        std::vector<std::thread> th;
+        std::atomic<int> next(0);
+        for (int t = 0; t < nt; ++t) th.emplace_back([&] { for (int b; (b = next.fetch_add(1)) < n_idx;) fn(b); });
+        for (std::thread &t : th) t.join();
+    };
+    run([&](int b) { info[b] = scan_block(buf, idx[b], idx[b + 1], m, g, nullptr, nullptr, 0, nullptr); });
+    std::vector<uint64_t> off((size_t)n_idx + 1, 0);
+    std::vector<int64_t> row0((size_t)n_idx + 1, 0);
+    for (int b = 0; b < n_idx; ++b) {
+        if (!info[b].ok || info[b].rows != (b + 1 < n_idx ? blk_rows : n_rows - (int64_t)b * blk_rows)) return false;
+        off[b + 1] = off[b] + info[b].packed; row0[b + 1] = row0[b] + info[b].rows;
+        out.payload += info[b].payload; out.n_empty1 += info[b].empty1;
+    }
+    if (off[n_idx] >= ((uint64_t)1 << kDescLenShift)) return false;
+    out.rows = n_rows;
+    out.rle_n = off[n_idx]; out.n_desc = (size_t)n_rows * g; out.n_perm = (size_t)n_idx * g * m;
+    out.rle = (uint8_t*)malloc(std::max<size_t>(out.rle_n, 1));
+    out.desc = (uint64_t*)malloc(out.n_desc * 8);
+    out.perms = (int32_t*)malloc(out.n_perm * 4);
+    if (!out.rle || !out.desc || !out.perms) throw std::bad_alloc();
+    run([&](int b) { scan_block(buf, idx[b], idx[b + 1], m, g, out.rle + off[b], out.desc + (size_t)row0[b] * g, off[b], out.perms + (size_t)b * g * m); });
+    return true;
+}
+
+// The record stream walked in order (format: SURVEY.md App. A; ref pbwt.c:288-311 writer, :313-337 reader): the path of
+// images without a usable block index, and the one that names what is wrong with a damaged file.
+static bool parse_sequential(const uint8_t *buf, size_t end, int m, int g, int shift, Parsed &ps)
+{
+    int64_t n_empty1 = 0;
+    std::vector<uint8_t> rle;
+    std::vector<uint64_t> desc;
+    std::vector<int32_t> perms;
+    int64_t payload = 0;
+    rle.reserve(end);
+    size_t pos = 16;
+    int64_t row = 0;
+    const int64_t blk_rows = (int64_t)1 << shift;
+    while (pos < end && buf[pos] != 'I') {
+        if (buf[pos] == 'S') {
+            if (row % blk_rows != 0) { set_err("[E::bgth_pbf_open] 'S' record at row %lld is not on a block boundary", (long long)row); return false; }
+            if (pos + 1 + (size_t)g * m * 4 > end) { set_err("[E::bgth_pbf_open] truncated 'S' record"); return false; }
+            const size_t at = perms.size();
+            perms.resize(at + (size_t)g * m);
+            memcpy(perms.data() + at, buf + pos + 1, (size_t)g * m * 4);
+            pos += 1 + (size_t)g * m * 4;
+        } else if (row % blk_rows == 0) { set_err("[E::bgth_pbf_open] missing 'S' record at row %lld", (long long)row); return false; }
+        if (pos >= end || buf[pos] != 'B') { set_err("[E::bgth_pbf_open] bad record tag at offset %zu", pos); return false; }
+        ++pos;
+        for (int k = 0; k < g; ++k) {
+            int32_t l;
+            if (pos + 4 > end) { set_err("[E::bgth_pbf_open] truncated 'B' record"); return false; }
+            memcpy(&l, buf + pos, 4);
+            pos += 4;
+            if (l < 0 || l >= (1 << 24) || pos + (size_t)l > end) { set_err("[E::bgth_pbf_open] bad RLE length %d at row %lld", l, (long long)row); return false; }
+            while (rle.size() & 3) rle.push_back(0);          // kernels read whole aligned dwords
+            desc.push_back((uint64_t)rle.size() | (uint64_t)l << kDescLenShift);
+            rle.insert(rle.end(), buf + pos, buf + pos + l);
+            if (k == 1 && string_is_all_zero(buf + pos, (size_t)l)) ++n_empty1;
+            payload += l;
+            pos += (size_t)l;
+        }
+        ++row;
+    }
+    ps.take(rle, desc, perms, payload, n_empty1, row);
+    return true;
+}
+
 static bgth_pbf_t *open_mem_impl(const void *image, size_t len, int device);
 extern "C" bgth_pbf_t *bgth_pbf_open_mem(const void *image, size_t len, int device)
 {
@@ -344,40 +487,14 @@ static bgth_pbf_t *open_mem_impl(const void *image, size_t len, int device)
     if (!p) return nullptr;
     t_building = p;
 
-    std::vector<uint8_t> rle;
-    std::vector<uint64_t> desc;
-    std::vector<int32_t> perms;
-    int64_t payload = 0;
-    rle.reserve(end);
-    size_t pos = 16;
-    int64_t row = 0;
-    const int64_t blk_rows = (int64_t)1 << shift;
-    while (pos < end && buf[pos] != 'I') {
-        if (buf[pos] == 'S') {
-            if (row % blk_rows != 0) { set_err("[E::bgth_pbf_open] 'S' record at row %lld is not on a block boundary", (long long)row); goto fail; }
-            if (pos + 1 + (size_t)g * m * 4 > end) { set_err("[E::bgth_pbf_open] truncated 'S' record"); goto fail; }
-            const size_t at = perms.size();
-            perms.resize(at + (size_t)g * m);
-            memcpy(perms.data() + at, buf + pos + 1, (size_t)g * m * 4);
-            pos += 1 + (size_t)g * m * 4;
-        } else if (row % blk_rows == 0) { set_err("[E::bgth_pbf_open] missing 'S' record at row %lld", (long long)row); goto fail; }
-        if (pos >= end || buf[pos] != 'B') { set_err("[E::bgth_pbf_open] bad record tag at offset %zu", pos); goto fail; }
-        ++pos;
-        for (int k = 0; k < g; ++k) {
-            int32_t l;
-            if (pos + 4 > end) { set_err("[E::bgth_pbf_open] truncated 'B' record"); goto fail; }
-            memcpy(&l, buf + pos, 4);
-            pos += 4;
-            if (l < 0 || l >= (1 << 24) || pos + (size_t)l > end) { set_err("[E::bgth_pbf_open] bad RLE length %d at row %lld", l, (long long)row); goto fail; }
-            while (rle.size() & 3) rle.push_back(0);          // kernels read whole aligned dwords
-            desc.push_back((uint64_t)rle.size() | (uint64_t)l << kDescLenShift);
-            rle.insert(rle.end(), buf + pos, buf + pos + l);
-            if (k == 1 && string_is_all_zero(buf + pos, (size_t)l)) ++p->n_empty1;
-            payload += l;
-            pos += (size_t)l;
-        }
-        ++row;
-    }
+    Parsed ps;
+    if (!parse_blocks_parallel(buf, end, len, m, g, shift, n_footer, ps) && !parse_sequential(buf, end, m, g, shift, ps)) goto fail;
+    p->n_empty1 = ps.n_empty1;
+    {
+    const int64_t row = ps.rows, payload = ps.payload;
+    struct { const Parsed &q; size_t size() const { return q.rle_n; } bool empty() const { return q.rle_n == 0; } const uint8_t *data() const { return q.rle; } } rle = {ps};
+    struct { const Parsed &q; size_t size() const { return q.n_desc; } bool empty() const { return q.n_desc == 0; } const uint64_t *data() const { return q.desc; } } desc = {ps};
+    struct { const Parsed &q; size_t size() const { return q.n_perm; } const int32_t *data() const { return q.perms; } } perms = {ps};
     if (n_footer >= 0 && n_footer != row) { set_err("[E::bgth_pbf_open] footer says %lld rows, stream has %lld", (long long)n_footer, (long long)row); goto fail; }
     if (rle.size() >= ((size_t)1 << kDescLenShift)) { set_err("[E::bgth_pbf_open] RLE payload too large"); goto fail; }
     set_rows(p, row);
@@ -419,6 +536,7 @@ static bgth_pbf_t *open_mem_impl(const void *image, size_t len, int device)
             tr.lap("sub-checkpoint pass");
         }
     }
+    }
     t_building = nullptr;
     return p;
 fail:
@@ -429,21 +547,22 @@ fail:
 
 extern "C" bgth_pbf_t *bgth_pbf_open(const char *path, int device)
 {
-    FILE *fp = fopen(path, "rb");
-    if (!fp) { set_err("[E::bgth_pbf_open] cannot open '%s'", path); return nullptr; }
-    long sz = -1;
-    if (fseek(fp, 0, SEEK_END) == 0) sz = ftell(fp);
-    if (sz < 0 || fseek(fp, 0, SEEK_SET) != 0) { fclose(fp); set_err("[E::bgth_pbf_open] '%s' is not a seekable file", path); return nullptr; }
-    try {
-        std::vector<uint8_t> buf((size_t)sz);
-        if (sz > 0 && fread(buf.data(), 1, (size_t)sz, fp) != (size_t)sz) { fclose(fp); set_err("[E::bgth_pbf_open] short read on '%s'", path); return nullptr; }
-        fclose(fp);
-        return bgth_pbf_open_mem(buf.data(), buf.size(), device);
-    } catch (const std::bad_alloc &) {                          // nothing C++ may cross the C ABI
-        fclose(fp);
-        set_err("[E::bgth_pbf_open] out of host memory for the %ld bytes of '%s'", sz, path);
+    // the file is mapped, not read: the parser copies every string once, from the page cache to its packed place
+    const int fd = open(path, O_RDONLY);
+    struct stat st;
+    if (fd < 0 || fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) {
+        if (fd >= 0) close(fd);
+        set_err("[E::bgth_pbf_open] cannot open '%s'", path);
         return nullptr;
     }
+    if (st.st_size == 0) { close(fd); set_err("[E::bgth_pbf_open] not a PBF image"); return nullptr; }
+    void *map = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (map == MAP_FAILED) { set_err("[E::bgth_pbf_open] cannot map '%s'", path); return nullptr; }
+    madvise(map, (size_t)st.st_size, MADV_SEQUENTIAL | MADV_WILLNEED);
+    bgth_pbf_t *p = bgth_pbf_open_mem(map, (size_t)st.st_size, device);
+    munmap(map, (size_t)st.st_size);
+    return p;
 }
 
 // A string without a byte of bit 1 describes an all-zero row (the row starts at 0 and nothing toggles it).

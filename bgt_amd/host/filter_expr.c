@@ -161,6 +161,23 @@ kexpr_t *ke_parse(const char *src, int *err)
 
 void ke_destroy(kexpr_t *ke) { if (ke) { free_items(ke->e, ke->n); free(ke); } }
 
+/* an independent copy (an expression carries its variable bindings: one per thread that evaluates it) */
+kexpr_t *ke_clone(const kexpr_t *ke)
+{
+    kexpr_t *c;
+    int i;
+    if (ke == NULL) return NULL;
+    c = (kexpr_t*)calloc(1, sizeof(*c));
+    c->n = ke->n;
+    c->e = (item_t*)malloc((size_t)(ke->n ? ke->n : 1) * sizeof(item_t));
+    memcpy(c->e, ke->e, (size_t)ke->n * sizeof(item_t));
+    for (i = 0; i < ke->n; ++i) {
+        if (ke->e[i].name) c->e[i].name = dupn(ke->e[i].name, strlen(ke->e[i].name));
+        if (ke->e[i].s) c->e[i].s = dupn(ke->e[i].s, strlen(ke->e[i].s));
+    }
+    return c;
+}
+
 #define FOR_VAR(ke, var, body) do { int i_, n_ = 0; for (i_ = 0; i_ < (ke)->n; ++i_) { item_t *e = &(ke)->e[i_]; \
     if (e->kind == T_VAL && e->name && strcmp(e->name, (var)) == 0) { body; ++n_; } } return n_; } while (0)
 

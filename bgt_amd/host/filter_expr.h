@@ -28,6 +28,7 @@ extern "C" {
 #endif
 kexpr_t *ke_parse(const char *s, int *err);
 void     ke_destroy(kexpr_t *ke);
+kexpr_t *ke_clone(const kexpr_t *ke);                /* extension: an independent copy (bindings included) */
 int      ke_set_int(kexpr_t *ke, const char *var, int64_t x);
 int      ke_set_real(kexpr_t *ke, const char *var, double x);
 int      ke_set_str(kexpr_t *ke, const char *var, const char *x);

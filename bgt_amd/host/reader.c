@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 #include <pthread.h>
 #include <zlib.h>
 #include "../../include/bgt_reader.h"
@@ -512,13 +513,24 @@ void bgt_set_bed(bgt_t *bgt, const void *bed, int excl) { bgt->bed = bed; bgt->b
 /* the HBM image of prefix.pbf is opened on first need and cached on the file handle, shared by every
  * reader of that file; each reader owns its own device reader (stream, selection, result buffers) */
 static pthread_mutex_t g_open_lock = PTHREAD_MUTEX_INITIALIZER;   /* readers of one file may start on different threads */
+static pthread_mutex_t g_sites_lock = PTHREAD_MUTEX_INITIALIZER;  /* the site table has a lock of its own: it loads beside the image */
 
 /* the site table of the whole file, read on first use */
+static const sitetab_t *file_sites(const bgt_file_t *cbf);
+static void *sites_loader(void *arg) { file_sites((const bgt_file_t*)arg); return NULL; }
+/* start reading the site table on a thread of its own while the caller opens the .pbf image (the two are the long
+ * steps before the first site of a whole-file walk); whoever needs the table first waits on the same lock */
+static int sites_prefetch(const bgt_file_t *bf, pthread_t *th)
+{
+    if (bf->idx) return 0;
+    return pthread_create(th, NULL, sites_loader, (void*)bf) == 0;
+}
+
 static const sitetab_t *file_sites(const bgt_file_t *cbf)
 {
     bgt_file_t *bf = (bgt_file_t*)cbf;
     static const sitetab_t empty;
-    pthread_mutex_lock(&g_open_lock);
+    pthread_mutex_lock(&g_sites_lock);
     if (bf->idx == NULL) {
         char *fn = (char*)malloc(strlen(bf->prefix) + 8);
         bgzr_t *fp;
@@ -531,7 +543,7 @@ static const sitetab_t *file_sites(const bgt_file_t *cbf)
         if (bf->idx == NULL) fprintf(stderr, "[E::%s] cannot read the sites of '%s'\n", __func__, fn);
         free(fn);
     }
-    pthread_mutex_unlock(&g_open_lock);
+    pthread_mutex_unlock(&g_sites_lock);
     return bf->idx ? (const sitetab_t*)bf->idx : &empty;
 }
 
@@ -547,9 +559,11 @@ static const sitetab_t *sites_of(const bgt_t *bgt)
  * instead of all of it (the reference seeks to the nearest checkpoint, pbwt.c:349-372). */
 static int needed_rows(const bgt_t *bgt, int64_t *r0, int64_t *r1)
 {
-    const sitetab_t *t = sites_of(bgt);
     const region_t *r = (const region_t*)bgt->itr;
+    const sitetab_t *t;
     int64_t i, lo, hi, mn = INT64_MAX, mx = -1;
+    if (r == NULL && ((const cursor_t*)bgt->bcf)->next <= 0) return 0;     /* a whole-file walk: no need to wait for the table */
+    t = sites_of(bgt);
     if (t->n == 0) return 0;
     if (r) {
         lo = r->at;
@@ -1269,6 +1283,11 @@ int bgtm_prepare(bgtm_t *bm)
     if (bm->n_bgt == 0) return 0;
     /* does any output depend on a genotype?  not for `-G` without -C / -f / several groups (ref bgt.c:850) */
     need_counts = (bm->flag & BGT_F_SET_AC) || bm->site_flt || bm->n_fields > 0 || bm->n_groups > 1;
+    for (i = 0; i < bm->n_bgt; ++i) {                          /* whole-file walks: the site tables load beside the images */
+        pthread_t th;
+        const devrd_t *dv = (const devrd_t*)bm->bgt[i]->pb;
+        if (bm->bgt[i]->itr == NULL && dv && dv->own_sites == NULL && sites_prefetch(bm->bgt[i]->f, &th)) pthread_detach(th);
+    }
     for (i = bm->n_out = 0; i < bm->n_bgt; ++i) {
         if (prepare_one(bm->bgt[i], bm->n_groups, !(bm->flag & BGT_F_NO_GT) || need_counts ||
                         (bm->h_al && (bm->flag & (BGT_F_CNT_AL | BGT_F_CNT_HAP)))) < 0) rc = -1;
@@ -1573,4 +1592,136 @@ int bgtm_read_vcf(bgtm_t *bm, bcf1_t *b, kstring_t *s)
     ks_puts(s, "\tGT");
     ks_putn(s, (const char*)bm->a[1], (size_t)bm->n_out << 2);
     return ret;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Extension: the whole walk of `bgt view -G [-C] [-f EXPR] [-s ..] prefix` in bulk.
+ * The site-by-site contract of bgtm_read (one call, one site) costs ~0.4 us of host work per site -- record
+ * assembly, INFO, the filter expression, text formatting -- on ONE thread, 30 times the device's time for the same
+ * sites.  When nothing in the query needs that contract (one database, no genotype columns, VCF text, the whole file
+ * or a start offset) the same per-site functions run here over the site table on several threads: one device scan
+ * delivers the counts of every row, the sites are cut into blocks, every thread formats blocks into buffers of its
+ * own with its own copy of the filter expression, and the blocks are written in order.  Byte-identical to the
+ * bgtm_read_vcf loop.  Returns the number of records written, or -1 if the query needs the site-by-site path.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    bgtm_t *bm; const sitetab_t *t; int64_t lo, hi, row_min; const int32_t *counts; int need_counts, cstride;
+    int64_t n_blocks, blk_sites;
+    kstring_t *out; int64_t *n_lines; volatile int *done;
+    int64_t next_block;
+    pthread_mutex_t lock; pthread_cond_t cond;
+} bulk_t;
+
+static void *bulk_worker(void *arg)
+{
+    bulk_t *k = (bulk_t*)arg;
+    bgtm_t *bm = k->bm;
+    const sitetab_t *t = k->t;
+    kexpr_t *flt = ke_clone(bm->site_flt);
+    bcf1_t *b = bcf_init1();
+    kstring_t line = {0, 0, 0};
+    for (;;) {
+        int64_t blk, i, i0, i1, n = 0;
+        kstring_t *o;
+        pthread_mutex_lock(&k->lock);
+        blk = k->next_block++;
+        pthread_mutex_unlock(&k->lock);
+        if (blk >= k->n_blocks) break;
+        o = &k->out[blk];
+        i0 = k->lo + blk * k->blk_sites; i1 = i0 + k->blk_sites < k->hi ? i0 + k->blk_sites : k->hi;
+        for (i = i0; i < i1; ++i) {                               /* what read_core does for one database without genotypes */
+            bcf_set_site(b, t->rid[i], t->pos[i], t->rlen[i], t->pool + t->ref_off[i], (int)t->ref_len[i],
+                         t->pool + t->alt_off[i], (int)t->alt_len[i], t->n_allele[i] > 2 ? "<M>" : NULL);
+            if ((int)t->ref_len[i] != b->rlen) { int32_t val = b->pos + b->rlen; bcf_append_info_ints(bm->h_out, b, "END", 1, &val); }
+            if (k->need_counts) {
+                const int32_t *c = k->counts + (size_t)(t->row[i] - k->row_min) * (size_t)k->cstride;
+                bgt_info_t ss;
+                int g;
+                memset(&ss, 0, sizeof(ss));
+                ss.n_groups = bm->n_groups;
+                ss.an = c[0]; ss.ac[0] = c[1]; ss.ac[1] = c[2];
+                if (bm->n_groups > 1)
+                    for (g = 0; g < bm->n_groups; ++g) { ss.gan[g] = c[3 * (1 + g)]; ss.gac[g][0] = c[3 * (1 + g) + 1]; ss.gac[g][1] = c[3 * (1 + g) + 2]; }
+                fill_info(bm->h_out, &ss, b);
+                if (!pass_site_flt(&ss, flt)) continue;
+            }
+            vcf_format1(bm->h_out, b, &line);
+            ks_putn(o, line.s, line.l); ks_putc(o, '\n');
+            ++n;
+        }
+        pthread_mutex_lock(&k->lock);
+        k->n_lines[blk] = n; k->done[blk] = 1;
+        pthread_cond_broadcast(&k->cond);
+        pthread_mutex_unlock(&k->lock);
+    }
+    free(line.s);
+    bcf_destroy1(b);
+    ke_destroy(flt);
+    return NULL;
+}
+
+long bgtm_write_vcf_bulk(bgtm_t *bm, FILE *fp, long n_rec)
+{
+    bgt_t *bgt;
+    devrd_t *dv;
+    const sitetab_t *t;
+    bulk_t k;
+    pthread_t th[16];
+    int32_t *counts = NULL;
+    int64_t i, lo, hi, row_min = INT64_MAX, row_max = -1;
+    long written = 0;
+    int n_threads, need_counts, j;
+    if (bm->h_out == NULL && bgtm_prepare(bm) < 0) return -2;
+    if (bm->n_bgt != 1 || !(bm->flag & BGT_F_NO_GT) || (bm->flag & (BGT_F_CNT_AL | BGT_F_CNT_HAP)) || bm->h_al || bm->n_fields > 0) return -1;
+    bgt = bm->bgt[0]; dv = (devrd_t*)bgt->pb;
+    if (bgt->bed || bgt->h_al || bgt->itr || dv->own_sites || bgt->n_out == 0) return -1;
+    t = sites_of(bgt);
+    lo = ((cursor_t*)bgt->bcf)->next; hi = t->n;
+    if (lo < 0) lo = 0;
+    if (lo >= hi) return 0;
+    if (n_rec < hi - lo) return -1;                              /* -n counts EMITTED records: site by site */
+    need_counts = (bm->flag & BGT_F_SET_AC) || bm->site_flt || bm->n_groups > 1;
+    memset(&k, 0, sizeof(k));
+    k.cstride = 3 * (1 + (bm->n_groups > 1 ? bm->n_groups : 0));
+    if (need_counts) {
+        if (dv->rd == NULL) return -1;
+        for (i = lo; i < hi; ++i) { if (t->row[i] < row_min) row_min = t->row[i]; if (t->row[i] > row_max) row_max = t->row[i]; }
+        counts = (int32_t*)malloc((size_t)(row_max - row_min + 1) * (size_t)k.cstride * 4);
+        if (counts == NULL) return -1;
+        if (bgth_reader_scan(dv->rd, row_min, row_max + 1, counts, NULL) < 0) {      /* every row's AN / AC in one device pass */
+            fprintf(stderr, "[E::%s] %s\n", __func__, bgth_last_error());
+            free(counts);
+            return -2;
+        }
+    }
+    k.bm = bm; k.t = t; k.lo = lo; k.hi = hi; k.row_min = row_min; k.counts = counts; k.need_counts = need_counts;
+    k.blk_sites = 8192;
+    k.n_blocks = (hi - lo + k.blk_sites - 1) / k.blk_sites;
+    k.out = (kstring_t*)calloc((size_t)k.n_blocks, sizeof(kstring_t));
+    k.n_lines = (int64_t*)calloc((size_t)k.n_blocks, 8);
+    k.done = (volatile int*)calloc((size_t)k.n_blocks, sizeof(int));
+    pthread_mutex_init(&k.lock, NULL); pthread_cond_init(&k.cond, NULL);
+    {
+        long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+        const char *e = getenv("BGT_THREADS");
+        n_threads = e ? atoi(e) : (int)(ncpu > 16 ? 16 : ncpu);
+        if (n_threads < 1) n_threads = 1;
+        if (n_threads > 16) n_threads = 16;
+        if (n_threads > k.n_blocks) n_threads = (int)k.n_blocks;
+    }
+    for (j = 0; j < n_threads; ++j) pthread_create(&th[j], NULL, bulk_worker, &k);
+    for (i = 0; i < k.n_blocks; ++i) {                            /* blocks leave in order, as soon as they are ready */
+        pthread_mutex_lock(&k.lock);
+        while (!k.done[i]) pthread_cond_wait(&k.cond, &k.lock);
+        pthread_mutex_unlock(&k.lock);
+        if (k.out[i].l) fwrite(k.out[i].s, 1, k.out[i].l, fp);
+        written += (long)k.n_lines[i];
+        free(k.out[i].s); k.out[i].s = NULL;
+    }
+    for (j = 0; j < n_threads; ++j) pthread_join(th[j], NULL);
+    pthread_mutex_destroy(&k.lock); pthread_cond_destroy(&k.cond);
+    bm->n_gt_read += (uint64_t)(hi - lo) * (uint64_t)bgt->n_out;
+    ((cursor_t*)bgt->bcf)->next = hi;
+    free(k.out); free(k.n_lines); free((void*)k.done); free(counts);
+    return written;
 }

@@ -2,6 +2,7 @@
  * reader. */
 #include <limits.h>
 #include <stdio.h>
+#include <time.h>
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
@@ -24,8 +25,18 @@ static int usage(const char *cmd)
     return 1;
 }
 
+/* BGT_TRACE=1: wall time of the stages of a `bgt view` on stderr */
+static double view_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+static void view_lap(double *t0, const char *what)
+{
+    const double t1 = view_now();
+    if (getenv("BGT_TRACE")) fprintf(stderr, "[bgt trace] %-34s %8.2f ms\n", what, t1 - *t0);
+    *t0 = t1;
+}
+
 int main_view(int argc, char *argv[])
 {
+    double t_lap = view_now();
     int i, c, n_files, out_bcf = 0, clevel = -1, flag = 0, u_set = 0, n_groups = 0, not_vcf = 0, excl = 0, in_mem = 0;
     fmf_t *vardb = NULL;
     void *bed = NULL;
@@ -79,6 +90,7 @@ int main_view(int argc, char *argv[])
             fprintf(stderr, "[E::%s] failed to open BGT with prefix '%s'\n", __func__, argv[optind + i]);
             return 1;
         }
+    view_lap(&t_lap, "open databases (header, samples)");
     bm = bgtm_reader_init(n_files, files);
     bgtm_set_flag(bm, flag);
     if (site_flt && bgtm_set_flt_site(bm, site_flt) != 0) {
@@ -109,6 +121,7 @@ int main_view(int argc, char *argv[])
         }
     if (!out_bcf && !not_vcf) bgtm_want_vcf_text(bm);
     if (bgtm_prepare(bm) < 0) { fprintf(stderr, "[E::%s] failed to prepare the readers.\n", __func__); return 1; }
+    view_lap(&t_lap, "prepare (.pbf image -> HBM)");
 
     /* the reference builds the mode string "wb%d" and takes its first digit as the level, so the default
      * -1 compresses at level 1 (view.c:144-146, bgzf.c:138-146) */
@@ -122,13 +135,19 @@ int main_view(int argc, char *argv[])
     else vcf_hdr_write_text(stdout, bm->h_out);
 
     b = bcf_init1();
-    while ((rd_ret = (bz || not_vcf) ? bgtm_read(bm, b) : bgtm_read_vcf(bm, b, &line)) >= 0 && n_read < n_rec) {
+    if (!bz && !not_vcf && !getenv("BGT_NO_BULK")) {                /* the whole walk at once where the query allows it */
+        const long nb = bgtm_write_vcf_bulk(bm, stdout, n_rec);
+        if (nb >= 0) n_read += nb;
+        else if (nb < -1) rd_ret = -2;
+    }
+    while (rd_ret >= -1 && (rd_ret = ((bz || not_vcf) ? bgtm_read(bm, b) : bgtm_read_vcf(bm, b, &line))) >= 0 && n_read < n_rec) {
         if (bz) bcf_write1_stream(bz, b);
         else if (!not_vcf) { fwrite(line.s, 1, line.l, stdout); fputc('\n', stdout); }
         if (fmt && bm->n_fields > 0) puts(bm->tbl_line.s);
         ++n_read;
     }
     bcf_destroy1(b);
+    view_lap(&t_lap, "sites: scan, filter, format, write");
     if (not_vcf && bm->n_aal > 0) {                                 /* ref view.c:158-173 */
         if (bm->flag & BGT_F_CNT_HAP) {
             int n_hap;
@@ -151,6 +170,7 @@ int main_view(int argc, char *argv[])
     if (vardb) fmf_destroy(vardb);
     for (i = 0; i < n_files; ++i) bgt_close(files[i]);
     free(files);
+    view_lap(&t_lap, "close");
     if (rd_ret < -1) {                                              /* -1 is the end of the data; anything below is a failure */
         fprintf(stderr, "[E::%s] reading stopped on an error (%d): the output is incomplete.\n", __func__, rd_ret);
         return 1;

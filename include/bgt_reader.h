@@ -154,6 +154,11 @@ int     bgtm_read(bgtm_t *bm, bcf1_t *b);                 /* >= 0 per emitted si
  * announce it before bgtm_prepare so that the device is asked for the text */
 void    bgtm_want_vcf_text(bgtm_t *bm);
 int     bgtm_read_vcf(bgtm_t *bm, bcf1_t *b, kstring_t *s);
+/* every remaining site as VCF text in one call -- one device scan for all counts, the lines formatted on several host
+ * threads (BGT_THREADS, default min(cores, 16)), written in order; the bytes of the bgtm_read_vcf loop.  Only for one
+ * database without genotype columns, region, BED, allele set or table; returns the records written, -1 if the query
+ * needs the site-by-site path (nothing was written), -2 on a device error. */
+long    bgtm_write_vcf_bulk(bgtm_t *bm, FILE *fp, long n_rec);
 
 /* ---- allele sets: samples carrying all of them (-S), haplotype counts (-H) ---- */
 char         *bgtm_alcnt_print(const bgtm_t *bm);                                  /* malloc'd text, caller frees */
