@@ -112,3 +112,24 @@ def test_random_vcfs_import_like_the_reference_binary(tmp_path, seed, n_samples,
         outs = [subprocess.run([exe, "view", "-C", "-r", reg, db], stdout=subprocess.PIPE, check=True).stdout
                 for exe in (BGT, ref) for db in (mine, want)]
         assert outs[0] == outs[1] == outs[2] == outs[3], reg
+
+
+@pytest.mark.gpu
+def test_bcf_input_imports_like_the_reference_binary(tmp_path):
+    """binary input: a BCF with genotypes (written by the reference's `view -b` from a database) imported by both builds"""
+    ref = require_ref("bgt")
+    vcf = str(tmp_path / "in.vcf")
+    random_vcf(np.random.default_rng(9), 25, 700, vcf)
+    db = str(tmp_path / "db")
+    subprocess.check_call([ref, "import", "-S", "-F", db, vcf], stderr=subprocess.DEVNULL)
+    bcf = str(tmp_path / "geno.bcf")
+    with open(bcf, "wb") as f:
+        subprocess.check_call([ref, "view", "-b", db], stdout=f)                # sites x 25 samples, GT as int8 pairs
+    mine, want = str(tmp_path / "mine"), str(tmp_path / "want")
+    subprocess.check_call([BGT, "import", mine, bcf], timeout=600, stderr=subprocess.DEVNULL)
+    subprocess.check_call([ref, "import", want, bcf], timeout=600, stderr=subprocess.DEVNULL)
+    for ext in ("spl", "pbf", "bcf"):
+        assert open(mine + "." + ext, "rb").read() == open(want + "." + ext, "rb").read(), ext
+    a = subprocess.run([BGT, "view", "-C", mine], stdout=subprocess.PIPE, check=True).stdout
+    b = subprocess.run([ref, "view", "-C", want], stdout=subprocess.PIPE, check=True).stdout
+    assert a == b and a.count(b"\n") > 500
