@@ -231,9 +231,17 @@ class Pipeline:
         self.flt.apply_device(self.counts[b].data_ptr(), self.n, 3, self.flags[b].data_ptr(), self.n_pass_d[b].data_ptr(),
                               self.main.cuda_stream)
         if self.world > 1:                                                       # per-shard AN/AC + flags over xGMI
-            self.dist.all_gather_into_tensor(self.g_counts[b], self.counts[b])
-            self.dist.all_gather_into_tensor(self.g_flags[b], self.flags[b])
-            self.dist.all_reduce(self.n_pass_d[b])
+            if self.dist.get_backend() == "gloo":                        # dry run of the multi-rank path without RCCL (tests)
+                self.main.synchronize()
+                gc, gf, npass = self.g_counts[b].cpu(), self.g_flags[b].cpu(), self.n_pass_d[b].cpu()
+                self.dist.all_gather_into_tensor(gc, self.counts[b].cpu())
+                self.dist.all_gather_into_tensor(gf, self.flags[b].cpu())
+                self.dist.all_reduce(npass)
+                self.g_counts[b].copy_(gc); self.g_flags[b].copy_(gf); self.n_pass_d[b].copy_(npass)
+            else:
+                self.dist.all_gather_into_tensor(self.g_counts[b], self.counts[b])
+                self.dist.all_gather_into_tensor(self.g_flags[b], self.flags[b])
+                self.dist.all_reduce(self.n_pass_d[b])
         self.ready[b].record(self.main)
         if self.rank == 0:
             with torch.cuda.stream(self.side):
@@ -338,6 +346,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=262144, help="sites for the CPU baseline (0 = skip)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 100,000-sample secondary records (N = 1)")
     ap.add_argument("--secondary-steps", type=int, default=3)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo = dry run through host copies)")
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--cpt", type=int, default=0)
     ap.add_argument("--batch", type=int, default=0)
@@ -355,12 +364,17 @@ def main():
     import bgt_amd
     from bgt_amd.shard import block_shards
 
+    if os.environ.get("BENCH_ALL_RANKS_ON_DEVICE0"):         # dry run of N > 1 on a one-GPU box (with --backend gloo)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)       # "nccl" is RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(args.backend)
 
     n_samples = SAMPLES[args.workload]
     m = 2 * n_samples
@@ -404,8 +418,11 @@ def main():
         host_flags = pipe.host_flags[last]
         if not strong:
             assert n_pass == int(host_flags.numpy().sum())
+        else:                                                   # the last shard is padded to the longest: count its real rows only
+            hf = host_flags.numpy()
+            n_pass = int(sum(hf[r * sites: r * sites + (shards[r][1] - shards[r][0])].sum() for r in range(world)))
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
