@@ -177,6 +177,9 @@ struct bgth_reader_s {
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     DevBuf raw, fin, h0, h1, gt, planes, gt8, gttext;
+    DevBuf carriers, hapsig;          // allele-set accumulators (bgth_reader_fold_last), zeroed when folds_live turns true
+    bool folds_live = false;
+    int64_t bits_row0 = 0, bits_row1 = 0;   // image rows whose bit planes h0/h1 currently hold
     HostBuf h_counts, h_planes, h_gt8, h_gttext;
     float t_ms[3] = {0, 0, 0};
     bool t_pending = false;           // events recorded on a caller stream, not yet read back
@@ -916,7 +919,7 @@ extern "C" void bgth_reader_destroy(bgth_reader_t *r)
     if (r->stream) hipStreamSynchronize(r->stream);
     r->sel.release();
     r->raw.release(); r->fin.release(); r->h0.release(); r->h1.release(); r->gt.release(); r->planes.release();
-    r->gt8.release(); r->gttext.release();
+    r->gt8.release(); r->gttext.release(); r->carriers.release(); r->hapsig.release();
     r->h_counts.release(); r->h_planes.release(); r->h_gt8.release(); r->h_gttext.release();
     for (int i = 0; i < 4; ++i) if (r->ev[i]) hipEventDestroy(r->ev[i]);
     if (r->stream) hipStreamDestroy(r->stream);
@@ -931,6 +934,7 @@ extern "C" int bgth_reader_select(bgth_reader_t *r, int n_sub, const int32_t *su
     hipStreamSynchronize(r->stream);
     if (!guarded("bgth_reader_select", false, [&] { return build_selection(r->sel, r->pbf->m, n_sub, sub, group, n_groups); })) return -1;
     r->ring0 = r->ring1 = 0;          // invalidate the pull ring
+    r->folds_live = false; r->bits_row0 = r->bits_row1 = 0;
     for (bgth_reader_t *sr : r->subs) if (bgth_reader_select(sr, n_sub, sub, group, n_groups) < 0) return -1;
     return 0;
 }
@@ -1162,6 +1166,7 @@ static bool decode_piece(bgth_reader_t *r, int want, int64_t row0, int64_t row1,
     }
     uint64_t *d_h0 = need_bits ? (uint64_t*)r->h0.p : nullptr, *d_h1 = need_bits ? (uint64_t*)r->h1.p : nullptr;
     if (enqueue_scan(r, row0, row1, (int32_t*)r->fin.p, d_h0, d_h1, r->stream, true) < 0) return false;
+    r->bits_row0 = need_bits ? row0 : 0; r->bits_row1 = need_bits ? row1 : 0;
     if (want & BGTH_WANT_PLANES) {
         uint8_t *d_a0 = (uint8_t*)r->planes.p, *d_a1 = d_a0 + by;
         HIP_TRY(launch_unpack_bytes(d_h0, d_h1, r->sel.d_slot_of_out, d_a0, d_a1, rows, r->sel.n_chunks, width, r->stream), return false);
@@ -1195,6 +1200,7 @@ static bool refill(bgth_reader_t *r)
     const bool need_bits = want != 0;                            // any genotype output needs the bit planes H0/H1
     const int per_hap = (want & BGTH_WANT_PLANES ? 2 : 0) + (want & BGTH_WANT_GT8 ? 1 : 0) + (want & BGTH_WANT_GTTEXT ? 2 : 0);
     int64_t max_rows = need_bits ? ((int64_t)256 << 20) / std::max(1, per_hap * width) : (int64_t)1 << 22;
+    if (want & BGTH_WANT_BITS) max_rows = std::min(max_rows, ((int64_t)512 << 20) / ((int64_t)r->sel.n_chunks * 16));   // H0 + H1 in HBM
     if (r->max_ahead > 0) max_rows = std::min(max_rows, r->max_ahead);
     max_rows = std::max<int64_t>(blk_rows, max_rows / blk_rows * blk_rows);
     const int64_t row0 = r->next;
@@ -1279,7 +1285,7 @@ extern "C" const uint8_t **bgth_reader_read(bgth_reader_t *r)
 extern "C" int bgth_reader_config(bgth_reader_t *r, int want_planes, int64_t max_rows_ahead)
 {
     if (!r) return -1;
-    if (want_planes & ~(BGTH_WANT_PLANES | BGTH_WANT_GT8 | BGTH_WANT_GTTEXT)) { set_err("[E::bgth_reader_config] unknown output bits 0x%x", want_planes); return -1; }
+    if (want_planes & ~(BGTH_WANT_PLANES | BGTH_WANT_GT8 | BGTH_WANT_GTTEXT | BGTH_WANT_BITS)) { set_err("[E::bgth_reader_config] unknown output bits 0x%x", want_planes); return -1; }
     r->want = want_planes;
     r->max_ahead = max_rows_ahead;
     return 0;
@@ -1288,6 +1294,69 @@ extern "C" int bgth_reader_config(bgth_reader_t *r, int want_planes, int64_t max
 extern "C" const int32_t *bgth_reader_last_counts(const bgth_reader_t *r) { return r->last_counts; }
 extern "C" const int8_t *bgth_reader_last_gt8(const bgth_reader_t *r) { return r->last_gt8; }
 extern "C" const char *bgth_reader_last_gt_text(const bgth_reader_t *r) { return r->last_gttext; }
+
+// ----------------------------------------------------------------------------------------------------
+// allele-set reductions on the device (reference bgt.c:859-876): the row of the last bgth_reader_read, still in HBM as
+// bit planes, is folded into per-reader accumulators; nothing of the row crosses PCIe
+// ----------------------------------------------------------------------------------------------------
+static bool folds_prepare(bgth_reader_t *r)
+{
+    if (r->folds_live) return true;
+    const size_t nc = (size_t)(r->sel.width / 2) * 4, nh = (size_t)r->sel.width * 8;
+    if (!r->carriers.reserve(nc ? nc : 4) || !r->hapsig.reserve(nh ? nh : 16)) { set_err("[E::bgth_reader_fold_last] out of HBM"); return false; }
+    HIP_TRY(hipMemsetAsync(r->carriers.p, 0, nc, r->stream), return false);
+    HIP_TRY(hipMemsetAsync(r->hapsig.p, 0, nh, r->stream), return false);
+    r->folds_live = true;
+    return true;
+}
+
+extern "C" int bgth_reader_fold_last(bgth_reader_t *r, int code, int bit)
+{
+    if (!r) return -1;
+    if (code > 3 || bit > 63) { set_err("[E::bgth_reader_fold_last] code %d / bit %d out of range", code, bit); return -1; }
+    if (r->sel.width & 1) { set_err("[E::bgth_reader_fold_last] needs whole samples (an even number of columns), have %d", r->sel.width); return -1; }
+    const int64_t row = r->next - 1;
+    if (row < r->ring0 || row >= r->ring1 || !(r->ring_has & BGTH_WANT_BITS)) {
+        set_err("[E::bgth_reader_fold_last] no row read, or the reader was not configured with BGTH_WANT_BITS");
+        return -1;
+    }
+    bgth_reader_t *sr = r;
+    int64_t lrow = row;
+    for (bgth_reader_t *sub : r->subs)
+        if (row >= sub->pbf->row_off && row < sub->pbf->row_off + sub->pbf->n) { sr = sub; lrow = row - sub->pbf->row_off; }
+    if (lrow < sr->bits_row0 || lrow >= sr->bits_row1) { set_err("[E::bgth_reader_fold_last] row %lld is not resident", (long long)row); return -1; }
+    if (!use_device(sr->pbf->device) || !folds_prepare(sr)) return -1;
+    const size_t off = (size_t)(lrow - sr->bits_row0) * sr->sel.n_chunks;
+    HIP_TRY(launch_fold_alleles((const uint64_t*)sr->h0.p + off, (const uint64_t*)sr->h1.p + off, sr->sel.d_slot_of_out,
+                                code >= 0 ? (int32_t*)sr->carriers.p : nullptr, bit >= 0 ? (uint64_t*)sr->hapsig.p : nullptr,
+                                sr->sel.width, code, bit, sr->stream), return -1);
+    return 0;
+}
+
+extern "C" int bgth_reader_take_folds(bgth_reader_t *r, int32_t *carriers, uint64_t *hap)
+{
+    if (!r) return -1;
+    return guarded("bgth_reader_take_folds", -1, [&]() -> int {
+        const int width = r->sel.width, ns = width / 2;
+        if (carriers) memset(carriers, 0, (size_t)ns * 4);
+        if (hap) memset(hap, 0, (size_t)width * 8);
+        std::vector<bgth_reader_t*> all(r->subs.begin(), r->subs.end());
+        if (all.empty()) all.push_back(r);
+        std::vector<int32_t> c((size_t)ns);
+        std::vector<uint64_t> h((size_t)width);
+        for (bgth_reader_t *sr : all) {                      // shards saw disjoint rows: their folds add / or together
+            if (!sr->folds_live) continue;
+            if (!use_device(sr->pbf->device)) return -1;
+            HIP_TRY(hipMemcpyAsync(c.data(), sr->carriers.p, (size_t)ns * 4, hipMemcpyDeviceToHost, sr->stream), return -1);
+            HIP_TRY(hipMemcpyAsync(h.data(), sr->hapsig.p, (size_t)width * 8, hipMemcpyDeviceToHost, sr->stream), return -1);
+            HIP_TRY(hipStreamSynchronize(sr->stream), return -1);
+            if (carriers) for (int i = 0; i < ns; ++i) carriers[i] += c[(size_t)i];
+            if (hap) for (int i = 0; i < width; ++i) hap[i] |= h[(size_t)i];
+            sr->folds_live = false;                          // the next fold starts from zero
+        }
+        return 0;
+    });
+}
 
 // ----------------------------------------------------------------------------------------------------
 // site filter on the device

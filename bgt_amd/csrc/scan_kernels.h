@@ -97,6 +97,8 @@ hipError_t launch_unpack_bytes(const uint64_t *h0, const uint64_t *h1, const int
 // order; width must be even (haplotype pairs = samples); either output may be NULL
 hipError_t launch_emit_gt(const uint64_t *h0, const uint64_t *h1, const int32_t *slot_of_out, uint8_t *gt8,
                           uint32_t *text, int64_t n_rows, int n_chunks, int width, hipStream_t s);
+hipError_t launch_fold_alleles(const uint64_t *h0_row, const uint64_t *h1_row, const int32_t *slot_of_out, int32_t *carriers,
+                               uint64_t *hap, int width, int code, int bit, hipStream_t s);
 
 // compiled `-f` expression (reverse Polish): op 0 = int constant, 1 = real constant, 2 = variable read from
 // counts[slot], 16 + k = operator k in the numbering of filter_expr.c

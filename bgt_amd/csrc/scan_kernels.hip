@@ -306,6 +306,46 @@ hipError_t launch_emit_gt(const uint64_t *h0, const uint64_t *h1, const int32_t 
 }
 
 // ----------------------------------------------------------------------------------------------------
+// Allele-set reductions (reference bgt.c:859-876, `bgt view -a ... -S / -H`): one decoded row folded into the two
+// per-reader accumulators.  One thread per output sample; both arrays live in HBM across the rows of a query.
+//   carriers[s] += 1 if either haplotype of sample s has code `code` (1 = the allele, 0 = a reference-allele query)
+//   hap[2s+k]   |= 1 << bit  if haplotype k of sample s has code 1
+// ----------------------------------------------------------------------------------------------------
+__global__ void fold_alleles_kernel(const uint64_t *h0, const uint64_t *h1, const int32_t *slot_of_out, int32_t *carriers,
+                                    uint64_t *hap, int n_samples, int code, int bit)
+{
+    const int smp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (smp >= n_samples) return;
+    uint32_t c[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int s = slot_of_out[2 * smp + k];
+        const uint32_t a0 = (uint32_t)(h0[s >> 6] >> (s & 63)) & 1u;
+        const uint32_t a1 = (uint32_t)(h1[s >> 6] >> (s & 63)) & 1u;
+        c[k] = a1 << 1 | a0;
+    }
+    if (carriers && code >= 0) carriers[smp] += (c[0] == (uint32_t)code || c[1] == (uint32_t)code);
+    if (hap && bit >= 0) {
+        uint4 *hp = reinterpret_cast<uint4*>(hap) + smp;                  // the sample's two 64-bit signatures in one access
+        uint4 v = *hp;
+        const uint32_t lo = bit < 32 ? 1u << bit : 0u, hi = bit < 32 ? 0u : 1u << (bit - 32);
+        if (c[0] == 1u) { v.x |= lo; v.y |= hi; }
+        if (c[1] == 1u) { v.z |= lo; v.w |= hi; }
+        *hp = v;
+    }
+}
+
+hipError_t launch_fold_alleles(const uint64_t *h0_row, const uint64_t *h1_row, const int32_t *slot_of_out, int32_t *carriers,
+                               uint64_t *hap, int width, int code, int bit, hipStream_t s)
+{
+    const int n_samples = width / 2;
+    if (n_samples <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fold_alleles_kernel, dim3((unsigned)((n_samples + 255) / 256)), dim3(256), 0, s,
+                       h0_row, h1_row, slot_of_out, carriers, hap, n_samples, code, bit);
+    return hipGetLastError();
+}
+
+// ----------------------------------------------------------------------------------------------------
 // Site filter on the device: the reverse-Polish program of a `-f` expression (exported by the host parser,
 // filter_expr.c ke_export) evaluated per site on the counts the scan produced.  Same value model as the host
 // evaluator (reference kexpr.c:105-153): every slot carries an int64 and a double view plus a type;

@@ -270,7 +270,7 @@ class HipReader:
         if lib().bgth_reader_seek(self.h, row) < 0:
             raise RuntimeError(last_error())
 
-    WANT_PLANES, WANT_GT8, WANT_GTTEXT = 1, 2, 4
+    WANT_PLANES, WANT_GT8, WANT_GTTEXT, WANT_BITS = 1, 2, 4, 8
 
     def config(self, want=1, max_rows_ahead=0):
         """What the pull interface materialises per row besides the counts (mask of WANT_*)."""
@@ -304,6 +304,26 @@ class HipReader:
         L.bgth_reader_last_gt_text.argtypes = [C.c_void_p]
         p = L.bgth_reader_last_gt_text(self.h)
         return C.string_at(p, 2 * self.width) if p else None
+
+    def fold_last(self, code=-1, bit=-1):
+        """Allele-set reductions over the row just read (reader configured with WANT_BITS; reference bgt.c:859-876):
+        carriers[s] += sample s has a haplotype of `code`; hap[i] |= 1 << bit for haplotypes of code 1."""
+        L = lib()
+        L.bgth_reader_fold_last.restype = C.c_int
+        L.bgth_reader_fold_last.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        if L.bgth_reader_fold_last(self.h, code, bit) < 0:
+            raise RuntimeError(last_error())
+
+    def take_folds(self):
+        """(carriers int32[width/2], hap uint64[width]) accumulated since the selection / the last take."""
+        L = lib()
+        L.bgth_reader_take_folds.restype = C.c_int
+        L.bgth_reader_take_folds.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        car = np.zeros(self.width // 2, np.int32)
+        hap = np.zeros(self.width, np.uint64)
+        if L.bgth_reader_take_folds(self.h, car.ctypes.data, hap.ctypes.data) < 0:
+            raise RuntimeError(last_error())
+        return car, hap
 
     def last_counts(self):
         p = lib().bgth_reader_last_counts(self.h)

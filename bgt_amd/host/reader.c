@@ -246,6 +246,9 @@ typedef struct {                                              /* bgt_t::pb */
     bgth_pbf_t *own_img;       /* a partial image of the .pbf that only this reader uses (region / start queries) */
     void *own_sites;           /* sitetab_t: the sites of this reader's region, loaded through the CSI index */
     int n_groups_total;        /* as passed to the last selection, to re-apply it on another image */
+    /* -S / -H: the device folds matched rows into per-reader accumulators (bgth_reader_fold_last); drained here */
+    int folded;                /* the device holds folds not yet drained */
+    int32_t *f_car; uint64_t *f_hap;   /* running totals: carriers[n_out], signatures[2 n_out] */
 } devrd_t;
 
 /* The whole-file image of a database.  BGT_GPUS spreads it over several devices (site-range shards behind the codec
@@ -342,7 +345,7 @@ void bgt_reader_destroy(bgt_t *bgt)
     devrd_t *dv;
     if (!bgt) return;
     dv = (devrd_t*)bgt->pb;
-    if (dv) { if (dv->rd) bgth_reader_destroy(dv->rd); if (dv->own_img) bgth_pbf_close(dv->own_img); st_free((sitetab_t*)dv->own_sites); free(dv); }
+    if (dv) { if (dv->rd) bgth_reader_destroy(dv->rd); if (dv->own_img) bgth_pbf_close(dv->own_img); st_free((sitetab_t*)dv->own_sites); free(dv->f_car); free(dv->f_hap); free(dv); }
     bcf_destroy1(bgt->b0);
     free(bgt->gtag); free(bgt->group); free(bgt->out); free(bgt->bcf); free(bgt->itr);
     if (bgt->h_out) bcf_hdr_destroy(bgt->h_out);
@@ -622,6 +625,30 @@ static int apply_selection(bgt_t *bgt)
     return rc;
 }
 
+/* bring the device's allele-set folds of this database into the host totals (before the device reader goes away, and
+ * before anybody looks at bm->alcnt / bm->hap) */
+static int drain_folds(bgt_t *bgt)
+{
+    devrd_t *dv = (devrd_t*)bgt->pb;
+    int32_t *c;
+    uint64_t *h;
+    int i, rc;
+    if (!dv->folded || dv->rd == NULL || bgt->n_out <= 0) return 0;
+    c = (int32_t*)malloc((size_t)bgt->n_out * 4);
+    h = (uint64_t*)malloc((size_t)bgt->n_out * 16);
+    rc = bgth_reader_take_folds(dv->rd, c, h);
+    if (rc < 0) fprintf(stderr, "[E::%s] %s\n", __func__, bgth_last_error());
+    else {
+        if (dv->f_car == NULL) dv->f_car = (int32_t*)calloc((size_t)bgt->n_out, 4);
+        if (dv->f_hap == NULL) dv->f_hap = (uint64_t*)calloc((size_t)bgt->n_out * 2, 8);
+        for (i = 0; i < bgt->n_out; ++i) dv->f_car[i] += c[i];
+        for (i = 0; i < bgt->n_out * 2; ++i) dv->f_hap[i] |= h[i];
+        dv->folded = 0;
+    }
+    free(c); free(h);
+    return rc;
+}
+
 /* a row outside the reader's partial image was asked for (the region or start changed after the image was
  * opened): switch to the shared image of the whole file */
 static int promote_to_full(bgt_t *bgt)
@@ -629,6 +656,7 @@ static int promote_to_full(bgt_t *bgt)
     devrd_t *dv = (devrd_t*)bgt->pb;
     bgt_file_t *wf = (bgt_file_t*)bgt->f;
     if (dv->own_img == NULL) return -1;
+    if (drain_folds(bgt) < 0) return -1;
     bgth_reader_destroy(dv->rd); dv->rd = NULL;
     bgth_pbf_close(dv->own_img); dv->own_img = NULL;
     pthread_mutex_lock(&g_open_lock);
@@ -775,7 +803,7 @@ int bgt_read(bgt_t *bgt, bcf1_t *b)                           /* ref bgt.c:347-3
         dv->want = BGTH_WANT_PLANES;
         if (dv->rd) bgth_reader_config(dv->rd, dv->want, 0);
         bgt->h_out = bcf_hdr_init();                          /* input header + FORMAT + the selected samples */
-        ks_putn(&s, bgt->f->h0->text, (size_t)bgt->f->h0->l_text);
+        ks_putn(&s, bgt->f->h0->text, bgt->f->h0->l_text > 0 ? (size_t)bgt->f->h0->l_text : 0);
         while (s.l && s.s[s.l - 1] == 0) --s.l;
         if (bgt->n_out > 0) {
             ks_puts(&s, "\tFORMAT");
@@ -1209,12 +1237,27 @@ static void hc_sort(bgt_hapcnt_t *a, int n)
     }
 }
 
+/* bm->alcnt / bm->hap = the per-database totals, after draining what the devices still hold */
+static int sync_folds(bgtm_t *bm)
+{
+    int i, off = 0, rc = 0;
+    for (i = 0; i < bm->n_bgt; ++i) {
+        bgt_t *bgt = bm->bgt[i];
+        const devrd_t *dv = (const devrd_t*)bgt->pb;
+        if (drain_folds(bgt) < 0) rc = -1;
+        if (bm->alcnt && dv->f_car) memcpy(bm->alcnt + off, dv->f_car, (size_t)bgt->n_out * 4);
+        if (bm->hap && dv->f_hap) memcpy(bm->hap + 2 * (size_t)off, dv->f_hap, (size_t)bgt->n_out * 16);
+        off += bgt->n_out;
+    }
+    return rc;
+}
+
 bgt_hapcnt_t *bgtm_hapcnt(const bgtm_t *bm, int *n_hap)
 {
     bgt_hapcnt_t *hc = NULL;
     int i, j, n = 0, m = 0, n_slot = 64, *slot;
     *n_hap = 0;
-    if (bm->hap == NULL || bm->n_out == 0) return NULL;
+    if (bm->hap == NULL || bm->n_out == 0 || sync_folds((bgtm_t*)bm) < 0) return NULL;
     while (n_slot < bm->n_out * 4) n_slot <<= 1;              /* open addressing: haplotype -> its number */
     slot = (int*)malloc((size_t)n_slot * sizeof(int));
     for (i = 0; i < n_slot; ++i) slot[i] = -1;
@@ -1263,7 +1306,7 @@ char *bgtm_alcnt_print(const bgtm_t *bm)
 {
     kstring_t s = {0, 0, 0};
     int i;
-    if (bm->alcnt == NULL) return NULL;
+    if (bm->alcnt == NULL || sync_folds((bgtm_t*)bm) < 0) return NULL;
     for (i = 0; i < bm->n_out; ++i) {
         if (bm->alcnt[i] == bm->n_aal) {
             const bgt_t *bgt = bm->bgt[bm->sample_idx[i] >> 32];
@@ -1349,6 +1392,10 @@ int bgtm_prepare(bgtm_t *bm)
     bm->a[1] = (uint8_t*)realloc(bm->a[1], (size_t)(bm->n_out ? bm->n_out : 1) << 2);   /* planes: 2 B, text: 4 B per sample */
 
     if (bm->h_al) {                                           /* ref bgt.c:668-674 */
+        for (i = 0; i < bm->n_bgt; ++i) {
+            devrd_t *dv = (devrd_t*)bm->bgt[i]->pb;
+            free(dv->f_car); free(dv->f_hap); dv->f_car = NULL; dv->f_hap = NULL; dv->folded = 0;
+        }
         free(bm->alcnt); bm->alcnt = NULL;
         if (bm->flag & BGT_F_CNT_AL) bm->alcnt = (int*)calloc((size_t)(bm->n_out ? bm->n_out : 1), sizeof(int));
         free(bm->hap); bm->hap = NULL;
@@ -1367,7 +1414,7 @@ int bgtm_prepare(bgtm_t *bm)
         int want = 0;
         for (i = m = 0; i < bm->n_out; ++i) if (bm->mgs[i] <= 1) ++m;
         if (!(bm->flag & BGT_F_NO_GT)) want = m == bm->n_out ? BGTH_WANT_GT8 : BGTH_WANT_PLANES;
-        if (bm->h_al && (bm->flag & (BGT_F_CNT_AL | BGT_F_CNT_HAP))) want = BGTH_WANT_PLANES;   /* -S reads the codes */
+        if (bm->h_al && (bm->flag & (BGT_F_CNT_AL | BGT_F_CNT_HAP))) want = BGTH_WANT_BITS;   /* -S / -H: the rows stay on the device */
         for (i = 0; i < bm->n_bgt; ++i) {
             devrd_t *dv = (devrd_t*)bm->bgt[i]->pb;
             dv->want = want | ((want & BGTH_WANT_GT8) && dv->text_mode ? BGTH_WANT_GTTEXT : 0);
@@ -1468,6 +1515,7 @@ static void fill_info(const bcf_hdr_t *h, const bgt_info_t *ss, bcf1_t *b)   /* 
 static int read_core(bgtm_t *bm, bcf1_t *b)
 {
     int i, off = 0, n_rest = 0, max_allele = 0, best = -1, l_ref, al_ret = 0;
+    uint8_t had[bm->n_bgt > 0 ? bm->n_bgt : 1];                /* which databases carry this site */
     const sitetab_t *bt = NULL;
     int64_t bs = -1;
     bgt_info_t ss;
@@ -1504,10 +1552,12 @@ static int read_core(bgtm_t *bm, bcf1_t *b)
         bgt_t *bgt = bm->bgt[i];
         const sitetab_t *t = sites_of(bgt);
         devrd_t *dv = (devrd_t*)bgt->pb;
+        had[i] = 0;
         if (bgt->n_out == 0) continue;
         if (bm->r[i].b0 && st_cmp(bt, bs, t, dv->site) == 0) {
             const int32_t *c = dv->counts;
             int g;
+            had[i] = 1;
             bm->r[i].b0 = NULL;
             if (bm->r[i].a[0]) {
                 memcpy(bm->a[0] + off, bm->r[i].a[0], (size_t)bgt->n_out << 1);
@@ -1540,16 +1590,20 @@ static int read_core(bgtm_t *bm, bcf1_t *b)
         if (!pass_site_flt(&ss, bm->site_flt)) return 1;
     }
     if (bm->h_al) {                                           /* ref bgt.c:859-876 */
-        if ((bm->flag & BGT_F_CNT_AL) && bm->alcnt) {         /* +1 for every sample that carries the allele */
-            const int want = al_ret == 2 ? 0 : 1;             /* a reference-allele query counts code 0 */
-            for (i = 0; i < bm->n_out; ++i) {
-                const int g1 = bm->a[0][i << 1] | bm->a[1][i << 1] << 1, g2 = bm->a[0][i << 1 | 1] | bm->a[1][i << 1 | 1] << 1;
-                bm->alcnt[i] += (g1 == want || g2 == want);
+        /* -S: +1 for every sample that carries the allele (a reference-allele query counts code 0); -H: bit n_aal of a
+         * haplotype = it carries this allele.  Both reductions run on the device over the row it just decoded, one fold
+         * per database that has the site (a database without it is all code 2 and adds nothing to either). */
+        const int do_al = (bm->flag & BGT_F_CNT_AL) && bm->alcnt, do_hap = (bm->flag & BGT_F_CNT_HAP) && bm->hap;
+        if (do_al || do_hap)
+            for (i = 0; i < bm->n_bgt; ++i) {
+                devrd_t *dv = (devrd_t*)bm->bgt[i]->pb;
+                if (!had[i] || dv->rd == NULL) continue;
+                if (bgth_reader_fold_last(dv->rd, do_al ? (al_ret == 2 ? 0 : 1) : -1, do_hap ? (bm->n_aal & 63) : -1) < 0) {
+                    fprintf(stderr, "[E::%s] %s\n", __func__, bgth_last_error());
+                    return -2;
+                }
+                dv->folded = 1;
             }
-        }
-        if ((bm->flag & BGT_F_CNT_HAP) && bm->hap)            /* bit n_aal of a haplotype: it carries this allele */
-            for (i = 0; i < bm->n_out << 1; ++i)
-                if (bm->a[0][i] == 1 && bm->a[1][i] == 0) bm->hap[i] |= 1ULL << bm->n_aal;
         al_from_site(bm->h_out->id[BCF_DT_CTG][b->rid].key, b->rid, b->pos, b->rlen, bt->pool + bt->ref_off[bs], bt->ref_len[bs],
                      bt->pool + bt->alt_off[bs], bt->alt_len[bs], &bm->aal[bm->n_aal++], NULL);
     }
@@ -1561,6 +1615,7 @@ int bgtm_read(bgtm_t *bm, bcf1_t *b)                          /* ref bgt.c:880-8
     int ret;
     if (bm->h_out == NULL && bgtm_prepare(bm) < 0) return -2;
     while ((ret = read_core(bm, b)) > 0) {}
+    if (ret == -1 && bm->h_al && sync_folds(bm) < 0) ret = -2;  /* the end: bm->alcnt / bm->hap are complete for callers that read them */
     if (ret >= 0 && (bm->flag & BGT_F_NO_GT) == 0) {
         if (bm->n_bgt > 0 && (((devrd_t*)bm->bgt[0]->pb)->want & BGTH_WANT_GT8)) gen_gt8(bm->h_out, b, bm->n_out, bm->a[0]);
         else gen_gt(bm->h_out, b, bm->n_out, (const uint8_t *const*)bm->a, bm->mgs);

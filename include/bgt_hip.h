@@ -149,12 +149,24 @@ const uint8_t **bgth_reader_read(bgth_reader_t *r);
 #define BGTH_WANT_PLANES 1
 #define BGTH_WANT_GT8    2
 #define BGTH_WANT_GTTEXT 4
+#define BGTH_WANT_BITS   8   /* keep the window's bit planes in HBM for bgth_reader_fold_last; nothing more is copied out */
 int             bgth_reader_config(bgth_reader_t *r, int want_planes, int64_t max_rows_ahead);
 /* genotype vector / text of the row returned by the last bgth_reader_read (NULL unless configured) */
 const int8_t   *bgth_reader_last_gt8(const bgth_reader_t *r);
 const char     *bgth_reader_last_gt_text(const bgth_reader_t *r);
 /* counts of the row returned by the last bgth_reader_read: int32[1+Gx][3] */
 const int32_t  *bgth_reader_last_counts(const bgth_reader_t *r);
+/* Allele-set reductions on the device -- what bgtm_read_core does per matched site for `bgt view -a ... -S / -H`
+ * (reference bgt.c:859-876) -- over the row returned by the last bgth_reader_read of a reader configured with
+ * BGTH_WANT_BITS (whole samples selected: an even number of columns, haplotypes 2s and 2s+1 of a sample adjacent):
+ *   code >= 0:  carriers[s] += 1 for every output sample s with a haplotype of that 2-bit code (1 = carries the
+ *               allele, 0 = a reference-allele query; bgt.c:862-869)
+ *   bit  >= 0:  hap[i] |= 1 << bit for every output haplotype i of code 1 (bgt.c:871-874), bit <= 63
+ * The accumulators (int32[width/2], uint64[width]) live in HBM and start at zero after bgth_reader_select and after
+ * bgth_reader_take_folds, which copies them out (either pointer may be NULL); with a sharded image every shard folds
+ * the rows it decoded and take adds / ors the shards together.  Return 0, or -1 with bgth_last_error. */
+int bgth_reader_fold_last(bgth_reader_t *r, int code, int bit);
+int bgth_reader_take_folds(bgth_reader_t *r, int32_t *carriers, uint64_t *hap);
 
 /* Timing of the last scan on the device (HIP events on the launch stream), milliseconds:
  * out[0] = decode kernel, out[1] = finalize kernel, out[2] = whole enqueue..done. */
