@@ -516,6 +516,7 @@ void bgt_set_bed(bgt_t *bgt, const void *bed, int excl) { bgt->bed = bed; bgt->b
 /* the HBM image of prefix.pbf is opened on first need and cached on the file handle, shared by every
  * reader of that file; each reader owns its own device reader (stream, selection, result buffers) */
 static pthread_mutex_t g_open_lock = PTHREAD_MUTEX_INITIALIZER;   /* readers of one file may start on different threads */
+static pthread_cond_t g_open_cond = PTHREAD_COND_INITIALIZER;     /* ... and wait here while another one loads the file's image */
 static pthread_mutex_t g_sites_lock = PTHREAD_MUTEX_INITIALIZER;  /* the site table has a lock of its own: it loads beside the image */
 
 /* the site table of the whole file, read on first use */
@@ -593,13 +594,24 @@ static int ensure_device(bgt_t *bgt)
     fn = (char*)malloc(strlen(wf->prefix) + 8);
     sprintf(fn, "%s.pbf", wf->prefix);
     partial = needed_rows(bgt, &r0, &r1) && r1 > r0;           /* (reads the site table: before taking the lock) */
+    /* The whole-file image is shared by every reader of the file and loaded by the first that needs it -- outside the
+     * lock, so that the databases of a merge load side by side (bgtm_prepare starts one thread per database). */
     pthread_mutex_lock(&g_open_lock);
+    while (wf->gpu_opening) pthread_cond_wait(&g_open_cond, &g_open_lock);
     if (wf->gpu == NULL && partial) {
         pthread_mutex_unlock(&g_open_lock);
         dv->own_img = bgth_pbf_open_rows(fn, r0, r1, 0);         /* private to this reader */
         if (dv->own_img) dv->rd = bgth_reader_create(dv->own_img);
     } else {
-        if (wf->gpu == NULL) wf->gpu = open_whole_image(fn);     /* the whole file, shared by every reader of it */
+        if (wf->gpu == NULL) {
+            void *img;
+            wf->gpu_opening = 1;
+            pthread_mutex_unlock(&g_open_lock);
+            img = open_whole_image(fn);                          /* the whole file */
+            pthread_mutex_lock(&g_open_lock);
+            wf->gpu = img; wf->gpu_opening = 0;
+            pthread_cond_broadcast(&g_open_cond);
+        }
         pthread_mutex_unlock(&g_open_lock);
         if (wf->gpu) dv->rd = bgth_reader_create((bgth_pbf_t*)wf->gpu);
     }
@@ -660,10 +672,17 @@ static int promote_to_full(bgt_t *bgt)
     bgth_reader_destroy(dv->rd); dv->rd = NULL;
     bgth_pbf_close(dv->own_img); dv->own_img = NULL;
     pthread_mutex_lock(&g_open_lock);
+    while (wf->gpu_opening) pthread_cond_wait(&g_open_cond, &g_open_lock);
     if (wf->gpu == NULL) {
         char *fn = (char*)malloc(strlen(wf->prefix) + 8);
+        void *img;
         sprintf(fn, "%s.pbf", wf->prefix);
-        wf->gpu = open_whole_image(fn);
+        wf->gpu_opening = 1;
+        pthread_mutex_unlock(&g_open_lock);
+        img = open_whole_image(fn);
+        pthread_mutex_lock(&g_open_lock);
+        wf->gpu = img; wf->gpu_opening = 0;
+        pthread_cond_broadcast(&g_open_cond);
         free(fn);
     }
     pthread_mutex_unlock(&g_open_lock);
@@ -1317,6 +1336,14 @@ char *bgtm_alcnt_print(const bgtm_t *bm)
     return s.s;
 }
 
+typedef struct { bgt_t *bgt; int n_groups, need_device, rc, started; pthread_t th; } prep_job_t;
+static void *prep_worker(void *p)
+{
+    prep_job_t *j = (prep_job_t*)p;
+    j->rc = prepare_one(j->bgt, j->n_groups, j->need_device);
+    return NULL;
+}
+
 /* merged sample list, groups, output header, device selections (ref bgt.c:597-676) */
 int bgtm_prepare(bgtm_t *bm)
 {
@@ -1331,10 +1358,20 @@ int bgtm_prepare(bgtm_t *bm)
         const devrd_t *dv = (const devrd_t*)bm->bgt[i]->pb;
         if (bm->bgt[i]->itr == NULL && dv && dv->own_sites == NULL && sites_prefetch(bm->bgt[i]->f, &th)) pthread_detach(th);
     }
-    for (i = bm->n_out = 0; i < bm->n_bgt; ++i) {
-        if (prepare_one(bm->bgt[i], bm->n_groups, !(bm->flag & BGT_F_NO_GT) || need_counts ||
-                        (bm->h_al && (bm->flag & (BGT_F_CNT_AL | BGT_F_CNT_HAP)))) < 0) rc = -1;
-        bm->n_out += bm->bgt[i]->n_out;
+    {   /* the databases of a merge get ready side by side: each one's .pbf image loads on its own host thread */
+        const int need_device = !(bm->flag & BGT_F_NO_GT) || need_counts || (bm->h_al && (bm->flag & (BGT_F_CNT_AL | BGT_F_CNT_HAP)));
+        prep_job_t *job = (prep_job_t*)calloc((size_t)bm->n_bgt, sizeof(prep_job_t));
+        for (i = 0; i < bm->n_bgt; ++i) {
+            job[i].bgt = bm->bgt[i]; job[i].n_groups = bm->n_groups; job[i].need_device = need_device;
+            if (i > 0 && need_device && pthread_create(&job[i].th, NULL, prep_worker, &job[i]) == 0) job[i].started = 1;
+        }
+        for (i = 0; i < bm->n_bgt; ++i) if (!job[i].started) prep_worker(&job[i]);
+        for (i = bm->n_out = 0; i < bm->n_bgt; ++i) {
+            if (job[i].started) pthread_join(job[i].th, NULL);
+            if (job[i].rc < 0) rc = -1;
+            bm->n_out += bm->bgt[i]->n_out;
+        }
+        free(job);
     }
     bm->mgs = (int32_t*)realloc(bm->mgs, (size_t)(bm->n_out ? bm->n_out : 1) * 4);
     bm->group = (uint32_t*)realloc(bm->group, (size_t)(bm->n_out ? bm->n_out : 1) * 4);
