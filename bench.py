@@ -194,6 +194,48 @@ def cli_end_to_end(n_samples, sites, seed, tmp):
                     "'prepare'; refills summed); the HIP runtime start-up alone is 60-220 ms of every process"}
 
 
+def c5_record(tmp, n_samples=50000, sites=65536):
+    """configs[4] (C5) in its product form on one device: two databases (seeds 5 and 6: the same positions, independent
+    alleles), two sample groups across both, `-f 'AC1>0&&AC2==0'` -- this repo's CLI (one device image per database, and
+    with BGT_GPUS every database dealt over four shards) and the compiled reference on the same files, stdout compared."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bgt_amd", "host")])
+    dbs = []
+    for tag, seed in (("c5a", 5), ("c5b", 6)):
+        prefix = os.path.join(tmp, "%s_%d_%d" % (tag, n_samples, sites))
+        subprocess.check_call([MY_BIN, "synth", prefix, str(n_samples), str(sites), str(seed)])
+        dbs.append(prefix)
+    cmd = ["view", "-G", "-s", 'pop=="A"', "-s", 'pop=="B"', "-f", "AC1>0&&AC2==0"] + dbs
+
+    def timed(binary, env=None, repeats=1):
+        best, sig = None, None
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            o = subprocess.run([binary] + cmd, stdout=subprocess.PIPE, check=True, env=env).stdout
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+            sig = (hashlib.md5(o).hexdigest(), len(o))
+        return best, sig
+
+    t_mine, sig_mine = timed(MY_BIN, repeats=2)
+    t_sh, sig_sh = timed(MY_BIN, env=dict(os.environ, BGT_GPUS="0,0,0,0"), repeats=2)
+    rec = {"name": "C5-cli", "workload": "C5 shape: two databases x %d samples x %d sites, two groups across both, "
+                                         "-G -f'AC1>0&&AC2==0' through `bgt view`" % (n_samples, sites),
+           "command": "bgt view -G -s 'pop==\"A\"' -s 'pop==\"B\"' -f 'AC1>0&&AC2==0' a b",
+           "wall_s": round(t_mine, 3), "merged_sites_per_s": 2 * sites / t_mine,
+           "sharded": {"BGT_GPUS": "0,0,0,0 (four shards per database, all on this box's one device)", "wall_s": round(t_sh, 3),
+                       "stdout_identical": sig_sh == sig_mine},
+           "stdout_bytes": sig_mine[1]}
+    if os.path.exists(REF_BIN):
+        t_ref, sig_ref = timed(REF_BIN)
+        rec["reference"] = {"wall_s": round(t_ref, 2), "cores": 1, "stdout_identical": sig_ref == sig_mine,
+                            "speedup": t_ref / t_mine}
+        if sig_ref != sig_mine or sig_sh != sig_mine:
+            rec["parity_error"] = "`bgt view` stdout over two databases differs (reference / sharded / single)"
+    elif sig_sh != sig_mine:
+        rec["parity_error"] = "`bgt view` stdout over two databases differs between the sharded and the single image"
+    return rec
+
+
 class Pipeline:
     """scan -> device filter -> (all_gather) -> pinned host copy, double buffered: the copy of step i overlaps step i+1."""
 
@@ -528,6 +570,13 @@ def main():
                         out["parity_error"] = name + ": " + rec["parity_error"]
                 except Exception as e:
                     out["secondary"].append({"name": name, "error": repr(e)[:300]})
+            try:
+                rec = c5_record(tmp)
+                out["secondary"].append(rec)
+                if rec.get("parity_error"):
+                    out["parity_error"] = "C5-cli: " + rec["parity_error"]
+            except Exception as e:
+                out["secondary"].append({"name": "C5-cli", "error": repr(e)[:300]})
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
