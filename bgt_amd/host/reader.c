@@ -620,6 +620,32 @@ static int ensure_device(bgt_t *bgt)
     return 0;
 }
 
+/* Extension for resident processes (the server): load the file's whole .pbf image into HBM and its site table now, so
+ * that no query pays for either.  0, or -1 if the image could not be built (a later query tries again). */
+int bgt_file_preload(const bgt_file_t *bf)
+{
+    bgt_file_t *wf = (bgt_file_t*)bf;
+    if (wf == NULL) return -1;
+    pthread_mutex_lock(&g_open_lock);
+    while (wf->gpu_opening) pthread_cond_wait(&g_open_cond, &g_open_lock);
+    if (wf->gpu == NULL) {
+        char *fn = (char*)malloc(strlen(wf->prefix) + 8);
+        void *img;
+        sprintf(fn, "%s.pbf", wf->prefix);
+        wf->gpu_opening = 1;
+        pthread_mutex_unlock(&g_open_lock);
+        img = open_whole_image(fn);
+        if (img == NULL) fprintf(stderr, "[E::%s] %s\n", __func__, bgth_last_error());
+        pthread_mutex_lock(&g_open_lock);
+        wf->gpu = img; wf->gpu_opening = 0;
+        pthread_cond_broadcast(&g_open_cond);
+        free(fn);
+    }
+    pthread_mutex_unlock(&g_open_lock);
+    (void)file_sites(bf);
+    return wf->gpu ? 0 : -1;
+}
+
 /* selection + output configuration of the reader's device side (also after a change of image) */
 static int apply_selection(bgt_t *bgt)
 {

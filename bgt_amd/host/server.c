@@ -1,0 +1,411 @@
+/* bgt-server: the query server of the reference (bgt-server.go:129-427) over this repo's libbgt.so.
+ *
+ * The reference's server is a Go program that binds libbgt through cgo; there is no Go toolchain in this image, and the
+ * program is nothing but a request handler around the reader API, so it is restated here in C: same command line
+ * (-p PORT | $PORT, -m max genotypes per query, -d variant annotations, -g minimal group size), same parameters
+ * (s r i n a f g C S H t), same call sequence per query (bgt-server.go:220-373: flags, then f r i n t a s, prepare,
+ * test_mgs, header, read loop with the n / n_gt_read caps, haplotype counts and sample list, the trailing "*"), same
+ * status codes and messages for its errors.  What the resident process buys here: the databases are opened once
+ * (bgt_no_file = 1, :416) and their .pbf images stay in HBM, so a query pays neither the HIP start-up nor the image
+ * build that dominate a `bgt view` process.
+ *
+ * One thread per connection; every query has its own bgtm_t over the shared bgt_file_t (the threading contract of the
+ * library).  `--query STRING` answers one query on stdout without opening a socket: the differential
+ * test links this same file with the compiled reference library and compares the two bodies.
+ *
+ * Only what the handler needs of HTTP is here: GET, the query string, `Connection: close`. */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#include <errno.h>
+#include <signal.h>
+#include <time.h>
+#include <unistd.h>
+#include <pthread.h>
+#include <sys/socket.h>
+#include <netinet/in.h>
+#include <arpa/inet.h>
+#include "../../include/bgt_reader.h"
+
+#ifndef BGS_REFERENCE_LIB
+int bgt_file_preload(const bgt_file_t *bf);        /* extension of this repo's libbgt.so: image + site table now */
+#endif
+
+#define BGS_MAX_FILES 64
+
+static bgt_file_t *g_files[BGS_MAX_FILES];
+static const char *g_prefix[BGS_MAX_FILES];
+static int g_n_files;
+static fmf_t *g_vardb;
+static uint64_t g_max_gt = 10000000;               /* bgt-server.go:127 */
+static int g_min_group;
+
+static long long now_ns(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_REALTIME, &ts);
+    return (long long)ts.tv_sec * 1000000000LL + ts.tv_nsec;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * the query string: key=value pairs, '+' and %XX decoded, a key may repeat (`s`), a bare key counts
+ * as present (`S`, `H`, `g`, `C`)
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct { char *key, *val; } pair_t;
+typedef struct { int n; pair_t *a; char *buf; } form_t;
+
+static int hexv(int c) { return c >= '0' && c <= '9' ? c - '0' : c >= 'a' && c <= 'f' ? c - 'a' + 10 : c >= 'A' && c <= 'F' ? c - 'A' + 10 : -1; }
+
+static int unescape(char *s)                        /* in place; -1 on a bad escape */
+{
+    char *d = s;
+    for (; *s; ++s) {
+        if (*s == '+') *d++ = ' ';
+        else if (*s == '%') {
+            const int h = hexv((unsigned char)s[1]), l = h < 0 ? -1 : hexv((unsigned char)s[2]);
+            if (l < 0) return -1;
+            *d++ = (char)(h << 4 | l); s += 2;
+        } else *d++ = *s;
+    }
+    *d = 0;
+    return 0;
+}
+
+/* the server protects a literal "&&" of an expression from the parameter split (bgt-server.go:221) */
+static char *protect_and(const char *q)
+{
+    const size_t n = strlen(q);
+    char *out = (char*)malloc(n * 3 + 1), *d = out;
+    size_t i;
+    for (i = 0; i < n; ++i) {
+        if (q[i] == '&' && q[i + 1] == '&') { memcpy(d, ".AND.", 5); d += 5; ++i; }
+        else *d++ = q[i];
+    }
+    *d = 0;
+    return out;
+}
+
+static void form_parse(form_t *f, const char *query)
+{
+    char *p;
+    memset(f, 0, sizeof(*f));
+    f->buf = protect_and(query);
+    f->a = (pair_t*)calloc(strlen(f->buf) / 2 + 2, sizeof(pair_t));
+    for (p = f->buf; p && *p;) {
+        char *amp = strchr(p, '&'), *eq;
+        if (amp) *amp = 0;
+        if (*p) {
+            eq = strchr(p, '=');
+            if (eq) *eq = 0;
+            if (unescape(p) == 0 && (eq == NULL || unescape(eq + 1) == 0) && *p) {   /* a pair with a bad escape is dropped */
+                f->a[f->n].key = p;
+                f->a[f->n++].val = eq ? eq + 1 : p + strlen(p);
+            }
+        }
+        p = amp ? amp + 1 : NULL;
+    }
+}
+
+static void form_free(form_t *f) { free(f->a); free(f->buf); }
+
+static const char *form_first(const form_t *f, const char *key)
+{
+    int i;
+    for (i = 0; i < f->n; ++i) if (strcmp(f->a[i].key, key) == 0) return f->a[i].val;
+    return NULL;
+}
+
+/* .AND. .and. .OR. .or. -> && || (bgt-server.go:212-218) */
+static char *replace_op(const char *t)
+{
+    static const char *from[4] = {".AND.", ".and.", ".OR.", ".or."};
+    static const char *to[4] = {"&&", "&&", "||", "||"};
+    char *out = (char*)malloc(strlen(t) + 1), *d = out;
+    while (*t) {
+        int k, hit = 0;
+        for (k = 0; k < 4 && !hit; ++k) {
+            const size_t n = strlen(from[k]);
+            if (strncmp(t, from[k], n) == 0) { *d++ = to[k][0]; *d++ = to[k][1]; t += n; hit = 1; }
+        }
+        if (!hit) *d++ = *t++;
+    }
+    *d = 0;
+    return out;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * the handler
+ * ------------------------------------------------------------------------------------------------ */
+static void fmf_keys(FILE *w, const fmf_t *f)      /* as Go prints a []string */
+{
+    int i;
+    fputc('[', w);
+    for (i = 0; i < f->n_keys; ++i) fprintf(w, "%s%s", i ? " " : "", f->keys[i]);
+    fputc(']', w);
+}
+
+static void help(FILE *w, const char *host)         /* bgt-server.go:160-210 */
+{
+    int i;
+    fputs("Server Configuration\n====================\n\n", w);
+    fputs("The following configurations were set when the server was launched. Clients can't override them.\n\n", w);
+    fputs(" * BGT file prefix(es) and queryable sample annotations:\n", w);
+    for (i = 0; i < g_n_files; ++i) { fprintf(w, "   - %s: ", g_prefix[i]); fmf_keys(w, g_files[i]->f); fputc('\n', w); }
+    fputc('\n', w);
+    if (g_vardb) { fputs(" * Queryable variant annotations: ", w); fmf_keys(w, g_vardb); fputs("\n\n", w); }
+    else fputs(" * No variant annotations specified.\n\n", w);
+    fputs(" * This server may report individual genotypes.\n\n", w);
+    fprintf(w, " * Maximal genotypes processed internally per query: %llu\n\n", (unsigned long long)g_max_gt);
+    fputs("Example Queries\n===============\n\n", w);
+    fputs(" * Variants present in both FIN and CEU populations (.and. represents the logical AND operator):\n\n", w);
+    fprintf(w, "   curl -s 'http://%s/?s=(population==\"FIN\")&s=(population==\"CEU\")&f=(AC1>0.and.AC2>0)'\n\n", host);
+    if (g_vardb) {
+        fputs(" * HIGH impact variants in the FIN population:\n\n", w);
+        fprintf(w, "   curl -s 'http://%s/?a=(impact==\"HIGH\")&s=(population==\"FIN\")&f=(AC>0)'\n\n", host);
+    }
+    fputs(" * Tabular output: chromosome, 1-based start, end positions, REF, ALT alleles and ALT allele frequency:\n\n", w);
+    fprintf(w, "   curl -s 'http://%s/?t=CHROM,POS,END,REF,ALT,AC/AN&f=(AN>0)&r=11:200,000-300,000'\n\n", host);
+    fputs(" * Samples in FIN that have three specified alleles:\n\n", w);
+    fprintf(w, "   curl -s 'http://%s/?a=,11:151344:1:G,11:110992:AACTT:A,11:160513::G&S&s=(population==\"FIN\")'\n\n", host);
+    fputs("Accepted Parameters\n===================\n\n", w);
+    fputs("Sample selection parameter:\n\n", w);
+    fputs("  s EXPR  List of samples in a comma-leading comma-separate list (e.g. ,sample1,sample2) or an\n", w);
+    fputs("          expression (e.g. s=population==\"FIN\"). There can be multiple 's' parameters. Each of\n", w);
+    fputs("          them defines a sample group.\n\n", w);
+    fputs("Site selection parameters:\n\n", w);
+    fputs("  r STR   Region in a format like '11:200,000-300,000'\n\n", w);
+    fputs("  i INT   Start from the i-th record; INT>0\n\n", w);
+    fputs("  n INT   Read at most INT records\n\n", w);
+    fputs("  a EXPR  List of alleles in a format similar to parameter 's'. An allele is specified by\n", w);
+    fputs("          chr:1basedPos:refLen:alleleSeq. Conditions may not work unless the server is launched with\n", w);
+    fputs("          a variant annotation database.\n\n", w);
+    fputs("  f EXPR  Filters on per sample group allele counts. EXPR could include AC (primary allele count),\n", w);
+    fputs("          AN (total called alleles), AC# (primary allele count of the #-th sample group) and AN#.\n\n", w);
+    fputs("VCF output parameters:\n\n", w);
+    fputs("  g       Output sample genotypes\n\n", w);
+    fputs("  C       Output AC and AN VCF INFO fields. This parameter is automatically set if 's' is applied.\n\n", w);
+    fputs("Non-VCF output parameters:\n\n", w);
+    fputs("  S       Output samples having requested alleles (requiring parameter 'a')\n\n", w);
+    fputs("  H       Output counts of haplotypes across requested alleles (requiring parameter 'a')\n\n", w);
+    fputs("  t STR   Comma-separated list of fields in tabular output. Accepted variables:\n", w);
+    fputs("          CHROM, POS, END, REF, ALT, AC, AN, AC#, AN# (# for a group number)\n\n", w);
+}
+
+typedef struct {
+    bgtm_t *bm;
+    int flag, max_read, vcf_out;
+} query_t;
+
+/* Everything of a query that can fail (bgt-server.go:226-326).  Returns the HTTP status; *msg = the error line. */
+static int query_setup(const form_t *f, query_t *q, const char **msg)
+{
+    const char *v;
+    char *t;
+    int i, ret;
+    bgtm_t *bm;
+    q->flag = BGT_F_NO_GT; q->max_read = 2147483647; q->vcf_out = 1;
+    q->bm = bm = bgtm_reader_init(g_n_files, g_files);
+    bgtm_set_mgs(bm, g_min_group);
+    if (form_first(f, "g")) q->flag &= ~BGT_F_NO_GT;
+    if (form_first(f, "C") || form_first(f, "s")) q->flag |= BGT_F_SET_AC;
+    if (form_first(f, "S")) q->flag |= BGT_F_CNT_AL;
+    if (form_first(f, "H")) q->flag |= BGT_F_CNT_HAP;
+    bgtm_set_flag(bm, q->flag);
+    if (q->flag & (BGT_F_CNT_AL | BGT_F_CNT_HAP)) q->vcf_out = 0;
+    if ((v = form_first(f, "f")) != NULL) {
+        t = replace_op(v); ret = bgtm_set_flt_site(bm, t); free(t);
+        if (ret != 0) { *msg = "400 Bad Request: failed to parse parameter 'f'"; return 400; }
+    }
+    if ((v = form_first(f, "r")) != NULL && bgtm_set_region(bm, v) < 0) {
+        *msg = "400 Bad Request: failed to set region with parameter 'r'"; return 400;
+    }
+    if ((v = form_first(f, "i")) != NULL) {
+        char *end;
+        const long k = strtol(v, &end, 10);
+        if (*v == 0 || *end || k < 1) { *msg = "400 Bad Request: failed to set start with parameter 'i'"; return 400; }
+        bgtm_set_start(bm, k);
+    }
+    if ((v = form_first(f, "n")) != NULL) {             /* strconv.Atoi: anything but a number reads as 0 */
+        char *end;
+        const long k = strtol(v, &end, 10);
+        q->max_read = (*v == 0 || *end || k > 2147483647L || k < -2147483647L) ? 0 : (int)k;
+    }
+    if ((v = form_first(f, "t")) != NULL) {
+        q->vcf_out = 0;
+        if (bgtm_set_table(bm, v) < 0) { *msg = "400 Bad Request: failed to parse tabular format with parameter 't'"; return 400; }
+    }
+    if ((v = form_first(f, "a")) != NULL) {
+        t = replace_op(v); ret = bgtm_set_alleles(bm, t, g_vardb, NULL); free(t);
+        if (ret < 0) { *msg = "400 Bad Request: failed to retrieve alleles with parameter 'a'"; return 400; }
+        if (ret == 0) { *msg = "204 No Content: no alleles matching parameter 'a'"; return 204; }
+    }
+    for (i = 0; i < f->n; ++i) {
+        if (strcmp(f->a[i].key, "s") != 0) continue;
+        t = replace_op(f->a[i].val); ret = bgtm_add_group(bm, t); free(t);
+        if (ret < 0) { *msg = "400 Bad Request: failed to set sample group with parameter 's'"; return 400; }
+    }
+    bgtm_prepare(bm);
+    if (bgtm_test_mgs(bm) == 0) { *msg = "403 Forbidden: genotype summary can't be computed for small sample groups"; return 403; }
+    return 200;
+}
+
+/* the body of a successful query (bgt-server.go:328-372) */
+static void query_stream(query_t *q, FILE *w)
+{
+    bgtm_t *bm = q->bm;
+    bcf1_t *b = bcf_init1();
+    kstring_t s = {0, 0, 0};
+    int n_read = 0;
+    if (q->vcf_out) { fputs(bm->h_out->text, w); fputc('\n', w); }
+    for (;;) {
+        if (n_read > q->max_read || bm->n_gt_read > g_max_gt) break;
+        if (bgtm_read(bm, b) < 0) break;
+        if (q->vcf_out) { s.l = 0; vcf_format1(bm->h_out, b, &s); fwrite(s.s, 1, s.l, w); fputc('\n', w); }
+        else if (bm->n_fields > 0) { fputs(bm->tbl_line.s, w); fputc('\n', w); }
+        ++n_read;
+    }
+    if (!q->vcf_out && bm->n_aal > 0) {
+        if (q->flag & BGT_F_CNT_HAP) {
+            int n_hap;
+            bgt_hapcnt_t *hc = bgtm_hapcnt(bm, &n_hap);
+            char *t = bgtm_hapcnt_print_destroy(bm, n_hap, hc);
+            if (t) { fputs(t, w); free(t); }
+        }
+        if (q->flag & BGT_F_CNT_AL) {
+            char *t = bgtm_alcnt_print(bm);
+            if (t) { fputs(t, w); free(t); }
+        }
+    }
+    if (n_read > q->max_read || bm->n_gt_read > g_max_gt) fputs("*\n", w);
+    free(s.s);
+    bcf_destroy1(b);
+}
+
+/* one query to `w`; with_http: status line and headers first.  Returns the status. */
+static int answer(const char *query, const char *host, FILE *w, int with_http)
+{
+    form_t f;
+    query_t q;
+    const char *msg = NULL;
+    int status = 200;
+    const long long t0 = now_ns();
+    fprintf(stderr, "[%lld] got request: %s\n", t0, query);
+    form_parse(&f, query);
+    memset(&q, 0, sizeof(q));
+    if (f.n > 0) status = query_setup(&f, &q, &msg);
+    if (with_http) {
+        fprintf(w, "HTTP/1.1 %d %s\r\nContent-Type: text/plain; charset=utf-8\r\n%sConnection: close\r\n\r\n", status,
+                status == 200 ? "OK" : status == 204 ? "No Content" : status == 403 ? "Forbidden" : "Bad Request",
+                status == 200 ? "" : "X-Content-Type-Options: nosniff\r\n");
+    }
+    if (f.n == 0) help(w, host);
+    else if (status == 200) query_stream(&q, w);
+    else if (status != 204) { fputs(msg, w); fputc('\n', w); }        /* (a 204 carries no body) */
+    if (q.bm) bgtm_reader_destroy(q.bm);
+    form_free(&f);
+    fflush(w);
+    fprintf(stderr, "[%lld] responded %lld\n", now_ns(), t0);
+    return status;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * HTTP: one thread per connection, GET only
+ * ------------------------------------------------------------------------------------------------ */
+static void *serve_connection(void *arg)
+{
+    const int fd = (int)(intptr_t)arg;
+    char *req = (char*)malloc(65536), *q, *sp, *host = NULL, *line;
+    size_t n = 0;
+    FILE *w;
+    while (n < 65535) {
+        const ssize_t k = read(fd, req + n, 65535 - n);
+        if (k <= 0) break;
+        n += (size_t)k; req[n] = 0;
+        if (strstr(req, "\r\n\r\n") || strstr(req, "\n\n")) break;
+    }
+    req[n] = 0;
+    w = fdopen(fd, "w");
+    if (w == NULL) { close(fd); free(req); return NULL; }
+    if (strncmp(req, "GET ", 4) != 0) {
+        fputs("HTTP/1.1 405 Method Not Allowed\r\nAllow: GET\r\nConnection: close\r\n\r\n", w);
+    } else {
+        for (line = req; (line = strstr(line, "\n")) != NULL;) {      /* Host: for the help text */
+            ++line;
+            if (strncasecmp(line, "Host:", 5) == 0) {
+                host = line + 5;
+                while (*host == ' ') ++host;
+                host[strcspn(host, "\r\n")] = 0;
+                break;
+            }
+        }
+        q = req + 4;
+        sp = q + strcspn(q, " \r\n"); *sp = 0;                        /* the request target */
+        q = strchr(q, '?');
+        answer(q ? q + 1 : "", host ? host : "localhost", w, 1);
+    }
+    fclose(w);                                                        /* closes fd */
+    free(req);
+    return NULL;
+}
+
+static int usage(const char *port)
+{
+    fprintf(stderr, "Usage: bgt-server [options] <bgt.pre1> [...]\n");
+    fprintf(stderr, "Options:\n");
+    fprintf(stderr, "  -p INT    port number [%s or from $PORT env]\n", port);
+    fprintf(stderr, "  -m INT    maximal genotypes processed per query [%llu]\n", (unsigned long long)g_max_gt);
+    fprintf(stderr, "  -d FILE   variant annotations in the FMF format []\n");
+    fprintf(stderr, "  -g INT    minimal sample group size (force -G if positive) [0]\n");
+    fprintf(stderr, "  -q STR    answer this one query string on stdout and exit (no socket)\n");
+    return 1;
+}
+
+int main(int argc, char **argv)
+{
+    const char *port = getenv("PORT") && *getenv("PORT") ? getenv("PORT") : "8000", *one_query = NULL;
+    int c, i, srv, on = 1;
+    struct sockaddr_in addr;
+    while ((c = getopt(argc, argv, "d:p:m:g:q:")) >= 0) {
+        if (c == 'p') port = optarg;
+        else if (c == 'm') g_max_gt = strtoull(optarg, NULL, 10);
+        else if (c == 'd') g_vardb = fmf_read(optarg);
+        else if (c == 'g') g_min_group = atoi(optarg);
+        else if (c == 'q') one_query = optarg;
+    }
+    if (optind == argc) return usage(port);
+    bgt_no_file = 1;                                                  /* bgt-server.go:416: arguments are never file names */
+    for (i = optind; i < argc && g_n_files < BGS_MAX_FILES; ++i) {
+        const char *base = strrchr(argv[i], '/');
+        if ((g_files[g_n_files] = bgt_open(argv[i])) == NULL) { fprintf(stderr, "[E::%s] failed to open '%s'\n", __func__, argv[i]); return 1; }
+        g_prefix[g_n_files++] = base ? base + 1 : argv[i];
+    }
+#ifndef BGS_REFERENCE_LIB
+    if (one_query == NULL)                                            /* resident images: no query pays for the load */
+        for (i = 0; i < g_n_files; ++i)
+            if (bgt_file_preload(g_files[i]) < 0) fprintf(stderr, "[W::%s] '%s' is not resident yet; the first query will load it\n", __func__, g_prefix[i]);
+#endif
+    if (one_query) {
+        const int status = answer(one_query, "localhost", stdout, 0);
+        for (i = 0; i < g_n_files; ++i) bgt_close(g_files[i]);
+        return status == 200 ? 0 : status / 100;
+    }
+    signal(SIGPIPE, SIG_IGN);
+    srv = socket(AF_INET, SOCK_STREAM, 0);
+    setsockopt(srv, SOL_SOCKET, SO_REUSEADDR, &on, sizeof(on));
+    memset(&addr, 0, sizeof(addr));
+    addr.sin_family = AF_INET; addr.sin_addr.s_addr = htonl(INADDR_ANY); addr.sin_port = htons((uint16_t)atoi(port));
+    if (srv < 0 || bind(srv, (struct sockaddr*)&addr, sizeof(addr)) < 0 || listen(srv, 128) < 0) {
+        fprintf(stderr, "[E::%s] cannot listen on port %s: %s\n", __func__, port, strerror(errno));
+        return 1;
+    }
+    fprintf(stderr, "[%lld] launched at port %s\n", now_ns(), port);
+    for (;;) {
+        pthread_t th;
+        const int fd = accept(srv, NULL, NULL);
+        if (fd < 0) { if (errno == EINTR) continue; break; }
+        if (pthread_create(&th, NULL, serve_connection, (void*)(intptr_t)fd) == 0) pthread_detach(th);
+        else close(fd);
+    }
+    return 0;
+}

@@ -116,6 +116,8 @@ typedef struct {
     uint64_t    *hap;               /* [2 n_out] -H                                              */
 } bgtm_t;
 
+/* extension (resident processes): build the whole-file device image and the site table now; 0 or -1 */
+int     bgt_file_preload(const bgt_file_t *bf);
 extern int bgt_no_file;             /* 1: never interpret an argument as a file name (server)    */
 
 #ifdef __cplusplus

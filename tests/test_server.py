@@ -1,0 +1,172 @@
+"""bgt-server (bgt_amd/host/server.c: the reference's bgt-server.go:129-427 restated in C over libbgt.so).
+
+The same source is linked once with this repo's library and once with the compiled reference library
+(oracle/_ref/libbgt_ref.so); `--query`/-q answers one query string on stdout, and the two bodies and exit statuses must be
+identical -- the per-query call sequence, the n / n_gt_read caps with their trailing "*", haplotype counts, sample lists,
+tables, error statuses.  Then the socket: a resident server with the images in HBM answers the same queries over HTTP, also
+concurrently, with the bodies of the one-shot mode."""
+import os
+import socket
+import subprocess
+import threading
+import time
+import urllib.error
+import urllib.parse
+import urllib.request
+
+import pytest
+
+from conftest import require_ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden", "bgt")
+SRC = os.path.join(ROOT, "bgt_amd", "host", "server.c")
+MINE = os.path.join(ROOT, "bgt_amd", "bin", "bgt-server")
+
+X, Y = 'pop=="X"', 'pop=="Y"'
+AL = ",11:1000:C:G,11:1030:TAG:T"
+
+
+def qs(*pairs):
+    """query string: ('k', 'v') pairs url-encoded, bare strings as flags"""
+    return "&".join(p if isinstance(p, str) else p[0] + "=" + urllib.parse.quote(p[1], safe="") for p in pairs)
+
+
+NO_DEVICE = [                                   # nothing depends on a genotype: runs on the CPU box too
+    (["synA", "synB"], [], ""),                                                   # the help page
+    (["synA", "synB"], [], qs(("r", "11:1000-1100"))),
+    (["synB", "synA"], [], qs(("i", "5"), ("n", "7"))),
+    (["synA"], [], qs(("n", "abc"))),                                             # Atoi fails: n = 0, one record and "*"
+    (["synA"], [], qs(("i", "0"))),                                               # 400
+    (["synA"], [], qs(("i", "x"))),                                               # 400
+    (["synA"], [], qs(("f", "AC>"))),                                             # 400
+    (["synA"], [], qs(("r", "nochr:1-2"))),                                       # 400 (unknown contig)
+    (["synA"], [], qs(("s", "pop=="))),                                           # 400
+    (["synA"], [], qs(("t", "CHROM,POS,,"))),
+    (["synA"], [], "zzz=1&%zz=3"),                                                # an unknown parameter, a bad escape
+]
+DEVICE = [
+    (["synA", "synB"], [], qs(("s", X), ("s", Y), ("f", "AC1>0"))),
+    (["synA", "synB"], [], qs(("s", X), ("s", Y), ("f", "(AC1>0.and.AC2==0)"))),
+    (["synA", "synB"], [], "s=" + urllib.parse.quote(X) + "&s=" + urllib.parse.quote(Y) + "&f=AC1>0&&AC2==0"),   # a literal &&
+    (["synA", "synB"], ["-m", "1500"], "C"),                                      # stops on the n_gt_read cap
+    (["synA"], [], qs("g", "C", ("r", "11:1000-1200"), ("n", "9"))),
+    (["synB", "synA"], [], qs("g", ("s", "idx<10"), ("i", "4"))),
+    # (AC1 / AN1 with ONE group are read from an uninitialised bgt_info_t in the reference -- bgtm_cal_info fills
+    #  gan / gac only for n_groups > 1, bgt.c:740 -- so tables name group fields only with two groups here)
+    (["synA", "synB"], [], qs(("s", X), ("s", Y), ("t", "CHROM,POS,REF,ALT,AC1,AN1,AC2,AN2"))),
+    (["synA", "synB"], [], qs(("s", X), ("t", "CHROM,POS,REF,ALT,AC,AN"))),
+    (["synA", "synB"], [], qs(("t", "CHROM,POS,END,REF,ALT,AC/AN"), ("f", "(AN>0)"), ("r", "11:1,000-1,300"))),
+    (["synA"], [], qs("S", ("a", AL))),
+    (["synA", "synB"], [], qs("H", ("a", AL), ("s", X), ("s", Y))),
+    (["synA"], [], qs("S", "H", ("a", AL), ("s", X))),
+    (["synA"], ["-d", "vardb.fmf"], qs(("a", "impact>=2"), ("s", X), ("f", "(AC>0)"))),
+    (["synA"], ["-d", "vardb.fmf"], qs(("a", "impact>=99"))),                     # 204: no allele matches
+    (["synA"], ["-g", "5"], qs(("s", "idx<3"), "C")),                             # 403: a group smaller than -g
+    (["synA"], ["-g", "5"], qs(("s", "idx<30"), "g", "C")),                       # large enough; -g forces no genotypes
+    (["ex2"], [], "g"), (["ex3", "ex2"], [], qs("g", "C")),
+]
+
+
+@pytest.fixture(scope="module")
+def servers(tmp_path_factory):
+    import bgt_amd
+    bgt_amd.build_library()
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bgt_amd", "host")])
+    require_ref("libbgt_ref.so")
+    ref = str(tmp_path_factory.mktemp("srv") / "bgt-server-ref")
+    refdir = os.path.join(ROOT, "oracle", "_ref")
+    subprocess.check_call(["gcc", "-O1", "-Wall", "-DBGS_REFERENCE_LIB", "-I", os.path.join(ROOT, "include"), SRC, "-o", ref,
+                           "-L", refdir, "-l:libbgt_ref.so", "-Wl,-rpath," + refdir, "-lz", "-lm", "-lpthread"])
+    return MINE, ref
+
+
+def one_shot(exe, dbs, opts, query):
+    p = subprocess.run([exe] + opts + ["-q", query] + dbs, cwd=GOLD, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    return p.returncode, p.stdout
+
+
+@pytest.mark.parametrize("dbs,opts,query", NO_DEVICE)
+def test_queries_that_touch_no_genotype(servers, dbs, opts, query):
+    mine, ref = (one_shot(exe, dbs, opts, query) for exe in servers)
+    assert mine == ref, query
+    assert len(mine[1]) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dbs,opts,query", DEVICE)
+def test_queries_like_the_reference_library(servers, dbs, opts, query):
+    mine, ref = (one_shot(exe, dbs, opts, query) for exe in servers)
+    assert mine == ref, query
+    assert mine[0] != 0 or len(mine[1]) > 0
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def http_get(port, query, timeout=120):
+    url = "http://127.0.0.1:%d/%s" % (port, "?" + query if query else "")
+    try:
+        with urllib.request.urlopen(url, timeout=timeout) as r:
+            return r.status, r.read()
+    except urllib.error.HTTPError as e:
+        return e.code, e.read()
+
+
+@pytest.mark.gpu
+def test_resident_server_over_http(servers):
+    """one process, images resident: every query of the lists above over the socket, then all of them at once from eight
+    client threads; bodies equal the one-shot answers, statuses are the handler's"""
+    port = free_port()
+    dbs = ["synA", "synB"]
+    cases = [(d, o, q) for d, o, q in NO_DEVICE + DEVICE if d == dbs and not o]
+    assert len(cases) >= 8
+    want = {q: one_shot(MINE, dbs, [], q) for _, _, q in cases}
+    srv = subprocess.Popen([MINE, "-p", str(port)] + dbs, cwd=GOLD, stderr=subprocess.PIPE)
+    try:
+        for _ in range(600):                                         # "launched at port" after the images are resident
+            try:
+                socket.create_connection(("127.0.0.1", port), timeout=1).close()
+                break
+            except OSError:
+                assert srv.poll() is None, srv.stderr.read().decode()[-400:]
+                time.sleep(0.1)
+        status = {0: 200, 4: 400, 2: 204}
+        for _, _, q in cases:
+            code, body = http_get(port, q)
+            rc, out = want[q]
+            assert code == status.get(rc, rc) or (rc == 4 and code in (400, 403)), (q, code, rc)
+            if q == "":                                               # the help page quotes the Host header in its examples
+                out = out.replace(b"http://localhost/", b"http://127.0.0.1:%d/" % port)
+                want[q] = (rc, out)
+            assert body == out, q
+        # concurrently: distinct bgtm_t over the shared files, one thread per connection (SURVEY.md 8b threading)
+        errs = []
+
+        def client(k):
+            for j in range(3):
+                _, _, q = cases[(k + j * 5) % len(cases)]
+                code, body = http_get(port, q)
+                if body != want[q][1]:
+                    errs.append((k, q, code))
+        th = [threading.Thread(target=client, args=(k,)) for k in range(8)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        # a resident query is quick: no HIP start-up, no image build
+        t0 = time.perf_counter()
+        code, body = http_get(port, qs("C", ("r", "11:1000-1100")))
+        dt = time.perf_counter() - t0
+        assert code == 200 and body.count(b"\n") > 10 and dt < 2.0, dt
+        code, _ = http_get(port, qs(("i", "0")))
+        assert code == 400
+    finally:
+        srv.terminate()
+        srv.wait(timeout=30)
