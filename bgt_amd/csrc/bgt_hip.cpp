@@ -79,6 +79,8 @@ struct Selection {
     std::vector<uint32_t> chunk_desc;
     int32_t *d_slot_col = nullptr, *d_slot_of_out = nullptr, *d_group_haps = nullptr;
     uint32_t *d_chunk_desc = nullptr;
+    size_t cap[4] = {0, 0, 0, 0};      // bytes behind the four device tables: a reader that is selected again (a pooled
+                                       // reader serves query after query) allocates only when a table grows
     void release()
     {
         if (d_slot_col) hipFree(d_slot_col);
@@ -87,6 +89,7 @@ struct Selection {
         if (d_chunk_desc) hipFree(d_chunk_desc);
         d_slot_col = d_slot_of_out = d_group_haps = nullptr;
         d_chunk_desc = nullptr;
+        cap[0] = cap[1] = cap[2] = cap[3] = 0;
     }
 };
 
@@ -113,6 +116,10 @@ struct bgth_pbf_s {
     // A SHARDED image (bgth_pbf_open_sharded): the file's blocks dealt out as contiguous block ranges, one partial image
     // per shard, each on its own device.  The parent holds no device data; n = n_total, row_off = 0.
     std::vector<bgth_pbf_t*> shards;
+    // Readers given back by bgth_reader_destroy wait here (stream, events, device and pinned buffers intact) for the next
+    // bgth_reader_create on this image: a resident process answers query after query without re-allocating any of it.
+    std::mutex pool_lock;
+    std::vector<bgth_reader_t*> pool;
 };
 
 // Test / tuning knob BGTH_VARIANT: picks between kernel variants that all give the SAME results (like bgth_reader_tune):
@@ -213,7 +220,6 @@ static bool use_device(int device)
 // {2*sample, 2*sample+1} in ascending sample order; ref bgt.c:154,612-621: one group id per sample.)
 static bool build_selection(Selection &s, int m, int n_sub, const int32_t *sub, const uint32_t *group, int G)
 {
-    s.release();
     if (n_sub <= 0 || n_sub >= m || sub == nullptr) { n_sub = m; sub = nullptr; }   // ref pbwt.c:377
     if (G < 1 || G > 32) { set_err("[E::bgth_reader_select] n_groups %d out of 1..32", G); return false; }
     if (group == nullptr) G = 1;
@@ -251,10 +257,16 @@ static bool build_selection(Selection &s, int m, int n_sub, const int32_t *sub, 
     s.n_chunks = (int)s.chunk_desc.size();
     if (s.n_chunks == 0) { set_err("[E::bgth_reader_select] empty selection"); return false; }
     const size_t nslot = s.slot_col.size();
-    HIP_TRY(hipMalloc((void**)&s.d_slot_col, nslot * 4), return false);
-    HIP_TRY(hipMalloc((void**)&s.d_slot_of_out, (size_t)n_sub * 4), return false);
-    HIP_TRY(hipMalloc((void**)&s.d_group_haps, (size_t)G * 4), return false);
-    HIP_TRY(hipMalloc((void**)&s.d_chunk_desc, (size_t)s.n_chunks * 4), return false);
+    auto grow = [&](void **ptr, size_t &have, size_t need) -> bool {
+        if (need <= have) return true;
+        if (*ptr) hipFree(*ptr);
+        *ptr = nullptr; have = 0;
+        HIP_TRY(hipMalloc(ptr, need), return false);
+        have = need;
+        return true;
+    };
+    if (!grow((void**)&s.d_slot_col, s.cap[0], nslot * 4) || !grow((void**)&s.d_slot_of_out, s.cap[1], (size_t)n_sub * 4) ||
+        !grow((void**)&s.d_group_haps, s.cap[2], (size_t)G * 4) || !grow((void**)&s.d_chunk_desc, s.cap[3], (size_t)s.n_chunks * 4)) return false;
     HIP_TRY(hipMemcpy(s.d_slot_col, s.slot_col.data(), nslot * 4, hipMemcpyHostToDevice), return false);
     HIP_TRY(hipMemcpy(s.d_slot_of_out, s.slot_of_out.data(), (size_t)n_sub * 4, hipMemcpyHostToDevice), return false);
     HIP_TRY(hipMemcpy(s.d_group_haps, s.group_haps.data(), (size_t)G * 4, hipMemcpyHostToDevice), return false);
@@ -293,10 +305,13 @@ static bgth_pbf_t *pbf_alloc(int device, int m, int g, int shift, int64_t n)
     return p;
 }
 
+static void reader_free(bgth_reader_t *r);
 extern "C" void bgth_pbf_close(bgth_pbf_t *p)
 {
     if (!p) return;
     for (bgth_pbf_t *sh : p->shards) bgth_pbf_close(sh);
+    for (bgth_reader_t *r : p->pool) reader_free(r);
+    p->pool.clear();
     hipSetDevice(p->device);
     if (p->d_rle) hipFree(p->d_rle);
     if (p->d_rowdesc) hipFree(p->d_rowdesc);
@@ -894,27 +909,9 @@ extern "C" int64_t bgth_pbf_hbm_bytes(const bgth_pbf_t *p)
 // ----------------------------------------------------------------------------------------------------
 // reader
 // ----------------------------------------------------------------------------------------------------
-extern "C" bgth_reader_t *bgth_reader_create(bgth_pbf_t *p)
+// frees everything a reader owns (its shard readers are already gone)
+static void reader_free(bgth_reader_t *r)
 {
-    if (!p) { set_err("[E::bgth_reader_create] NULL image"); return nullptr; }
-    if (!use_device(p->device)) return nullptr;
-    bgth_reader_t *r = new bgth_reader_s();
-    r->pbf = p;
-    HIP_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking), { delete r; return nullptr; });
-    for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&r->ev[i]), { delete r; return nullptr; });
-    if (!build_selection(r->sel, p->m, 0, nullptr, nullptr, 1)) { bgth_reader_destroy(r); return nullptr; }
-    for (bgth_pbf_t *sh : p->shards) {
-        bgth_reader_t *sub = bgth_reader_create(sh);
-        if (!sub) { bgth_reader_destroy(r); return nullptr; }
-        r->subs.push_back(sub);
-    }
-    return r;
-}
-
-extern "C" void bgth_reader_destroy(bgth_reader_t *r)
-{
-    if (!r) return;
-    for (bgth_reader_t *sub : r->subs) bgth_reader_destroy(sub);
     hipSetDevice(r->pbf->device);
     if (r->stream) hipStreamSynchronize(r->stream);
     r->sel.release();
@@ -924,6 +921,57 @@ extern "C" void bgth_reader_destroy(bgth_reader_t *r)
     for (int i = 0; i < 4; ++i) if (r->ev[i]) hipEventDestroy(r->ev[i]);
     if (r->stream) hipStreamDestroy(r->stream);
     delete r;
+}
+
+constexpr size_t kReaderPoolMax = 8;           // per image; more concurrent readers than that are created and freed as before
+
+extern "C" bgth_reader_t *bgth_reader_create(bgth_pbf_t *p)
+{
+    if (!p) { set_err("[E::bgth_reader_create] NULL image"); return nullptr; }
+    if (!use_device(p->device)) return nullptr;
+    bgth_reader_t *r = nullptr;
+    {
+        std::lock_guard<std::mutex> g(p->pool_lock);
+        if (!p->pool.empty()) { r = p->pool.back(); p->pool.pop_back(); }
+    }
+    if (r) {
+        // a pooled reader: stream, events, device and pinned buffers as they were; every piece of per-use state back to
+        // what a new reader has
+        r->t_ms[0] = r->t_ms[1] = r->t_ms[2] = 0.f; r->t_pending = false;
+        r->tune_threads = r->tune_cpt = r->tune_K = 0;
+        r->next = r->ring0 = r->ring1 = 0; r->ring_has = 0;
+        r->want = BGTH_WANT_PLANES; r->max_ahead = 0; r->ahead = 0;
+        r->ret[0] = r->ret[1] = nullptr; r->last_counts = nullptr; r->last_gt8 = nullptr; r->last_gttext = nullptr;
+        r->folds_live = false; r->bits_row0 = r->bits_row1 = 0;
+    } else {
+        r = new bgth_reader_s();
+        r->pbf = p;
+        HIP_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking), { reader_free(r); return nullptr; });
+        for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&r->ev[i]), { reader_free(r); return nullptr; });
+    }
+    if (!guarded("bgth_reader_create", false, [&] { return build_selection(r->sel, p->m, 0, nullptr, nullptr, 1); })) { reader_free(r); return nullptr; }
+    for (bgth_pbf_t *sh : p->shards) {
+        bgth_reader_t *sub = bgth_reader_create(sh);
+        if (!sub) { bgth_reader_destroy(r); return nullptr; }
+        r->subs.push_back(sub);
+    }
+    return r;
+}
+
+// A destroyed reader goes back to its image's pool (up to kReaderPoolMax of them) with everything it has allocated; the
+// image frees the pool when it is closed.  Readers must be destroyed before their image, as before.
+extern "C" void bgth_reader_destroy(bgth_reader_t *r)
+{
+    if (!r) return;
+    for (bgth_reader_t *sub : r->subs) bgth_reader_destroy(sub);
+    r->subs.clear();
+    hipSetDevice(r->pbf->device);
+    if (r->stream) hipStreamSynchronize(r->stream);
+    {
+        std::lock_guard<std::mutex> g(r->pbf->pool_lock);
+        if (r->pbf->pool.size() < kReaderPoolMax) { r->pbf->pool.push_back(r); return; }
+    }
+    reader_free(r);
 }
 
 extern "C" int bgth_reader_select(bgth_reader_t *r, int n_sub, const int32_t *sub, const uint32_t *group,

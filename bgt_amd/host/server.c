@@ -294,6 +294,7 @@ static int answer(const char *query, const char *host, FILE *w, int with_http)
     form_parse(&f, query);
     memset(&q, 0, sizeof(q));
     if (f.n > 0) status = query_setup(&f, &q, &msg);
+    const long long t1 = now_ns();
     if (with_http) {
         fprintf(w, "HTTP/1.1 %d %s\r\nContent-Type: text/plain; charset=utf-8\r\n%sConnection: close\r\n\r\n", status,
                 status == 200 ? "OK" : status == 204 ? "No Content" : status == 403 ? "Forbidden" : "Bad Request",
@@ -302,9 +303,11 @@ static int answer(const char *query, const char *host, FILE *w, int with_http)
     if (f.n == 0) help(w, host);
     else if (status == 200) query_stream(&q, w);
     else if (status != 204) { fputs(msg, w); fputc('\n', w); }        /* (a 204 carries no body) */
+    const long long t2 = now_ns();
     if (q.bm) bgtm_reader_destroy(q.bm);
     form_free(&f);
     fflush(w);
+    if (getenv("BGS_TRACE")) fprintf(stderr, "[bgs trace] setup %.2f ms, body %.2f ms, destroy %.2f ms\n", (t1 - t0) * 1e-6, (t2 - t1) * 1e-6, (now_ns() - t2) * 1e-6);
     fprintf(stderr, "[%lld] responded %lld\n", now_ns(), t0);
     return status;
 }

@@ -21,7 +21,8 @@ db = os.path.join(tmp, "db")
 subprocess.check_call([os.path.join(BIN, "bgt"), "synth", db, str(n_samples), str(n_sites), "2"], stdout=subprocess.DEVNULL)
 s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
 t0 = time.perf_counter()
-srv = subprocess.Popen([os.path.join(BIN, "bgt-server"), "-p", str(port), "-m", "4000000000", db], stderr=subprocess.DEVNULL)
+srv = subprocess.Popen([os.path.join(BIN, "bgt-server"), "-p", str(port), "-m", "4000000000", db], stderr=open(os.path.join(tmp, "server.log"), "w"),
+                       env=dict(os.environ, BGS_TRACE="1", BGT_TRACE="1", BGTH_TRACE="1"))
 while True:
     try:
         socket.create_connection(("127.0.0.1", port), timeout=1).close()
@@ -58,3 +59,5 @@ for label, q, va in QUERIES:
     print(line + " | %d lines" % body.count(b"\n"))
 srv.terminate()
 srv.wait()
+if os.environ.get("SHOW_SERVER_LOG"):
+    print("".join(open(os.path.join(tmp, "server.log")).readlines()[-60:]))
