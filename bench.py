@@ -236,6 +236,55 @@ def c5_record(tmp, n_samples=50000, sites=65536):
     return rec
 
 
+def server_record(prefix, n_sites):
+    """The resident query server (bgt_amd/bin/bgt-server, the reference's bgt-server.go restated in C) on the database
+    cli_end_to_end wrote: images in HBM once, then per-query latency over HTTP next to one reference `bgt view` process per
+    query; the record lines of every answer are compared with the reference's."""
+    import socket
+    import urllib.request
+    srv_bin = os.path.join(ROOT, "bgt_amd", "bin", "bgt-server")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    t0 = time.perf_counter()
+    srv = subprocess.Popen([srv_bin, "-p", str(port), "-m", "4000000000", prefix], stderr=subprocess.DEVNULL)
+    try:
+        while True:
+            try:
+                socket.create_connection(("127.0.0.1", port), timeout=1).close()
+                break
+            except OSError:
+                if srv.poll() is not None or time.perf_counter() - t0 > 120:
+                    raise RuntimeError("bgt-server did not come up")
+                time.sleep(0.02)
+        ready = time.perf_counter() - t0
+        mid = 1000 + 10 * (n_sites // 2)
+        out = {"name": "server", "program": "bgt-server -p PORT -m 4000000000 <prefix> (images resident in HBM)",
+               "ready_after_s": round(ready, 2), "queries": []}
+        for label, q, va in (
+                ("100 sites of a region, AC/AN", "C&r=11:%d-%d" % (mid, mid + 999), ["-G", "-C", "-r", "11:%d-%d" % (mid, mid + 999)]),
+                ("10,000 sites of a region, -f'AC>0'", "f=AC%%3E0&r=11:%d-%d" % (mid, mid + 99999), ["-G", "-f", "AC>0", "-r", "11:%d-%d" % (mid, mid + 99999)]),
+                ("genotypes of 20 samples over 1,000 sites", "g&s=idx%%3C20&r=11:%d-%d" % (mid, mid + 9999), ["-C", "-s", "idx<20", "-r", "11:%d-%d" % (mid, mid + 9999)])):     # (the server sets -C whenever s is given)
+            best, body = None, b""
+            for _ in range(5):
+                t = time.perf_counter()
+                body = urllib.request.urlopen("http://127.0.0.1:%d/?%s" % (port, q), timeout=600).read()
+                dt = time.perf_counter() - t
+                best = dt if best is None or dt < best else best
+            rec = {"query": label, "server_ms": round(best * 1e3, 2), "lines": body.count(b"\n")}
+            if os.path.exists(REF_BIN):
+                t = time.perf_counter()
+                ref = subprocess.run([REF_BIN, "view"] + va + [prefix], stdout=subprocess.PIPE, check=True).stdout
+                rec["reference_view_process_ms"] = round((time.perf_counter() - t) * 1e3, 2)
+                recs = lambda b: [ln for ln in b.split(b"\n") if ln and not ln.startswith(b"#")]
+                rec["records_identical_to_reference"] = recs(body) == recs(ref)
+                if not rec["records_identical_to_reference"]:
+                    out["parity_error"] = "bgt-server records differ from reference `bgt view` (%s)" % label
+            out["queries"].append(rec)
+        return out
+    finally:
+        srv.terminate()
+        srv.wait(timeout=30)
+
+
 class Pipeline:
     """scan -> device filter -> (all_gather) -> pinned host copy, double buffered: the copy of step i overlaps step i+1."""
 
@@ -547,6 +596,12 @@ def main():
                 out["cli_end_to_end"] = cli_end_to_end(n_samples, sites, seed, tmp)
             except Exception as e:
                 out["cli_end_to_end"] = {"error": repr(e)[:200]}
+            try:
+                out["server"] = server_record(os.path.join(tmp, "full_%d_%d" % (n_samples, sites)), sites)
+                if out["server"].get("parity_error"):
+                    out["parity_error"] = out["server"]["parity_error"]
+            except Exception as e:
+                out["server"] = {"error": repr(e)[:200]}
         # ---- secondary records at the north-star width (100,000 samples), N = 1 only
         if rank == 0 and world == 1 and args.workload == "c2" and not args.no_secondary and not args.every:
             del pipe
