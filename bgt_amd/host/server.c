@@ -23,6 +23,8 @@
 #include <time.h>
 #include <unistd.h>
 #include <pthread.h>
+#include <strings.h>
+#include <sys/time.h>
 #include <sys/socket.h>
 #include <netinet/in.h>
 #include <arpa/inet.h>
@@ -321,6 +323,8 @@ static void *serve_connection(void *arg)
     char *req = (char*)malloc(65536), *q, *sp, *host = NULL, *line;
     size_t n = 0;
     FILE *w;
+    struct timeval tv = {10, 0};                                     /* a client that never finishes its request does not keep the thread */
+    setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
     while (n < 65535) {
         const ssize_t k = read(fd, req + n, 65535 - n);
         if (k <= 0) break;
