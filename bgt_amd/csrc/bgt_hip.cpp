@@ -923,7 +923,7 @@ static void reader_free(bgth_reader_t *r)
     delete r;
 }
 
-constexpr size_t kReaderPoolMax = 8;           // per image; more concurrent readers than that are created and freed as before
+constexpr size_t kReaderPoolMax = 32;          // per image; more concurrent readers than that are created and freed as before
 
 extern "C" bgth_reader_t *bgth_reader_create(bgth_pbf_t *p)
 {

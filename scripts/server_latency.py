@@ -57,6 +57,29 @@ for label, q, va in QUERIES:
         t_ref, ro = best(lambda: subprocess.run([REF, "view"] + va + [db], stdout=subprocess.PIPE, check=True).stdout, 2)
         line += " | reference bgt view %8.1f ms (same bytes as this repo's: %s)" % (t_ref * 1e3, ro == out)
     print(line + " | %d lines" % body.count(b"\n"))
+# throughput: many clients at once, each a stream of different small region queries (one thread per connection in the server,
+# one pooled reader and HIP stream per query in flight)
+import random
+import threading
+for n_clients in (1, 4, 16, 64):
+    per = 40
+    bad = []
+
+    def client(k):
+        rnd = random.Random(k)
+        for _ in range(per):
+            a = 1000 + 10 * rnd.randrange(0, max(1, n_sites - 200))
+            body = urllib.request.urlopen("http://127.0.0.1:%d/?C&r=11:%d-%d" % (port, a, a + 999), timeout=600).read()
+            if body.count(b"\n") < 100:
+                bad.append(a)
+    th = [threading.Thread(target=client, args=(k,)) for k in range(n_clients)]
+    t = time.perf_counter()
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    dt = time.perf_counter() - t
+    print("%3d concurrent clients x %d region queries (100 sites, AC/AN): %7.0f queries/s, %d short answers" % (n_clients, per, n_clients * per / dt, len(bad)))
 srv.terminate()
 srv.wait()
 if os.environ.get("SHOW_SERVER_LOG"):
