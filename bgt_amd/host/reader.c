@@ -314,9 +314,11 @@ fail:
     return NULL;
 }
 
+static void wait_for_site_loads(bgt_file_t *bf);
 void bgt_close(bgt_file_t *bf)
 {
     if (!bf) return;
+    wait_for_site_loads(bf);
     if (bf->gpu) bgth_pbf_close((bgth_pbf_t*)bf->gpu);
     free(bf->mgs);
     st_free((sitetab_t*)bf->idx);
@@ -521,13 +523,43 @@ static pthread_mutex_t g_sites_lock = PTHREAD_MUTEX_INITIALIZER;  /* the site ta
 
 /* the site table of the whole file, read on first use */
 static const sitetab_t *file_sites(const bgt_file_t *cbf);
-static void *sites_loader(void *arg) { file_sites((const bgt_file_t*)arg); return NULL; }
-/* start reading the site table on a thread of its own while the caller opens the .pbf image (the two are the long
- * steps before the first site of a whole-file walk); whoever needs the table first waits on the same lock */
-static int sites_prefetch(const bgt_file_t *bf, pthread_t *th)
+static pthread_cond_t g_sites_cond = PTHREAD_COND_INITIALIZER;     /* bgt_close waits here for background loads of its file */
+static void *sites_loader(void *arg)
 {
-    if (bf->idx) return 0;
-    return pthread_create(th, NULL, sites_loader, (void*)bf) == 0;
+    bgt_file_t *bf = (bgt_file_t*)arg;
+    file_sites(bf);
+    pthread_mutex_lock(&g_sites_lock);
+    --bf->sites_pending;
+    pthread_cond_broadcast(&g_sites_cond);
+    pthread_mutex_unlock(&g_sites_lock);
+    return NULL;
+}
+/* start reading the site table on a thread of its own while the caller opens the .pbf image (the two are the long
+ * steps before the first site of a whole-file walk); whoever needs the table first waits on the same lock.  The file
+ * counts the loads in flight: bgt_close must not free it under a loader that has not finished (or not even started). */
+static int sites_prefetch(const bgt_file_t *cbf, pthread_t *th)
+{
+    bgt_file_t *bf = (bgt_file_t*)cbf;
+    int ok;
+    pthread_mutex_lock(&g_sites_lock);
+    if (bf->idx) { pthread_mutex_unlock(&g_sites_lock); return 0; }
+    ++bf->sites_pending;
+    pthread_mutex_unlock(&g_sites_lock);
+    ok = pthread_create(th, NULL, sites_loader, (void*)bf) == 0;
+    if (!ok) {
+        pthread_mutex_lock(&g_sites_lock);
+        --bf->sites_pending;
+        pthread_cond_broadcast(&g_sites_cond);
+        pthread_mutex_unlock(&g_sites_lock);
+    }
+    return ok;
+}
+
+static void wait_for_site_loads(bgt_file_t *bf)
+{
+    pthread_mutex_lock(&g_sites_lock);
+    while (bf->sites_pending > 0) pthread_cond_wait(&g_sites_cond, &g_sites_lock);
+    pthread_mutex_unlock(&g_sites_lock);
 }
 
 static const sitetab_t *file_sites(const bgt_file_t *cbf)

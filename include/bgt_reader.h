@@ -45,6 +45,7 @@ typedef struct {
     int32_t   *mgs;                 /* per sample: smallest group it may appear in, -1 = unset   */
     void      *gpu;                 /* appended: bgth_pbf_t*, the whole-file image in HBM        */
     int        gpu_opening;         /* appended: a reader is loading that image right now        */
+    int        sites_pending;       /* appended: background loads of the site table in flight    */
 } bgt_file_t;
 
 /* a reader over one database */

@@ -44,6 +44,7 @@ NO_DEVICE = [                                   # nothing depends on a genotype:
     (["synA"], [], qs(("s", "pop=="))),                                           # 400
     (["synA"], [], qs(("t", "CHROM,POS,,"))),
     (["synA"], [], "zzz=1&%zz=3"),                                                # an unknown parameter, a bad escape
+    (["ex3"], ["-m", "50", "-g", "3"], "n=1000"),                                 # 403 before anything is read
 ]
 DEVICE = [
     (["synA", "synB"], [], qs(("s", X), ("s", Y), ("f", "AC1>0"))),
@@ -99,6 +100,13 @@ def test_queries_like_the_reference_library(servers, dbs, opts, query):
     mine, ref = (one_shot(exe, dbs, opts, query) for exe in servers)
     assert mine == ref, query
     assert mine[0] != 0 or len(mine[1]) > 0
+
+
+def test_a_query_that_ends_at_once_does_not_race_the_site_table_load(servers):
+    """found by scripts/fuzz_server.py: the 403 answer comes before the background load of the site table has finished (or
+    started); closing the database must wait for it"""
+    for _ in range(40):
+        assert one_shot(MINE, ["ex3"], ["-m", "50", "-g", "3"], "n=1000")[0] == 4
 
 
 def free_port():
