@@ -108,6 +108,38 @@ while time.time() < t_end:
         if body != want[1]:
             bad += 1
             print("HTTP DIFF", repr(q2), len(body), len(want[1]))
+# concurrency: sixteen clients draw from a set of queries with known answers and hit the resident server at once
+import threading
+known = {}
+while len(known) < 40:
+    dbs, opts, query = make()
+    if dbs == ["synA", "synB"] and not opts and query:
+        known[query] = one_shot(MINE, dbs, [], query)[1]
+keys = sorted(known)
+conc_bad = []
+
+
+def client(k):
+    r = random.Random(1000 + k)
+    for _ in range(60):
+        q = r.choice(keys)
+        try:
+            body = urllib.request.urlopen("http://127.0.0.1:%d/?%s" % (port, q), timeout=120).read()
+        except urllib.error.HTTPError as e:
+            body = e.read()
+        if body != known[q]:
+            conc_bad.append(q)
+
+
+th = [threading.Thread(target=client, args=(k,)) for k in range(16)]
+for t in th:
+    t.start()
+for t in th:
+    t.join()
+for q in conc_bad[:5]:
+    print("CONCURRENT DIFF", repr(q))
+bad += len(conc_bad)
+print("concurrent phase: 16 clients x 60 queries, %d wrong answers" % len(conc_bad))
 srv.terminate()
 srv.wait()
 print("server fuzz: %d queries (%d also over HTTP), %d differences" % (n, n_http, bad))
