@@ -125,7 +125,7 @@ struct bgth_pbf_s {
 // Test / tuning knob BGTH_VARIANT: picks between kernel variants that all give the SAME results (like bgth_reader_tune):
 //   1 = team mode without the separate toggle array (the code path of cohorts too wide for it)
 //   2 / 4 = never / always the kernels with the all-zero-plane-1 shortcut
-enum { kVariantNoTog = 1, kVariantNeverZP = 2, kVariantAlwaysZP = 4 };
+enum { kVariantNoTog = 1, kVariantNeverZP = 2, kVariantAlwaysZP = 4, kVariantNoPrefetch = 16 };   // 16: no window prefetch in the pull interface
 static bool variant_flag(int bit) { const char *d = getenv("BGTH_VARIANT"); return d && (atoi(d) & bit); }
 
 // Builds the row index once per image; later calls only return it.  The build is enqueued on `s`, the
@@ -178,22 +178,40 @@ struct HostBuf {   // pinned
     void release() { if (p) hipHostFree(p); p = nullptr; cap = 0; }
 };
 
+// Buffers of one window of the pull interface.  A reader has two: while the caller consumes the current window the next
+// one is decoded and copied behind it on the reader's stream (single-device readers; the shards of a sharded reader fill the
+// parent's host buffers from their own first window).
+struct PullWindow {
+    DevBuf fin, h0, h1, planes, gt8, gttext;
+    HostBuf h_counts, h_planes, h_gt8, h_gttext;
+    int64_t row0 = 0, row1 = 0;       // image rows it holds (device bit planes and host ring alike)
+    int has = 0;                      // BGTH_WANT_* bits it was filled with
+    bool valid = false;               // row0 / row1 / has describe its contents
+    bool pending = false;             // enqueued on the stream and not waited for yet
+    void release()
+    {
+        fin.release(); h0.release(); h1.release(); planes.release(); gt8.release(); gttext.release();
+        h_counts.release(); h_planes.release(); h_gt8.release(); h_gttext.release();
+        valid = pending = false;
+    }
+};
+
 struct bgth_reader_s {
     bgth_pbf_t *pbf = nullptr;
     Selection sel;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    DevBuf raw, fin, h0, h1, gt, planes, gt8, gttext;
+    DevBuf raw, fin, h0, h1, gt;      // scratch of every scan; results of bgth_reader_scan
     DevBuf carriers, hapsig;          // allele-set accumulators (bgth_reader_fold_last), zeroed when folds_live turns true
     bool folds_live = false;
-    int64_t bits_row0 = 0, bits_row1 = 0;   // image rows whose bit planes h0/h1 currently hold
-    HostBuf h_counts, h_planes, h_gt8, h_gttext;
+    PullWindow win[2];                // pull interface: current window and the one being prefetched
+    int cur = 0;
     float t_ms[3] = {0, 0, 0};
     bool t_pending = false;           // events recorded on a caller stream, not yet read back
     Geometry geom = {0, 0, 0, 0, 0, 0, 1, 1};
     int tune_threads = 0, tune_cpt = 0, tune_K = 0;
     // pull interface
-    int64_t next = 0, ring0 = 0, ring1 = 0;
+    int64_t next = 0, ring0 = 0, ring1 = 0;   // ring0 / ring1 / ring_has: the current window
     int ring_has = 0;                 // BGTH_WANT_* bits the ring was filled with
     int want = BGTH_WANT_PLANES;      // pull interface: what a refill materialises besides the counts
     int64_t max_ahead = 0;            // rows per refill (0 = automatic)
@@ -915,9 +933,9 @@ static void reader_free(bgth_reader_t *r)
     hipSetDevice(r->pbf->device);
     if (r->stream) hipStreamSynchronize(r->stream);
     r->sel.release();
-    r->raw.release(); r->fin.release(); r->h0.release(); r->h1.release(); r->gt.release(); r->planes.release();
-    r->gt8.release(); r->gttext.release(); r->carriers.release(); r->hapsig.release();
-    r->h_counts.release(); r->h_planes.release(); r->h_gt8.release(); r->h_gttext.release();
+    r->raw.release(); r->fin.release(); r->h0.release(); r->h1.release(); r->gt.release();
+    r->carriers.release(); r->hapsig.release();
+    r->win[0].release(); r->win[1].release();
     for (int i = 0; i < 4; ++i) if (r->ev[i]) hipEventDestroy(r->ev[i]);
     if (r->stream) hipStreamDestroy(r->stream);
     delete r;
@@ -937,12 +955,15 @@ extern "C" bgth_reader_t *bgth_reader_create(bgth_pbf_t *p)
     if (r) {
         // a pooled reader: stream, events, device and pinned buffers as they were; every piece of per-use state back to
         // what a new reader has
+        HIP_TRY(hipStreamSynchronize(r->stream), { reader_free(r); return nullptr; });
         r->t_ms[0] = r->t_ms[1] = r->t_ms[2] = 0.f; r->t_pending = false;
         r->tune_threads = r->tune_cpt = r->tune_K = 0;
         r->next = r->ring0 = r->ring1 = 0; r->ring_has = 0;
         r->want = BGTH_WANT_PLANES; r->max_ahead = 0; r->ahead = 0;
         r->ret[0] = r->ret[1] = nullptr; r->last_counts = nullptr; r->last_gt8 = nullptr; r->last_gttext = nullptr;
-        r->folds_live = false; r->bits_row0 = r->bits_row1 = 0;
+        r->folds_live = false;
+        r->cur = 0;
+        for (PullWindow &w : r->win) w.valid = w.pending = false;
     } else {
         r = new bgth_reader_s();
         r->pbf = p;
@@ -965,9 +986,8 @@ extern "C" void bgth_reader_destroy(bgth_reader_t *r)
     if (!r) return;
     for (bgth_reader_t *sub : r->subs) bgth_reader_destroy(sub);
     r->subs.clear();
-    hipSetDevice(r->pbf->device);
-    if (r->stream) hipStreamSynchronize(r->stream);
-    {
+    {   // (not waiting for the stream: a window prefetched behind the last row read may still be on its way -- it lands in
+        //  buffers the pooled reader keeps, and whoever takes the reader next drains the stream first)
         std::lock_guard<std::mutex> g(r->pbf->pool_lock);
         if (r->pbf->pool.size() < kReaderPoolMax) { r->pbf->pool.push_back(r); return; }
     }
@@ -981,8 +1001,9 @@ extern "C" int bgth_reader_select(bgth_reader_t *r, int n_sub, const int32_t *su
     if (!use_device(r->pbf->device)) return -1;
     hipStreamSynchronize(r->stream);
     if (!guarded("bgth_reader_select", false, [&] { return build_selection(r->sel, r->pbf->m, n_sub, sub, group, n_groups); })) return -1;
-    r->ring0 = r->ring1 = 0;          // invalidate the pull ring
-    r->folds_live = false; r->bits_row0 = r->bits_row1 = 0;
+    r->ring0 = r->ring1 = 0;          // invalidate the pull ring (the stream is idle: nothing is pending any more)
+    for (PullWindow &w : r->win) w.valid = w.pending = false;
+    r->folds_live = false;
     for (bgth_reader_t *sr : r->subs) if (bgth_reader_select(sr, n_sub, sub, group, n_groups) < 0) return -1;
     return 0;
 }
@@ -1197,41 +1218,92 @@ extern "C" int bgth_reader_seek(bgth_reader_t *r, int64_t row)
 // Host destinations of one piece of a refill window (already offset to the piece's first row)
 struct PieceDst { int32_t *counts; uint8_t *a0, *a1, *gt8, *gttext; };
 
-// Decode image rows [row0,row1) of a single-device reader into its device buffers and copy what `want` asks for to the
-// host destinations; returns when the copies have landed.
-static bool decode_piece(bgth_reader_t *r, int want, int64_t row0, int64_t row1, const PieceDst &d)
+// Enqueue on the reader's stream: decode image rows [row0,row1) of a single-device reader into the device buffers of `w`
+// and copy what `want` asks for to the host destinations.  Nothing is waited for.
+static bool enqueue_piece(bgth_reader_t *r, PullWindow &w, int want, int64_t row0, int64_t row1, const PieceDst &d)
 {
     const int width = r->sel.width;
     const size_t cstride = (size_t)(1 + gx_of(r->sel.G)) * 3;
     const bool need_bits = want != 0;                            // any genotype output needs the bit planes H0/H1
     const int64_t rows = row1 - row0;
     const size_t pl = (size_t)rows * r->sel.n_chunks * 8, by = (size_t)rows * width;
-    if (!r->fin.reserve((size_t)rows * cstride * 4) || (need_bits && (!r->h0.reserve(pl) || !r->h1.reserve(pl))) ||
-        ((want & BGTH_WANT_PLANES) && !r->planes.reserve(2 * by)) || ((want & BGTH_WANT_GT8) && !r->gt8.reserve(by)) ||
-        ((want & BGTH_WANT_GTTEXT) && !r->gttext.reserve(2 * by))) {
+    if (!w.fin.reserve((size_t)rows * cstride * 4) || (need_bits && (!w.h0.reserve(pl) || !w.h1.reserve(pl))) ||
+        ((want & BGTH_WANT_PLANES) && !w.planes.reserve(2 * by)) || ((want & BGTH_WANT_GT8) && !w.gt8.reserve(by)) ||
+        ((want & BGTH_WANT_GTTEXT) && !w.gttext.reserve(2 * by))) {
         set_err("[E::bgth_reader_read] out of HBM for a %lld-row batch", (long long)rows);
         return false;
     }
-    uint64_t *d_h0 = need_bits ? (uint64_t*)r->h0.p : nullptr, *d_h1 = need_bits ? (uint64_t*)r->h1.p : nullptr;
-    if (enqueue_scan(r, row0, row1, (int32_t*)r->fin.p, d_h0, d_h1, r->stream, true) < 0) return false;
-    r->bits_row0 = need_bits ? row0 : 0; r->bits_row1 = need_bits ? row1 : 0;
+    uint64_t *d_h0 = need_bits ? (uint64_t*)w.h0.p : nullptr, *d_h1 = need_bits ? (uint64_t*)w.h1.p : nullptr;
+    if (enqueue_scan(r, row0, row1, (int32_t*)w.fin.p, d_h0, d_h1, r->stream, true) < 0) return false;
     if (want & BGTH_WANT_PLANES) {
-        uint8_t *d_a0 = (uint8_t*)r->planes.p, *d_a1 = d_a0 + by;
+        uint8_t *d_a0 = (uint8_t*)w.planes.p, *d_a1 = d_a0 + by;
         HIP_TRY(launch_unpack_bytes(d_h0, d_h1, r->sel.d_slot_of_out, d_a0, d_a1, rows, r->sel.n_chunks, width, r->stream), return false);
         HIP_TRY(hipMemcpyAsync(d.a0, d_a0, by, hipMemcpyDeviceToHost, r->stream), return false);
         HIP_TRY(hipMemcpyAsync(d.a1, d_a1, by, hipMemcpyDeviceToHost, r->stream), return false);
     }
     if (want & (BGTH_WANT_GT8 | BGTH_WANT_GTTEXT)) {
-        uint8_t *d_gt8 = (want & BGTH_WANT_GT8) ? (uint8_t*)r->gt8.p : nullptr;
-        uint32_t *d_txt = (want & BGTH_WANT_GTTEXT) ? (uint32_t*)r->gttext.p : nullptr;
+        uint8_t *d_gt8 = (want & BGTH_WANT_GT8) ? (uint8_t*)w.gt8.p : nullptr;
+        uint32_t *d_txt = (want & BGTH_WANT_GTTEXT) ? (uint32_t*)w.gttext.p : nullptr;
         HIP_TRY(launch_emit_gt(d_h0, d_h1, r->sel.d_slot_of_out, d_gt8, d_txt, rows, r->sel.n_chunks, width, r->stream), return false);
         if (d_gt8) HIP_TRY(hipMemcpyAsync(d.gt8, d_gt8, by, hipMemcpyDeviceToHost, r->stream), return false);
         if (d_txt) HIP_TRY(hipMemcpyAsync(d.gttext, d_txt, 2 * by, hipMemcpyDeviceToHost, r->stream), return false);
     }
-    HIP_TRY(hipMemcpyAsync(d.counts, r->fin.p, (size_t)rows * cstride * 4, hipMemcpyDeviceToHost, r->stream), return false);
+    HIP_TRY(hipMemcpyAsync(d.counts, w.fin.p, (size_t)rows * cstride * 4, hipMemcpyDeviceToHost, r->stream), return false);
+    w.row0 = row0; w.row1 = row1; w.has = want; w.valid = true;   // (rows of THIS reader's image: a shard's are local)
+    return true;
+}
+
+// the same, and wait until the copies have landed (a shard's piece of the parent's window)
+static bool decode_piece(bgth_reader_t *r, int want, int64_t row0, int64_t row1, const PieceDst &d)
+{
+    if (!enqueue_piece(r, r->win[0], want, row0, row1, d)) return false;
     HIP_TRY(hipStreamSynchronize(r->stream), return false);
     collect_timing(r);
     return true;
+}
+
+// host buffers of a window for `rows` rows
+static bool window_host(bgth_reader_t *r, PullWindow &w, int want, int64_t rows, PieceDst &base)
+{
+    const int width = r->sel.width;
+    const size_t cstride = (size_t)(1 + gx_of(r->sel.G)) * 3, by = (size_t)rows * width;
+    if (!w.h_counts.reserve((size_t)rows * cstride * 4) || ((want & BGTH_WANT_PLANES) && !w.h_planes.reserve(2 * by)) ||
+        ((want & BGTH_WANT_GT8) && !w.h_gt8.reserve(by)) || ((want & BGTH_WANT_GTTEXT) && !w.h_gttext.reserve(2 * by))) {
+        set_err("[E::bgth_reader_read] out of memory for a %lld-row batch", (long long)rows);
+        return false;
+    }
+    base = PieceDst{(int32_t*)w.h_counts.p, (uint8_t*)w.h_planes.p, (uint8_t*)w.h_planes.p + by, (uint8_t*)w.h_gt8.p, (uint8_t*)w.h_gttext.p};
+    return true;
+}
+
+// rows a window may hold: with byte planes while they stay under 256 MiB, with counts only a wide window (the whole point
+// of the device: one launch, many sites), always whole sub-blocks
+static int64_t window_max_rows(const bgth_reader_t *r, int want)
+{
+    const int64_t blk_rows = (int64_t)1 << r->pbf->sub_shift;
+    const int per_hap = (want & BGTH_WANT_PLANES ? 2 : 0) + (want & BGTH_WANT_GT8 ? 1 : 0) + (want & BGTH_WANT_GTTEXT ? 2 : 0);
+    int64_t max_rows = want != 0 ? ((int64_t)256 << 20) / std::max(1, per_hap * r->sel.width) : (int64_t)1 << 22;
+    if (want & BGTH_WANT_BITS) max_rows = std::min(max_rows, ((int64_t)512 << 20) / ((int64_t)r->sel.n_chunks * 16));   // H0 + H1 in HBM
+    if (r->max_ahead > 0) max_rows = std::min(max_rows, r->max_ahead);
+    return std::max<int64_t>(blk_rows, max_rows / blk_rows * blk_rows);
+}
+
+// A sequential walk: start the window behind the current one now, four times its size (up to the maximum); its scan and
+// copies run while the caller consumes the current window.  Failures only mean there is no prefetched window.
+static void prefetch_next(bgth_reader_t *r)
+{
+    bgth_pbf_t *p = r->pbf;
+    PullWindow &nx = r->win[r->cur ^ 1];
+    nx.valid = nx.pending = false;
+    if (!r->subs.empty() || r->ring1 >= p->n || variant_flag(kVariantNoPrefetch)) return;
+    const int want = r->ring_has;
+    const int64_t blk_rows = (int64_t)1 << p->sub_shift, max_rows = window_max_rows(r, want);
+    if (r->max_ahead <= 0) r->ahead = std::min(max_rows, std::max<int64_t>(blk_rows, r->ahead * 4));
+    const int64_t row0 = r->ring1;
+    const int64_t row1 = std::min<int64_t>(p->n, ((row0 >> p->sub_shift) << p->sub_shift) + (r->max_ahead > 0 ? max_rows : r->ahead));
+    PieceDst base;
+    if (!window_host(r, nx, want, row1 - row0, base) || !enqueue_piece(r, nx, want, row0, row1, base)) { nx.valid = false; return; }
+    nx.pending = true;
 }
 
 static bool refill(bgth_reader_t *r)
@@ -1239,48 +1311,48 @@ static bool refill(bgth_reader_t *r)
     bgth_pbf_t *p = r->pbf;
     const int64_t blk_rows = (int64_t)1 << p->sub_shift;
     const int width = r->sel.width;
-    const int gx = gx_of(r->sel.G);
-    const size_t cstride = (size_t)(1 + gx) * 3;
-    // Decode to the end of a block, several blocks per refill: with byte planes while they stay under
-    // 256 MiB, with counts only a wide window (the whole point of the device: one launch, many sites).
+    const size_t cstride = (size_t)(1 + gx_of(r->sel.G)) * 3;
     Trace tr;
     const int want = r->want;
-    const bool need_bits = want != 0;                            // any genotype output needs the bit planes H0/H1
-    const int per_hap = (want & BGTH_WANT_PLANES ? 2 : 0) + (want & BGTH_WANT_GT8 ? 1 : 0) + (want & BGTH_WANT_GTTEXT ? 2 : 0);
-    int64_t max_rows = need_bits ? ((int64_t)256 << 20) / std::max(1, per_hap * width) : (int64_t)1 << 22;
-    if (want & BGTH_WANT_BITS) max_rows = std::min(max_rows, ((int64_t)512 << 20) / ((int64_t)r->sel.n_chunks * 16));   // H0 + H1 in HBM
-    if (r->max_ahead > 0) max_rows = std::min(max_rows, r->max_ahead);
-    max_rows = std::max<int64_t>(blk_rows, max_rows / blk_rows * blk_rows);
     const int64_t row0 = r->next;
-    // Adaptive look-ahead: a refill that continues where the last window ended is a sequential walk and gets four times
-    // the previous window (up to max_rows); one that lands elsewhere (sparse access: BED / allele sets, merges with gaps)
-    // starts again at one sub-block, so a visited site costs a pre-roll of at most one sub-block, not a 256 MiB window.
-    if (r->max_ahead <= 0) {
-        const bool sequential = r->ring1 > r->ring0 && row0 == r->ring1 && r->ring_has == want;
-        r->ahead = sequential ? std::min(max_rows, std::max<int64_t>(blk_rows, r->ahead * 4)) : blk_rows;
-        max_rows = std::min(max_rows, r->ahead);
-    }
-    int64_t row1 = std::min<int64_t>(p->n, ((row0 >> p->sub_shift) << p->sub_shift) + max_rows);
-    const int64_t rows = row1 - row0;
-    const size_t by = (size_t)rows * width;
-    if (!r->h_counts.reserve((size_t)rows * cstride * 4)) {
-        set_err("[E::bgth_reader_read] out of memory for a %lld-row batch", (long long)rows);
-        return false;
-    }
     if ((want & (BGTH_WANT_GT8 | BGTH_WANT_GTTEXT)) && (width & 1)) {
         set_err("[E::bgth_reader_read] genotype vectors need whole samples (an even number of columns), have %d", width);
         return false;
     }
-    if (((want & BGTH_WANT_PLANES) && !r->h_planes.reserve(2 * by)) ||
-        ((want & BGTH_WANT_GT8) && !r->h_gt8.reserve(by)) ||
-        ((want & BGTH_WANT_GTTEXT) && !r->h_gttext.reserve(2 * by))) {
-        set_err("[E::bgth_reader_read] out of memory for a %lld-row batch", (long long)rows);
-        return false;
+    // the prefetched window, if it is the one wanted
+    PullWindow &nx = r->win[r->cur ^ 1];
+    if (nx.pending) {
+        HIP_TRY(hipStreamSynchronize(r->stream), { nx.pending = nx.valid = false; return false; });
+        nx.pending = false;
+        collect_timing(r);
     }
+    if (nx.valid && row0 >= nx.row0 && row0 < nx.row1 && !(want & ~nx.has)) {
+        r->cur ^= 1;
+        r->ring0 = nx.row0; r->ring1 = nx.row1; r->ring_has = nx.has;
+        tr.lap("refill: prefetched window");
+        prefetch_next(r);
+        return true;
+    }
+    nx.valid = false;
+    int64_t max_rows = window_max_rows(r, want);
+    // Adaptive look-ahead: a refill that continues where the last window ended is a sequential walk and gets four times
+    // the previous window (up to max_rows); one that lands elsewhere (sparse access: BED / allele sets, merges with gaps)
+    // starts again at one sub-block, so a visited site costs a pre-roll of at most one sub-block, not a 256 MiB window.
+    const bool sequential = r->ring1 > r->ring0 && row0 == r->ring1 && r->ring_has == want;
+    if (r->max_ahead <= 0) {
+        r->ahead = sequential ? std::min(max_rows, std::max<int64_t>(blk_rows, r->ahead * 4)) : blk_rows;
+        max_rows = std::min(max_rows, r->ahead);
+    }
+    const int64_t row1 = std::min<int64_t>(p->n, ((row0 >> p->sub_shift) << p->sub_shift) + max_rows);
+    PullWindow &w = r->win[r->cur];
+    w.valid = false;
+    PieceDst base;
+    if (!window_host(r, w, want, row1 - row0, base)) return false;
     tr.lap("refill: buffers");
-    PieceDst base = {(int32_t*)r->h_counts.p, (uint8_t*)r->h_planes.p, (uint8_t*)r->h_planes.p + by, (uint8_t*)r->h_gt8.p, (uint8_t*)r->h_gttext.p};
     if (r->subs.empty()) {
-        if (!decode_piece(r, want, row0, row1, base)) return false;
+        if (!enqueue_piece(r, w, want, row0, row1, base)) return false;
+        HIP_TRY(hipStreamSynchronize(r->stream), { w.valid = false; return false; });
+        collect_timing(r);
     } else {
         // the window is cut at the shard boundaries; every shard decodes its piece on its own device, concurrently, and
         // copies it to its place in the (portable, pinned) host ring
@@ -1300,9 +1372,11 @@ static bool refill(bgth_reader_t *r)
         }
         for (std::thread &t : th) t.join();
         for (const std::string &e : errs) if (!e.empty()) { set_err("%s", e.c_str()); return false; }
+        w.row0 = row0; w.row1 = row1; w.has = want; w.valid = true;
     }
     tr.lap("refill: scan + copies");
     r->ring0 = row0; r->ring1 = row1; r->ring_has = want;
+    if (sequential) prefetch_next(r);
     return true;
 }
 
@@ -1316,16 +1390,17 @@ extern "C" const uint8_t **bgth_reader_read(bgth_reader_t *r)
     }
     if (!use_device(p->device)) return nullptr;
     if (r->next < r->ring0 || r->next >= r->ring1 || (r->want & ~r->ring_has)) if (!refill(r)) return nullptr;
+    const PullWindow &w = r->win[r->cur];
     const int width = r->sel.width;
     const size_t by = (size_t)(r->ring1 - r->ring0) * width;
     const size_t k = (size_t)(r->next - r->ring0);
     if (r->want & BGTH_WANT_PLANES) {
-        r->ret[0] = (const uint8_t*)r->h_planes.p + k * width;
-        r->ret[1] = (const uint8_t*)r->h_planes.p + by + k * width;
+        r->ret[0] = (const uint8_t*)w.h_planes.p + k * width;
+        r->ret[1] = (const uint8_t*)w.h_planes.p + by + k * width;
     } else r->ret[0] = r->ret[1] = nullptr;
-    r->last_gt8 = (r->want & BGTH_WANT_GT8) ? (const int8_t*)r->h_gt8.p + k * width : nullptr;
-    r->last_gttext = (r->want & BGTH_WANT_GTTEXT) ? (const char*)r->h_gttext.p + 2 * k * width : nullptr;
-    r->last_counts = (const int32_t*)r->h_counts.p + k * (size_t)(1 + gx_of(r->sel.G)) * 3;
+    r->last_gt8 = (r->want & BGTH_WANT_GT8) ? (const int8_t*)w.h_gt8.p + k * width : nullptr;
+    r->last_gttext = (r->want & BGTH_WANT_GTTEXT) ? (const char*)w.h_gttext.p + 2 * k * width : nullptr;
+    r->last_counts = (const int32_t*)w.h_counts.p + k * (size_t)(1 + gx_of(r->sel.G)) * 3;
     ++r->next;
     return r->ret;
 }
@@ -1372,10 +1447,11 @@ extern "C" int bgth_reader_fold_last(bgth_reader_t *r, int code, int bit)
     int64_t lrow = row;
     for (bgth_reader_t *sub : r->subs)
         if (row >= sub->pbf->row_off && row < sub->pbf->row_off + sub->pbf->n) { sr = sub; lrow = row - sub->pbf->row_off; }
-    if (lrow < sr->bits_row0 || lrow >= sr->bits_row1) { set_err("[E::bgth_reader_fold_last] row %lld is not resident", (long long)row); return -1; }
+    const PullWindow &w = sr->win[sr->cur];                       // (a shard decodes into its first window, in its own rows)
+    if (!w.valid || !(w.has & BGTH_WANT_BITS) || lrow < w.row0 || lrow >= w.row1) { set_err("[E::bgth_reader_fold_last] row %lld is not resident", (long long)row); return -1; }
     if (!use_device(sr->pbf->device) || !folds_prepare(sr)) return -1;
-    const size_t off = (size_t)(lrow - sr->bits_row0) * sr->sel.n_chunks;
-    HIP_TRY(launch_fold_alleles((const uint64_t*)sr->h0.p + off, (const uint64_t*)sr->h1.p + off, sr->sel.d_slot_of_out,
+    const size_t off = (size_t)(lrow - w.row0) * sr->sel.n_chunks;
+    HIP_TRY(launch_fold_alleles((const uint64_t*)w.h0.p + off, (const uint64_t*)w.h1.p + off, sr->sel.d_slot_of_out,
                                 code >= 0 ? (int32_t*)sr->carriers.p : nullptr, bit >= 0 ? (uint64_t*)sr->hapsig.p : nullptr,
                                 sr->sel.width, code, bit, sr->stream), return -1);
     return 0;
