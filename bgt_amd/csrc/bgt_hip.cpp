@@ -986,6 +986,15 @@ extern "C" void bgth_reader_destroy(bgth_reader_t *r)
     if (!r) return;
     for (bgth_reader_t *sub : r->subs) bgth_reader_destroy(sub);
     r->subs.clear();
+    {   // a reader that served a big streaming query does not keep its windows (up to 2 x 256 MiB pinned + as much HBM)
+        size_t held = 0;
+        for (const PullWindow &w : r->win) held += w.h_counts.cap + w.h_planes.cap + w.h_gt8.cap + w.h_gttext.cap;
+        if (held > ((size_t)64 << 20)) {
+            hipSetDevice(r->pbf->device);
+            if (r->stream) hipStreamSynchronize(r->stream);
+            r->win[0].release(); r->win[1].release();
+        }
+    }
     {   // (not waiting for the stream: a window prefetched behind the last row read may still be on its way -- it lands in
         //  buffers the pooled reader keeps, and whoever takes the reader next drains the stream first)
         std::lock_guard<std::mutex> g(r->pbf->pool_lock);

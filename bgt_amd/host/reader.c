@@ -1745,17 +1745,22 @@ int bgtm_read_vcf(bgtm_t *bm, bcf1_t *b, kstring_t *s)
 }
 
 /* ------------------------------------------------------------------------------------------------
- * Extension: the whole walk of `bgt view -G [-C] [-f EXPR] [-s ..] prefix` in bulk.
+ * Extension: the whole walk of `bgt view -G [-C] [-f EXPR] [-s ..] prefix [prefix2 ...]` in bulk.
  * The site-by-site contract of bgtm_read (one call, one site) costs ~0.4 us of host work per site -- record
  * assembly, INFO, the filter expression, text formatting -- on ONE thread, 30 times the device's time for the same
- * sites.  When nothing in the query needs that contract (one database, no genotype columns, VCF text, the whole file
- * or a start offset) the same per-site functions run here over the site table on several threads: one device scan
- * delivers the counts of every row, the sites are cut into blocks, every thread formats blocks into buffers of its
+ * sites.  When nothing in the query needs that contract (no genotype columns, VCF text, the whole files or a start
+ * offset) the same per-site functions run here over the merged site walk on several threads: one device scan per
+ * database (side by side) delivers the counts of every row, the sites are cut into blocks, every thread formats blocks into buffers of its
  * own with its own copy of the filter expression, and the blocks are written in order.  Byte-identical to the
  * bgtm_read_vcf loop.  Returns the number of records written, or -1 if the query needs the site-by-site path.
  * ------------------------------------------------------------------------------------------------ */
+#define BULK_MAX_DB 64
 typedef struct {
-    bgtm_t *bm; const sitetab_t *t; int64_t lo, hi, row_min; const int32_t *counts; int need_counts, cstride;
+    bgtm_t *bm; int n_db; int need_counts, cstride;
+    const sitetab_t *t[BULK_MAX_DB]; int64_t row_min[BULK_MAX_DB]; const int32_t *counts[BULK_MAX_DB];
+    /* the merged walk: site j of the output is site idx[d][j] of database d (-1: that database lacks it); lead[j] = the
+     * database whose record describes the site (the smallest look-ahead, first of equals: read_core's `best`) */
+    int64_t n_sites; int32_t *idx[BULK_MAX_DB]; uint8_t *lead;
     int64_t n_blocks, blk_sites;
     kstring_t *out; int64_t *n_lines; volatile int *done;
     int64_t next_block;
@@ -1766,32 +1771,40 @@ static void *bulk_worker(void *arg)
 {
     bulk_t *k = (bulk_t*)arg;
     bgtm_t *bm = k->bm;
-    const sitetab_t *t = k->t;
     kexpr_t *flt = ke_clone(bm->site_flt);
     bcf1_t *b = bcf_init1();
     kstring_t line = {0, 0, 0};
     for (;;) {
-        int64_t blk, i, i0, i1, n = 0;
+        int64_t blk, j, j0, j1, n = 0;
         kstring_t *o;
         pthread_mutex_lock(&k->lock);
         blk = k->next_block++;
         pthread_mutex_unlock(&k->lock);
         if (blk >= k->n_blocks) break;
         o = &k->out[blk];
-        i0 = k->lo + blk * k->blk_sites; i1 = i0 + k->blk_sites < k->hi ? i0 + k->blk_sites : k->hi;
-        for (i = i0; i < i1; ++i) {                               /* what read_core does for one database without genotypes */
+        j0 = blk * k->blk_sites; j1 = j0 + k->blk_sites < k->n_sites ? j0 + k->blk_sites : k->n_sites;
+        for (j = j0; j < j1; ++j) {                               /* what read_core does for one merged site without genotypes */
+            const sitetab_t *t = k->t[k->lead[j]];
+            const int64_t i = k->idx[k->lead[j]][j];
+            int d, max_allele = 0;
+            for (d = 0; d < k->n_db; ++d)
+                if (k->idx[d][j] >= 0 && k->t[d]->n_allele[k->idx[d][j]] > max_allele) max_allele = k->t[d]->n_allele[k->idx[d][j]];
             bcf_set_site(b, t->rid[i], t->pos[i], t->rlen[i], t->pool + t->ref_off[i], (int)t->ref_len[i],
-                         t->pool + t->alt_off[i], (int)t->alt_len[i], t->n_allele[i] > 2 ? "<M>" : NULL);
+                         t->pool + t->alt_off[i], (int)t->alt_len[i], max_allele > 2 ? "<M>" : NULL);
             if ((int)t->ref_len[i] != b->rlen) { int32_t val = b->pos + b->rlen; bcf_append_info_ints(bm->h_out, b, "END", 1, &val); }
             if (k->need_counts) {
-                const int32_t *c = k->counts + (size_t)(t->row[i] - k->row_min) * (size_t)k->cstride;
                 bgt_info_t ss;
                 int g;
                 memset(&ss, 0, sizeof(ss));
                 ss.n_groups = bm->n_groups;
-                ss.an = c[0]; ss.ac[0] = c[1]; ss.ac[1] = c[2];
-                if (bm->n_groups > 1)
-                    for (g = 0; g < bm->n_groups; ++g) { ss.gan[g] = c[3 * (1 + g)]; ss.gac[g][0] = c[3 * (1 + g) + 1]; ss.gac[g][1] = c[3 * (1 + g) + 2]; }
+                for (d = 0; d < k->n_db; ++d) {                   /* the databases that carry the site add their counts */
+                    const int32_t *c;
+                    if (k->idx[d][j] < 0) continue;
+                    c = k->counts[d] + (size_t)(k->t[d]->row[k->idx[d][j]] - k->row_min[d]) * (size_t)k->cstride;
+                    ss.an += c[0]; ss.ac[0] += c[1]; ss.ac[1] += c[2];
+                    if (bm->n_groups > 1)
+                        for (g = 0; g < bm->n_groups; ++g) { ss.gan[g] += c[3 * (1 + g)]; ss.gac[g][0] += c[3 * (1 + g) + 1]; ss.gac[g][1] += c[3 * (1 + g) + 2]; }
+                }
                 fill_info(bm->h_out, &ss, b);
                 if (!pass_site_flt(&ss, flt)) continue;
             }
@@ -1810,43 +1823,98 @@ static void *bulk_worker(void *arg)
     return NULL;
 }
 
+typedef struct { bgth_reader_t *rd; int64_t r0, r1; int32_t *counts; int rc; char err[256]; pthread_t th; int started; } bulk_scan_t;
+static void *bulk_scan_worker(void *arg)
+{
+    bulk_scan_t *q = (bulk_scan_t*)arg;
+    q->rc = bgth_reader_scan(q->rd, q->r0, q->r1, q->counts, NULL) < 0 ? -1 : 0;      /* every row's AN / AC in one device pass */
+    if (q->rc < 0) { strncpy(q->err, bgth_last_error(), sizeof(q->err) - 1); q->err[sizeof(q->err) - 1] = 0; }
+    return NULL;
+}
+
 long bgtm_write_vcf_bulk(bgtm_t *bm, FILE *fp, long n_rec)
 {
-    bgt_t *bgt;
-    devrd_t *dv;
-    const sitetab_t *t;
     bulk_t k;
+    bulk_scan_t scan[BULK_MAX_DB];
     pthread_t th[16];
-    int32_t *counts = NULL;
-    int64_t i, lo, hi, row_min = INT64_MAX, row_max = -1;
+    int64_t i, lo[BULK_MAX_DB], hi[BULK_MAX_DB], cur[BULK_MAX_DB], total = 0, cap = 0;
     long written = 0;
-    int n_threads, need_counts, j;
+    int n_threads, j, d, failed = 0;
     if (bm->h_out == NULL && bgtm_prepare(bm) < 0) return -2;
-    if (bm->n_bgt != 1 || !(bm->flag & BGT_F_NO_GT) || (bm->flag & (BGT_F_CNT_AL | BGT_F_CNT_HAP)) || bm->h_al || bm->n_fields > 0) return -1;
-    bgt = bm->bgt[0]; dv = (devrd_t*)bgt->pb;
-    if (bgt->bed || bgt->h_al || bgt->itr || dv->own_sites || bgt->n_out == 0) return -1;
-    t = sites_of(bgt);
-    lo = ((cursor_t*)bgt->bcf)->next; hi = t->n;
-    if (lo < 0) lo = 0;
-    if (lo >= hi) return 0;
-    if (n_rec < hi - lo) return -1;                              /* -n counts EMITTED records: site by site */
-    need_counts = (bm->flag & BGT_F_SET_AC) || bm->site_flt || bm->n_groups > 1;
+    if (bm->n_bgt < 1 || bm->n_bgt > BULK_MAX_DB || !(bm->flag & BGT_F_NO_GT) || (bm->flag & (BGT_F_CNT_AL | BGT_F_CNT_HAP)) || bm->h_al || bm->n_fields > 0) return -1;
     memset(&k, 0, sizeof(k));
+    k.bm = bm; k.n_db = bm->n_bgt;
+    k.need_counts = (bm->flag & BGT_F_SET_AC) || bm->site_flt || bm->n_groups > 1;
     k.cstride = 3 * (1 + (bm->n_groups > 1 ? bm->n_groups : 0));
-    if (need_counts) {
-        if (dv->rd == NULL) return -1;
-        for (i = lo; i < hi; ++i) { if (t->row[i] < row_min) row_min = t->row[i]; if (t->row[i] > row_max) row_max = t->row[i]; }
-        counts = (int32_t*)malloc((size_t)(row_max - row_min + 1) * (size_t)k.cstride * 4);
-        if (counts == NULL) return -1;
-        if (bgth_reader_scan(dv->rd, row_min, row_max + 1, counts, NULL) < 0) {      /* every row's AN / AC in one device pass */
-            fprintf(stderr, "[E::%s] %s\n", __func__, bgth_last_error());
-            free(counts);
-            return -2;
+    for (d = 0; d < k.n_db; ++d) {                                /* every database: a plain walk from its cursor to its end */
+        const bgt_t *bgt = bm->bgt[d];
+        const devrd_t *dv = (const devrd_t*)bgt->pb;
+        if (bgt->bed || bgt->h_al || bgt->itr || dv->own_sites || bgt->n_out == 0 || bm->r[d].b0) return -1;
+        if (k.need_counts && dv->rd == NULL) return -1;
+        k.t[d] = sites_of(bgt);
+        lo[d] = ((cursor_t*)bgt->bcf)->next; hi[d] = k.t[d]->n;
+        if (lo[d] < 0) lo[d] = 0;
+        if (lo[d] > hi[d]) lo[d] = hi[d];
+        total += hi[d] - lo[d];
+    }
+    if (total == 0) return 0;
+    if (n_rec < total) return -1;                                /* -n counts EMITTED records: site by site */
+    /* the merged order, exactly as read_core finds it: the smallest look-ahead site, every database at that site consumed */
+    for (d = 0; d < k.n_db; ++d) { cur[d] = lo[d]; k.idx[d] = NULL; }
+    cap = k.n_db == 1 ? total : total / 2 + 1024;
+    for (d = 0; d < k.n_db; ++d) k.idx[d] = (int32_t*)malloc((size_t)cap * 4);
+    k.lead = (uint8_t*)malloc((size_t)cap);
+    for (;;) {
+        int best = -1;
+        for (d = 0; d < k.n_db; ++d) {
+            if (cur[d] >= hi[d]) continue;
+            if (best < 0 || st_cmp(k.t[best], cur[best], k.t[d], cur[d]) > 0) best = d;
+        }
+        if (best < 0) break;
+        if (k.n_sites == cap) {
+            cap += cap / 2 + 1024;
+            for (d = 0; d < k.n_db; ++d) k.idx[d] = (int32_t*)realloc(k.idx[d], (size_t)cap * 4);
+            k.lead = (uint8_t*)realloc(k.lead, (size_t)cap);
+        }
+        k.lead[k.n_sites] = (uint8_t)best;
+        {
+            const int64_t at = cur[best];                         /* (compare the others with the chosen head before it moves) */
+            for (d = 0; d < k.n_db; ++d) {
+                if (d != best && cur[d] < hi[d] && st_cmp(k.t[best], at, k.t[d], cur[d]) == 0) k.idx[d][k.n_sites] = (int32_t)cur[d]++;
+                else if (d != best) k.idx[d][k.n_sites] = -1;
+            }
+            k.idx[best][k.n_sites] = (int32_t)cur[best]++;
+        }
+        ++k.n_sites;
+    }
+    /* counts: one device pass per database over the rows its sites use, the databases side by side */
+    memset(scan, 0, sizeof(scan));
+    if (k.need_counts) {
+        for (d = 0; d < k.n_db; ++d) {
+            const sitetab_t *t = k.t[d];
+            int64_t row_min = INT64_MAX, row_max = -1;
+            for (i = lo[d]; i < hi[d]; ++i) { if (t->row[i] < row_min) row_min = t->row[i]; if (t->row[i] > row_max) row_max = t->row[i]; }
+            if (row_max < 0) { k.row_min[d] = 0; continue; }
+            k.row_min[d] = row_min;
+            scan[d].rd = ((devrd_t*)bm->bgt[d]->pb)->rd; scan[d].r0 = row_min; scan[d].r1 = row_max + 1;
+            scan[d].counts = (int32_t*)malloc((size_t)(row_max - row_min + 1) * (size_t)k.cstride * 4);
+            if (scan[d].counts == NULL) { failed = 1; break; }
+            k.counts[d] = scan[d].counts;
+            if (d > 0 && pthread_create(&scan[d].th, NULL, bulk_scan_worker, &scan[d]) == 0) scan[d].started = 1;
+        }
+        for (d = 0; d < k.n_db && !failed; ++d) if (scan[d].rd && !scan[d].started) bulk_scan_worker(&scan[d]);
+        for (d = 0; d < k.n_db; ++d) {
+            if (scan[d].started) pthread_join(scan[d].th, NULL);
+            if (scan[d].rd && scan[d].rc < 0) { fprintf(stderr, "[E::%s] %s\n", __func__, scan[d].err); failed = 2; }
+        }
+        if (failed) {
+            for (d = 0; d < k.n_db; ++d) { free(scan[d].counts); free(k.idx[d]); }
+            free(k.lead);
+            return failed == 2 ? -2 : -1;
         }
     }
-    k.bm = bm; k.t = t; k.lo = lo; k.hi = hi; k.row_min = row_min; k.counts = counts; k.need_counts = need_counts;
     k.blk_sites = 8192;
-    k.n_blocks = (hi - lo + k.blk_sites - 1) / k.blk_sites;
+    k.n_blocks = (k.n_sites + k.blk_sites - 1) / k.blk_sites;
     k.out = (kstring_t*)calloc((size_t)k.n_blocks, sizeof(kstring_t));
     k.n_lines = (int64_t*)calloc((size_t)k.n_blocks, 8);
     k.done = (volatile int*)calloc((size_t)k.n_blocks, sizeof(int));
@@ -1870,8 +1938,12 @@ long bgtm_write_vcf_bulk(bgtm_t *bm, FILE *fp, long n_rec)
     }
     for (j = 0; j < n_threads; ++j) pthread_join(th[j], NULL);
     pthread_mutex_destroy(&k.lock); pthread_cond_destroy(&k.cond);
-    bm->n_gt_read += (uint64_t)(hi - lo) * (uint64_t)bgt->n_out;
-    ((cursor_t*)bgt->bcf)->next = hi;
-    free(k.out); free(k.n_lines); free((void*)k.done); free(counts);
+    for (d = 0; d < k.n_db; ++d) {
+        bm->n_gt_read += (uint64_t)(hi[d] - lo[d]) * (uint64_t)bm->bgt[d]->n_out;
+        ((cursor_t*)bm->bgt[d]->bcf)->next = hi[d];
+        free(scan[d].counts); free(k.idx[d]);
+    }
+    free(k.lead);
+    free(k.out); free(k.n_lines); free((void*)k.done);
     return written;
 }
