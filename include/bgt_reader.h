@@ -179,6 +179,7 @@ void  bed_destroy(void *bed);
 
 /* ---- command line front ends: `bgt view` (reference view.c:14-183), `bgt import` (import.c:8-120) ---- */
 int main_view(int argc, char *argv[]);
+int main_pbfview(int argc, char **argv);   /* `bgt pbfview` (reference pbfview.c) */
 int main_import(int argc, char *argv[]);
 
 #ifdef __cplusplus
