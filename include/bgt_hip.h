@@ -97,7 +97,12 @@ void            bgth_encoder_close(bgth_encoder_t *e);
 double          bgth_encoder_kernel_ms(const bgth_encoder_t *e);           /* device time of the encode kernels   */
 const char     *bgth_encoder_last_error(void);
 
-/* ---- reader ---- */
+/* ---- reader ----
+ * A reader belongs to one image and one caller thread at a time (its own HIP stream, selection tables, result buffers);
+ * any number of readers may work on one image concurrently (reference bgt.h:27: many bgt_t over one bgt_file_t).  Readers
+ * are pooled per image: bgth_reader_destroy hands the reader -- stream, events, device and pinned buffers -- back to its
+ * image, bgth_reader_create takes one from there and resets it to the state of a new reader (all columns, one group, row 0),
+ * so a resident process pays for those allocations once.  Destroy every reader before closing its image. */
 bgth_reader_t *bgth_reader_create(bgth_pbf_t *p);
 void           bgth_reader_destroy(bgth_reader_t *r);
 
