@@ -428,8 +428,8 @@ def secondary_record(torch, bgt_amd, np, peak, name, what, n_samples, sites, see
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c2", choices=sorted(SAMPLES))
     ap.add_argument("--sites", type=int, default=0, help="sites per GPU (default 1,000,000; c4: all 10,000,000 split over the GPUs)")
     ap.add_argument("--every", type=int, default=0, help="select every N-th sample only (C3: --workload c3 --every 20)")
