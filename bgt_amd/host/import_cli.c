@@ -472,7 +472,7 @@ static bcf_hdr_t *site_header(const bcf_hdr_t *h0)
     bcf_hdr_t *h;
     int i, n_added = 1;
     for (p = h0->text; (p = strstr(p, "#CHROM\t")) != NULL; ++p) if (p == h0->text || p[-1] == '\n') { chrom = p; break; }
-    if (chrom == NULL || chrom < h0->text) return NULL;
+    if (chrom == NULL || chrom < h0->text || (size_t)(chrom - h0->text) > (size_t)INT32_MAX) return NULL;
     for (p = chrom, i = 0; i < 8 && (p = strchr(p, '\t')) != NULL; ++i) ++p;      /* p: behind the tab after INFO, or NULL */
     ks_putn(&s, h0->text, (size_t)(chrom - h0->text));
     if (bcf_id2int(h0, BCF_DT_ID, "GT") < 0) { ks_puts(&s, "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n"); ++n_added; }
