@@ -47,13 +47,11 @@ MY_BIN = os.path.join(ROOT, "bgt_amd", "bin", "bgt")
 def lookup_peak(bgt_amd, device):
     """G rank-lookups/s the chip sustains running only the product's row step (live microbenchmark, ~40 ms)."""
     import ctypes as C
-    L = bgt_amd.lib()
-    L.bgth_debug_issue_rate.restype = C.c_int
-    L.bgth_debug_issue_rate.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    L = bgt_amd.bench_lib()                                                       # measurement tools: not in the product library
     out = (C.c_double * 4)()
     iters, waves = 20000, 4
     if L.bgth_debug_issue_rate(device, 7, waves, iters, out) != 0:            # mix 7: step4 + ds_read_b64, random entries
-        raise RuntimeError(bgt_amd.last_error())
+        raise RuntimeError("bgth_debug_issue_rate failed")
     cycles, ms, valu = out[0], out[1], out[2]
     lookups = 256.0 * (4 * waves) * 64 * (valu / 8.0)                           # CUs x waves x lanes x lookups per wave
     return {"g_lookups_per_s": lookups / (ms * 1e-3) / 1e9, "cycles_per_valu_instr": cycles / (waves * valu),

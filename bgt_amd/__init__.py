@@ -6,7 +6,7 @@ gfx950 kernels for PBWT run-length decode, rank-tracking column reconstruction, 
 that ABI for tests, the benchmark and multi-GPU launch (torch.distributed over RCCL); it contains no
 decoder of its own and raises if the HIP library or a device is missing.
 """
-from .hip import (HipEncoder, HipFilter, HipPbf, HipReader, build_host_shell, build_library, host_lib, device_count, library_path, last_error, lib,  # noqa: F401
+from .hip import (bench_lib, HipEncoder, HipFilter, HipPbf, HipReader, build_host_shell, build_library, host_lib, device_count, library_path, last_error, lib,  # noqa: F401
                   shard_ranges, synth_rows)
 
-__all__ = ["HipEncoder", "HipFilter", "HipPbf", "HipReader", "build_host_shell", "build_library", "host_lib", "device_count", "library_path", "last_error", "lib", "shard_ranges", "synth_rows"]
+__all__ = ["bench_lib", "HipEncoder", "HipFilter", "HipPbf", "HipReader", "build_host_shell", "build_library", "host_lib", "device_count", "library_path", "last_error", "lib", "shard_ranges", "synth_rows"]

@@ -125,7 +125,10 @@ struct bgth_pbf_s {
 // Test / tuning knob BGTH_VARIANT: picks between kernel variants that all give the SAME results (like bgth_reader_tune):
 //   1 = team mode without the separate toggle array (the code path of cohorts too wide for it)
 //   2 / 4 = never / always the kernels with the all-zero-plane-1 shortcut
-enum { kVariantNoTog = 1, kVariantNeverZP = 2, kVariantAlwaysZP = 4, kVariantNoPrefetch = 16 };   // 16: no window prefetch in the pull interface
+//   32 / 64 = always / never the directory path (rows built once into an HBM arena, walk-only workgroups; default: wide
+//   cohorts whose columns span several workgroups);  128 = no reuse of an arena that already holds the rows of a scan
+enum { kVariantNoTog = 1, kVariantNeverZP = 2, kVariantAlwaysZP = 4, kVariantNoPrefetch = 16,    // 16: no window prefetch in the pull interface
+       kVariantDirAlways = 32, kVariantDirNever = 64, kVariantDirNoReuse = 128, kVariantDirNoWarm = 256 };
 static bool variant_flag(int bit) { const char *d = getenv("BGTH_VARIANT"); return d && (atoi(d) & bit); }
 
 // Builds the row index once per image; later calls only return it.  The build is enqueued on `s`, the
@@ -202,6 +205,14 @@ struct bgth_reader_s {
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     DevBuf raw, fin, h0, h1, gt;      // scratch of every scan; results of bgth_reader_scan
+    // directory path: the arena of {bits, ones before} rows and their zero counts; [dir_lo, dir_hi) = image rows it holds
+    // from the last producer pass (a later scan inside that range only walks), dir_passes/dir_built = what the last scan did
+    DevBuf dir, dir_n0;
+    int64_t dir_lo = 0, dir_hi = 0;
+    hipStream_t dir_stream = nullptr; // the stream the arena was filled on (another stream would have to wait for it)
+    int dir_passes = 0, dir_built = 0;
+    float dir_build_ms = 0;
+    hipEvent_t ev_dir[2] = {nullptr, nullptr};
     DevBuf carriers, hapsig;          // allele-set accumulators (bgth_reader_fold_last), zeroed when folds_live turns true
     bool folds_live = false;
     PullWindow win[2];                // pull interface: current window and the one being prefetched
@@ -936,7 +947,9 @@ static void reader_free(bgth_reader_t *r)
     r->raw.release(); r->fin.release(); r->h0.release(); r->h1.release(); r->gt.release();
     r->carriers.release(); r->hapsig.release();
     r->win[0].release(); r->win[1].release();
+    r->dir.release(); r->dir_n0.release();
     for (int i = 0; i < 4; ++i) if (r->ev[i]) hipEventDestroy(r->ev[i]);
+    for (int i = 0; i < 2; ++i) if (r->ev_dir[i]) hipEventDestroy(r->ev_dir[i]);
     if (r->stream) hipStreamDestroy(r->stream);
     delete r;
 }
@@ -963,12 +976,14 @@ extern "C" bgth_reader_t *bgth_reader_create(bgth_pbf_t *p)
         r->ret[0] = r->ret[1] = nullptr; r->last_counts = nullptr; r->last_gt8 = nullptr; r->last_gttext = nullptr;
         r->folds_live = false;
         r->cur = 0;
+        r->dir_lo = r->dir_hi = 0;                  // (a selection change does not invalidate the arena, a new query may not rely on it)
         for (PullWindow &w : r->win) w.valid = w.pending = false;
     } else {
         r = new bgth_reader_s();
         r->pbf = p;
         HIP_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking), { reader_free(r); return nullptr; });
         for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&r->ev[i]), { reader_free(r); return nullptr; });
+        for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreate(&r->ev_dir[i]), { reader_free(r); return nullptr; });
     }
     if (!guarded("bgth_reader_create", false, [&] { return build_selection(r->sel, p->m, 0, nullptr, nullptr, 1); })) { reader_free(r); return nullptr; }
     for (bgth_pbf_t *sh : p->shards) {
@@ -989,10 +1004,11 @@ extern "C" void bgth_reader_destroy(bgth_reader_t *r)
     {   // a reader that served a big streaming query does not keep its windows (up to 2 x 256 MiB pinned + as much HBM)
         size_t held = 0;
         for (const PullWindow &w : r->win) held += w.h_counts.cap + w.h_planes.cap + w.h_gt8.cap + w.h_gttext.cap;
-        if (held > ((size_t)64 << 20)) {
+        if (held > ((size_t)64 << 20) || r->dir.cap > ((size_t)256 << 20)) {
             hipSetDevice(r->pbf->device);
             if (r->stream) hipStreamSynchronize(r->stream);
-            r->win[0].release(); r->win[1].release();
+            if (held > ((size_t)64 << 20)) { r->win[0].release(); r->win[1].release(); }
+            if (r->dir.cap > ((size_t)256 << 20)) { r->dir.release(); r->dir_n0.release(); r->dir_lo = r->dir_hi = 0; }
         }
     }
     {   // (not waiting for the stream: a window prefetched behind the last row read may still be on its way -- it lands in
@@ -1034,6 +1050,34 @@ extern "C" int bgth_reader_tune(bgth_reader_t *r, int threads, int cpt, int K)
 
 static int gx_of(int G) { return G > 1 ? G : 0; }
 
+// ---- directory path (scan_dir.hip) ------------------------------------------------------------------
+// Bytes the arena of a reader may take: BGTH_DIR_ARENA_MB, default 60 % of the HBM that is free when first asked.
+static size_t dir_arena_cap(int device)
+{
+    if (const char *e = getenv("BGTH_DIR_ARENA_MB")) return (size_t)std::max(1ll, atoll(e)) << 20;
+    static std::mutex lock;
+    static std::vector<size_t> cap;
+    std::lock_guard<std::mutex> g(lock);
+    if ((size_t)device >= cap.size()) cap.resize(device + 1, 0);
+    if (!cap[device]) {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess) fr = (size_t)8 << 30;
+        cap[device] = fr / 10 * 6;
+    }
+    return cap[device];
+}
+
+// Should this scan build its rows once into the arena and walk them from there?  Yes for a wide cohort whose columns
+// span several workgroups (every slice of the team kernels rebuilds the row); BGTH_VARIANT 32 / 64 force / forbid it.
+static bool want_dir_path(const bgth_pbf_t *p, const Geometry &classic, bool tuned)
+{
+    if (variant_flag(kVariantDirNever)) return false;
+    if (variant_flag(kVariantDirAlways)) return true;
+    if (use_zp(p)) return false;                         // (the walk-only kernel has no empty-plane shortcut: it looks plane 1 up)
+    if (tuned) return false;                             // bgth_reader_tune names a classic geometry
+    return classic.nbuf == 1 && classic.wpp > 1 && classic.slices >= 2;
+}
+
 // enqueue decode+reduce of [row0,row1) on stream s; results in d_fin (+ optional planes)
 static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_t *d_fin, uint64_t *d_h0,
                             uint64_t *d_h1, hipStream_t s, bool timed)
@@ -1050,10 +1094,19 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
         set_err("[E::bgth_reader_scan] no launch geometry for m=%d (threads=%d cpt=%d)", p->m, r->tune_threads, r->tune_cpt);
         return -1;
     }
-    r->geom = geo;
+    bool dirpath = want_dir_path(p, geo, r->tune_threads || r->tune_cpt || r->tune_K);
+    Geometry wgeo;
+    if (dirpath) {
+        int wt = 0, wc = 0;                              // BGTH_WALK_GEOM=threads,cols: tuning knob of the walk-only kernel
+        if (const char *e = getenv("BGTH_WALK_GEOM")) sscanf(e, "%d,%d", &wt, &wc);
+        if (!choose_walk_geometry(p->m, r->sel.n_chunks, G, (int)(blk1 - blk0 + 1), wt, wc, &wgeo)) dirpath = false;
+    }
+    r->geom = dirpath ? wgeo : geo;
+    r->dir_passes = r->dir_built = 0;
     if (!r->raw.reserve((size_t)rows * G * 3 * 4)) { set_err("[E::bgth_reader_scan] out of HBM"); return -1; }
     ScanArgs a;
-    if (!common_scan_args(a, p, r->sel, geo, s)) return -1;
+    if (dirpath) { Geometry team = wgeo; team.wpp = 2; if (!common_scan_args(a, p, r->sel, team, s)) return -1; a.wpp = wgeo.wpp; }   // (wpp > 1: row index)
+    else if (!common_scan_args(a, p, r->sel, geo, s)) return -1;
     a.shift = p->sub_shift;                              // units = sub-blocks
     a.rank0_blk_stride = (int64_t)2 * p->m;
     a.raw_counts = (int32_t*)r->raw.p;
@@ -1073,10 +1126,56 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
     }
 #endif
     if (timed) HIP_TRY(hipEventRecord(r->ev[0], s), return -1);
-    if (G > 1 || geo.slices > 1)                             // a single-group, single-slice launch stores its counts
+    if (G > 1 || r->geom.slices > 1)                         // a single-group, single-slice launch stores its counts
         HIP_TRY(hipMemsetAsync(r->raw.p, 0, (size_t)rows * G * 3 * 4, s), return -1);
     if (timed) HIP_TRY(hipEventRecord(r->ev[1], s), return -1);
-    HIP_TRY(launch_scan(a, geo, s), return -1);
+    if (!dirpath) HIP_TRY(launch_scan(a, geo, s), return -1);
+    else {
+        // Passes over ranges of sub-blocks whose rows fit the arena: producer, then the walk-only kernel.  An arena that
+        // already holds the rows of this scan (the previous scan of this reader covered them in one pass) is walked as is.
+        const int nwp = ((p->m + 31) / 32 + 2) & ~1;
+        const size_t row_bytes = (size_t)2 * nwp * 8;
+        const int64_t sub_rows = (int64_t)1 << p->sub_shift;
+        const int64_t first = blk0 << p->sub_shift;                                  // decoding starts at a sub-checkpoint
+        const bool reuse = !variant_flag(kVariantDirNoReuse) && r->dir.p && r->dir_stream == s && r->dir_lo <= first && row1 <= r->dir_hi;
+        int64_t per_pass = blk1 - blk0 + 1;
+        if (!reuse) {
+            const size_t cap = dir_arena_cap(p->device);
+            const int64_t fit = (int64_t)(cap / (row_bytes * (size_t)sub_rows));
+            if (fit < 1) { set_err("[E::bgth_reader_scan] the directory arena (%zu MB) does not hold one sub-block of m=%d", cap >> 20, p->m); return -1; }
+            if (per_pass > fit) per_pass = std::max<int64_t>(8, fit / 8 * 8);     // whole XCD rounds of workgroups
+            if (per_pass > fit) per_pass = fit;
+            const int64_t arena_rows = std::min<int64_t>(per_pass * sub_rows, row1 - first);
+            if (!r->dir.reserve((size_t)arena_rows * row_bytes) || !r->dir_n0.reserve((size_t)arena_rows * 2 * 4)) {
+                r->dir_lo = r->dir_hi = 0;
+                set_err("[E::bgth_reader_scan] out of HBM (directory arena of %lld rows)", (long long)arena_rows);
+                return -1;
+            }
+            r->dir_lo = r->dir_hi = 0;
+        }
+        a.dir = (uint2*)r->dir.p;
+        a.dir_n0 = (uint32_t*)r->dir_n0.p;
+        a.dir_nwp = nwp;
+        a.dir_stage = wgeo.dir_stage | (variant_flag(kVariantDirNoWarm) ? 0 : 2);   // bit 1: warm the L2 with the next row's plane 1
+        for (int64_t b = blk0; b <= blk1; b += per_pass) {
+            const int64_t be = std::min(blk1 + 1, b + per_pass);
+            const int64_t lo = b << p->sub_shift, hi = std::min(row1, be << p->sub_shift);
+            Geometry pg = wgeo;
+            pg.workgroups = (int)(((be - b) + 7) / 8 * 8 * wgeo.slices);
+            a.blk0 = (int32_t)b;
+            a.n_blk = (int32_t)(be - b);
+            a.dir_row0 = reuse ? r->dir_lo : lo;
+            if (!reuse) {
+                if (timed && b == blk0) HIP_TRY(hipEventRecord(r->ev_dir[0], s), return -1);
+                HIP_TRY(launch_dirbuild(a, lo, hi, s), return -1);
+                if (timed && b == blk0) HIP_TRY(hipEventRecord(r->ev_dir[1], s), return -1);
+                ++r->dir_built;
+            }
+            HIP_TRY(launch_walk(a, pg, s), return -1);
+            ++r->dir_passes;
+        }
+        if (!reuse && r->dir_passes == 1) { r->dir_lo = first; r->dir_hi = row1; r->dir_stream = s; }
+    }
     if (timed) HIP_TRY(hipEventRecord(r->ev[2], s), return -1);
     if (d_times) {
         unsigned long long h[8];
@@ -1099,6 +1198,8 @@ static void collect_timing(bgth_reader_t *r)
     if (hipEventElapsedTime(&t[1], r->ev[2], r->ev[3]) != hipSuccess) return;
     if (hipEventElapsedTime(&t[2], r->ev[0], r->ev[3]) != hipSuccess) return;
     r->t_ms[0] = t[0]; r->t_ms[1] = t[1]; r->t_ms[2] = t[2];
+    r->dir_build_ms = 0.f;
+    if (r->dir_built) hipEventElapsedTime(&r->dir_build_ms, r->ev_dir[0], r->ev_dir[1]);   // (first pass)
     r->t_pending = false;
 }
 
@@ -1201,6 +1302,15 @@ extern "C" int bgth_reader_last_timing(const bgth_reader_t *rc, float out[3])
     }
     if (r->t_pending) { hipSetDevice(r->pbf->device); collect_timing(r); }
     out[0] = r->t_ms[0]; out[1] = r->t_ms[1]; out[2] = r->t_ms[2];
+    return 0;
+}
+
+extern "C" int bgth_reader_last_path(const bgth_reader_t *rc, float out[4])
+{
+    bgth_reader_t *r = const_cast<bgth_reader_t*>(rc);
+    if (!r->subs.empty()) return bgth_reader_last_path(r->subs[0], out);
+    if (r->t_pending) { hipSetDevice(r->pbf->device); collect_timing(r); }
+    out[0] = r->geom.dir_stage >= 0 ? 1.f : 0.f; out[1] = (float)r->dir_passes; out[2] = (float)r->dir_built; out[3] = r->dir_build_ms;
     return 0;
 }
 
@@ -1536,19 +1646,3 @@ extern "C" int bgth_debug_stream_read(int device, size_t bytes, int width, int r
     hipFree(buf); hipFree(sink);
     return 0;
 }
-
-// Issue-rate calibration behind the roofline of the scan kernel: see microbench.hip.
-extern "C" int bgth_debug_issue_rate(int device, int mix, int waves_per_simd, int iters, double out[4])
-{
-    if (!use_device(device)) return -1;
-    HIP_TRY(run_issue_rate(mix, waves_per_simd, iters, out), return -1);
-    return 0;
-}
-extern "C" const char *bgth_debug_issue_rate_name(int mix) { return issue_rate_mix_name(mix); }
-extern "C" int bgth_debug_op_rate(int device, int op, int waves_per_simd, int iters, double out[3])
-{
-    if (!use_device(device)) return -1;
-    HIP_TRY(run_op_rate(op, waves_per_simd, iters, out), return -1);
-    return 0;
-}
-extern "C" const char *bgth_debug_op_rate_name(int op) { return op_rate_name(op); }

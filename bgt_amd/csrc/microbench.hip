@@ -323,3 +323,18 @@ hipError_t run_issue_rate(int mix, int waves_per_simd, int iters, double out[4])
 const char *issue_rate_mix_name(int mix) { return mix >= 0 && mix < MIX_N ? kMix[mix].name : nullptr; }
 
 }  // namespace bgth
+
+// ---- C entry points of libbgt_hip_bench.so (include/bgt_hip_bench.h).  The calibration kernels are measurement
+// tools, not product: they live in a library of their own that bench.py and scripts/valu_calibration.py load.
+extern "C" int bgth_debug_issue_rate(int device, int mix, int waves_per_simd, int iters, double out[4])
+{
+    if (hipSetDevice(device) != hipSuccess) return -1;
+    return bgth::run_issue_rate(mix, waves_per_simd, iters, out) == hipSuccess ? 0 : -1;
+}
+extern "C" const char *bgth_debug_issue_rate_name(int mix) { return bgth::issue_rate_mix_name(mix); }
+extern "C" int bgth_debug_op_rate(int device, int op, int waves_per_simd, int iters, double out[3])
+{
+    if (hipSetDevice(device) != hipSuccess) return -1;
+    return bgth::run_op_rate(op, waves_per_simd, iters, out) == hipSuccess ? 0 : -1;
+}
+extern "C" const char *bgth_debug_op_rate_name(int op) { return bgth::op_rate_name(op); }

@@ -37,6 +37,12 @@ constexpr int kThreads = 1024;                 // one word of the bit-vector per
 constexpr int kMaxM = kThreads * 32;             // registers hold the ranks up to here
 constexpr int kMaxWideM = kThreads * 32 * 8;     // beyond: ranks in memory, up to 8 directory words per thread
 
+#ifdef BGTH_ABLATE
+#define ENC_ABLATE(a, bits) ((a).debug & (bits))
+#else
+#define ENC_ABLATE(a, bits) 0
+#endif
+
 struct EncodeArgs {
     const uint8_t *codes;      // [n_rows][CPT * 1024]  bit k of a byte = plane k, zero beyond column m
     int64_t n_rows, row0;      // row0 = file row of codes[0]
@@ -54,7 +60,8 @@ struct EncodeArgs {
     const int32_t *snap_base;  // [n_units] index of the first of them in each unit
     int32_t n_snap;
     int32_t *status;           // != 0: output capacity exceeded
-    int32_t debug;             // BGTH_ENC_DEBUG: ablation switches for timing (1 no byte stores, 2 no run passes, 4 no run list)
+    int32_t debug;             // profiling build only (make ABLATE=1): BGTH_ENC_DEBUG ablation switches for timing (1 no byte
+                               // stores, 2 no run passes, 4 no run list); the shipped encoder compiles them out (ENC_ABLATE = 0)
 };
 
 // inclusive prefix sum / prefix maximum over the 64 lanes in the VALU (DPP row shifts + the two row broadcasts);
@@ -183,7 +190,7 @@ __global__ __launch_bounds__(kThreads) void encode_kernel(EncodeArgs a)
                 const uint32_t se = wave_incl_add(ve);
                 n_runs = lane_value(se, 15);
                 uint32_t k = (wave ? lane_value(se, wave - 1) : 0u) + incl_e - ne;
-                if (!(a.debug & 4)) for (uint32_t x = ends; x; x &= x - 1u) run_end[k++] = (uint16_t)(tid * 32 + __builtin_ctz(x));
+                if (!ENC_ABLATE(a, 4)) for (uint32_t x = ends; x; x &= x - 1u) run_end[k++] = (uint16_t)(tid * 32 + __builtin_ctz(x));
                 first_bit = agg[3][0];
             }
         }
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(kThreads) void encode_kernel(EncodeArgs a)
         // the runs dealt evenly to the threads (a row of C2 has ~165: three waves emit, thirteen only take part in the scan)
         const uint32_t rpt = (n_runs + kThreads - 1) >> 10, k0 = (uint32_t)tid * rpt, k1 = k0 + rpt < n_runs ? k0 + rpt : n_runs;
         uint32_t nb = 0;
-        if (EMIT && !(a.debug & 2))
+        if (EMIT && !ENC_ABLATE(a, 2))
             for (uint32_t k = k0; k < k1; ++k) nb += run_bytes((uint32_t)run_end[k] - (k ? (uint32_t)run_end[k - 1] : 0xffffffffu));
         uint32_t bbase = 0, total = 0, incl2 = 0;
         if (EMIT) {
@@ -204,7 +211,7 @@ __global__ __launch_bounds__(kThreads) void encode_kernel(EncodeArgs a)
             bbase = wave ? lane_value(sb, wave - 1) : 0u;
         }
         if (EMIT && off + (int64_t)total > a.cap) { if (tid == 0) *a.status = 1; break; }  // uniform
-        if (EMIT && !(a.debug & 3)) {
+        if (EMIT && !ENC_ABLATE(a, 3)) {
             uint8_t *dst = out + off + bbase + incl2 - nb;
             for (uint32_t k = k0; k < k1; ++k)
                 dst += put_run(dst, (uint32_t)run_end[k] - (k ? (uint32_t)run_end[k - 1] : 0xffffffffu), first_bit ^ (k & 1u));
@@ -699,7 +706,11 @@ static int encode_batch(bgth_encoder_t *e, const uint8_t *codes, int64_t rows, b
     const size_t gm = (size_t)g * m;
     EncodeArgs a;
     a.codes = e->d_codes; a.n_rows = rows; a.row0 = e->n; a.m = m; a.mask = (int32_t)mask; a.g = g; a.unit_rows = (int32_t)unit_rows; a.stride = e->stride;
+#ifdef BGTH_ABLATE
     a.debug = getenv("BGTH_ENC_DEBUG") ? atoi(getenv("BGTH_ENC_DEBUG")) : 0;
+#else
+    a.debug = 0;
+#endif
     a.out = e->d_out; a.cap = unit_rows * (int64_t)m; a.out_len = e->d_out_len; a.row_len = e->d_row_len;
     a.snap = e->d_snap; a.snap_base = e->d_snap_base; a.n_snap = n_snap; a.status = e->d_status;
     if (packed) {                                           // a quarter of the bytes over PCIe, spread on the device

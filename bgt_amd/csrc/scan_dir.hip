@@ -1,0 +1,354 @@
+// Directory path for wide cohorts (m = 200,000: a row's two bit-vectors with their rank directory are 100 KB).
+//
+// The team kernels of scan_wide.hip rebuild every row's {bits, ones before} directory in each of the column slices
+// that share a sub-block (4 at m = 200,000): a third of their VALU instructions and most of their barrier time.
+// Here the row is built ONCE:
+//
+//   dirbuild_kernel   RLE string -> toggles (LDS) -> directory entries, written to an HBM arena.  Every plane-row is an
+//                     independent unit of work (its chunk positions and trip carries come from the row index), so the
+//                     kernel runs with small workgroups at high occupancy instead of inside a 256-VGPR walker.
+//   walk_kernel       workgroup = (sub-block, column slice) as before; the ranks of its columns stay in VGPRs, the row
+//                     comes from the arena by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no VALU) into one of three
+//                     50 KB plane buffers: plane 0 of row r+1 lands while row r is walked, plane 1 of row r+1 goes to
+//                     plane 1 of row r's buffer after the barrier that ends the walk.  No toggle array, no build.
+//
+// Same arithmetic as the other kernels (reference pbwt.c:69-90, 129-170; bgt.c:735-757); the row step is the
+// hand-scheduled statement of scan_device.inc.h.
+#include "scan_device.inc.h"
+
+namespace bgth {
+
+static const int kLdsBytesDir = 160 * 1024;
+
+// ----------------------------------------------------------------------------------------------------
+// producer
+// ----------------------------------------------------------------------------------------------------
+// Workgroup = team of NT/64 waves over a contiguous range of plane-rows; two toggle arrays alternate so that one
+// barrier per plane-row suffices:  toggles(i) | barrier | directory(i) (reads and clears the array) ; toggles(i+1) ...
+template <int NT>
+__global__ __launch_bounds__(NT) void dirbuild_kernel(const ScanArgs a, const uint64_t *__restrict__ rowdesc,
+                                                      const uint8_t *__restrict__ rle, const uint32_t *__restrict__ chunkinfo,
+                                                      const uint32_t *__restrict__ segc, int64_t str_lo, int64_t str_hi, int per_wg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int WPP = NT / 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int tw = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = a.m, nw = a.nw, nwp = a.dir_nwp;
+    const int nwt = (nw + 4) & ~3;
+    uint32_t *TOG = reinterpret_cast<uint32_t*>(smem);                   // [2][nwt]
+    for (int i = tid; i < 2 * nwt; i += NT) TOG[i] = 0u;
+    lds_barrier();
+    const uint32_t tail_mask = (m & 31) ? ((1u << (m & 31)) - 1u) : 0xffffffffu;
+    const int ntrip = (nw + 255) >> 8;
+    const int64_t s0 = str_lo + (int64_t)blockIdx.x * per_wg;
+    int64_t s1 = s0 + per_wg;
+    if (s1 > str_hi) s1 = str_hi;
+
+    uint64_t desc = s0 < s1 ? rowdesc[s0] : 0ull;
+    for (int64_t sidx = s0; sidx < s1; ++sidx) {
+        uint32_t *trow = TOG + (size_t)((sidx - s0) & 1) * nwt;
+        const uint64_t cd0 = desc;
+        if (sidx + 1 < s1) desc = rowdesc[sidx + 1];
+        const uint32_t slen = (uint32_t)(cd0 >> kDescLenShift);
+        const uint64_t off = cd0 & kDescOffMask;
+        // carries of this wave's directory trips (lane u <-> trip tw + u * WPP) and the row's number of ones
+        const uint32_t *sc = segc + (size_t)sidx * (size_t)(a.S8 + 1);
+        const int t = tw + lane * WPP;
+        const uint32_t cyl = t < ntrip ? sc[t] : 0u;
+        const uint32_t tot1 = sc[a.S8];
+        for (int c = tw; (uint32_t)c * 256u < slen; c += WPP) {
+            const uint32_t k0 = (uint32_t)c * 256u + 4u * (uint32_t)lane;
+            const uint32_t w = k0 < slen ? reinterpret_cast<const uint32_t*>(rle + off)[c * 64 + lane] : 0u;
+            const uint32_t ci = chunkinfo[((off + (uint64_t)c * 256u) >> 8) + (uint64_t)sidx];
+            if (ci & kChunkDead) break;                                  // behind a terminating zero byte
+            const ChunkDecode cd = decode_chunk(w, k0, slen, lane);
+            chunk_toggles(a, trow, 1, cd, ci & kChunkPosMask, ci >> 31, lane);
+        }
+        lds_barrier();
+        uint2 *dst = a.dir + (size_t)(sidx - 2 * a.dir_row0) * (size_t)nwp;
+        directory_trips_tog<2>(trow, dst, tw, WPP, ntrip, nw, tail_mask, cyl, lane);
+        if (tw == 0 && lane == 0) {
+            for (int i = nw; i < nwp; ++i) dst[i] = make_uint2(0u, 0u);  // the sentinel entry padding slots read
+            a.dir_n0[sidx - 2 * a.dir_row0] = (uint32_t)m - tot1;
+        }
+    }
+}
+
+hipError_t launch_dirbuild(const ScanArgs &a, int64_t row_lo, int64_t row_hi, hipStream_t s)
+{
+    if (row_hi <= row_lo) return hipSuccess;
+    const int nwt = (a.nw + 4) & ~3;
+    const int lds = 2 * nwt * 4;
+    if (lds > kLdsBytesDir) return hipErrorInvalidConfiguration;
+    auto fn = dirbuild_kernel<256>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    const int64_t n_str = 2 * (row_hi - row_lo);
+    // plane-rows per workgroup: enough to amortise the start of a workgroup, few enough to spread short ranges over the chip
+    int per_wg = 16;
+    while (per_wg > 2 && (n_str + per_wg - 1) / per_wg < 3072) per_wg >>= 1;
+    const int64_t grid = (n_str + per_wg - 1) / per_wg;
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(256), lds, s, a, a.rowdesc, a.rle, a.chunkinfo, a.segc,
+                       2 * row_lo, 2 * row_hi, per_wg);
+    return hipGetLastError();
+}
+
+// ----------------------------------------------------------------------------------------------------
+// consumer
+// ----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <int NT, int CPT, bool MULTI, bool GT, bool S4>
+__global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32_t *__restrict__ n0tab)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NWAVE = NT / 64;
+    static_assert(CPT % 2 == 0, "columns per thread are stepped in pairs");
+    static_assert(CPT * 64 < 65536, "per-wave counts of a row are kept in 16 bits");
+    const int tid  = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int S   = a.n_slices;                                          // (sub-block, slice): all slices of a sub-block on one XCD
+    const int wg  = blockIdx.x;
+    const int sup = wg / (8 * S), rem = wg % (8 * S);
+    const int slice = rem >> 3;
+    const int bl    = sup * 8 + (rem & 7);
+    if (bl >= a.n_blk) return;
+
+    const int m = a.m, nw = a.nw, nwp = a.dir_nwp, G = a.G;
+    const uint32_t plane_bytes = (uint32_t)nwp * 8u;                     // multiple of 16
+    const bool staged = a.dir_stage & 1, warm = a.dir_stage & 2;
+    const int nplane = staged ? 3 : 2;
+    int32_t *lcnt = reinterpret_cast<int32_t*>(smem + (size_t)nplane * plane_bytes);   // [2][cnt_stride]: rows alternate
+    const int cnt_stride = MULTI ? G * 3 : NWAVE * 2;
+    const uint32_t pad_rank = 32u * (uint32_t)nw;
+    const uint32_t lds0 = __builtin_amdgcn_groupstaticsize();
+
+    const int64_t blk      = (int64_t)a.blk0 + bl;
+    const int64_t blk_beg  = blk << a.shift;
+    int64_t       blk_end  = (blk + 1) << a.shift;
+    if (blk_end > a.row1) blk_end = a.row1;
+
+    const int chunk0 = (slice * NWAVE + wave) * CPT;
+    uint32_t r0[CPT], r1[CPT];
+    {
+        const int32_t *rk = a.rank0 + blk * a.rank0_blk_stride;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int c = chunk0 + j;
+            const int col = c < a.n_chunks ? a.slot_col[c * 64 + lane] : -1;
+            r0[j] = ~(col >= 0 ? (uint32_t)rk[col] : pad_rank);         // complemented ranks (see the row step)
+            r1[j] = ~(col >= 0 ? (uint32_t)rk[m + col] : pad_rank);
+        }
+    }
+    if (MULTI) for (int i = tid; i < 2 * cnt_stride; i += NT) lcnt[i] = 0;
+
+    // LDS-DMA of one plane-row: pieces of 1 KiB (64 lanes x 16 bytes) dealt round-robin over the waves
+    const unsigned char *dirbase = reinterpret_cast<const unsigned char*>(a.dir);
+    const int npiece = (int)((plane_bytes + 1023u) >> 10);
+    auto dma_plane = [&](int buf, int64_t row, int plane) {
+        const unsigned char *src = dirbase + (size_t)(2 * (row - a.dir_row0) + plane) * plane_bytes;
+        for (int pc = wave; pc < npiece; pc += NWAVE) {
+            const uint32_t off = (uint32_t)pc * 1024u + (uint32_t)lane * 16u;
+            if (off < plane_bytes)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off),
+                                                 (__attribute__((address_space(3))) void*)(smem + (size_t)buf * plane_bytes + (size_t)pc * 1024u),
+                                                 16, 0, 0);
+        }
+    };
+
+    int c0 = 0, c1 = 1, st = 2;                                          // plane buffers: current row's planes, staging
+    if (blk_beg < blk_end) { dma_plane(c0, blk_beg, 0); dma_plane(c1, blk_beg, 1); }
+    wait_vm0();
+    lds_barrier();
+
+    for (int64_t row = blk_beg; row < blk_end; ++row) {
+        const bool more = row + 1 < blk_end;
+        if (staged && more) dma_plane(st, row + 1, 0);                   // lands during the walk
+        // Plane 1 of the next row can only be fetched when this row's buffer is free, i.e. behind the barrier that ends
+        // the walk; one dword per 128-byte line now (8 KB per wave-instruction) brings it into this XCD's L2 meanwhile.
+        uint32_t touched = 0;
+        if (warm && more) {
+            const uint32_t off = ((uint32_t)wave * 64u + (uint32_t)lane) * 128u;
+            if (off < plane_bytes)
+                touched = *reinterpret_cast<const uint32_t*>(dirbase + (size_t)(2 * (row + 1 - a.dir_row0) + 1) * plane_bytes + off);
+        }
+        // ---- walk the row: ranks stay in registers
+        {
+            const uint32_t base0 = lds0 + (uint32_t)c0 * plane_bytes - 8u;
+            const uint32_t base1 = lds0 + (uint32_t)c1 * plane_bytes - 8u;
+            const int64_t pr = 2 * (row - a.dir_row0);
+            const uint32_t n00 = 0u - n0tab[pr];
+            const uint32_t n01 = 0u - n0tab[pr + 1];
+            int32_t *lcb = lcnt + (int)(row & 1) * cnt_stride;
+            const bool emit = row >= a.row0;
+            uint32_t ca = 0, cb = 0, cc = 0;
+            constexpr int NKEEP = (CPT + 63) / 64;
+            uint64_t keep0[NKEEP] = {}, keep1[NKEEP] = {};
+            constexpr int STEP = S4 ? 4 : 2;                              // lookups in flight per statement: 8 or 4
+#pragma unroll
+            for (int j = 0; j < CPT; j += STEP) {
+                uint64_t m0[4] = {0, 0, 0, 0}, m1[4] = {0, 0, 0, 0};
+                const int NC = (CPT - j) >= STEP ? STEP : 2;              // CPT is even: the tail is one pair
+                if (NC == 4) {
+                    uint32_t q0[4] = {r0[j], r0[j + 1], r0[j + 2], r0[j + 3]};
+                    uint32_t q1[4] = {r1[j], r1[j + 1], r1[j + 2], r1[j + 3]};
+                    step4<false>(q0, q1, m0, m1, ca, cb, cc, base0, base1, n00, n01);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { r0[j + u] = q0[u]; r1[j + u] = q1[u]; }
+                } else {
+                    step2<false>(r0[j], r1[j], r0[j + 1], r1[j + 1], m0[0], m1[0], m0[1], m1[1], ca, cb, cc, base0, base1, n00, n01);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (u >= NC) break;
+                    if (GT && lane == ((j + u) & 63)) { keep0[(j + u) >> 6] = m0[u]; keep1[(j + u) >> 6] = m1[u]; }
+                    if (MULTI) {
+                        const int c = chunk0 + j + u;
+                        if (emit && lane == 0 && c < a.n_chunks) {
+                            int32_t *dst = lcb + (a.chunk_desc[c] & 255u) * 3;
+                            atomicAdd(dst + 0, __builtin_amdgcn_readfirstlane(__popcll(m0[u] & ~m1[u])));
+                            atomicAdd(dst + 1, __builtin_amdgcn_readfirstlane(__popcll(~m0[u] & m1[u])));
+                            atomicAdd(dst + 2, __builtin_amdgcn_readfirstlane(__popcll(m0[u] & m1[u])));
+                        }
+                    }
+                }
+            }
+            if (!MULTI && lane == 0)
+                reinterpret_cast<uint2*>(lcb)[wave] = make_uint2((ca - cc) | (cb - cc) << 16, cc);
+            if (GT && emit) {
+#pragma unroll
+                for (int q = 0; q < NKEEP; ++q) {
+                    const int c = q * 64 + lane;
+                    if (c < CPT && chunk0 + c < a.n_chunks) {
+                        const size_t at = (size_t)(row - a.row0) * a.n_chunks + chunk0 + c;
+                        a.h0[at] = keep0[q];
+                        a.h1[at] = keep1[q];
+                    }
+                }
+            }
+        }
+        asm volatile("" :: "v"(touched));                                // (the touch is waited for here, not before the walk)
+        wait_vm0();                                                      // this wave's pieces of the staged plane have landed
+        lds_barrier();                                                   // every wave is past its walk: both planes are free
+        // ---- counts of this row and slice -> HBM
+        {
+            int32_t *lcb = lcnt + (int)(row & 1) * cnt_stride;
+            if (row >= a.row0) {
+                if (MULTI) {
+                    for (int i = tid; i < G * 3; i += NT) {
+                        const int32_t v = lcb[i];
+                        if (v) { atomicAdd(a.raw_counts + (size_t)(row - a.row0) * G * 3 + i, v); lcb[i] = 0; }
+                    }
+                } else if (tid < 3) {
+                    const int comp = tid;
+                    int32_t v = 0;
+#pragma unroll
+                    for (int w = 0; w < NWAVE; ++w) {
+                        const uint32_t x = (uint32_t)lcb[w * 2 + (comp >> 1)];
+                        v += (int32_t)(comp == 0 ? x & 0xffffu : comp == 1 ? x >> 16 : x);
+                    }
+                    int32_t *dst = a.raw_counts + (size_t)(row - a.row0) * 3 + comp;
+                    if (a.n_slices == 1) *dst = v;
+                    else if (v) atomicAdd(dst, v);
+                }
+            }
+        }
+        if (more) {
+            if (staged) { const int nc0 = st; dma_plane(c1, row + 1, 1); st = c0; c0 = nc0; }
+            else { dma_plane(c0, row + 1, 0); dma_plane(c1, row + 1, 1); }
+            wait_vm0();
+            lds_barrier();
+        }
+    }
+
+    if (a.final_rank) {
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int c = chunk0 + j;
+            if (c < a.n_chunks) {
+                const int col = a.slot_col[c * 64 + lane];
+                if (col >= 0) { a.final_rank[col] = (int32_t)~r0[j]; a.final_rank[m + col] = (int32_t)~r1[j]; }
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------
+// geometry and launch
+// ----------------------------------------------------------------------------------------------------
+#define BGTH_WALK_GEOMS(X) X(512, 64) X(512, 80) X(512, 98) X(1024, 50)
+
+static int walk_lds_need(int nw, int G, int threads, int nplane)
+{
+    const int nwp = (nw + 2) & ~1;
+    const int cnt = G > 1 ? G * 3 * 4 : (threads / 64) * 8;
+    return nplane * nwp * 8 + 2 * cnt + 64;
+}
+
+bool choose_walk_geometry(int m, int n_chunks, int G, int n_blk, int want_threads, int want_cpt, Geometry *g)
+{
+    const int nw = (m + 31) / 32;
+    static const int geoms[][2] = {
+#define X(nt, cpt) {nt, cpt},
+        BGTH_WALK_GEOMS(X)
+#undef X
+    };
+    int best = -1;
+    long best_key = 0;
+    for (int i = 0; i < (int)(sizeof(geoms) / sizeof(geoms[0])); ++i) {
+        const int nt = geoms[i][0], cpt = geoms[i][1];
+        if (want_threads && nt != want_threads) continue;
+        if (want_cpt && cpt != want_cpt) continue;
+        if (walk_lds_need(nw, G, nt, 2) > kLdsBytesDir) continue;
+        const int cap = nt / 64 * cpt;
+        const long slices = (n_chunks + cap - 1) / cap;
+        const long waste = slices * cap - n_chunks;
+        // fewest slices (every slice pulls the whole row into its LDS); then four waves per SIMD rather than two (the row
+        // step issues at 4.0 instead of 4.6 cycles per instruction and the DMA waits hide better: m = 200,000, 262,144
+        // sites, 28.1 ms with 1024 x 50 against 30.7 ms with 512 x 98); then least idle slots
+        const long key = slices * 10000000 + (nt == 1024 ? 0 : 1000000) + waste;
+        if (best < 0 || key < best_key) best = i, best_key = key;
+    }
+    if (best < 0) return false;
+    g->threads = geoms[best][0];
+    g->cpt = geoms[best][1];
+    const int cap = g->threads / 64 * g->cpt;
+    g->slices = (n_chunks + cap - 1) / cap;
+    g->K = 1; g->wpp = g->threads / 64; g->nbuf = 1; g->tog_off = 0;
+    g->dir_stage = walk_lds_need(nw, G, g->threads, 3) <= kLdsBytesDir ? 1 : 0;
+    g->lds_bytes = (walk_lds_need(nw, G, g->threads, g->dir_stage ? 3 : 2) + 15) & ~15;
+    g->workgroups = ((n_blk + 7) / 8) * 8 * g->slices;
+    return true;
+}
+
+template <int NT, int CPT, bool MULTI, bool GT>
+static hipError_t launch_walk_one(const ScanArgs &a, const Geometry &g, hipStream_t s)
+{
+    auto fn = walk_kernel<NT, CPT, MULTI, GT, (NT <= 512)>;           // 1024 threads: 128 VGPRs, lookups in pairs (8 scratch registers)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fn, dim3(g.workgroups), dim3(NT), g.lds_bytes, s, a, a.dir_n0);
+    return hipGetLastError();
+}
+
+hipError_t launch_walk(const ScanArgs &a, const Geometry &g, hipStream_t s)
+{
+    const int v = (a.G > 1 ? 2 : 0) | (a.h0 ? 1 : 0);
+#define X(NT_, CPT_)                                                                \
+    if (g.threads == NT_ && g.cpt == CPT_) {                                        \
+        switch (v) {                                                                \
+        case 0: return launch_walk_one<NT_, CPT_, false, false>(a, g, s);           \
+        case 1: return launch_walk_one<NT_, CPT_, false, true>(a, g, s);            \
+        case 2: return launch_walk_one<NT_, CPT_, true, false>(a, g, s);            \
+        default: return launch_walk_one<NT_, CPT_, true, true>(a, g, s);            \
+        }                                                                           \
+    }
+    BGTH_WALK_GEOMS(X)
+#undef X
+    return hipErrorInvalidConfiguration;
+}
+
+}  // namespace bgth

@@ -43,6 +43,16 @@ struct ScanArgs {
     int32_t  tog_off;            // team mode: byte offset in LDS of the separate toggle array [2K][(nw+4)&~3], 0 = toggles in place
     int32_t  blk0, n_blk, n_slices;
     int64_t  row0, row1;         // rows whose results are emitted; decoding starts at blk0<<shift
+    // Directory path (scan_dir.hip; wide cohorts whose columns span several workgroups): dirbuild_kernel writes the
+    // {bits, ones before} entries of every plane-row ONCE into an HBM arena, walk_kernel pulls them into LDS with LDS-DMA
+    // and only walks.  Plane-row (row, plane) occupies dir_nwp entries at dir[(2 (row - dir_row0) + plane) dir_nwp]:
+    // nw entries, an all-zero sentinel, padding to 16 bytes; dir_n0[2 (row - dir_row0) + plane] = its number of zeros.
+    uint2    *dir;
+    uint32_t *dir_n0;
+    int64_t   dir_row0;
+    int32_t   dir_nwp;
+    int32_t   dir_stage;         // bit 0: three plane buffers in LDS (plane 0 of the next row lands while this row is walked; else
+                                 // two); bit 1: touch the next row's plane 1 during the walk so that its DMA finds it in the L2
     // Profiling builds only (make ABLATE=1 -> libbgt_hip_ablate.so, used by scripts/profile.sh): the shipped library
     // compiles every one of these switches out (BGTH_SKIP / BGTH_TIMES below are constant 0) and never reads the
     // environment variables that set them -- an ablation switch makes the kernels return wrong numbers faster.
@@ -68,13 +78,18 @@ struct ScanArgs {
 // workgroup hold, so that few column slices repeat the per-row bit-vector build)
 #define BGTH_CPT_512_WIDE(X) X(64) X(80) X(98)
 
-struct Geometry { int threads, cpt, slices, K, lds_bytes, workgroups, wpp, nbuf, tog_off; };
+struct Geometry { int threads, cpt, slices, K, lds_bytes, workgroups, wpp, nbuf, tog_off; int dir_stage = -1; };   // dir_stage >= 0: directory path
 
 // Picks threads/columns-per-thread/slices/K for a selection of n_chunks*64 slots over n_blk blocks.
 // Returns false if the row bit-vectors of this m cannot fit in LDS.
 bool choose_geometry(int m, int n_chunks, int G, int n_blk, int want_threads, int want_cpt, int want_K,
                      Geometry *g, bool allow_tog = true);
 hipError_t launch_scan(const ScanArgs &a, const Geometry &g, hipStream_t s);
+// directory path: geometry of the walk-only kernel (false: one plane-row pair does not fit the LDS), the producer over the
+// plane-rows [2 row_lo, 2 row_hi) of the image into a.dir / a.dir_n0 (needs the row index), and the walk itself
+bool choose_walk_geometry(int m, int n_chunks, int G, int n_blk, int want_threads, int want_cpt, Geometry *g);
+hipError_t launch_dirbuild(const ScanArgs &a, int64_t row_lo, int64_t row_hi, hipStream_t s);
+hipError_t launch_walk(const ScanArgs &a, const Geometry &g, hipStream_t s);
 // row index of n_str strings (see above); chunkinfo must hold packed_bytes/256 + n_str + 1 records
 hipError_t launch_rowindex(const uint64_t *rowdesc, const uint8_t *rle, int64_t n_str, int m, int S8,
                            uint32_t *chunkinfo, uint32_t *segc, hipStream_t s);
@@ -107,7 +122,7 @@ struct FilterProgram { int32_t n; int32_t op[kFilterMaxItems]; int32_t slot[kFil
 hipError_t launch_filter(const FilterProgram &prog, const int32_t *counts, int64_t n_rows, int ints_per_row,
                          uint8_t *flags, unsigned long long *n_pass, hipStream_t s);
 hipError_t launch_stream_read(const void *src, size_t bytes, int width, uint32_t *sink, hipStream_t s);
-// issue-rate calibration (microbench.hip): out = {cycles of the slowest wave, ms, VALU wave-instr per wave, LDS wave-instr per wave}
+// issue-rate calibration (microbench.hip, linked into libbgt_hip_bench.so only): out = {cycles of the slowest wave, ms, VALU wave-instr per wave, LDS wave-instr per wave}
 hipError_t run_issue_rate(int mix, int waves_per_simd, int iters, double out[4]);
 const char *issue_rate_mix_name(int mix);
 hipError_t run_op_rate(int op, int waves_per_simd, int iters, double out[3]);

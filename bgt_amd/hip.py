@@ -26,6 +26,31 @@ def build_library(force=False):
     return _LIB_PATH
 
 
+_BENCH_LIB = None
+
+
+def bench_lib():
+    """libbgt_hip_bench.so (include/bgt_hip_bench.h): the issue-rate calibration kernels behind bench.py's roofline --
+    measurement tools, kept out of the product library."""
+    global _BENCH_LIB
+    if _BENCH_LIB is None:
+        _hip_runtime_first()
+        path = os.path.join(_HERE, "lib", "libbgt_hip_bench.so")
+        if not os.path.exists(path):
+            raise RuntimeError("bgt_amd: %s is missing -- build it with `make -C bgt_amd/csrc`" % path)
+        L = C.CDLL(path)
+        L.bgth_debug_issue_rate.restype = C.c_int
+        L.bgth_debug_issue_rate.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        L.bgth_debug_issue_rate_name.restype = C.c_char_p
+        L.bgth_debug_issue_rate_name.argtypes = [C.c_int]
+        L.bgth_debug_op_rate.restype = C.c_int
+        L.bgth_debug_op_rate.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        L.bgth_debug_op_rate_name.restype = C.c_char_p
+        L.bgth_debug_op_rate_name.argtypes = [C.c_int]
+        _BENCH_LIB = L
+    return _BENCH_LIB
+
+
 def build_host_shell():
     """Compile the C host shell (bgt_amd/host -> lib/libbgt.so, bin/bgt); needs lib/libbgt_hip.so."""
     subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "host")])
@@ -93,6 +118,8 @@ def _load():
     L.bgth_reader_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.bgth_reader_last_geometry.restype = C.c_int
     L.bgth_reader_last_geometry.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    L.bgth_reader_last_path.restype = C.c_int
+    L.bgth_reader_last_path.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.bgth_reader_tune.restype = C.c_int
     L.bgth_reader_tune.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     return L
@@ -333,6 +360,11 @@ class HipReader:
         t = (C.c_float * 3)()
         lib().bgth_reader_last_timing(self.h, t)
         return {"scan_ms": t[0], "finalize_ms": t[1], "total_ms": t[2]}
+
+    def path(self):
+        t = (C.c_float * 4)()
+        lib().bgth_reader_last_path(self.h, t)
+        return {"directory_path": bool(t[0]), "passes": int(t[1]), "producer_launches": int(t[2]), "producer_ms": t[3]}
 
     def geometry(self):
         g = (C.c_int * 6)()

@@ -26,7 +26,8 @@ int bgt_no_file = 0;
 typedef struct {
     int64_t n;
     int32_t *rid, *pos, *rlen, *row, *n_allele;
-    uint32_t *ref_off, *alt_off, *raw_off;                       /* raw: the record's `shared` block as in the file (bgt_read) */
+    uint64_t *raw_off;                                           /* the record's `shared` block as in the file (bgt_read); 64-bit: */
+    uint64_t *ref_off, *alt_off;                                 /* WGS-scale tables pass 4 GiB.  REF / ALT point INTO that block */
     uint32_t *ref_len, *alt_len, *raw_len;
     uint16_t *n_info; float *qual;
     char *pool; size_t pool_len, pool_cap;
@@ -41,16 +42,16 @@ static void st_free(sitetab_t *t)
     free(t->n_info); free(t->qual); free(t->pool); free(t);
 }
 
-static uint32_t st_intern(sitetab_t *t, const uint8_t *s, int n)
+static uint64_t st_intern(sitetab_t *t, const uint8_t *s, int n)
 {
-    uint32_t at = (uint32_t)t->pool_len;
+    const uint64_t at = t->pool_len;
     if (t->pool_len + (size_t)n + 1 > t->pool_cap) {
         t->pool_cap = t->pool_cap ? t->pool_cap * 2 : 1 << 16;
         while (t->pool_len + (size_t)n + 1 > t->pool_cap) t->pool_cap *= 2;
         t->pool = (char*)realloc(t->pool, t->pool_cap);
     }
     memcpy(t->pool + at, s, (size_t)n);
-    t->pool[at + (uint32_t)n] = 0;
+    t->pool[at + (uint64_t)n] = 0;
     t->pool_len += (size_t)n + 1;
     return at;
 }
@@ -74,24 +75,25 @@ static int tv_size(const uint8_t *p, const uint8_t **q, int *type)
  * samples).  Returns 0, or <0 for a record this format does not allow. */
 static int st_append(sitetab_t *t, int64_t *cap, const bcf1_t *b, int row_key)
 {
-    const uint8_t *p = (const uint8_t*)b->shared.s, *q;
+    const uint8_t *p = (const uint8_t*)b->shared.s, *q, *ref, *alt;
     int n, type, i, row = -1;
+    uint64_t at;
     if (t->n == *cap) {
         const int64_t c = *cap = *cap ? *cap * 2 : 1 << 12;
         t->rid = (int32_t*)realloc(t->rid, (size_t)c * 4); t->pos = (int32_t*)realloc(t->pos, (size_t)c * 4);
         t->rlen = (int32_t*)realloc(t->rlen, (size_t)c * 4); t->row = (int32_t*)realloc(t->row, (size_t)c * 4);
         t->n_allele = (int32_t*)realloc(t->n_allele, (size_t)c * 4);
-        t->ref_off = (uint32_t*)realloc(t->ref_off, (size_t)c * 4); t->alt_off = (uint32_t*)realloc(t->alt_off, (size_t)c * 4);
+        t->ref_off = (uint64_t*)realloc(t->ref_off, (size_t)c * 8); t->alt_off = (uint64_t*)realloc(t->alt_off, (size_t)c * 8);
         t->ref_len = (uint32_t*)realloc(t->ref_len, (size_t)c * 4); t->alt_len = (uint32_t*)realloc(t->alt_len, (size_t)c * 4);
-        t->raw_off = (uint32_t*)realloc(t->raw_off, (size_t)c * 4); t->raw_len = (uint32_t*)realloc(t->raw_len, (size_t)c * 4);
+        t->raw_off = (uint64_t*)realloc(t->raw_off, (size_t)c * 8); t->raw_len = (uint32_t*)realloc(t->raw_len, (size_t)c * 4);
         t->n_info = (uint16_t*)realloc(t->n_info, (size_t)c * 2); t->qual = (float*)realloc(t->qual, (size_t)c * 4);
     }
     if (b->n_sample != 0 || b->n_allele < 2) return -3;
     n = tv_size(p, &q, &type); p = q + n;                                   /* ID */
     n = tv_size(p, &q, &type);                                              /* REF */
-    t->ref_off[t->n] = st_intern(t, q, n); t->ref_len[t->n] = (uint32_t)n; p = q + n;
+    ref = q; t->ref_len[t->n] = (uint32_t)n; p = q + n;
     n = tv_size(p, &q, &type);                                              /* first ALT */
-    t->alt_off[t->n] = st_intern(t, q, n); t->alt_len[t->n] = (uint32_t)n; p = q + n;
+    alt = q; t->alt_len[t->n] = (uint32_t)n; p = q + n;
     for (i = 2; i < (int)b->n_allele; ++i) { n = tv_size(p, &q, &type); p = q + n; }
     n = tv_size(p, &q, &type); p = q + (size_t)n * tv_bytes(type);          /* FILTER */
     for (i = 0; i < (int)b->n_info; ++i) {
@@ -104,7 +106,11 @@ static int st_append(sitetab_t *t, int64_t *cap, const bcf1_t *b, int row_key)
     if (row < 0) return -3;
     t->rid[t->n] = b->rid; t->pos[t->n] = b->pos; t->rlen[t->n] = b->rlen;
     t->row[t->n] = row; t->n_allele[t->n] = b->n_allele;
-    t->raw_off[t->n] = st_intern(t, (const uint8_t*)b->shared.s, (int)b->shared.l); t->raw_len[t->n] = (uint32_t)b->shared.l;
+    /* one copy of the record: every user of REF / ALT passes their lengths, none needs a terminator */
+    at = st_intern(t, (const uint8_t*)b->shared.s, (int)b->shared.l);
+    t->raw_off[t->n] = at; t->raw_len[t->n] = (uint32_t)b->shared.l;
+    t->ref_off[t->n] = at + (uint64_t)(ref - (const uint8_t*)b->shared.s);
+    t->alt_off[t->n] = at + (uint64_t)(alt - (const uint8_t*)b->shared.s);
     t->n_info[t->n] = (uint16_t)b->n_info; t->qual[t->n] = b->qual;
     if (b->rlen > t->max_rlen) t->max_rlen = b->rlen;
     ++t->n;

@@ -179,6 +179,13 @@ int bgth_reader_last_timing(const bgth_reader_t *r, float out[3]);
 /* Launch geometry of the last scan: out = {threads, cols_per_thread, slices, rows_per_batch,
  * lds_bytes, workgroups}. */
 int bgth_reader_last_geometry(const bgth_reader_t *r, int out[6]);
+/* Which kernels the last scan ran: out[0] = 1 if it took the directory path (wide cohorts whose columns span several
+ * workgroups: every row's {bits, ones before} directory is built once into an HBM arena by a producer kernel and the
+ * column slices only walk it, pulling rows into LDS by LDS-DMA), 0 for the kernels that rebuild the row per workgroup;
+ * out[1] = passes over the arena, out[2] = producer launches (0: the arena still held the rows from the previous scan
+ * of this reader), out[3] = milliseconds of the first producer launch.  BGTH_DIR_ARENA_MB bounds the arena
+ * (default: 60 % of the HBM free at first use). */
+int bgth_reader_last_path(const bgth_reader_t *r, float out[4]);
 /* Override the automatic launch geometry (0 = automatic). For tuning and tests. */
 int bgth_reader_tune(bgth_reader_t *r, int threads, int cols_per_thread, int rows_per_batch);
 
@@ -198,17 +205,6 @@ int  bgth_filter_apply_device(const bgth_filter_t *f, const void *d_counts, int6
 /* Diagnostics: stream `bytes` of HBM `repeats` times with `width`-byte loads per lane (4 or 16); used under
  * rocprofv3 to calibrate the FETCH_SIZE counter against a known byte count. */
 int bgth_debug_stream_read(int device, size_t bytes, int width, int repeats);
-/* Issue-rate calibration for the roofline of the scan kernel (which is bound by VALU issue and LDS gathers, not by
- * HBM): runs `iters` iterations of instruction mix `mix` (bgth_debug_issue_rate_name(mix) describes it; NULL past the
- * last one) on every CU with `waves_per_simd` (1..4) waves per SIMD.  out[0] = shader cycles of the slowest wave,
- * out[1] = milliseconds of the launch, out[2] / out[3] = VALU / LDS wave-instructions issued per wave. */
-int         bgth_debug_issue_rate(int device, int mix, int waves_per_simd, int iters, double out[4]);
-const char *bgth_debug_issue_rate_name(int mix);
-/* The same for single VALU opcodes (instruction classes: which issue in 2 cycles per wave64, which in 4 or more):
- * out[0] = cycles, out[1] = ms, out[2] = instructions per wave. */
-int         bgth_debug_op_rate(int device, int op, int waves_per_simd, int iters, double out[3]);
-const char *bgth_debug_op_rate_name(int op);
-
 #ifdef __cplusplus
 }
 #endif

@@ -1,7 +1,7 @@
 import ctypes as C, sys
 sys.path.insert(0, '.')
 import bgt_amd
-L = bgt_amd.lib()
+L = bgt_amd.bench_lib()
 L.bgth_debug_issue_rate.restype = C.c_int
 L.bgth_debug_issue_rate.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
 L.bgth_debug_issue_rate_name.restype = C.c_char_p

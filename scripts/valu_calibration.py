@@ -13,7 +13,7 @@ import bgt_amd  # noqa: E402
 
 
 def main():
-    L = bgt_amd.lib()
+    L = bgt_amd.bench_lib()
     L.bgth_debug_issue_rate.restype = C.c_int
     L.bgth_debug_issue_rate.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
     L.bgth_debug_issue_rate_name.restype = C.c_char_p

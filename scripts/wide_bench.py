@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Wide-cohort scan: the team kernels (every column slice rebuilds the row) against the directory path (rows built once
+into an HBM arena, walk-only slices), one-shot and with the arena reused.  GPU box.
+usage: python scripts/wide_bench.py [samples] [sites] [every-nth-sample]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bgt_amd  # noqa: E402
+
+samples = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+sites = int(sys.argv[2]) if len(sys.argv) > 2 else 262144
+sub = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+m = 2 * samples
+t0 = time.time()
+rle, lens = bgt_amd.synth_rows(m, 0, sites, 2)
+pbf = bgt_amd.HipPbf.from_rle(m, 13, rle, lens)
+print("cohort m=%d sites=%d rle=%.1f MB setup %.1fs" % (m, sites, rle.size / 1e6, time.time() - t0), flush=True)
+rd = bgt_amd.HipReader(pbf)
+if sub:
+    s = np.arange(0, samples, sub)
+    rd.select(np.stack([2 * s, 2 * s + 1], 1).reshape(-1))
+
+
+def run(label, variant, reps=3):
+    if variant is None:
+        os.environ.pop("BGTH_VARIANT", None)
+    else:
+        os.environ["BGTH_VARIANT"] = str(variant)
+    out = None
+    for i in range(reps):
+        t = time.time()
+        out = rd.scan(0, sites)
+        wall = (time.time() - t) * 1e3
+        tm, g, p = rd.timing(), rd.geometry(), rd.path()
+        print("%-22s rep %d: scan %8.2f ms (producer %6.2f ms, passes %d, built %d) wall %8.1f ms  %6.2f Msites/s   %dthr x %d cols x %d slices, lds %d, wgs %d" %
+              (label, i, tm["scan_ms"], p["producer_ms"], p["passes"], p["producer_launches"], wall, sites / tm["scan_ms"] / 1e3,
+               g["threads"], g["cols_per_thread"], g["slices"], g["lds_bytes"], g["workgroups"]), flush=True)
+    return out
+
+
+rd.scan(0, min(sites, 8192))
+ref = run("team kernels", 64, 2)
+a = run("directory, arena kept", None)
+b = run("directory, one-shot", 128, 2)
+c = run("directory, no L2 warm", 256, 3)
+os.environ["BGTH_WALK_GEOM"] = "1024,50"
+d = run("directory 1024x50", None, 3)
+e = run("dir 1024x50, no warm", 256, 3)
+os.environ.pop("BGTH_WALK_GEOM")
+print("same counts:", [np.array_equal(ref, x) for x in (a, b, c, d, e)])

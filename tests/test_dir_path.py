@@ -1,0 +1,104 @@
+"""GPU parity of the directory path (bgt_amd/csrc/scan_dir.hip): rows built ONCE into an HBM arena by the producer
+kernel, column slices that only walk them (LDS-DMA).  Forced with BGTH_VARIANT=32 on shapes small enough for the
+oracle; the automatic choice is checked on a wide cohort.  Bit-exact against the oracle (reference pbwt.c:69-170,
+bgt.c:735-757)."""
+import numpy as np
+import pytest
+
+import orc
+import scenarios
+from test_hip_parity import oracle_scan, unpack_gt
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import bgt_amd
+    assert bgt_amd.device_count() > 0, bgt_amd.last_error()
+    return bgt_amd
+
+
+@pytest.mark.parametrize("seed,m,rows,shift", [(1, 37, 40, 3), (2, 1000, 70, 4), (3, 4097, 33, 5), (4, 20000, 20, 2),
+                                               (5, 64, 9, 13), (6, 1, 12, 2), (7, 2, 5, 1), (8, 6400, 130, 6)])
+def test_forced_directory_path_small_shapes(hip, monkeypatch, seed, m, rows, shift):
+    """Every shape class the classic kernels are tested on, through producer + walk-only kernel: partial tail words,
+    one column, several checkpoint blocks, scans that start inside a block, subsets, groups, genotype planes."""
+    monkeypatch.setenv("BGTH_VARIANT", "32")
+    rng = np.random.default_rng(seed)
+    mat = scenarios.ld_matrix(rng, rows, m, n_founders=7, switch=0.1) if m > 8 else rng.integers(0, 4, (rows, m)).astype(np.uint8)
+    if rows > 6:
+        mat[2] = 0; mat[3] = 1; mat[4] = 3
+        mat[5] = rng.integers(0, 4, m)
+    data = orc.encode_pbf(mat, 2, shift)
+    pbf = hip.HipPbf.from_bytes(data)
+    rd = hip.HipReader(pbf)
+    oc, ogt = oracle_scan(data, 0, rows)
+    counts, gt = rd.scan(0, rows, want_gt=True)
+    assert rd.path()["directory_path"], rd.geometry()
+    assert np.array_equal(counts, oc) and np.array_equal(gt, ogt), rd.geometry()
+    assert np.array_equal(unpack_gt(gt, m), mat)
+    a, b = rows // 3, rows - 1
+    assert np.array_equal(rd.scan(a, b), oc[a:b])                      # pre-roll inside a block, counts only
+    assert np.array_equal(rd.scan(0, rows), oc)                         # arena reused or rebuilt: same numbers
+    if m >= 8:
+        ns = max(2, (m // 2) // 3)
+        smp = np.sort(rng.choice(m // 2, ns, replace=False))
+        cols = np.stack([2 * smp, 2 * smp + 1], 1).reshape(-1).astype(np.int32)
+        group = (1 + (np.arange(ns) % 3)).astype(np.uint32)
+        rd.select(cols, group=group, n_groups=3)
+        c2, g2 = rd.scan(0, rows, want_gt=True)
+        assert rd.path()["directory_path"]
+        o2, og2 = oracle_scan(data, 0, rows, cols=cols, group=group, n_groups=3)
+        assert np.array_equal(c2, o2) and np.array_equal(g2, og2)
+    rd.close()
+    pbf.close()
+
+
+def test_wide_cohort_takes_the_directory_path(hip, monkeypatch):
+    """m = 120,000 columns: 2+ column slices, so the automatic choice is producer + walk-only kernel with three plane
+    buffers; noisy rows, single-run rows, a row that stops short; the arena is reused by the second scan (no producer
+    launch) and rebuilt when it is too small for the range (several passes, BGTH_DIR_ARENA_MB)."""
+    rng = np.random.default_rng(99)
+    m, rows, shift = 120000, 40, 3
+    mat = scenarios.ld_matrix(rng, rows, m, n_founders=30, switch=0.2)
+    mat[3] = 0; mat[4] = 1; mat[5] = 3; mat[6, :70000] = 2; mat[6, 70000:] = 0
+    mat[7] = rng.integers(0, 4, m)
+    data = orc.encode_pbf(mat, 2, shift)
+    pbf = hip.HipPbf.from_bytes(data)
+    rd = hip.HipReader(pbf)
+    oc, ogt = oracle_scan(data, 0, rows)
+    counts, gt = rd.scan(0, rows, want_gt=True)
+    p1 = rd.path()
+    assert p1["directory_path"] and p1["producer_launches"] == 1, (p1, rd.geometry())
+    assert np.array_equal(counts, oc) and np.array_equal(gt, ogt)
+    c2 = rd.scan(0, rows)
+    p2 = rd.path()
+    assert p2["directory_path"] and p2["producer_launches"] == 0, p2
+    assert np.array_equal(c2, oc)
+    assert np.array_equal(rd.scan(9, 31), oc[9:31])
+    # the classic team kernels give the same numbers
+    monkeypatch.setenv("BGTH_VARIANT", "64")
+    c3 = rd.scan(0, rows)
+    assert not rd.path()["directory_path"]
+    assert np.array_equal(c3, oc)
+    rd.close()
+    pbf.close()
+
+
+def test_directory_path_in_several_passes(hip, monkeypatch):
+    """An arena smaller than the range: sub-block ranges are built and walked pass by pass."""
+    monkeypatch.setenv("BGTH_VARIANT", "32")
+    monkeypatch.setenv("BGTH_DIR_ARENA_MB", "1")                       # 13 sub-blocks of 8 rows x 10 KB
+    rng = np.random.default_rng(5)
+    m, rows, shift = 20000, 300, 3
+    mat = scenarios.ld_matrix(rng, rows, m, n_founders=9, switch=0.1)
+    data = orc.encode_pbf(mat, 2, shift)
+    pbf = hip.HipPbf.from_bytes(data)
+    rd = hip.HipReader(pbf)
+    oc, _ = oracle_scan(data, 0, rows)
+    assert np.array_equal(rd.scan(0, rows), oc)
+    assert rd.path()["passes"] >= 4, rd.path()
+    assert np.array_equal(rd.scan(17, 299), oc[17:299])
+    rd.close()
+    pbf.close()
