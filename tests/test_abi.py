@@ -54,8 +54,22 @@ def test_shipped_library_has_no_ablation_switches(libpath):
     environment to return wrong numbers faster."""
     blob = open(libpath, "rb").read()
     assert b"BGTH_DEBUG_SKIP" not in blob and b"BGTH_DEBUG_TIMES" not in blob
+    assert b"BGTH_ENC_DEBUG" not in blob                       # the encoder's ablation switches (pbf_encoder.hip) likewise
     host = open(os.path.join(ROOT, "bgt_amd", "lib", "libbgt.so"), "rb").read() if os.path.exists(os.path.join(ROOT, "bgt_amd", "lib", "libbgt.so")) else b""
     assert b"BGTH_DEBUG_SKIP" not in host
+
+
+def test_measurement_tools_live_in_their_own_library(libpath):
+    """The issue-rate calibration kernels behind bench.py's roofline are not product: libbgt_hip_bench.so exports exactly
+    what include/bgt_hip_bench.h declares, and the product library carries none of it."""
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "bgt_hip_bench.h")).read(), flags=re.S)
+    declared = sorted(set(re.findall(r"\b(bgth_[a-z0-9_]+)\s*\(", text)))
+    bench = os.path.join(os.path.dirname(libpath), "libbgt_hip_bench.so")
+    assert os.path.exists(bench)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", bench]).decode()
+    assert sorted(set(re.findall(r" T (bgth_[a-z0-9_]+)", out))) == declared and len(declared) == 4
+    prod = subprocess.check_output(["nm", "-D", "--defined-only", libpath]).decode()
+    assert "issue_rate" not in prod and "op_rate" not in prod
 
 
 def test_fails_loudly_without_a_device(libpath):

@@ -29,7 +29,7 @@ BGT = os.path.join(ROOT, "bgt_amd", "bin", "bgt")
 pytestmark = pytest.mark.gpu
 
 
-def test_c4_shard_ranges_equal_the_whole_scan(tmp_path):
+def test_c4_shard_ranges_equal_the_whole_scan(tmp_path, monkeypatch):
     import torch
     import bgt_amd
     n_samples, shift, world = 100000, 13, 8
@@ -39,7 +39,11 @@ def test_c4_shard_ranges_equal_the_whole_scan(tmp_path):
     pbf = bgt_amd.HipPbf.from_rle(m, shift, rle, lens)
     rd = bgt_amd.HipReader(pbf)
     whole = rd.scan(0, sites)
-    assert rd.geometry()["threads"] == 512 and rd.geometry()["slices"] >= 1
+    # the per-GPU shape of C4 takes the directory path (rows built once, walk-only slices); the team kernels agree
+    assert rd.path()["directory_path"] and rd.geometry()["slices"] >= 4, (rd.path(), rd.geometry())
+    monkeypatch.setenv("BGTH_VARIANT", "64")
+    assert np.array_equal(rd.scan(0, sites), whole) and rd.geometry()["threads"] == 512 and not rd.path()["directory_path"]
+    monkeypatch.delenv("BGTH_VARIANT")
     # plane popcounts of every site (independent of any permutation state)
     ones = ones_per_string(rle, lens)
     c = whole[:, 0, :].astype(np.int64)
