@@ -108,6 +108,7 @@ struct bgth_pbf_s {
     uint8_t  *d_rle = nullptr;
     uint64_t *d_rowdesc = nullptr;
     int32_t  *d_rank0 = nullptr;      // [n_sub][2][m] ranks by column at every (sub-)checkpoint
+    int32_t  *d_final = nullptr;      // [2][m] ranks by column after the last row (images built by bgth_pbf_from_rle only)
     // row index (scan_kernels.h), built on the first wide-cohort (team-mode) launch
     uint32_t *d_chunkinfo = nullptr, *d_segc = nullptr;
     int32_t   S8 = 0;
@@ -128,7 +129,8 @@ struct bgth_pbf_s {
 //   32 / 64 = always / never the directory path (rows built once into an HBM arena, walk-only workgroups; default: wide
 //   cohorts whose columns span several workgroups);  128 = no reuse of an arena that already holds the rows of a scan
 enum { kVariantNoTog = 1, kVariantNeverZP = 2, kVariantAlwaysZP = 4, kVariantNoPrefetch = 16,    // 16: no window prefetch in the pull interface
-       kVariantDirAlways = 32, kVariantDirNever = 64, kVariantDirNoReuse = 128, kVariantDirNoWarm = 256 };
+       kVariantDirAlways = 32, kVariantDirNever = 64, kVariantDirNoReuse = 128, kVariantDirNoWarm = 256,
+       kVariantSeqCheckpoints = 512 };                     // 512: bgth_pbf_from_rle derives its checkpoints block after block
 static bool variant_flag(int bit) { const char *d = getenv("BGTH_VARIANT"); return d && (atoi(d) & bit); }
 
 // Builds the row index once per image; later calls only return it.  The build is enqueued on `s`, the
@@ -345,6 +347,7 @@ extern "C" void bgth_pbf_close(bgth_pbf_t *p)
     if (p->d_rle) hipFree(p->d_rle);
     if (p->d_rowdesc) hipFree(p->d_rowdesc);
     if (p->d_rank0) hipFree(p->d_rank0);
+    if (p->d_final) hipFree(p->d_final);
     if (p->d_chunkinfo) hipFree(p->d_chunkinfo);
     if (p->d_segc) hipFree(p->d_segc);
     delete p;
@@ -352,6 +355,8 @@ extern "C" void bgth_pbf_close(bgth_pbf_t *p)
 
 static bool derive_sub_checkpoints(bgth_pbf_t *p);
 static bool string_is_all_zero(const uint8_t *q, size_t l);
+static bool run_block_pass(bgth_pbf_t *p, Selection &all, int64_t blk, int64_t n_blk, int32_t *d_final, hipStream_t s,
+                           int64_t final_blk_stride);
 
 // BGTH_TRACE=1: wall-clock of the image-open stages on stderr (tuning aid)
 struct Trace {
@@ -661,7 +666,8 @@ static bool common_scan_args(ScanArgs &a, bgth_pbf_t *p, const Selection &sel, c
 // Decode pass over the FILE blocks [blk, blk + n_blk) that emits nothing but ranks: the sub-checkpoints inside
 // the blocks (always) and the ranks after the last row (d_final, optional: the next block's checkpoint when an
 // image is built from bare RLE strings).
-static bool run_block_pass(bgth_pbf_t *p, Selection &all, int64_t blk, int64_t n_blk, int32_t *d_final, hipStream_t s)
+static bool run_block_pass(bgth_pbf_t *p, Selection &all, int64_t blk, int64_t n_blk, int32_t *d_final, hipStream_t s,
+                           int64_t final_blk_stride)
 {
     Geometry geo;
     if (!choose_geometry(p->m, all.n_chunks, 1, (int)n_blk, 0, 0, 0, &geo, !variant_flag(kVariantNoTog))) { set_err("[E::bgth] geometry"); return false; }
@@ -670,6 +676,7 @@ static bool run_block_pass(bgth_pbf_t *p, Selection &all, int64_t blk, int64_t n
     a.shift = p->shift;                                                                   // units = file blocks,
     a.rank0_blk_stride = ((int64_t)2 * p->m) << (p->shift - p->sub_shift);               // whose checkpoint sits at its sub index
     a.final_rank = d_final;
+    a.final_blk_stride = final_blk_stride;               // != 0: one record of final ranks per block of the launch
     if (p->sub_shift < p->shift) { a.snap = p->d_rank0; a.snap_shift = p->sub_shift; }
     a.blk0 = (int32_t)blk;
     a.n_blk = (int32_t)n_blk;
@@ -798,10 +805,130 @@ static bool derive_sub_checkpoints(bgth_pbf_t *p)
 {
     if (p->sub_shift >= p->shift || p->n <= ((int64_t)1 << p->sub_shift)) return true;
     Selection all;
-    bool ok = build_selection(all, p->m, 0, nullptr, nullptr, 1) && run_block_pass(p, all, 0, p->n_blk, nullptr, nullptr);
+    bool ok = build_selection(all, p->m, 0, nullptr, nullptr, 1) && run_block_pass(p, all, 0, p->n_blk, nullptr, nullptr, 0);
     if (ok && hipDeviceSynchronize() != hipSuccess) { set_err("[E::bgth_pbf_open] sub-checkpoint pass failed"); ok = false; }
     all.release();
     return ok;
+}
+
+// Checkpoints of an image built from bare RLE strings, derived WITHOUT walking the file in order.  A row moves whatever
+// sits at position R to LF(R) (pbwt.c:76-88), so what a block does to the order is a map of positions, F_b, and it does
+// not depend on the order the block starts from:
+//   1. every file block at once from the identity order (one launch, n_blk units): F_b = its final ranks, and the ranks at
+//      its sub-checkpoints as maps of positions too;
+//   2. true checkpoint of block b+1 = F_b o (true checkpoint of block b): n_blk small gathers, in order;
+//   3. every sub-checkpoint re-based by one gather through its block's true checkpoint.
+// (Before: one launch per block, each waiting for the one before -- 0.1 s per block at 100,000 samples.)
+// Leaves the ranks after the last row in p->d_final.  BGTH_VARIANT 512 keeps the sequential form (tests compare the two).
+static bool derive_all_checkpoints(bgth_pbf_t *p, Selection &all, const std::vector<int32_t> &ident)
+{
+    const size_t per = (size_t)2 * p->m;
+    const int64_t spb = (int64_t)1 << (p->shift - p->sub_shift);           // sub-checkpoints per file block
+    HIP_TRY(hipMalloc((void**)&p->d_final, per * 4), return false);
+    if (p->n_blk == 0) { HIP_TRY(hipMemcpy(p->d_final, ident.data(), per * 4, hipMemcpyHostToDevice), return false); return true; }
+    if (variant_flag(kVariantSeqCheckpoints) || p->n_blk == 1) {
+        HIP_TRY(hipMemcpy(p->d_rank0, ident.data(), per * 4, hipMemcpyHostToDevice), return false);
+        // block b's final ranks are block b+1's checkpoint: strictly sequential, one launch per block
+        // (the pass over a block also leaves the block's sub-checkpoints)
+        for (int64_t b = 0; b < p->n_blk; ++b)
+            if (!run_block_pass(p, all, b, 1, b + 1 < p->n_blk ? p->d_rank0 + (size_t)((b + 1) * spb) * per : p->d_final, nullptr, 0)) return false;
+        HIP_TRY(hipDeviceSynchronize(), return false);
+        return true;
+    }
+    int32_t *fin = nullptr, *tru = nullptr, *rebased = nullptr;
+    bool ok = false;
+    do {
+        HIP_TRY(hipMalloc((void**)&fin, (size_t)p->n_blk * per * 4), break);
+        HIP_TRY(hipMalloc((void**)&tru, (size_t)(p->n_blk + 1) * per * 4), break);
+        for (int64_t b = 0; b < p->n_blk; ++b)                             // 1. every block starts from the identity order
+            HIP_TRY(hipMemcpyAsync(p->d_rank0 + (size_t)(b * spb) * per, b ? (const void*)p->d_rank0 : (const void*)ident.data(), per * 4,
+                                   b ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, nullptr), goto done);
+        if (!run_block_pass(p, all, 0, p->n_blk, fin, nullptr, (int64_t)per)) break;
+        HIP_TRY(hipMemcpyAsync(tru, p->d_rank0, per * 4, hipMemcpyDeviceToDevice, nullptr), break);   // 2. (block 0: the identity)
+        for (int64_t b = 0; b < p->n_blk; ++b)
+            HIP_TRY(launch_compose(fin + (size_t)b * per, 0, tru + (size_t)b * per, 0, tru + (size_t)(b + 1) * per, 0, p->m, 1, nullptr), goto done);
+        HIP_TRY(hipMemcpyAsync(p->d_final, tru + (size_t)p->n_blk * per, per * 4, hipMemcpyDeviceToDevice, nullptr), break);
+        // 3. sub-checkpoint k of block b: virtual ranks through the block's true checkpoint (k = 0: the checkpoint itself)
+        HIP_TRY(hipMalloc((void**)&rebased, (size_t)std::max<int64_t>(p->n_sub, 1) * per * 4), break);
+        for (int64_t b = 0; b < p->n_blk; ++b) {
+            const int64_t s0 = b * spb, ns = std::min<int64_t>(spb, p->n_sub - s0);
+            HIP_TRY(hipMemcpyAsync(rebased + (size_t)s0 * per, tru + (size_t)b * per, per * 4, hipMemcpyDeviceToDevice, nullptr), goto done);
+            if (ns > 1)
+                HIP_TRY(launch_compose(p->d_rank0 + (size_t)(s0 + 1) * per, (int64_t)per, tru + (size_t)b * per, 0,
+                                       rebased + (size_t)(s0 + 1) * per, (int64_t)per, p->m, ns - 1, nullptr), goto done);
+        }
+        HIP_TRY(hipDeviceSynchronize(), break);
+        hipFree(p->d_rank0);
+        p->d_rank0 = rebased; rebased = nullptr;
+        ok = true;
+    } while (0);
+done:
+    if (fin) hipFree(fin);
+    if (tru) hipFree(tru);
+    if (rebased) hipFree(rebased);
+    return ok;
+}
+
+// The ranks (by column, [2][m]) after the last row of an image built by bgth_pbf_from_rle, and the re-basing of such an image
+// onto another start order: how the shards of ONE database are opened side by side (include/bgt_hip.h).
+extern "C" int bgth_pbf_final_ranks(const bgth_pbf_t *p, int32_t *out)
+{
+    if (!p || !out) { set_err("[E::bgth_pbf_final_ranks] NULL argument"); return -1; }
+    if (!p->d_final) { set_err("[E::bgth_pbf_final_ranks] only images built by bgth_pbf_from_rle keep their final ranks"); return -1; }
+    if (!use_device(p->device)) return -1;
+    HIP_TRY(hipMemcpy(out, p->d_final, (size_t)2 * p->m * 4, hipMemcpyDeviceToHost), return -1);
+    return 0;
+}
+
+extern "C" int bgth_pbf_ranks_at(const bgth_pbf_t *p, int64_t row, int32_t *out)
+{
+    if (!p || !out) { set_err("[E::bgth_pbf_ranks_at] NULL argument"); return -1; }
+    if (!p->shards.empty()) {
+        for (const bgth_pbf_t *sh : p->shards) if (row >= sh->row_off && row < sh->row_off + sh->n) return bgth_pbf_ranks_at(sh, row, out);
+        set_err("[E::bgth_pbf_ranks_at] row %lld is in no shard", (long long)row); return -1;
+    }
+    const int64_t r = row - p->row_off;
+    if (r < 0 || r >= p->n || (r & (((int64_t)1 << p->sub_shift) - 1))) {
+        set_err("[E::bgth_pbf_ranks_at] row %lld: the image keeps ranks every %lld rows of its rows [%lld,%lld)", (long long)row,
+                (long long)1 << p->sub_shift, (long long)p->row_off, (long long)(p->row_off + p->n));
+        return -1;
+    }
+    if (!use_device(p->device)) return -1;
+    HIP_TRY(hipMemcpy(out, p->d_rank0 + (size_t)(r >> p->sub_shift) * 2 * p->m, (size_t)2 * p->m * 4, hipMemcpyDeviceToHost), return -1);
+    return 0;
+}
+
+extern "C" int bgth_pbf_rebase(bgth_pbf_t *p, const int32_t *start_ranks)
+{
+    if (!p || !start_ranks) { set_err("[E::bgth_pbf_rebase] NULL argument"); return -1; }
+    if (!p->d_final) { set_err("[E::bgth_pbf_rebase] only images built by bgth_pbf_from_rle can be re-based"); return -1; }
+    if (!use_device(p->device)) return -1;
+    const size_t per = (size_t)2 * p->m;
+    for (int k = 0; k < 2; ++k)                                            // a start order that is no permutation would address outside the tables
+        for (int j = 0; j < p->m; ++j) {
+            const int32_t v = start_ranks[(size_t)k * p->m + j];
+            if (v < 0 || v >= p->m) { set_err("[E::bgth_pbf_rebase] rank %d out of range", v); return -1; }
+        }
+    int32_t *via = nullptr, *out = nullptr;
+    const int64_t n = std::max<int64_t>(p->n_sub, 1);
+    int rc = -1;
+    do {
+        HIP_TRY(hipMalloc((void**)&via, per * 4), break);
+        HIP_TRY(hipMalloc((void**)&out, (size_t)(n + 1) * per * 4), break);
+        HIP_TRY(hipMemcpy(via, start_ranks, per * 4, hipMemcpyHostToDevice), break);
+        HIP_TRY(launch_compose(p->d_rank0, (int64_t)per, via, 0, out, (int64_t)per, p->m, n, nullptr), break);
+        HIP_TRY(launch_compose(p->d_final, 0, via, 0, out + (size_t)n * per, 0, p->m, 1, nullptr), break);
+        HIP_TRY(hipMemcpy(p->d_final, out + (size_t)n * per, per * 4, hipMemcpyDeviceToDevice), break);
+        HIP_TRY(hipDeviceSynchronize(), break);
+        {   // readers of the image keep no ranks of their own; an arena a reader filled holds directory rows, which do not depend on the order
+            hipFree(p->d_rank0);
+            p->d_rank0 = out; out = nullptr;
+        }
+        rc = 0;
+    } while (0);
+    if (via) hipFree(via);
+    if (out) hipFree(out);
+    return rc;
 }
 
 static bgth_pbf_t *from_rle_impl(int m, int g, int shift, int64_t n_rows, const uint8_t *rle, const uint32_t *len, int device);
@@ -849,12 +976,8 @@ static bgth_pbf_t *from_rle_impl(int m, int g, int shift, int64_t n_rows, const 
         HIP_TRY(hipMalloc((void**)&p->d_rank0, std::max<int64_t>(p->n_sub, 1) * per * 4), goto fail);
         std::vector<int32_t> ident(per);
         for (int k = 0; k < 2; ++k) for (int j = 0; j < m; ++j) ident[(size_t)k * m + j] = j;   // ref pbwt.c:103
-        HIP_TRY(hipMemcpy(p->d_rank0, ident.data(), per * 4, hipMemcpyHostToDevice), goto fail);
         if (!build_selection(all, m, 0, nullptr, nullptr, 1)) goto fail;
-        // block b's final ranks are block b+1's checkpoint: strictly sequential, one launch per block
-        // (the pass over a block also leaves the block's sub-checkpoints)
-        for (int64_t b = 0; b < p->n_blk; ++b)
-            if (!run_block_pass(p, all, b, 1, b + 1 < p->n_blk ? p->d_rank0 + ((size_t)(b + 1) << (p->shift - p->sub_shift)) * per : nullptr, nullptr)) goto fail;
+        if (!derive_all_checkpoints(p, all, ident)) goto fail;
         HIP_TRY(hipDeviceSynchronize(), goto fail);
     }
     all.release();

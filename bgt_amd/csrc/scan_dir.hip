@@ -265,12 +265,13 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
     }
 
     if (a.final_rank) {
+        int32_t *fin = a.final_rank + (int64_t)bl * a.final_blk_stride;
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
             const int c = chunk0 + j;
             if (c < a.n_chunks) {
                 const int col = a.slot_col[c * 64 + lane];
-                if (col >= 0) { a.final_rank[col] = (int32_t)~r0[j]; a.final_rank[m + col] = (int32_t)~r1[j]; }
+                if (col >= 0) { fin[col] = (int32_t)~r0[j]; fin[m + col] = (int32_t)~r1[j]; }
             }
         }
     }

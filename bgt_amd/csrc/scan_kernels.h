@@ -33,7 +33,8 @@ struct ScanArgs {
     const uint32_t *chunk_desc;  // [n_chunks]
     int32_t        *raw_counts;  // [(row1-row0)][G][3] += {n(code1), n(code2), n(code3)}
     uint64_t       *h0, *h1;     // optional [(row1-row0)][n_chunks] bit planes in slot order
-    int32_t        *final_rank;  // optional [2][m]: ranks by column after the last row of the launch
+    int32_t        *final_rank;  // optional [2][m]: ranks by column after the last row of the launch; with final_blk_stride != 0
+    int64_t         final_blk_stride;   //   one record per block of the launch: [n_blk][2][m] at final_rank + bl * stride
     int32_t        *snap;        // optional: sub-checkpoints, ranks by column BEFORE every row that is a multiple of
     int32_t         snap_shift;  //   1 << snap_shift (block starts excepted), at snap[(row >> snap_shift) * 2m]
     const uint32_t *chunkinfo;   // row index (see above); only read by the team (wide-cohort) kernels
@@ -100,6 +101,10 @@ hipError_t launch_finalize(const int32_t *raw, int32_t *out, const int32_t *grou
 // inv[perm[j]] = j for n_perm permutations of m entries each.  bad != NULL (untrusted input): entries outside
 // 0..m-1 are not stored and every record is checked to be a permutation; *bad (device int) becomes non-zero otherwise
 hipError_t launch_invert(const int32_t *perm, int32_t *inv, int m, int64_t n_perm, hipStream_t s, int *bad = nullptr);
+// out[i][p][c] = table[i * table_stride][p][ via[i * via_stride][p][c] ] for n records of [2][m] ranks: the composition of rank maps
+// behind the parallel checkpoint derivation (bgt_hip.cpp: from_rle_impl, bgth_pbf_rebase)
+hipError_t launch_compose(const int32_t *table, int64_t table_stride, const int32_t *via, int64_t via_stride, int32_t *out,
+                          int64_t out_stride, int m, int64_t n, hipStream_t s);
 // slot-ordered bit planes -> 2-bit codes in output-column order (4 per byte)
 hipError_t launch_pack2(const uint64_t *h0, const uint64_t *h1, const int32_t *slot_of_out, uint8_t *gt,
                         int64_t n_rows, int n_chunks, int width, hipStream_t s);

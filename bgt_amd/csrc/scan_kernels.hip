@@ -209,6 +209,30 @@ hipError_t launch_invert(const int32_t *perm, int32_t *inv, int m, int64_t n_per
     return hipGetLastError();
 }
 
+// Composition of rank maps.  A row moves whatever sits at position R to LF(R) (reference pbwt.c:76-88): the ranks after a
+// stretch of rows are a map of POSITIONS, so the ranks a stretch produces from the identity order (`table`: virtual column
+// v started at position v) turn into the ranks it produces from any start order `via` by one gather per plane.
+__global__ void compose_kernel(const int32_t *table, int64_t table_stride, const int32_t *via, int64_t via_stride, int32_t *out,
+                               int64_t out_stride, int m, int64_t total)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int64_t rec = i / (2 * m);
+    const int k = (int)(i - rec * 2 * m), plane = k >= m;
+    const int32_t pos = via[rec * via_stride + k];
+    out[rec * out_stride + k] = table[rec * table_stride + (int64_t)plane * m + pos];
+}
+
+hipError_t launch_compose(const int32_t *table, int64_t table_stride, const int32_t *via, int64_t via_stride, int32_t *out,
+                          int64_t out_stride, int m, int64_t n, hipStream_t s)
+{
+    const int64_t total = n * 2 * m;
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(compose_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                       table, table_stride, via, via_stride, out, out_stride, m, total);
+    return hipGetLastError();
+}
+
 // 2-bit codes a1<<1|a0 of output column i at bits 2*(i&3) of byte i>>2 (feeds bgt.c:306-311)
 __global__ void pack2_kernel(const uint64_t *h0, const uint64_t *h1, const int32_t *slot_of_out,
                              uint8_t *gt, int64_t n_rows, int n_chunks, int width)

@@ -118,6 +118,12 @@ def _load():
     L.bgth_reader_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.bgth_reader_last_geometry.restype = C.c_int
     L.bgth_reader_last_geometry.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    L.bgth_pbf_final_ranks.restype = C.c_int
+    L.bgth_pbf_final_ranks.argtypes = [C.c_void_p, C.c_void_p]
+    L.bgth_pbf_ranks_at.restype = C.c_int
+    L.bgth_pbf_ranks_at.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    L.bgth_pbf_rebase.restype = C.c_int
+    L.bgth_pbf_rebase.argtypes = [C.c_void_p, C.c_void_p]
     L.bgth_reader_last_path.restype = C.c_int
     L.bgth_reader_last_path.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.bgth_reader_tune.restype = C.c_int
@@ -189,6 +195,28 @@ class HipPbf:
         lens = np.ascontiguousarray(lens, np.uint32)
         assert lens.size % 2 == 0 and int(lens.sum(dtype=np.int64)) == rle.size
         return cls(lib().bgth_pbf_from_rle(m, 2, shift, lens.size // 2, rle.ctypes.data, lens.ctypes.data, device))
+
+    def final_ranks(self):
+        """int32[2][m]: rank of every column after the last row (images built by from_rle)."""
+        out = np.empty((2, self.m), np.int32)
+        if lib().bgth_pbf_final_ranks(self.h, out.ctypes.data) != 0:
+            raise RuntimeError(last_error())
+        return out
+
+    def ranks_at(self, row):
+        """int32[2][m]: rank of every column before `row` (a checkpoint row of the image)."""
+        out = np.empty((2, self.m), np.int32)
+        if lib().bgth_pbf_ranks_at(self.h, row, out.ctypes.data) != 0:
+            raise RuntimeError(last_error())
+        return out
+
+    def rebase(self, start_ranks):
+        """Make the image start from start_ranks (int32[2][m], rank of every column before its first row) instead of the
+        identity order -- how the site-range shards of one database are opened side by side."""
+        st = np.ascontiguousarray(start_ranks, np.int32)
+        assert st.shape == (2, self.m)
+        if lib().bgth_pbf_rebase(self.h, st.ctypes.data) != 0:
+            raise RuntimeError(last_error())
 
     def save(self, path):
         n = lib().bgth_pbf_save(self.h, os.fsencode(path))

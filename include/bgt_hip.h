@@ -59,11 +59,25 @@ void        bgth_shard_ranges(int64_t n_rows, int shift, int n_shards, int64_t *
 int64_t     bgth_pbf_first_row(const bgth_pbf_t *p);     /* first loaded row (0 for a full image)        */
 int64_t     bgth_pbf_loaded_rows(const bgth_pbf_t *p);   /* number of loaded rows                         */
 /* Build an image from bare RLE strings (row-major, plane-minor: row0/plane0,row0/plane1,row1/plane0..)
- * and derive every checkpoint on the device by one sequential decode pass: the device-side
+ * and derive every checkpoint on the device: the device-side
  * equivalent of what pbf_write records while encoding (pbwt.c:292-301).  len[i] is the byte length
  * of string i; strings are concatenated in `rle`.  g must be 2. */
 bgth_pbf_t *bgth_pbf_from_rle(int m, int g, int shift, int64_t n_rows, const uint8_t *rle,
                               const uint32_t *len, int device);
+/* Images built by bgth_pbf_from_rle derive their checkpoints in parallel (every file block from the identity order at
+ * once, then one composition of rank maps per block) and keep the ranks after their last row:
+ *   bgth_pbf_final_ranks   out[2][m]: rank of every column after the last row, per plane
+ *   bgth_pbf_rebase        make the image start from start_ranks[2][m] (rank of every column before its first row) instead
+ *                          of the identity order: every checkpoint and the final ranks are re-based by one gather.
+ * Together they open the site-range shards of ONE database side by side, one per GPU: every rank builds its
+ * shard from the identity order, the final ranks are exchanged, and shard r is re-based onto final(r-1) o ... o final(0).
+ * No reader of the image may be scanning during bgth_pbf_rebase.  Return 0, or -1 with bgth_last_error. */
+int         bgth_pbf_final_ranks(const bgth_pbf_t *p, int32_t *out);
+/* out[2][m]: the rank of every column BEFORE row `row` (a multiple of the image's checkpoint spacing, 2048 rows unless
+ * BGTH_SUB_SHIFT says otherwise): the checkpoint in the form the kernels start from (the inverse of an 'S' record,
+ * reference pbwt.c:343).  Any image. */
+int         bgth_pbf_ranks_at(const bgth_pbf_t *p, int64_t row, int32_t *out);
+int         bgth_pbf_rebase(bgth_pbf_t *p, const int32_t *start_ranks);
 /* Serialise an image back to the on-disk format (header, 'S'/'B' records, 'I' footer; pbwt.c:199-311).
  * Returns bytes written or <0. */
 int64_t     bgth_pbf_save(const bgth_pbf_t *p, const char *path);

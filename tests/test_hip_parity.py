@@ -332,9 +332,16 @@ def split_rle(data):
     return m, shift, strings
 
 
-@pytest.mark.parametrize("seed,m,rows,shift", [(51, 300, 200, 4), (52, 5008, 100, 5), (53, 70, 33, 3)])
-def test_checkpoints_rebuilt_on_device(hip, tmp_path, seed, m, rows, shift):
-    """bgth_pbf_from_rle derives every 'S' record on the GPU; saved file == the encoder's file, byte for byte."""
+@pytest.mark.parametrize("sequential", [False, True])
+@pytest.mark.parametrize("seed,m,rows,shift", [(51, 300, 200, 4), (52, 5008, 100, 5), (53, 70, 33, 3), (54, 41000, 50, 3),
+                                               (55, 9, 16, 4), (56, 2600, 8192 + 4096 + 17, 12)])
+def test_checkpoints_rebuilt_on_device(hip, tmp_path, monkeypatch, seed, m, rows, shift, sequential):
+    """bgth_pbf_from_rle derives every 'S' record on the GPU; saved file == the encoder's file, byte for byte.  Default:
+    every block at once from the identity order + composition of the blocks' rank maps; sequential (BGTH_VARIANT 512): one
+    launch per block.  Cases: many blocks, a ragged last block, exactly one block, team-mode width, sub-checkpoints
+    inside the file blocks (shift 12 > the sub-block shift 11)."""
+    if sequential:
+        monkeypatch.setenv("BGTH_VARIANT", "512")
     mat, data, rng = make_case(seed, m, rows, shift)
     m_, shift_, strings = split_rle(data)
     rle = np.frombuffer(b"".join(strings), np.uint8)
@@ -343,6 +350,53 @@ def test_checkpoints_rebuilt_on_device(hip, tmp_path, seed, m, rows, shift):
     out = str(tmp_path / "re.pbf")
     pbf.save(out)
     assert open(out, "rb").read() == data
+    fin = pbf.final_ranks()                                          # (checked against a chained shard in the next test)
+    assert sorted(fin[0].tolist()) == list(range(m)) and sorted(fin[1].tolist()) == list(range(m))
+    rd = hip.HipReader(pbf)
+    oc, _ = oracle_scan(data, 0, rows)
+    assert np.array_equal(rd.scan(0, rows), oc)
+
+
+def test_shards_of_one_database_opened_side_by_side(hip, tmp_path):
+    """SURVEY 8e with ONE database: every shard is built from the identity order on its own (bgth_pbf_from_rle), the
+    final ranks are chained (shard r starts from final(r-1) o ... o final(0), bgth_pbf_rebase) and the shards' scans
+    concatenate to the scan of the whole image; every shard re-saved equals the corresponding records of the file."""
+    rng = np.random.default_rng(2024)
+    m, shift, rows = 3000, 5, 32 * 9 + 11                            # 10 blocks, the last one ragged
+    mat = scenarios.ld_matrix(rng, rows, m, n_founders=12, switch=0.1)
+    mat[rng.integers(0, rows, 40), rng.integers(0, m, 40)] = 2
+    mat[rng.integers(0, rows, 40), rng.integers(0, m, 40)] = 3
+    data = orc.encode_pbf(mat, 2, shift)
+    _, _, strings = split_rle(data)
+    whole = hip.HipPbf.from_bytes(data)
+    wr = hip.HipReader(whole)
+    want, want_gt = wr.scan(0, rows, want_gt=True)
+    oc, ogt = oracle_scan(data, 0, rows)
+    assert np.array_equal(want, oc) and np.array_equal(want_gt, ogt)
+    bounds = [0, 32 * 3, 32 * 4, 32 * 8, rows]                       # shards of 3, 1, 4 and 1+ blocks
+    start = np.stack([np.arange(m, dtype=np.int32)] * 2)
+    got, got_gt = [], []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        ss = strings[2 * a: 2 * b]
+        rle = np.frombuffer(b"".join(ss), np.uint8)
+        lens = np.array([len(x) for x in ss], np.uint32)
+        sh = hip.HipPbf.from_rle(m, shift, rle, lens)
+        own_final = sh.final_ranks()
+        sh.rebase(start)
+        # final ranks after re-basing = own final map through the start order
+        nxt = sh.final_ranks()
+        assert np.array_equal(nxt, np.stack([own_final[p][start[p]] for p in range(2)]))
+        rd = hip.HipReader(sh)
+        c, g = rd.scan(0, b - a, want_gt=True)
+        got.append(c); got_gt.append(g)
+        assert np.array_equal(rd.scan(5, b - a - 1), want[a + 5: b - 1])   # a scan that starts inside a block
+        rd.close(); sh.close()
+        start = nxt
+    assert np.array_equal(np.concatenate(got), want)
+    assert np.array_equal(np.concatenate(got_gt), want_gt)
+    with pytest.raises(RuntimeError):
+        whole.final_ranks()                                          # an image read from a file keeps none
+    wr.close(); whole.close()
 
 
 def test_bad_inputs_fail_loudly(hip):
