@@ -10,10 +10,14 @@ strings, row directory, checkpoints) are resident in HBM before the timed region
           then `secondary` records at 100,000 samples (the north-star width): C3 (1,000,000 sites, every 20th sample =
           10,000 tracked columns) and one C4 shard (153 file blocks = 1,253,376 sites, whole cohort), each with its own
           roofline and a CPU baseline from the compiled reference on the first sites of the same database.
-  N > 1   weak scaling (--workload c2, default): rank r scans sites [r*1M, (r+1)*1M) of the same cohort (site-range
-          sharding, no data-path collective), then an all_gather over RCCL/xGMI of the per-shard counts and flags.
-          --workload c4: BASELINE configs[3] itself, strong scaling: the 1,221 file blocks of 100,000 samples x
-          10,000,000 sites split over the N ranks (153 blocks per rank at N = 8), gather of the per-shard counts.
+  N > 1   default --workload c4 = BASELINE configs[3] itself, strong scaling: the 1,221 file blocks of ONE database of
+          100,000 samples x 10,000,000 sites split over the N ranks (153 blocks per rank at N = 8; site-range sharding, no
+          data-path collective), then an all_gather over RCCL/xGMI of the per-shard counts and flags.  Every rank builds
+          its shard from the identity order, the shards' final ranks are exchanged and each shard is re-based onto the
+          composition of the earlier ones (bgth_pbf_rebase), so the gathered counts are those of the one database.  Rank 0
+          checks them after the timed region: the plane-popcount identity on every site of every shard and a CPU-oracle
+          window that runs across the boundary between shard 0 and shard 1 (`parity_ok`).  (The N = 1 point of this
+          workload: `bench.py --workload c4`.)  --workload c2: weak scaling, rank r scans sites [r*1M, (r+1)*1M).
 
 Prints one JSON line (rank 0).
 
@@ -24,6 +28,8 @@ the product's own row-step statement (8 VALU + 1 ds_read_b64 per lookup, random 
 waves per SIMD -- what the chip sustains if nothing but lookups ran; `achieved` = algorithmic lookups of the launch /
 its duration (HIP events).  `algorithmic_equiv_gbs` keeps SURVEY 8d's figure (reference-algorithm bytes / kernel time) and
 `hbm_traffic` / `valu` / `lds` the rocprofv3 PMC numbers of the same kernel, replayed from profiles/ (marked so).
+`peak_ideal_mix` is a ceiling that does not move with the code: the minimal row step (5 instructions of the 4-cycle
+class, 3 of the 2-cycle class) priced with class rates measured live, as if nothing else ever issued.
 `cpu_baseline` = the compiled reference (oracle/_ref/bgt) timed on this box's host cores on a bounded sample.
 """
 import argparse
@@ -54,7 +60,20 @@ def lookup_peak(bgt_amd, device):
         raise RuntimeError("bgth_debug_issue_rate failed")
     cycles, ms, valu = out[0], out[1], out[2]
     lookups = 256.0 * (4 * waves) * 64 * (valu / 8.0)                           # CUs x waves x lanes x lookups per wave
+    # class rates for the code-independent ceiling: v_add_u32 (the 2-cycle class) and v_bcnt_u32_b32 (the 4-cycle class
+    # of the VOP3 integer forms), dependency-free streams at 4 waves per SIMD
+    cls = {}
+    for name, mix in (("c2", 1), ("c4", 3)):
+        o = (C.c_double * 4)()
+        if L.bgth_debug_issue_rate(device, mix, waves, iters, o) != 0:
+            raise RuntimeError("bgth_debug_issue_rate failed")
+        cls[name] = o[0] / (waves * o[2])
+    clock_hz = cycles / (ms * 1e-3)
+    ideal_cycles = 5.0 * cls["c4"] + 3.0 * cls["c2"]                            # v_mad_i32_i24 v_lshlrev v_bcnt v_cmp v_cndmask | v_ashrrev v_sub v_add
     return {"g_lookups_per_s": lookups / (ms * 1e-3) / 1e9, "cycles_per_valu_instr": cycles / (waves * valu),
+            "ideal_mix_g_lookups_per_s": 1024.0 * 64.0 * clock_hz / ideal_cycles / 1e9,
+            "class_cycles": {"two_cycle_class_v_add_u32": cls["c2"], "four_cycle_class_v_bcnt_u32_b32": cls["c4"],
+                             "minimal_step_cycles_per_lookup_wave": ideal_cycles},
             "valu_instr_per_cycle_per_simd": waves * valu / cycles, "clock_ghz": cycles / (ms * 1e6), "ms": ms,
             "source": "live: bgth_debug_issue_rate(mix 7 = the scan kernel's own 8-lookup statement incl. ds_read_b64 on "
                       "random entries and SALU counts, 256 CUs x 4 waves/SIMD, %d iterations)" % iters}
@@ -92,16 +111,20 @@ def replayed_counters(workload, sites, kernel_name):
     return out
 
 
-def make_roofline(peak, T, sites, k_ms, rle_bytes_per_site, geo, workload, counters_sites):
+def make_roofline(peak, T, sites, k_ms, rle_bytes_per_site, geo, workload, counters_sites, path=None):
     lookups = 2.0 * T * sites                                                      # tracked columns x 2 planes x sites
     achieved = lookups / (k_ms * 1e-3) / 1e9
     alg_bytes_per_site = 16.0 * T + rle_bytes_per_site + 12.0
-    kname = "scan_kernel<%d, %d" % (geo["threads"], geo["cols_per_thread"])
+    kname = ("walk_kernel<%d, %d" if path and path.get("directory_path") else "scan_kernel<%d, %d") % (geo["threads"], geo["cols_per_thread"])
     r = {"bound": "valu_issue", "achieved": achieved, "peak": peak["g_lookups_per_s"], "unit": "G rank-lookups/s",
          "frac": achieved / peak["g_lookups_per_s"], "traffic": None,
          "kernel": kname + ", ...>", "kernel_ms": k_ms, "lookups_per_launch": lookups,
          "peak_source": peak["source"], "peak_cycles_per_valu_instr": peak["cycles_per_valu_instr"],
          "peak_clock_ghz": peak["clock_ghz"],
+         "peak_ideal_mix": peak["ideal_mix_g_lookups_per_s"], "frac_of_ideal_mix": achieved / peak["ideal_mix_g_lookups_per_s"],
+         "peak_ideal_mix_source": "code-independent: 1024 SIMDs x 64 lanes x clock / (5 x four-cycle-class + 3 x two-cycle-class "
+                                  "cycles), class rates measured live (%.2f / %.2f cycles per wave-instruction at 4 waves per SIMD)"
+                                  % (peak["class_cycles"]["four_cycle_class_v_bcnt_u32_b32"], peak["class_cycles"]["two_cycle_class_v_add_u32"]),
          "algorithmic_bytes_per_site": alg_bytes_per_site,
          "algorithmic_equiv_gbs": alg_bytes_per_site * sites / (k_ms * 1e-3) / 1e9,
          "hbm_peak_gbs": HBM_PEAK_GBS,
@@ -113,9 +136,67 @@ def make_roofline(peak, T, sites, k_ms, rle_bytes_per_site, geo, workload, count
         r["counters"] = rc
         r["traffic"] = rc.get("hbm_bytes_per_launch")
         r["traffic_replayed_from"] = rc["replayed_from"]
+        if rc.get("hbm_bytes_per_launch") and rc.get("profiled_kernel_ms"):
+            r["hbm_frac_measured"] = rc["hbm_bytes_per_launch"] / (rc["profiled_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
         if rc.get("valu_instr_per_cycle_per_simd"):
             r["valu_issue_frac_profiled"] = rc["valu_instr_per_cycle_per_simd"] / peak["valu_instr_per_cycle_per_simd"]
     return r
+
+
+
+def plane_ones(np, rle, lens, chunk_strings=1 << 16):
+    """Ones of every RLE string (rows x 2 planes) straight from the bytes (reference pbwt.c:12-21: len = (code & 15) <<
+    4 (code >> 4), bit = byte & 1) -- independent of any permutation state."""
+    b = np.arange(256, dtype=np.int64)
+    tab = np.where(b & 1, ((b >> 1) & 15) << (4 * (b >> 5)), 0)
+    lens64 = lens.astype(np.int64)
+    off = np.concatenate([[0], np.cumsum(lens64)])
+    out = np.zeros(lens.size, np.int64)
+    for a in range(0, lens.size, chunk_strings):
+        z = min(lens.size, a + chunk_strings)
+        seg = tab[rle[off[a]:off[z]]]
+        if seg.size:
+            starts = off[a:z] - off[a]
+            tot = np.add.reduceat(seg, np.minimum(starts, seg.size - 1))
+            tot[lens64[a:z] == 0] = 0
+            out[a:z] = tot
+    return out.reshape(-1, 2)
+
+
+def popcount_identity(np, counts, ones, m):
+    """counts int32[n][3] = {AN, AC, AC<M>} of a whole-cohort scan against the strings' ones: n(1) + n(3) = ones(plane 0),
+    n(2) + n(3) = ones(plane 1), n(2) = m - AN."""
+    c = counts.reshape(-1, 3).astype(np.int64)
+    return bool(np.array_equal(c[:, 1] + c[:, 2], ones[:, 0]) and np.array_equal((m - c[:, 0]) + c[:, 2], ones[:, 1]))
+
+
+def oracle_window(bgt_amd, np, img, m, shift, seed, abs_row, img_row, n_rows, tmp, device, cols=None):
+    """CPU-oracle counts of cohort rows [abs_row, abs_row + n_rows): the strings are drawn again (the generator is
+    addressable by row), built into a small image from the identity order, re-based onto the ranks the big image `img`
+    holds before its row img_row (= the same cohort row), saved as a .pbf and decoded by the oracle from that 'S' record
+    on, sequentially -- across every block / shard boundary inside the window."""
+    import orc                                                    # CPU oracle: checker only
+    # Subset decoding (reference pbwt.c:340-388) takes its order from an 'S' record only when it SEEKS more than a block
+    # ahead (pbwt.c:349-372: nearer targets are reached by decoding forward) -- a reader at row 0 assumes the identity
+    # order, as every real file has there.  With a column subset the window therefore gets a lead of two 2048-row blocks:
+    # the oracle seeks past them, picks up the order from the third block's 'S' record and carries its own tracked ranks
+    # from there on (it never reloads them while reading on).
+    lead = 4096 if cols is not None else 0
+    assert img_row >= lead and abs_row >= lead
+    rle, lens = bgt_amd.synth_rows(m, abs_row - lead, lead + n_rows, seed)
+    wshift = 11 if lead else max(shift, int(n_rows - 1).bit_length())   # whole cohort: ONE block, no 'S' record inside the window,
+    small = bgt_amd.HipPbf.from_rle(m, wshift, rle, lens, device=device)   # so the oracle carries its own order across the boundaries
+    small.rebase(img.ranks_at(img_row - lead))
+    path = os.path.join(tmp, "window_%d.pbf" % abs_row)
+    small.save(path)
+    small.close()
+    ora = orc.Pbf(open(path, "rb").read())
+    os.remove(path)
+    if cols is not None:
+        ora.subset(cols)
+    t0 = time.perf_counter()
+    oc = ora.scan(lead, lead + n_rows)
+    return oc.reshape(n_rows, 1, 3), time.perf_counter() - t0
 
 
 def reference_cli_baseline(n_samples, ns, seed, view_args, tmp, what, all_cores=False):
@@ -305,6 +386,7 @@ class Pipeline:
             self.host_flags = [torch.empty(world * n, dtype=torch.uint8).pin_memory() for _ in range(2)]
             self.host_n_pass = [torch.zeros(1, dtype=torch.int64).pin_memory() for _ in range(2)]
         self.ready = [torch.cuda.Event() for _ in range(2)]
+        self.gather_ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         self.copied = [torch.cuda.Event() for _ in range(2)]
         for e in self.copied:
             e.record(self.main)
@@ -320,6 +402,7 @@ class Pipeline:
         self.flt.apply_device(self.counts[b].data_ptr(), self.n, 3, self.flags[b].data_ptr(), self.n_pass_d[b].data_ptr(),
                               self.main.cuda_stream)
         if self.world > 1:                                                       # per-shard AN/AC + flags over xGMI
+            self.gather_ev[0].record(self.main)
             if self.dist.get_backend() == "gloo":                        # dry run of the multi-rank path without RCCL (tests)
                 self.main.synchronize()
                 gc, gf, npass = self.g_counts[b].cpu(), self.g_flags[b].cpu(), self.n_pass_d[b].cpu()
@@ -331,6 +414,7 @@ class Pipeline:
                 self.dist.all_gather_into_tensor(self.g_counts[b], self.counts[b])
                 self.dist.all_gather_into_tensor(self.g_flags[b], self.flags[b])
                 self.dist.all_reduce(self.n_pass_d[b])
+            self.gather_ev[1].record(self.main)
         self.ready[b].record(self.main)
         if self.rank == 0:
             with torch.cuda.stream(self.side):
@@ -357,6 +441,7 @@ class Pipeline:
         self.barrier()                                                           # includes the side stream: all results on the host
         dt = time.perf_counter() - t0
         k_ms = self.rd.timing()["scan_ms"]                                       # HIP events around the scan kernel of the last step
+        self.gather_ms = self.gather_ev[0].elapsed_time(self.gather_ev[1]) if self.world > 1 else 0.0   # (last step)
         return dt, k_ms, last
 
 
@@ -370,15 +455,7 @@ def secondary_record(torch, bgt_amd, np, peak, name, what, n_samples, sites, see
     pbf = bgt_amd.HipPbf.from_rle(m, 13, rle, lens, device=local)
     t_load = time.time() - t0
     rle_bytes_per_site = rle.size / sites
-    n_chk, chk = min(sites, 1024), None
-    try:                                                          # a small image of the first sites for the oracle check
-        nb = int(lens[:2 * n_chk].sum(dtype=np.int64))
-        small = bgt_amd.HipPbf.from_rle(m, 13, rle[:nb], lens[:2 * n_chk], device=local)
-        small.save(os.path.join(tmp, "chk.pbf"))
-        small.close()
-        chk = open(os.path.join(tmp, "chk.pbf"), "rb").read()
-    except Exception:
-        chk = None
+    ones = plane_ones(np, rle, lens) if every <= 1 else None
     del rle
     rd = bgt_amd.HipReader(pbf)
     view_args = ["-G", "-f", "AC>0"]
@@ -388,25 +465,47 @@ def secondary_record(torch, bgt_amd, np, peak, name, what, n_samples, sites, see
         view_args = ["-G", "-f", "AC>0", "-s", "idx%%%d==0" % every]
     T = rd.width
     pipe = Pipeline(torch, bgt_amd, rd, 0, sites, dev, local, 1, 0, None)
-    dt, k_ms, last = pipe.run(steps, warmup)
-    geo = rd.geometry()
+    # ONE-SHOT figures first: every step builds its rows again (the directory path would otherwise walk the arena the
+    # previous step left; BGTH_VARIANT 128 forbids that) -- then the same steps with the arena kept, labelled so
+    kept = None
+    os.environ["BGTH_VARIANT"] = "128"
+    try:
+        dt, k_ms, last = pipe.run(steps, warmup)
+    finally:
+        os.environ.pop("BGTH_VARIANT")
+    geo, path = rd.geometry(), rd.path()
+    if path["directory_path"]:
+        dt2, k2, _ = pipe.run(steps, 1)
+        kept = {"sites_per_s": sites / (dt2 / steps), "ms_per_step": dt2 / steps * 1e3, "kernel_ms": k2,
+                "note": "second and later passes of a reader over the same rows: the directory arena (%.1f GB) still holds "
+                        "them, only the walk-only kernel runs" % (sites * 2.0 * (((m + 31) // 32 + 2) & ~1) * 8 / 1e9)}
     rec = {"workload": what, "haplotypes": m, "tracked_columns": T, "sites": sites,
            "sites_per_s": sites / (dt / steps), "ms_per_step": dt / steps * 1e3, "kernel_ms": k_ms, "steps": steps,
-           "sites_passing_filter": int(pipe.host_n_pass[last].item()), "launch": geo,
+           "sites_passing_filter": int(pipe.host_n_pass[last].item()), "launch": geo, "kernel_path": path,
            "rle_bytes_per_site": round(rle_bytes_per_site, 1), "hbm_resident_bytes": pbf.hbm_bytes,
            "setup": {"generate_s": round(t_gen, 1), "upload_and_checkpoints_s": round(t_load, 1)},
-           "roofline": make_roofline(peak, T, sites, k_ms, rle_bytes_per_site, geo, counters_workload, sites)}
-    # the timed step's output against the CPU oracle (port of the reference path) on the first sites
-    if chk is not None:
-        import orc                                                # checker only
-        ora = orc.Pbf(chk)
-        if every > 1:
-            ora.subset(np.stack([2 * sel, 2 * sel + 1], 1).reshape(-1))
-        oc = ora.scan(0, n_chk)
-        rec["gpu_matches_cpu_oracle_on_first_sites"] = bool(np.array_equal(oc.reshape(n_chk, 1, 3), pipe.host[last].numpy()[:n_chk]))
-        rec["oracle_sites_checked"] = n_chk
-        if not rec["gpu_matches_cpu_oracle_on_first_sites"]:
-            rec["parity_error"] = "GPU counts differ from the CPU oracle on the first %d sites" % n_chk
+           "roofline": make_roofline(peak, T, sites, k_ms, rle_bytes_per_site, geo, counters_workload, sites, path)}
+    if kept:
+        kept["roofline_frac"] = 2.0 * T * sites / (kept["kernel_ms"] * 1e-3) / 1e9 / peak["g_lookups_per_s"]
+        rec["arena_kept"] = kept
+    # ---- the timed step's output: (1) whole cohort: the plane-popcount identity on EVERY site; (2) a CPU-oracle window
+    # across a mid-file block boundary (the oracle starts from the order the image holds 2048 rows before the boundary and
+    # carries its own order across it)
+    host = pipe.host[last].numpy()
+    par = {}
+    if ones is not None:
+        par["popcount_identity_ok"] = popcount_identity(np, host[:sites], ones[:sites], m)
+        par["sites_checked_popcount_identity"] = sites
+    mid = (sites // 2) // 8192 * 8192
+    if mid >= 8192:
+        cols = np.stack([2 * sel, 2 * sel + 1], 1).reshape(-1) if every > 1 else None
+        oc, t_or = oracle_window(bgt_amd, np, pbf, m, 13, seed, mid - 2048, mid - 2048, 2048 + 512, tmp, local, cols)
+        par["oracle_window"] = {"rows": [mid - 2048, mid + 512], "block_boundary_at_row": mid,
+                                "matches": bool(np.array_equal(oc, host[mid - 2048: mid + 512])), "oracle_s": round(t_or, 2)}
+    par["parity_ok"] = bool(par.get("popcount_identity_ok", True) and par.get("oracle_window", {"matches": True})["matches"])
+    rec["parity"], rec["parity_ok"] = par, par["parity_ok"]
+    if not par["parity_ok"]:
+        rec["parity_error"] = "timed output fails the on-box checks: %s" % json.dumps(par)
     if os.path.exists(REF_BIN) and cpu_sites > 0:
         try:
             base, same = reference_cli_baseline(n_samples, cpu_sites, seed, view_args, tmp, what)
@@ -428,7 +527,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c2", choices=sorted(SAMPLES))
+    ap.add_argument("--workload", default=None, choices=sorted(SAMPLES),
+                    help="default: c2 on one GPU, c4 (BASELINE configs[3], strong scaling over one database) on several")
     ap.add_argument("--sites", type=int, default=0, help="sites per GPU (default 1,000,000; c4: all 10,000,000 split over the GPUs)")
     ap.add_argument("--every", type=int, default=0, help="select every N-th sample only (C3: --workload c3 --every 20)")
     ap.add_argument("--seed", type=int, default=0)
@@ -465,6 +565,8 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
+    if args.workload is None:
+        args.workload = "c2" if world == 1 else "c4"
     n_samples = SAMPLES[args.workload]
     m = 2 * n_samples
     shift = 13
@@ -491,6 +593,26 @@ def main():
     pbf = bgt_amd.HipPbf.from_rle(m, shift, rle, lens, device=local)   # upload + checkpoints on the GPU
     t_load = time.time() - t0
     rle_bytes_per_site = rle.size / my_rows
+    t_chain = 0.0
+    if world > 1:
+        # ONE database: shard r starts from the order the rows before it leave behind = final(r-1) o ... o final(0),
+        # every final(i) being what rank i's shard does to the identity order (ranks by column; one gather per plane)
+        t0 = time.time()
+        mine = torch.from_numpy(pbf.final_ranks())                # (the last, padded shard's is used by nobody)
+        finals = [torch.empty_like(mine) for _ in range(world)]
+        if args.backend == "nccl":
+            g = [f.to(dev) for f in finals]
+            dist.all_gather(g, mine.to(dev))
+            finals = [f.cpu() for f in g]
+        else:
+            dist.all_gather(finals, mine)
+        start = np.stack([np.arange(m, dtype=np.int32)] * 2)
+        for i in range(rank):
+            f = finals[i].numpy()
+            start = np.stack([f[0][start[0]], f[1][start[1]]])
+        if rank:
+            pbf.rebase(start)
+        t_chain = time.time() - t0
     rd = bgt_amd.HipReader(pbf)
     if args.every > 1:                                          # sample subset (-s): fewer tracked columns, same rows
         sel = np.arange(0, n_samples, args.every)
@@ -510,10 +632,45 @@ def main():
         else:                                                   # the last shard is padded to the longest: count its real rows only
             hf = host_flags.numpy()
             n_pass = int(sum(hf[r * sites: r * sites + (shards[r][1] - shards[r][0])].sum() for r in range(world)))
+    rank_kernel_ms, parity = [k_ms], None
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        cdev = dev if args.backend == "nccl" else "cpu"
+        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        ks = [torch.zeros(1, dtype=torch.float64, device=cdev) for _ in range(world)]
+        dist.all_gather(ks, torch.tensor([k_ms], dtype=torch.float64, device=cdev))
+        rank_kernel_ms = [float(k.item()) for k in ks]
+        # ---- parity of the gathered result, after the timed region.  (1) every rank counts the ones of its strings; rank 0
+        # holds the gathered counts and checks the plane-popcount identity on every site of every shard
+        real = row_hi - row_lo
+        ones = torch.zeros((sites, 2), dtype=torch.int64)
+        if args.every <= 1:
+            ones[:real] = torch.from_numpy(plane_ones(np, rle, lens)[:real])
+        all_ones = [torch.empty_like(ones, device=cdev) for _ in range(world)]
+        dist.all_gather(all_ones, ones.to(cdev))
+        if rank == 0:
+            parity = {"sites_checked_popcount_identity": 0, "popcount_identity_ok": None}
+            if args.every <= 1:
+                ok = True
+                for r in range(world):
+                    n_r = (shards[r][1] - shards[r][0]) if strong else sites
+                    ok = ok and popcount_identity(np, host.numpy()[r * sites: r * sites + n_r], all_ones[r].cpu().numpy()[:n_r], m)
+                    parity["sites_checked_popcount_identity"] += n_r
+                parity["popcount_identity_ok"] = ok
+            # (2) a CPU-oracle window across the boundary between shard 0 and shard 1: the last rows of rank 0's shard and the
+            # first rows of rank 1's, decoded sequentially from the order rank 0's image holds before the window
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            with tempfile.TemporaryDirectory() as wtmp:
+                edge = row_hi - row_lo                                   # rank 0: rows [0, edge) of its image
+                back = edge - max(0, (edge - (2048 if m > 20000 else 8192)) // 2048 * 2048)   # (starts on a checkpoint row)
+                ahead = min(sites, 512 if m > 20000 else 2048)
+                cols = np.stack([2 * sel, 2 * sel + 1], 1).reshape(-1) if args.every > 1 else None
+                oc, t_or = oracle_window(bgt_amd, np, pbf, m, shift, seed, row_hi - back, edge - back, back + ahead, wtmp, local, cols)
+                got = np.concatenate([host.numpy()[edge - back: edge], host.numpy()[sites: sites + ahead]])
+                parity["oracle_window"] = {"rows": [int(row_hi - back), int(row_hi + ahead)], "shard_boundary_at_row": int(row_hi),
+                                           "matches": bool(np.array_equal(oc, got)), "oracle_s": round(t_or, 2)}
+            parity["parity_ok"] = bool(parity["oracle_window"]["matches"] and parity["popcount_identity_ok"] is not False)
 
     ms_per_step = dt / args.steps * 1e3
     value = total / (dt / args.steps)
@@ -532,7 +689,9 @@ def main():
         out = {
             "metric": "sites/sec `bgt view -G -f'AC>0'` whole-cohort scan",
             "value": value, "unit": "sites/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": ("strong" if strong else "weak") if world > 1 else None,      # (one GPU: nothing scales)
+            "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": wl,
                        "haplotypes": m, "tracked_columns": T, "sites_per_gpu": sites, "sites_total": total,
@@ -542,10 +701,23 @@ def main():
                        "filter": "AC>0 evaluated on the device (bgth_filter_apply_device); counts + flags copied "
                                  "to pinned host memory, the copy of step i overlapping the scan of step i+1",
                        "launch": geo},
-            "roofline": make_roofline(peak, T, sites, k_ms, rle_bytes_per_site, geo, args.workload, sites),
+            "roofline": make_roofline(peak, T, sites, k_ms, rle_bytes_per_site, geo, args.workload, sites, rd.path()),
             "setup": {"generate_s": round(t_gen, 2), "upload_and_checkpoints_s": round(t_load, 2),
                       "hbm_resident_bytes": pbf.hbm_bytes},
         }
+        if world > 1:
+            out["parity_ok"] = parity["parity_ok"]
+            out["parity"] = parity
+            out["per_rank_kernel_ms"] = rank_kernel_ms
+            out["gather_ms"] = pipe.gather_ms
+            out["setup"]["chain_shards_s"] = round(t_chain, 2)
+            out["config"]["one_database"] = ("every shard built from the identity order, then re-based onto the composition of "
+                                             "the earlier shards' final ranks (bgth_pbf_final_ranks / bgth_pbf_rebase)")
+            out["config"]["kernel_path"] = rd.path()
+            if not parity["parity_ok"]:
+                out["parity_error"] = "gathered counts fail the on-box checks: %s" % json.dumps(parity)
+            if strong:
+                out["config"]["n1_point"] = "python bench.py --workload c4 (the same database on one GPU)"
 
     # ---- CPU baseline + on-box parity check (rank 0, N=1 only) on a bounded sample of the same cohort:
     # the first `cpu_sample` sites.  The COMPILED REFERENCE (oracle/_ref/bgt, built from /root/reference in the build
@@ -578,6 +750,19 @@ def main():
             out["cpu_baseline"] = port
             if not same:
                 out["parity_error"] = "GPU counts differ from the CPU oracle on the sample"
+            # every site of the timed output against the strings' ones, and an oracle window across a mid-file block boundary
+            par = {"popcount_identity_ok": popcount_identity(np, host.numpy()[:sites], plane_ones(np, rle, lens)[:sites], m),
+                   "sites_checked_popcount_identity": sites}
+            mid = (sites // 2) // (1 << shift) * (1 << shift)
+            if mid >= (1 << shift):
+                back, ahead = (1 << shift) if m <= 20000 else 2048, 1024 if m <= 20000 else 512
+                oc, t_or = oracle_window(bgt_amd, np, pbf, m, shift, seed, row_lo + mid - back, mid - back, back + ahead, tmp, local)
+                par["oracle_window"] = {"rows": [mid - back, mid + ahead], "block_boundary_at_row": mid,
+                                        "matches": bool(np.array_equal(oc, host.numpy()[mid - back: mid + ahead])), "oracle_s": round(t_or, 2)}
+            par["parity_ok"] = bool(same and par["popcount_identity_ok"] and par.get("oracle_window", {"matches": True})["matches"])
+            out["parity"], out["parity_ok"] = par, par["parity_ok"]
+            if not par["parity_ok"] and "parity_error" not in out:
+                out["parity_error"] = "timed output fails the on-box checks: %s" % json.dumps(par)
             if os.path.exists(REF_BIN):
                 try:
                     base, cli_same = reference_cli_baseline(n_samples, ns, seed, ["-G", "-f", "AC>0"], tmp,
@@ -616,7 +801,7 @@ def main():
                                  "configuration), whole cohort, -G -f'AC>0'", 153 * 8192, 4, 0, "c4shard")):
                 try:
                     rec = secondary_record(torch, bgt_amd, np, peak, name, what, 100000, s_sites, s_seed, s_every,
-                                           args.secondary_steps, 1, dev, local, tmp, 4096, cw)
+                                           args.secondary_steps, 1, dev, local, tmp, 8192 + 2048, cw)   # (past the second 'S' record)
                     rec["name"] = name
                     out["secondary"].append(rec)
                     if rec.get("parity_error"):

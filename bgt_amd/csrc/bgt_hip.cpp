@@ -62,6 +62,26 @@ static R guarded(const char *who, R on_fail, F body)
 }
 extern "C" const char *bgth_version(void) { return "bgt-hip 0.1 (gfx950)"; }
 
+// The HIP runtime takes 60-220 ms to start and the first launch loads the code objects: a process that knows it will
+// need the device starts both on a thread of their own while it parses headers, sample tables and the site side-car.
+// (Whoever touches the device first simply waits on the runtime's own initialisation lock.)
+extern "C" void bgth_runtime_warmup_async(int device)
+{
+    try {
+        std::thread([device] {
+            if (hipSetDevice(device) != hipSuccess) return;
+            hipFree(nullptr);
+            int32_t *d = nullptr;                                                           // first launch: code object load
+            if (hipMalloc((void**)&d, 64) == hipSuccess) {
+                hipMemset(d, 0, 64);
+                launch_finalize(d, d + 8, d + 4, 1, 1, nullptr);
+                hipDeviceSynchronize();
+                hipFree(d);
+            }
+        }).detach();
+    } catch (...) {}
+}
+
 extern "C" int bgth_device_count(void)
 {
     int n = 0;
@@ -1223,6 +1243,9 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
         int wt = 0, wc = 0;                              // BGTH_WALK_GEOM=threads,cols: tuning knob of the walk-only kernel
         if (const char *e = getenv("BGTH_WALK_GEOM")) sscanf(e, "%d,%d", &wt, &wc);
         if (!choose_walk_geometry(p->m, r->sel.n_chunks, G, (int)(blk1 - blk0 + 1), wt, wc, &wgeo)) dirpath = false;
+        // the team kernels also slice the columns of a SHORT scan to fill the chip; the directory path is for selections whose
+        // columns do not fit one workgroup (every slice then repeats the build), not for those
+        else if (wgeo.slices < 2 && !variant_flag(kVariantDirAlways)) dirpath = false;
     }
     r->geom = dirpath ? wgeo : geo;
     r->dir_passes = r->dir_built = 0;

@@ -1761,8 +1761,19 @@ int bgtm_read_vcf(bgtm_t *bm, bcf1_t *b, kstring_t *s)
  * bgtm_read_vcf loop.  Returns the number of records written, or -1 if the query needs the site-by-site path.
  * ------------------------------------------------------------------------------------------------ */
 #define BULK_MAX_DB 64
+#define BULK_MAX_THREADS 128
+/* one database's device pass, in pieces: `ready` rows (from r0 on) have their counts on the host; formatters start on a
+ * block of sites as soon as the rows it uses are there, while the device scans the next piece */
+typedef struct bulk_scan_s {
+    bgth_reader_t *rd; int64_t r0, r1, piece; int32_t *counts; int cstride; int rc; char err[256]; pthread_t th; int started;
+    volatile int64_t ready;
+    volatile int *failed;                                         /* set (under the lock) when a piece fails: releases every waiter */
+    pthread_mutex_t *lock; pthread_cond_t *cond;
+} bulk_scan_t;
+
 typedef struct {
     bgtm_t *bm; int n_db; int need_counts, cstride;
+    bulk_scan_t *scan; volatile int failed;
     const sitetab_t *t[BULK_MAX_DB]; int64_t row_min[BULK_MAX_DB]; const int32_t *counts[BULK_MAX_DB];
     /* the merged walk: site j of the output is site idx[d][j] of database d (-1: that database lacks it); lead[j] = the
      * database whose record describes the site (the smallest look-ahead, first of equals: read_core's `best`) */
@@ -1789,6 +1800,19 @@ static void *bulk_worker(void *arg)
         if (blk >= k->n_blocks) break;
         o = &k->out[blk];
         j0 = blk * k->blk_sites; j1 = j0 + k->blk_sites < k->n_sites ? j0 + k->blk_sites : k->n_sites;
+        if (k->need_counts) {                                     /* wait for the pieces that hold this block's rows */
+            int d;
+            for (d = 0; d < k->n_db; ++d) {
+                int64_t need = -1;
+                if (k->scan[d].rd == NULL) continue;
+                for (j = j0; j < j1; ++j) if (k->idx[d][j] >= 0 && k->t[d]->row[k->idx[d][j]] > need) need = k->t[d]->row[k->idx[d][j]];
+                if (need < 0) continue;
+                pthread_mutex_lock(&k->lock);
+                while (!k->failed && k->scan[d].ready <= need - k->scan[d].r0) pthread_cond_wait(&k->cond, &k->lock);
+                pthread_mutex_unlock(&k->lock);
+            }
+        }
+        if (k->failed) j1 = j0;                                   /* a device pass failed: nothing more is formatted */
         for (j = j0; j < j1; ++j) {                               /* what read_core does for one merged site without genotypes */
             const sitetab_t *t = k->t[k->lead[j]];
             const int64_t i = k->idx[k->lead[j]][j];
@@ -1829,12 +1853,24 @@ static void *bulk_worker(void *arg)
     return NULL;
 }
 
-typedef struct { bgth_reader_t *rd; int64_t r0, r1; int32_t *counts; int rc; char err[256]; pthread_t th; int started; } bulk_scan_t;
 static void *bulk_scan_worker(void *arg)
 {
     bulk_scan_t *q = (bulk_scan_t*)arg;
-    q->rc = bgth_reader_scan(q->rd, q->r0, q->r1, q->counts, NULL) < 0 ? -1 : 0;      /* every row's AN / AC in one device pass */
-    if (q->rc < 0) { strncpy(q->err, bgth_last_error(), sizeof(q->err) - 1); q->err[sizeof(q->err) - 1] = 0; }
+    int64_t a0;
+    q->rc = 0;
+    for (a0 = q->r0; a0 < q->r1 && q->rc == 0; ) {              /* every row's AN / AC, a piece of whole sub-blocks at a time */
+        int64_t a1 = a0 + q->piece < q->r1 ? (a0 + q->piece) / q->piece * q->piece : q->r1;
+        if (a1 <= a0 || a1 > q->r1) a1 = q->r1;
+        if (bgth_reader_scan(q->rd, a0, a1, q->counts + (size_t)(a0 - q->r0) * (size_t)q->cstride, NULL) < 0) {
+            q->rc = -1;
+            strncpy(q->err, bgth_last_error(), sizeof(q->err) - 1); q->err[sizeof(q->err) - 1] = 0;
+        }
+        pthread_mutex_lock(q->lock);
+        if (q->rc == 0) q->ready = a1 - q->r0; else *q->failed = 1;
+        pthread_cond_broadcast(q->cond);
+        pthread_mutex_unlock(q->lock);
+        a0 = a1;
+    }
     return NULL;
 }
 
@@ -1842,7 +1878,8 @@ long bgtm_write_vcf_bulk(bgtm_t *bm, FILE *fp, long n_rec)
 {
     bulk_t k;
     bulk_scan_t scan[BULK_MAX_DB];
-    pthread_t th[16];
+    pthread_t th[BULK_MAX_THREADS];
+    int n_started = 0;
     int64_t i, lo[BULK_MAX_DB], hi[BULK_MAX_DB], cur[BULK_MAX_DB], total = 0, cap = 0;
     long written = 0;
     int n_threads, j, d, failed = 0;
@@ -1893,8 +1930,11 @@ long bgtm_write_vcf_bulk(bgtm_t *bm, FILE *fp, long n_rec)
         }
         ++k.n_sites;
     }
-    /* counts: one device pass per database over the rows its sites use, the databases side by side */
+    /* counts: one device pass per database over the rows its sites use, the databases side by side and each in pieces, so
+     * that the formatters below work on the sites of piece k while the device scans piece k+1 */
     memset(scan, 0, sizeof(scan));
+    k.scan = scan;
+    pthread_mutex_init(&k.lock, NULL); pthread_cond_init(&k.cond, NULL);
     if (k.need_counts) {
         for (d = 0; d < k.n_db; ++d) {
             const sitetab_t *t = k.t[d];
@@ -1903,46 +1943,51 @@ long bgtm_write_vcf_bulk(bgtm_t *bm, FILE *fp, long n_rec)
             if (row_max < 0) { k.row_min[d] = 0; continue; }
             k.row_min[d] = row_min;
             scan[d].rd = ((devrd_t*)bm->bgt[d]->pb)->rd; scan[d].r0 = row_min; scan[d].r1 = row_max + 1;
+            scan[d].piece = 131072; scan[d].cstride = k.cstride; scan[d].lock = &k.lock; scan[d].cond = &k.cond; scan[d].failed = &k.failed;
             scan[d].counts = (int32_t*)malloc((size_t)(row_max - row_min + 1) * (size_t)k.cstride * 4);
             if (scan[d].counts == NULL) { failed = 1; break; }
             k.counts[d] = scan[d].counts;
-            if (d > 0 && pthread_create(&scan[d].th, NULL, bulk_scan_worker, &scan[d]) == 0) scan[d].started = 1;
-        }
-        for (d = 0; d < k.n_db && !failed; ++d) if (scan[d].rd && !scan[d].started) bulk_scan_worker(&scan[d]);
-        for (d = 0; d < k.n_db; ++d) {
-            if (scan[d].started) pthread_join(scan[d].th, NULL);
-            if (scan[d].rd && scan[d].rc < 0) { fprintf(stderr, "[E::%s] %s\n", __func__, scan[d].err); failed = 2; }
         }
         if (failed) {
             for (d = 0; d < k.n_db; ++d) { free(scan[d].counts); free(k.idx[d]); }
             free(k.lead);
-            return failed == 2 ? -2 : -1;
+            pthread_mutex_destroy(&k.lock); pthread_cond_destroy(&k.cond);
+            return -1;
         }
+        for (d = 0; d < k.n_db; ++d)
+            if (scan[d].rd && pthread_create(&scan[d].th, NULL, bulk_scan_worker, &scan[d]) == 0) scan[d].started = 1;
     }
     k.blk_sites = 8192;
     k.n_blocks = (k.n_sites + k.blk_sites - 1) / k.blk_sites;
     k.out = (kstring_t*)calloc((size_t)k.n_blocks, sizeof(kstring_t));
     k.n_lines = (int64_t*)calloc((size_t)k.n_blocks, 8);
     k.done = (volatile int*)calloc((size_t)k.n_blocks, sizeof(int));
-    pthread_mutex_init(&k.lock, NULL); pthread_cond_init(&k.cond, NULL);
     {
         long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
         const char *e = getenv("BGT_THREADS");
-        n_threads = e ? atoi(e) : (int)(ncpu > 16 ? 16 : ncpu);
+        n_threads = e ? atoi(e) : (int)(ncpu > 64 ? 64 : ncpu);   /* (formatting is memory-bound long before 64 threads) */
         if (n_threads < 1) n_threads = 1;
-        if (n_threads > 16) n_threads = 16;
+        if (n_threads > BULK_MAX_THREADS) n_threads = BULK_MAX_THREADS;
         if (n_threads > k.n_blocks) n_threads = (int)k.n_blocks;
     }
-    for (j = 0; j < n_threads; ++j) pthread_create(&th[j], NULL, bulk_worker, &k);
+    for (j = 0; j < n_threads; ++j) if (pthread_create(&th[n_started], NULL, bulk_worker, &k) == 0) ++n_started;
+    for (d = 0; d < k.n_db; ++d) if (scan[d].rd && !scan[d].started) {   /* no thread for it: the device pass runs here */
+        bulk_scan_worker(&scan[d]);
+    }
+    if (n_started == 0) bulk_worker(&k);                          /* no formatter thread could be started: format here */
     for (i = 0; i < k.n_blocks; ++i) {                            /* blocks leave in order, as soon as they are ready */
         pthread_mutex_lock(&k.lock);
         while (!k.done[i]) pthread_cond_wait(&k.cond, &k.lock);
         pthread_mutex_unlock(&k.lock);
-        if (k.out[i].l) fwrite(k.out[i].s, 1, k.out[i].l, fp);
+        if (k.out[i].l && !k.failed) fwrite(k.out[i].s, 1, k.out[i].l, fp);
         written += (long)k.n_lines[i];
         free(k.out[i].s); k.out[i].s = NULL;
     }
-    for (j = 0; j < n_threads; ++j) pthread_join(th[j], NULL);
+    for (j = 0; j < n_started; ++j) pthread_join(th[j], NULL);
+    for (d = 0; d < k.n_db; ++d) {
+        if (scan[d].started) pthread_join(scan[d].th, NULL);
+        if (scan[d].rd && scan[d].rc < 0) { fprintf(stderr, "[E::%s] %s\n", __func__, scan[d].err); failed = 2; }
+    }
     pthread_mutex_destroy(&k.lock); pthread_cond_destroy(&k.cond);
     for (d = 0; d < k.n_db; ++d) {
         bm->n_gt_read += (uint64_t)(hi[d] - lo[d]) * (uint64_t)bm->bgt[d]->n_out;
@@ -1951,5 +1996,5 @@ long bgtm_write_vcf_bulk(bgtm_t *bm, FILE *fp, long n_rec)
     }
     free(k.lead);
     free(k.out); free(k.n_lines); free((void*)k.done);
-    return written;
+    return failed ? -2 : written;
 }

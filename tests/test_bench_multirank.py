@@ -1,0 +1,38 @@
+"""The exact command the driver uses for N > 1 (python -m torch.distributed.run ... bench.py --gpus N), dry-run on the one
+GPU of the test box: two ranks, both on device 0 (BENCH_ALL_RANKS_ON_DEVICE0), collectives over gloo instead of RCCL.
+Everything else is the real path: C4 shape (100,000 samples) sharded by file blocks, every rank's shard built from the
+identity order and re-based onto the composition of the earlier shards (ONE database), per-shard scans on the device,
+gather, and rank 0's on-box parity checks (plane-popcount identity on every site of every shard + a CPU-oracle window
+across the boundary between shard 0 and shard 1)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("workload,sites,extra", [("c4", 6 * 8192 - 1000, []), ("c2", 40000, [])])
+def test_two_ranks_on_one_device(workload, sites, extra):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--backend", "gloo", "--sites", str(sites)] + (["--workload", workload] if workload != "c4" else []) + extra
+    env = dict(os.environ, BENCH_ALL_RANKS_ON_DEVICE0="1", BGTH_DIR_ARENA_MB="6000")
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=1200, cwd=ROOT)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    line = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["value"] > 0
+    assert out["scaling"] == ("strong" if workload == "c4" else "weak")
+    if workload == "c4":
+        assert "C4" in out["config"]["workload"] and out["config"]["haplotypes"] == 200000
+    assert out["parity_ok"] is True, out["parity"]
+    assert out["parity"]["popcount_identity_ok"] is True and out["parity"]["oracle_window"]["matches"] is True
+    assert out["parity"]["sites_checked_popcount_identity"] == out["config"]["sites_total"]
+    assert len(out["per_rank_kernel_ms"]) == 2 and "parity_error" not in out

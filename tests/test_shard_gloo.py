@@ -63,3 +63,54 @@ def test_gathered_shards_equal_single_scan(world):
         p.join(60)
         assert p.exitcode == 0
     assert np.array_equal(got, full)
+
+
+def _s_records(data):
+    """rank form (column -> rank, per plane) of every 'S' record of a .pbf image (reference pbwt.c:292-301 writes the
+    permutation rank -> column; :343 inverts it)."""
+    import struct
+    m, g, shift = struct.unpack("<iii", data[4:16])
+    pos, out = 16, []
+    while data[pos:pos + 1] != b"I":
+        if data[pos:pos + 1] == b"S":
+            perm = np.frombuffer(data, np.int32, g * m, pos + 1).reshape(g, m)
+            inv = np.empty_like(perm)
+            for p in range(g):
+                inv[p][perm[p]] = np.arange(m, dtype=np.int32)
+            out.append(inv)
+            pos += 1 + 4 * g * m
+        pos += 1
+        for _ in range(g):
+            (l,) = struct.unpack("<i", data[pos:pos + 4])
+            pos += 4 + l
+    return out
+
+
+def test_rank_map_composition_on_the_oracle():
+    """The arithmetic behind bgth_pbf_rebase and the parallel checkpoint derivation, pinned to the oracle writer's 'S'
+    records on the CPU: a row moves whatever sits at position R to LF(R) = bit ? n0 + rank1(R) : R - rank1(R)
+    (reference pbwt.c:76-88), so what a block does to the order is a map F_b of POSITIONS -- the ranks it produces from
+    the identity order -- and the checkpoint after the block is F_b o (the checkpoint before it), whatever that was."""
+    rng = np.random.default_rng(11)
+    m, shift, rows = 97, 3, 8 * 9
+    mat = scenarios.ld_matrix(rng, rows, m, n_founders=6, switch=0.2)
+    mat[rng.integers(0, rows, 30), rng.integers(0, m, 30)] = 3
+    mat[rng.integers(0, rows, 30), rng.integers(0, m, 30)] = 2
+    whole = _s_records(orc.encode_pbf(mat, 2, shift))              # column -> rank before rows 0, 8, 16, ...
+    assert len(whole) == 9
+    for p in range(2):
+        bits = (mat >> p) & 1
+        for b in range(8):
+            # the block's rows in PBWT order (what its strings spell), from the order the file holds before the block
+            rank = whole[b][p].copy()
+            fmap = np.arange(m)                                      # F_b so far: position before the block -> position now
+            for r in range(8 * b, 8 * b + 8):
+                row = np.empty(m, np.int64)
+                row[rank] = bits[r]                                  # B[rank of column c] = bit of column c
+                n0 = int((row == 0).sum())
+                before = np.concatenate([[0], np.cumsum(row)])[:-1]  # rank1(R)
+                lf = np.where(row == 1, n0 + before, np.arange(m) - before)
+                rank = lf[rank]
+                fmap = lf[fmap]
+            assert np.array_equal(rank, whole[b + 1][p]), (p, b)    # the numpy restatement agrees with the oracle writer
+            assert np.array_equal(fmap[whole[b][p]], whole[b + 1][p])   # checkpoint(b+1) = F_b o checkpoint(b)
