@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -91,6 +92,52 @@ extern "C" int bgth_device_count(void)
 }
 
 // ----------------------------------------------------------------------------------------------------
+// RCCL (the gather of per-shard counts over xGMI).  The library is bound at first use, not at link time: a
+// process that has torch loaded already holds torch's own copy of librccl, and a second RCCL runtime in the process is
+// the same trap as a second HIP runtime (bgt_amd/hip.py) -- so a copy that is already mapped is preferred.
+// ----------------------------------------------------------------------------------------------------
+struct Rccl {
+    void *h = nullptr;
+    int (*CommInitAll)(void **comm, int ndev, const int *devlist) = nullptr;
+    int (*CommDestroy)(void *comm) = nullptr;
+    int (*Send)(const void *buf, size_t count, int dtype, int peer, void *comm, hipStream_t s) = nullptr;
+    int (*Recv)(void *buf, size_t count, int dtype, int peer, void *comm, hipStream_t s) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+static Rccl &rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *names[] = {"librccl.so", "librccl.so.1"};
+        for (int pass = 0; pass < 2 && !r.h; ++pass)
+            for (const char *n : names) {
+                r.h = dlopen(n, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
+                if (r.h) break;
+            }
+        if (!r.h) r.h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!r.h) return;
+        r.CommInitAll = (decltype(r.CommInitAll))dlsym(r.h, "ncclCommInitAll");
+        r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.h, "ncclCommDestroy");
+        r.Send = (decltype(r.Send))dlsym(r.h, "ncclSend");
+        r.Recv = (decltype(r.Recv))dlsym(r.h, "ncclRecv");
+        r.GroupStart = (decltype(r.GroupStart))dlsym(r.h, "ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.h, "ncclGroupEnd");
+        r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
+        r.ok = r.CommInitAll && r.CommDestroy && r.Send && r.Recv && r.GroupStart && r.GroupEnd && r.GetErrorString;
+    });
+    return r;
+}
+#define RCCL_TRY(expr, onfail)                                                           \
+    do {                                                                                 \
+        const int e_ = (expr);                                                           \
+        if (e_ != 0) { set_err("[E::%s] %s: %s", __func__, #expr, rccl().GetErrorString(e_)); onfail; } \
+    } while (0)
+
+// ----------------------------------------------------------------------------------------------------
 // objects
 // ----------------------------------------------------------------------------------------------------
 struct Selection {
@@ -137,6 +184,11 @@ struct bgth_pbf_s {
     // A SHARDED image (bgth_pbf_open_sharded): the file's blocks dealt out as contiguous block ranges, one partial image
     // per shard, each on its own device.  The parent holds no device data; n = n_total, row_off = 0.
     std::vector<bgth_pbf_t*> shards;
+    // RCCL communicator over the DISTINCT devices of the shards (bgth_reader_scan_device on a sharded image gathers the
+    // per-shard counts on shard 0's device): comm[i] belongs to comm_dev[i]; built at the first gather
+    std::vector<void*> comm;
+    std::vector<int> comm_dev;
+    std::mutex comm_lock;
     // Readers given back by bgth_reader_destroy wait here (stream, events, device and pinned buffers intact) for the next
     // bgth_reader_create on this image: a resident process answers query after query without re-allocating any of it.
     std::mutex pool_lock;
@@ -150,7 +202,9 @@ struct bgth_pbf_s {
 //   cohorts whose columns span several workgroups);  128 = no reuse of an arena that already holds the rows of a scan
 enum { kVariantNoTog = 1, kVariantNeverZP = 2, kVariantAlwaysZP = 4, kVariantNoPrefetch = 16,    // 16: no window prefetch in the pull interface
        kVariantDirAlways = 32, kVariantDirNever = 64, kVariantDirNoReuse = 128, kVariantDirNoWarm = 256,
-       kVariantSeqCheckpoints = 512 };                     // 512: bgth_pbf_from_rle derives its checkpoints block after block
+       kVariantSeqCheckpoints = 512,                       // 512: bgth_pbf_from_rle derives its checkpoints block after block
+       kVariantRcclSelf = 1024 };                          // 1024: sharded scan_device gathers through RCCL even between shards of ONE device
+                                                           //       (send / receive to self): runs the RCCL path on a one-GPU box
 static bool variant_flag(int bit) { const char *d = getenv("BGTH_VARIANT"); return d && (atoi(d) & bit); }
 
 // Builds the row index once per image; later calls only return it.  The build is enqueued on `s`, the
@@ -235,6 +289,7 @@ struct bgth_reader_s {
     int dir_passes = 0, dir_built = 0;
     float dir_build_ms = 0;
     hipEvent_t ev_dir[2] = {nullptr, nullptr};
+    hipEvent_t ev_gather = nullptr;   // sharded scan_device: this shard's counts have left for the root device
     DevBuf carriers, hapsig;          // allele-set accumulators (bgth_reader_fold_last), zeroed when folds_live turns true
     bool folds_live = false;
     PullWindow win[2];                // pull interface: current window and the one being prefetched
@@ -360,6 +415,8 @@ static void reader_free(bgth_reader_t *r);
 extern "C" void bgth_pbf_close(bgth_pbf_t *p)
 {
     if (!p) return;
+    for (void *c : p->comm) if (c) rccl().CommDestroy(c);
+    p->comm.clear();
     for (bgth_pbf_t *sh : p->shards) bgth_pbf_close(sh);
     for (bgth_reader_t *r : p->pool) reader_free(r);
     p->pool.clear();
@@ -1093,6 +1150,7 @@ static void reader_free(bgth_reader_t *r)
     r->dir.release(); r->dir_n0.release();
     for (int i = 0; i < 4; ++i) if (r->ev[i]) hipEventDestroy(r->ev[i]);
     for (int i = 0; i < 2; ++i) if (r->ev_dir[i]) hipEventDestroy(r->ev_dir[i]);
+    if (r->ev_gather) hipEventDestroy(r->ev_gather);
     if (r->stream) hipStreamDestroy(r->stream);
     delete r;
 }
@@ -1127,6 +1185,7 @@ extern "C" bgth_reader_t *bgth_reader_create(bgth_pbf_t *p)
         HIP_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking), { reader_free(r); return nullptr; });
         for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&r->ev[i]), { reader_free(r); return nullptr; });
         for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreate(&r->ev_dir[i]), { reader_free(r); return nullptr; });
+        HIP_TRY(hipEventCreateWithFlags(&r->ev_gather, hipEventDisableTiming), { reader_free(r); return nullptr; });
     }
     if (!guarded("bgth_reader_create", false, [&] { return build_selection(r->sel, p->m, 0, nullptr, nullptr, 1); })) { reader_free(r); return nullptr; }
     for (bgth_pbf_t *sh : p->shards) {
@@ -1193,6 +1252,26 @@ extern "C" int bgth_reader_tune(bgth_reader_t *r, int threads, int cpt, int K)
 
 static int gx_of(int G) { return G > 1 ? G : 0; }
 
+
+// communicator of a sharded image over its distinct devices; false (error set) if RCCL cannot be used
+static bool ensure_comm(bgth_pbf_t *p)
+{
+    std::lock_guard<std::mutex> g(p->comm_lock);
+    if (!p->comm.empty()) return true;
+    if (!rccl().ok) { set_err("[E::bgth] librccl.so could not be loaded: the shards of this image are on several devices and their counts are gathered over RCCL"); return false; }
+    std::vector<int> devs;
+    for (const bgth_pbf_t *sh : p->shards) if (std::find(devs.begin(), devs.end(), sh->device) == devs.end()) devs.push_back(sh->device);
+    std::vector<void*> comm(devs.size(), nullptr);
+    RCCL_TRY(rccl().CommInitAll(comm.data(), (int)devs.size(), devs.data()), return false);
+    p->comm = comm; p->comm_dev = devs;
+    return true;
+}
+static int comm_rank(const bgth_pbf_t *p, int device)
+{
+    for (size_t i = 0; i < p->comm_dev.size(); ++i) if (p->comm_dev[i] == device) return (int)i;
+    return -1;
+}
+
 // ---- directory path (scan_dir.hip) ------------------------------------------------------------------
 // Bytes the arena of a reader may take: BGTH_DIR_ARENA_MB, default 60 % of the HBM that is free when first asked.
 static size_t dir_arena_cap(int device)
@@ -1221,6 +1300,7 @@ static bool want_dir_path(const bgth_pbf_t *p, const Geometry &classic, bool tun
     return classic.nbuf == 1 && classic.wpp > 1 && classic.slices >= 2;
 }
 
+static void collect_timing(bgth_reader_t *r);
 // enqueue decode+reduce of [row0,row1) on stream s; results in d_fin (+ optional planes)
 static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_t *d_fin, uint64_t *d_h0,
                             uint64_t *d_h1, hipStream_t s, bool timed)
@@ -1365,10 +1445,87 @@ static bool to_image_rows(const bgth_pbf_t *p, int64_t &row0, int64_t &row1, con
     return true;
 }
 
+
+// bgth_reader_scan_device on a sharded image: every shard scans its part of [row0,row1) on its own device and stream, then
+// the per-shard counts are GATHERED into d_counts on shard 0's device (the "root"), in shard = row order:
+//   shards on another device      ncclSend on their communicator rank / ncclRecv on the root's, one group (RCCL over xGMI)
+//   shards on the root's device   a device-to-device copy (virtual shards: several shards of one device)
+// The caller's stream (on the root device; NULL = the root shard's stream, synchronised before returning) waits for all of
+// it, so a consumer enqueued behind this call -- the device filter -- sees the gathered counts.  Genotype planes stay
+// per shard (d_h0 / d_h1 must be NULL).
+static int64_t scan_device_sharded(bgth_reader_t *r, int64_t row0, int64_t row1, void *d_counts, void *d_h0, void *d_h1, void *stream)
+{
+    bgth_pbf_t *p = r->pbf;
+    if (d_h0 || d_h1) { set_err("[E::bgth_reader_scan_device] a sharded image gathers counts only: bit planes stay on the shard that decoded them"); return -1; }
+    if (row0 < 0 || row1 > p->n_total || row0 > row1) { set_err("[E::bgth_reader_scan_device] rows [%lld,%lld) outside 0..%lld", (long long)row0, (long long)row1, (long long)p->n_total); return -1; }
+    if (row0 == row1) return 0;
+    const int root_dev = r->subs[0]->pbf->device;
+    const bool self = variant_flag(kVariantRcclSelf);
+    bool several = self;
+    for (bgth_reader_t *sr : r->subs) several = several || sr->pbf->device != root_dev;
+    if (several && !ensure_comm(p)) return -1;
+    const int gx = gx_of(r->sel.G);
+    const size_t cstride = (size_t)(1 + gx) * 3 * 4;                     // bytes per row
+    if (!use_device(root_dev)) return -1;
+    hipStream_t root_s = stream ? (hipStream_t)stream : r->subs[0]->stream;
+    struct Piece { bgth_reader_t *sr; int64_t a0, a1; };
+    std::vector<Piece> pieces;
+    for (bgth_reader_t *sr : r->subs) {
+        const int64_t a0 = std::max(row0, sr->pbf->row_off), a1 = std::min(row1, sr->pbf->row_off + sr->pbf->n);
+        if (a0 < a1) pieces.push_back({sr, a0, a1});
+    }
+    // 1. every shard's scan, enqueued on its own stream (nothing here waits for the device)
+    for (Piece &q : pieces) {
+        bgth_reader_t *sr = q.sr;
+        if (!use_device(sr->pbf->device)) return -1;
+        if (!sr->fin.reserve((size_t)(q.a1 - q.a0) * cstride)) { set_err("[E::bgth_reader_scan_device] out of HBM"); return -1; }
+        if (enqueue_scan(sr, q.a0 - sr->pbf->row_off, q.a1 - sr->pbf->row_off, (int32_t*)sr->fin.p, nullptr, nullptr, sr->stream, true) < 0) return -1;
+        sr->t_pending = true;
+    }
+    // 2. the gather.  Pieces of the root's device: copies on the shard's stream, the root stream waits for them;
+    //    pieces of other devices: send / receive pairs in one RCCL group, the receives on the root stream
+    if (several) RCCL_TRY(rccl().GroupStart(), return -1);
+    bool failed = false;
+    for (Piece &q : pieces) {
+        bgth_reader_t *sr = q.sr;
+        char *dst = (char*)d_counts + (size_t)(q.a0 - row0) * cstride;
+        const size_t bytes = (size_t)(q.a1 - q.a0) * cstride;
+        if (sr->pbf->device == root_dev && !self) {
+            if (hipSetDevice(root_dev) != hipSuccess || hipMemcpyAsync(dst, sr->fin.p, bytes, hipMemcpyDeviceToDevice, sr->stream) != hipSuccess) { failed = true; break; }
+        } else if (sr->pbf->device == root_dev) {                        // (test knob: the same bytes through RCCL, rank to itself)
+            const int root = comm_rank(p, root_dev);
+            if (hipSetDevice(root_dev) != hipSuccess || rccl().Send(sr->fin.p, bytes, 0, root, p->comm[root], sr->stream) != 0 ||
+                rccl().Recv(dst, bytes, 0, root, p->comm[root], sr->stream) != 0) { failed = true; break; }
+        } else {
+            const int peer = comm_rank(p, sr->pbf->device), root = comm_rank(p, root_dev);
+            if (hipSetDevice(sr->pbf->device) != hipSuccess || rccl().Send(sr->fin.p, bytes, 0 /* ncclInt8 */, root, p->comm[peer], sr->stream) != 0) { failed = true; break; }
+            if (hipSetDevice(root_dev) != hipSuccess || rccl().Recv(dst, bytes, 0, peer, p->comm[root], root_s) != 0) { failed = true; break; }
+        }
+    }
+    if (several) {
+        const int e = rccl().GroupEnd();
+        if (e != 0) { set_err("[E::bgth_reader_scan_device] ncclGroupEnd: %s", rccl().GetErrorString(e)); return -1; }
+    }
+    if (failed) { set_err("[E::bgth_reader_scan_device] gathering the shards' counts failed"); return -1; }
+    for (Piece &q : pieces) {                                            // the root stream waits for what left on the shards' own streams
+        bgth_reader_t *sr = q.sr;
+        if (sr->pbf->device != root_dev || sr->stream == root_s) continue;
+        if (hipSetDevice(root_dev) != hipSuccess || hipEventRecord(sr->ev_gather, sr->stream) != hipSuccess ||
+            hipStreamWaitEvent(root_s, sr->ev_gather, 0) != hipSuccess) { set_err("[E::bgth_reader_scan_device] stream hand-over failed"); return -1; }
+    }
+    if (!stream) {
+        if (!use_device(root_dev)) return -1;
+        HIP_TRY(hipStreamSynchronize(root_s), return -1);
+        for (Piece &q : pieces) { hipSetDevice(q.sr->pbf->device); collect_timing(q.sr); }
+    }
+    return row1 - row0;
+}
+
 extern "C" int64_t bgth_reader_scan_device(bgth_reader_t *r, int64_t row0, int64_t row1, void *d_counts,
                                            void *d_h0, void *d_h1, void *stream)
 {
     if (!r || !d_counts) { set_err("[E::bgth_reader_scan_device] NULL argument"); return -1; }
+    if (!r->subs.empty()) return guarded("bgth_reader_scan_device", (int64_t)-1, [&] { return scan_device_sharded(r, row0, row1, d_counts, d_h0, d_h1, stream); });
     if (!use_device(r->pbf->device)) return -1;
     hipStream_t s = stream ? (hipStream_t)stream : r->stream;
     if (!to_image_rows(r->pbf, row0, row1, "bgth_reader_scan_device")) return -1;

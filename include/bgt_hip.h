@@ -53,7 +53,11 @@ bgth_pbf_t *bgth_pbf_open_rows(const char *path, int64_t row0, int64_t row1, int
  * devices[i] (a device may be listed more than once: several shards on one GPU).  Readers of a sharded image run every
  * bgth_reader_scan / refill of the pull interface on all shards concurrently -- one host thread and stream per shard --
  * and deliver rows in file order; the per-shard results meet in the caller's host arrays (each device copies its rows to
- * their place: no device-to-device hop).  bgth_reader_scan_device is refused: its output lives on one device.
+ * their place: no device-to-device hop).  bgth_reader_scan_device GATHERS the shards' counts on shard 0's device (where
+ * d_counts must live; the stream, if any, belongs to that device): every shard scans on its own device and stream, the
+ * counts of shards on other devices travel by ncclSend / ncclRecv in one group (RCCL over xGMI; librccl is bound at first
+ * use), those of shards on shard 0's device by a device copy, and the caller's stream waits for all of it -- so a consumer
+ * enqueued behind the call (bgth_filter_apply_device) sees the gathered counts.  Bit planes are not gathered (NULL).
  * The multi-process form (one rank per GPU, RCCL all-gather of the counts) is bench.py --gpus N. */
 bgth_pbf_t *bgth_pbf_open_sharded(const char *path, int n_shards, const int *devices);
 int         bgth_pbf_n_shards(const bgth_pbf_t *p);      /* 0 for a single-device image                    */

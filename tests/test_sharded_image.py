@@ -64,9 +64,34 @@ def test_sharded_image_equals_the_single_image(tmp_path, n_shards):
             assert np.array_equal(a, b) and np.array_equal(one.last_gt8(), rd.last_gt8())
             assert np.array_equal(one.last_counts(), rd.last_counts())
     rd.seek(rows - 1); assert rd.read() is not None and rd.read() is None
+    # counts that STAY on the device: the shards' pieces are gathered on shard 0's device (device copies between shards of
+    # one device; BGTH_VARIANT 1024 sends the same bytes through RCCL, rank to itself -- the code path of real multi-GPU
+    # nodes, exercised here on one device), and the device filter runs on the gathered array
     import torch
-    with pytest.raises(RuntimeError):                                 # a device pointer belongs to one device
-        rd.scan_device(0, rows, torch.empty((rows, 4, 3), dtype=torch.int32, device="cuda").data_ptr())
+    want = one.scan(0, rows)
+    for variant in (None, "1024"):
+        if variant:
+            os.environ["BGTH_VARIANT"] = variant
+        try:
+            for a, b in ((0, rows), (7, rows - 9), (16, 17)):
+                d = torch.full((b - a, 4, 3), -1, dtype=torch.int32, device="cuda")
+                assert rd.scan_device(a, b, d.data_ptr()) == b - a
+                torch.cuda.synchronize()
+                assert np.array_equal(d.cpu().numpy(), want[a:b]), (variant, a, b)
+            st = torch.cuda.Stream()
+            d = torch.zeros((rows, 4, 3), dtype=torch.int32, device="cuda")
+            flags = torch.zeros(rows, dtype=torch.uint8, device="cuda")
+            n_pass = torch.zeros(1, dtype=torch.int64, device="cuda")
+            flt = bgt_amd.HipFilter("AC1>0&&AC2==0", n_groups=3)
+            rd.scan_device(0, rows, d.data_ptr(), stream=st.cuda_stream)          # caller's stream: nothing waits on the host
+            flt.apply_device(d.data_ptr(), rows, 12, flags.data_ptr(), n_pass.data_ptr(), st.cuda_stream)
+            st.synchronize()
+            exp = (want[:, 1, 1] > 0) & (want[:, 2, 1] == 0)
+            assert np.array_equal(flags.cpu().numpy() != 0, exp) and int(n_pass.item()) == int(exp.sum())
+        finally:
+            os.environ.pop("BGTH_VARIANT", None)
+    with pytest.raises(RuntimeError):                                 # bit planes are not gathered
+        rd.scan_device(0, rows, d.data_ptr(), d.data_ptr(), d.data_ptr())
 
 
 def md5_of(cmd, env=None):
