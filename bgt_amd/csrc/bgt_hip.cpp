@@ -16,6 +16,8 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <stdexcept>
@@ -275,6 +277,54 @@ struct PullWindow {
     }
 };
 
+
+// One host thread per shard of a sharded reader, alive as long as the reader: bgth_reader_scan and every refill of the pull
+// interface hand each shard's piece to its worker instead of creating and joining a thread per call (eight thread
+// creations per window on an 8-GPU node).  The worker binds its device once.
+struct ShardWorker {
+    std::thread th;
+    std::mutex lock;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool busy = false, stop = false;
+    explicit ShardWorker(int device)
+    {
+        th = std::thread([this, device] {
+            hipSetDevice(device);
+            std::unique_lock<std::mutex> g(lock);
+            for (;;) {
+                cv.wait(g, [this] { return stop || (busy && job); });
+                if (stop) return;
+                std::function<void()> f = std::move(job);
+                job = nullptr;
+                g.unlock();
+                try { f(); } catch (...) {}                  // (jobs report through their own error slots)
+                g.lock();
+                busy = false;
+                cv.notify_all();
+            }
+        });
+    }
+    void submit(std::function<void()> f)
+    {
+        std::unique_lock<std::mutex> g(lock);
+        cv.wait(g, [this] { return !busy; });
+        job = std::move(f); busy = true;
+        cv.notify_all();
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> g(lock);
+        cv.wait(g, [this] { return !busy; });
+    }
+    ~ShardWorker()
+    {
+        { std::lock_guard<std::mutex> g(lock); stop = true; }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+};
+
 struct bgth_reader_s {
     bgth_pbf_t *pbf = nullptr;
     Selection sel;
@@ -309,6 +359,7 @@ struct bgth_reader_s {
     const int8_t *last_gt8 = nullptr;
     const char *last_gttext = nullptr;
     std::vector<bgth_reader_t*> subs; // reader of a sharded image: one reader per shard (own device, stream, buffers)
+    std::vector<ShardWorker*> workers; //   and one persistent host thread per shard
 };
 
 static bool use_device(int device)
@@ -688,7 +739,8 @@ extern "C" bgth_pbf_t *bgth_pbf_open(const char *path, int device)
     void *map = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
     close(fd);
     if (map == MAP_FAILED) { set_err("[E::bgth_pbf_open] cannot map '%s'", path); return nullptr; }
-    madvise(map, (size_t)st.st_size, MADV_SEQUENTIAL | MADV_WILLNEED);
+    madvise(map, (size_t)st.st_size, MADV_SEQUENTIAL);       // (advice values are enumerators, not flags: one call each)
+    madvise(map, (size_t)st.st_size, MADV_WILLNEED);
     bgth_pbf_t *p = bgth_pbf_open_mem(map, (size_t)st.st_size, device);
     munmap(map, (size_t)st.st_size);
     return p;
@@ -1192,6 +1244,7 @@ extern "C" bgth_reader_t *bgth_reader_create(bgth_pbf_t *p)
         bgth_reader_t *sub = bgth_reader_create(sh);
         if (!sub) { bgth_reader_destroy(r); return nullptr; }
         r->subs.push_back(sub);
+        r->workers.push_back(new ShardWorker(sh->device));
     }
     return r;
 }
@@ -1201,6 +1254,8 @@ extern "C" bgth_reader_t *bgth_reader_create(bgth_pbf_t *p)
 extern "C" void bgth_reader_destroy(bgth_reader_t *r)
 {
     if (!r) return;
+    for (ShardWorker *w : r->workers) delete w;
+    r->workers.clear();
     for (bgth_reader_t *sub : r->subs) bgth_reader_destroy(sub);
     r->subs.clear();
     {   // a reader that served a big streaming query does not keep its windows (up to 2 x 256 MiB pinned + as much HBM)
@@ -1545,24 +1600,23 @@ extern "C" int64_t bgth_reader_scan(bgth_reader_t *r, int64_t row0, int64_t row1
     const int G = r->sel.G, gx = gx_of(G);
     const size_t cstride = (size_t)(1 + gx) * 3;
     const int nb = (r->sel.width + 3) / 4;
-    if (!r->subs.empty()) {
-        // every shard scans its part of the range on its own device, concurrently (one host thread each), straight into
-        // the caller's arrays at the shard's offset: the "gather in shard order" of SURVEY 8e is the address arithmetic
-        std::vector<std::thread> th;
+    if (!r->subs.empty()) return guarded("bgth_reader_scan", (int64_t)-1, [&]() -> int64_t {
+        // every shard scans its part of the range on its own device, concurrently (one persistent host thread each), straight
+        // into the caller's arrays at the shard's offset: the "gather in shard order" of SURVEY 8e is the address arithmetic
         std::vector<std::string> errs(r->subs.size());
         for (size_t i = 0; i < r->subs.size(); ++i) {
             bgth_reader_t *sr = r->subs[i];
             const int64_t a0 = std::max(row0, sr->pbf->row_off), a1 = std::min(row1, sr->pbf->row_off + sr->pbf->n);
             if (a0 >= a1) continue;
-            th.emplace_back([=, &errs] {
+            r->workers[i]->submit([=, &errs] {
                 if (bgth_reader_scan(sr, a0, a1, counts ? counts + (size_t)(a0 - row0) * cstride : nullptr,
                                      gt ? gt + (size_t)(a0 - row0) * nb : nullptr) < 0) errs[i] = g_err;
             });
         }
-        for (std::thread &t : th) t.join();
+        for (ShardWorker *w : r->workers) w->wait();
         for (const std::string &e : errs) if (!e.empty()) { set_err("%s", e.c_str()); return -1; }
         return row1 - row0;
-    }
+    });
     // with genotypes the planes are large: walk the range in pieces of whole blocks
     int64_t piece = row1 - row0;
     if (gt) {
@@ -1778,7 +1832,6 @@ static bool refill(bgth_reader_t *r)
     } else {
         // the window is cut at the shard boundaries; every shard decodes its piece on its own device, concurrently, and
         // copies it to its place in the (portable, pinned) host ring
-        std::vector<std::thread> th;
         std::vector<std::string> errs(r->subs.size());
         for (size_t i = 0; i < r->subs.size(); ++i) {
             bgth_reader_t *sr = r->subs[i];
@@ -1787,12 +1840,13 @@ static bool refill(bgth_reader_t *r)
             const size_t k = (size_t)(a0 - row0);
             PieceDst d = {base.counts + k * cstride, base.a0 ? base.a0 + k * width : nullptr, base.a1 ? base.a1 + k * width : nullptr,
                           base.gt8 ? base.gt8 + k * width : nullptr, base.gttext ? base.gttext + 2 * k * width : nullptr};
-            th.emplace_back([=, &errs] {
+            r->workers[i]->submit([=, &errs] {                             // (the shard's persistent thread: its device is bound)
+                g_err[0] = 0;
                 if (hipSetDevice(sr->pbf->device) != hipSuccess || !decode_piece(sr, want, a0 - sr->pbf->row_off, a1 - sr->pbf->row_off, d))
                     errs[i] = g_err[0] ? g_err : "shard failed";
             });
         }
-        for (std::thread &t : th) t.join();
+        for (ShardWorker *w : r->workers) w->wait();
         for (const std::string &e : errs) if (!e.empty()) { set_err("%s", e.c_str()); return false; }
         w.row0 = row0; w.row1 = row1; w.has = want; w.valid = true;
     }
@@ -1811,7 +1865,8 @@ extern "C" const uint8_t **bgth_reader_read(bgth_reader_t *r)
         return nullptr;
     }
     if (!use_device(p->device)) return nullptr;
-    if (r->next < r->ring0 || r->next >= r->ring1 || (r->want & ~r->ring_has)) if (!refill(r)) return nullptr;
+    if (r->next < r->ring0 || r->next >= r->ring1 || (r->want & ~r->ring_has))
+        if (!guarded("bgth_reader_read", false, [&] { return refill(r); })) return nullptr;
     const PullWindow &w = r->win[r->cur];
     const int width = r->sel.width;
     const size_t by = (size_t)(r->ring1 - r->ring0) * width;
