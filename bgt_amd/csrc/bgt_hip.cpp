@@ -205,8 +205,9 @@ struct bgth_pbf_s {
 enum { kVariantNoTog = 1, kVariantNeverZP = 2, kVariantAlwaysZP = 4, kVariantNoPrefetch = 16,    // 16: no window prefetch in the pull interface
        kVariantDirAlways = 32, kVariantDirNever = 64, kVariantDirNoReuse = 128, kVariantDirNoWarm = 256,
        kVariantSeqCheckpoints = 512,                       // 512: bgth_pbf_from_rle derives its checkpoints block after block
-       kVariantRcclSelf = 1024 };                          // 1024: sharded scan_device gathers through RCCL even between shards of ONE device
+       kVariantRcclSelf = 1024,                          // 1024: sharded scan_device gathers through RCCL even between shards of ONE device
                                                            //       (send / receive to self): runs the RCCL path on a one-GPU box
+       kVariantPlaneNever = 2048, kVariantPlaneAlways = 4096 };   // the plane-split kernels (sparse selections of wide cohorts)
 static bool variant_flag(int bit) { const char *d = getenv("BGTH_VARIANT"); return d && (atoi(d) & bit); }
 
 // Builds the row index once per image; later calls only return it.  The build is enqueued on `s`, the
@@ -331,6 +332,8 @@ struct bgth_reader_s {
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     DevBuf raw, fin, h0, h1, gt;      // scratch of every scan; results of bgth_reader_scan
+    DevBuf ph0, ph1;                  // bit planes of the plane-split kernels when the caller wants counts only
+    int plane_path = 0;               // the last scan ran the plane-split kernels
     // directory path: the arena of {bits, ones before} rows and their zero counts; [dir_lo, dir_hi) = image rows it holds
     // from the last producer pass (a later scan inside that range only walks), dir_passes/dir_built = what the last scan did
     DevBuf dir, dir_n0;
@@ -1200,6 +1203,7 @@ static void reader_free(bgth_reader_t *r)
     r->carriers.release(); r->hapsig.release();
     r->win[0].release(); r->win[1].release();
     r->dir.release(); r->dir_n0.release();
+    r->ph0.release(); r->ph1.release();
     for (int i = 0; i < 4; ++i) if (r->ev[i]) hipEventDestroy(r->ev[i]);
     for (int i = 0; i < 2; ++i) if (r->ev_dir[i]) hipEventDestroy(r->ev_dir[i]);
     if (r->ev_gather) hipEventDestroy(r->ev_gather);
@@ -1261,11 +1265,12 @@ extern "C" void bgth_reader_destroy(bgth_reader_t *r)
     {   // a reader that served a big streaming query does not keep its windows (up to 2 x 256 MiB pinned + as much HBM)
         size_t held = 0;
         for (const PullWindow &w : r->win) held += w.h_counts.cap + w.h_planes.cap + w.h_gt8.cap + w.h_gttext.cap;
-        if (held > ((size_t)64 << 20) || r->dir.cap > ((size_t)256 << 20)) {
+        if (held > ((size_t)64 << 20) || r->dir.cap > ((size_t)256 << 20) || r->ph0.cap > ((size_t)256 << 20)) {
             hipSetDevice(r->pbf->device);
             if (r->stream) hipStreamSynchronize(r->stream);
             if (held > ((size_t)64 << 20)) { r->win[0].release(); r->win[1].release(); }
             if (r->dir.cap > ((size_t)256 << 20)) { r->dir.release(); r->dir_n0.release(); r->dir_lo = r->dir_hi = 0; }
+            if (r->ph0.cap > ((size_t)256 << 20)) { r->ph0.release(); r->ph1.release(); }
         }
     }
     {   // (not waiting for the stream: a window prefetched behind the last row read may still be on its way -- it lands in
@@ -1382,11 +1387,25 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
         // columns do not fit one workgroup (every slice then repeats the build), not for those
         else if (wgeo.slices < 2 && !variant_flag(kVariantDirAlways)) dirpath = false;
     }
-    r->geom = dirpath ? wgeo : geo;
+    // Plane-split kernels: a selection of few columns of a WIDE cohort (the team kernels would run one workgroup per CU,
+    // mostly building): one workgroup per plane, two per CU.  BGTH_VARIANT 2048 / 4096 forbid / force them.
+    Geometry pgeo;
+    bool planepath = !dirpath && !variant_flag(kVariantPlaneNever) && !(r->tune_threads || r->tune_cpt || r->tune_K) &&
+                     ((geo.nbuf == 1 && geo.wpp > 1 && geo.K == 1) || variant_flag(kVariantPlaneAlways)) &&
+                     choose_plane_geometry(p->m, r->sel.n_chunks, (int)(blk1 - blk0 + 1), &pgeo);
+    uint64_t *p_h0 = d_h0, *p_h1 = d_h1;
+    if (planepath && !d_h0) {
+        const size_t pl = (size_t)rows * r->sel.n_chunks * 8;
+        if (!r->ph0.reserve(pl) || !r->ph1.reserve(pl)) planepath = false;        // (no room for the planes: the team kernels count in place)
+        else { p_h0 = (uint64_t*)r->ph0.p; p_h1 = (uint64_t*)r->ph1.p; }
+    }
+    r->geom = dirpath ? wgeo : planepath ? pgeo : geo;
+    r->plane_path = planepath;
     r->dir_passes = r->dir_built = 0;
     if (!r->raw.reserve((size_t)rows * G * 3 * 4)) { set_err("[E::bgth_reader_scan] out of HBM"); return -1; }
     ScanArgs a;
     if (dirpath) { Geometry team = wgeo; team.wpp = 2; if (!common_scan_args(a, p, r->sel, team, s)) return -1; a.wpp = wgeo.wpp; }   // (wpp > 1: row index)
+    else if (planepath) { if (!common_scan_args(a, p, r->sel, pgeo, s)) return -1; }
     else if (!common_scan_args(a, p, r->sel, geo, s)) return -1;
     a.shift = p->sub_shift;                              // units = sub-blocks
     a.rank0_blk_stride = (int64_t)2 * p->m;
@@ -1407,10 +1426,15 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
     }
 #endif
     if (timed) HIP_TRY(hipEventRecord(r->ev[0], s), return -1);
-    if (G > 1 || r->geom.slices > 1)                         // a single-group, single-slice launch stores its counts
+    if (!planepath && (G > 1 || r->geom.slices > 1))         // a single-group, single-slice launch stores its counts
         HIP_TRY(hipMemsetAsync(r->raw.p, 0, (size_t)rows * G * 3 * 4, s), return -1);
     if (timed) HIP_TRY(hipEventRecord(r->ev[1], s), return -1);
-    if (!dirpath) HIP_TRY(launch_scan(a, geo, s), return -1);
+    if (planepath) {
+        a.h0 = p_h0; a.h1 = p_h1;
+        HIP_TRY(launch_plane_scan(a, pgeo, s), return -1);
+        HIP_TRY(launch_count_planes(p_h0, p_h1, r->sel.d_chunk_desc, (int32_t*)r->raw.p, rows, r->sel.n_chunks, G, s), return -1);
+    }
+    else if (!dirpath) HIP_TRY(launch_scan(a, geo, s), return -1);
     else {
         // Passes over ranges of sub-blocks whose rows fit the arena: producer, then the walk-only kernel.  An arena that
         // already holds the rows of this scan (the previous scan of this reader covered them in one pass) is walked as is.
@@ -1667,7 +1691,7 @@ extern "C" int bgth_reader_last_path(const bgth_reader_t *rc, float out[4])
     bgth_reader_t *r = const_cast<bgth_reader_t*>(rc);
     if (!r->subs.empty()) return bgth_reader_last_path(r->subs[0], out);
     if (r->t_pending) { hipSetDevice(r->pbf->device); collect_timing(r); }
-    out[0] = r->geom.dir_stage >= 0 ? 1.f : 0.f; out[1] = (float)r->dir_passes; out[2] = (float)r->dir_built; out[3] = r->dir_build_ms;
+    out[0] = r->geom.dir_stage >= 0 ? 1.f : r->plane_path ? 2.f : 0.f; out[1] = (float)r->dir_passes; out[2] = (float)r->dir_built; out[3] = r->dir_build_ms;
     return 0;
 }
 

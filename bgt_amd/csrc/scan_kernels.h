@@ -101,6 +101,12 @@ hipError_t launch_finalize(const int32_t *raw, int32_t *out, const int32_t *grou
 // inv[perm[j]] = j for n_perm permutations of m entries each.  bad != NULL (untrusted input): entries outside
 // 0..m-1 are not stored and every record is checked to be a permutation; *bad (device int) becomes non-zero otherwise
 hipError_t launch_invert(const int32_t *perm, int32_t *inv, int m, int64_t n_perm, hipStream_t s, int *bad = nullptr);
+// plane-split kernels (scan_plane.hip; sparse selections of wide cohorts): one workgroup per (sub-block, plane), two per CU;
+// the planes meet in count_planes (raw[row][g][3] = the three popcounts per group from the bit planes h0 / h1)
+bool choose_plane_geometry(int m, int n_chunks, int n_blk, Geometry *g);
+hipError_t launch_plane_scan(const ScanArgs &a, const Geometry &g, hipStream_t s);
+hipError_t launch_count_planes(const uint64_t *h0, const uint64_t *h1, const uint32_t *chunk_desc, int32_t *raw, int64_t n_rows,
+                               int n_chunks, int G, hipStream_t s);
 // out[i][p][c] = table[i * table_stride][p][ via[i * via_stride][p][c] ] for n records of [2][m] ranks: the composition of rank maps
 // behind the parallel checkpoint derivation (bgt_hip.cpp: from_rle_impl, bgth_pbf_rebase)
 hipError_t launch_compose(const int32_t *table, int64_t table_stride, const int32_t *via, int64_t via_stride, int32_t *out,

@@ -1,0 +1,191 @@
+// Plane-split kernels for SPARSE selections of a wide cohort (configs[2]: 5,000 of 100,000 samples).
+//
+// With few tracked columns the walk is a small part of a row (20,000 lookups against two 6,250-word directories to
+// build at m = 200,000) and the team kernel of scan_device.inc.h spends its time in the latency chain of the build and
+// at its barriers: one workgroup per CU (100 KB of directory + 50 KB of toggles), two barriers per row, nothing to
+// overlap them with.  The two planes never meet in the walk (plane p's ranks move by plane p's row alone, reference
+// pbwt.c:129-170), only in the counts.  So here a workgroup owns ONE plane:
+//
+//   plane_kernel    grid = (sub-block, plane).  512 threads track the selection's ranks of that plane (CPT chunks per
+//                   wave), build one 50 KB plane-row per row from the row index (team of 8 waves: chunks -> toggles ->
+//                   directory trips, as the team kernel does) and walk it; 75 KB of LDS, <= 128 VGPRs: TWO workgroups
+//                   share a CU, and while one sits in its build or at a barrier the other walks.  Output: the plane's
+//                   64-bit ballot of every chunk and row (the bit planes H0 / H1 the genotype path uses anyway).
+//   count_kernel    counts[row][group] = popcounts of H0 & ~H1, ~H0 & H1, H0 & H1 per chunk (reference bgt.c:735-757).
+//
+// Same arithmetic, same row step (the plane-0 branch of the hand-scheduled statement).
+#include "scan_device.inc.h"
+
+namespace bgth {
+
+static const int kLdsBytesPlane = 160 * 1024;
+
+template <int CPT>
+__global__ __launch_bounds__(512, 4) void plane_kernel(const ScanArgs a, const uint64_t *__restrict__ rowdesc,
+                                                       const uint8_t *__restrict__ rle, const uint32_t *__restrict__ chunkinfo,
+                                                       const uint32_t *__restrict__ segc)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NT = 512, WPP = 8;                                    // 8 waves: one team on the plane-row
+    static_assert(CPT % 4 == 0, "columns are stepped four at a time");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // workgroup -> (sub-block, plane): the two planes of a sub-block are neighbours (same XCD round-robin slot +- 8)
+    const int plane = (blockIdx.x >> 3) & 1;
+    const int bl = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7);
+    if (bl >= a.n_blk) return;
+
+    const int m = a.m, nw = a.nw, nwp = (nw + 2) & ~1, nwt = (nw + 4) & ~3;
+    uint2 *BD = reinterpret_cast<uint2*>(smem);                         // [nwp] {bits, ones before} + sentinel
+    uint32_t *TOG = reinterpret_cast<uint32_t*>(smem + (size_t)nwp * 8); // [nwt] toggles of the NEXT row
+    uint32_t *n0s = TOG + nwt;                                           // [2]: alternates by row
+    const uint32_t pad_rank = 32u * (uint32_t)nw;
+    const uint32_t lds0 = __builtin_amdgcn_groupstaticsize();
+    const uint32_t tail_mask = (m & 31) ? ((1u << (m & 31)) - 1u) : 0xffffffffu;
+    const int ntrip = (nw + 255) >> 8;
+
+    const int64_t blk = (int64_t)a.blk0 + bl;
+    const int64_t blk_beg = blk << a.shift;
+    int64_t blk_end = (blk + 1) << a.shift;
+    if (blk_end > a.row1) blk_end = a.row1;
+
+    const int chunk0 = wave * CPT;
+    uint32_t rk_[CPT];
+    {
+        const int32_t *rk = a.rank0 + blk * a.rank0_blk_stride + (int64_t)plane * m;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int c = chunk0 + j;
+            const int col = c < a.n_chunks ? a.slot_col[c * 64 + lane] : -1;
+            rk_[j] = ~(col >= 0 ? (uint32_t)rk[col] : pad_rank);
+        }
+    }
+    for (int i = tid; i < nwt; i += NT) TOG[i] = 0u;
+    if (tid == 0) BD[nw] = make_uint2(0u, 0u);
+    lds_barrier();
+
+    uint64_t *hout = plane ? a.h1 : a.h0;
+    const int tw = wave;
+
+    // toggles of row `row` into TOG (the array is clean: the directory pass clears what it reads)
+    uint32_t keep_cyl = 0, keep_tot = 0;
+    auto toggles = [&](int64_t row) {
+        const int64_t sidx = 2 * row + plane;
+        const uint64_t d = rowdesc[sidx];
+        const uint32_t slen = (uint32_t)(d >> kDescLenShift);
+        const uint64_t off = d & kDescOffMask;
+        const uint32_t *sc = segc + (size_t)sidx * (size_t)(a.S8 + 1);
+        const int t = tw + lane * WPP;
+        keep_cyl = t < ntrip ? sc[t] : 0u;
+        keep_tot = sc[a.S8];
+        for (int c = tw; (uint32_t)c * 256u < slen; c += WPP) {
+            const uint32_t k0 = (uint32_t)c * 256u + 4u * (uint32_t)lane;
+            const uint32_t w = k0 < slen ? reinterpret_cast<const uint32_t*>(rle + off)[c * 64 + lane] : 0u;
+            const uint32_t ci = chunkinfo[((off + (uint64_t)c * 256u) >> 8) + (uint64_t)sidx];
+            if (ci & kChunkDead) break;
+            const ChunkDecode cd = decode_chunk(w, k0, slen, lane);
+            chunk_toggles(a, TOG, 1, cd, ci & kChunkPosMask, ci >> 31, lane);
+        }
+    };
+
+    // Loop (iteration -1 only prepares row blk_beg):   walk(row) + toggles(row+1) | directory(row+1) |     two barriers per row
+    for (int64_t row = blk_beg - 1; row < blk_end; ++row) {
+        const bool cur = row >= blk_beg, more = row + 1 < blk_end;
+        if (cur) {
+            const uint32_t base = lds0 - 8u;
+            const uint32_t n0 = 0u - n0s[row & 1];
+            const bool emit = row >= a.row0;
+            uint32_t ca = 0, cb = 0, cc = 0;
+            uint64_t keep = 0;                                           // lane l keeps the ballot of column l (CPT <= 64)
+#pragma unroll
+            for (int j = 0; j < CPT; j += 4) {
+                uint32_t q0[4] = {rk_[j], rk_[j + 1], rk_[j + 2], rk_[j + 3]};
+                uint32_t q1[4] = {0u, 0u, 0u, 0u};                       // (plane-0 branch of the statement: untouched)
+                uint64_t m0[4] = {0, 0, 0, 0}, m1[4] = {0, 0, 0, 0};
+                step4<true>(q0, q1, m0, m1, ca, cb, cc, base, 0u, n0, 0u);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    rk_[j + u] = q0[u];
+                    if (lane == j + u) keep = m0[u];
+                }
+            }
+            if (emit && lane < CPT && chunk0 + lane < a.n_chunks)
+                hout[(size_t)(row - a.row0) * a.n_chunks + chunk0 + lane] = keep;
+        }
+        if (more) toggles(row + 1);
+        lds_barrier();                                                   // every wave is past its walk; the toggles are complete
+        if (more) {
+            directory_trips_tog<2>(TOG, BD, tw, WPP, ntrip, nw, tail_mask, keep_cyl, lane);
+            if (tid == 0) n0s[(row + 1) & 1] = (uint32_t)m - keep_tot;
+        }
+        lds_barrier();
+    }
+}
+
+// counts[row][g][3] += {n(code 1), n(code 2), n(code 3)} from the bit planes, one wave per row
+__global__ __launch_bounds__(256) void count_planes_kernel(const uint64_t *__restrict__ h0, const uint64_t *__restrict__ h1,
+                                                           const uint32_t *__restrict__ chunk_desc, int32_t *raw, int64_t n_rows,
+                                                           int n_chunks, int G)
+{
+    __shared__ int32_t acc[4][32 * 3];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + w;
+    for (int i = lane; i < G * 3; i += 64) acc[w][i] = 0;
+    __syncthreads();
+    if (row < n_rows) {
+        for (int c = lane; c < n_chunks; c += 64) {
+            const uint64_t x = h0[row * n_chunks + c], y = h1[row * n_chunks + c];
+            const int g = (int)(chunk_desc[c] & 255u);
+            const int c1 = __popcll(x & ~y), c2 = __popcll(~x & y), c3 = __popcll(x & y);
+            if (c1) atomicAdd(&acc[w][3 * g], c1);
+            if (c2) atomicAdd(&acc[w][3 * g + 1], c2);
+            if (c3) atomicAdd(&acc[w][3 * g + 2], c3);
+        }
+    }
+    __syncthreads();
+    if (row < n_rows) for (int i = lane; i < G * 3; i += 64) raw[row * G * 3 + i] = acc[w][i];
+}
+
+#define BGTH_PLANE_CPTS(X) X(4) X(8) X(12) X(20) X(32)
+
+bool choose_plane_geometry(int m, int n_chunks, int n_blk, Geometry *g)
+{
+    const int nw = (m + 31) / 32, nwp = (nw + 2) & ~1, nwt = (nw + 4) & ~3;
+    const int lds = nwp * 8 + nwt * 4 + 16;
+    if (2 * lds > kLdsBytesPlane) return false;                         // two workgroups must share a CU: that is the point
+    int cpt = 0;
+#define X(C) if (!cpt && 8 * C >= n_chunks) cpt = C;
+    BGTH_PLANE_CPTS(X)
+#undef X
+    if (!cpt) return false;
+    g->threads = 512; g->cpt = cpt; g->slices = 1; g->K = 1; g->wpp = 8; g->nbuf = 1; g->tog_off = nwp * 8;
+    g->lds_bytes = (lds + 15) & ~15;
+    g->workgroups = ((n_blk + 7) / 8) * 16;                              // 8 sub-blocks x 2 planes per group of 16 ids
+    g->dir_stage = -1;
+    return true;
+}
+
+hipError_t launch_plane_scan(const ScanArgs &a, const Geometry &g, hipStream_t s)
+{
+#define X(C)                                                                                                        \
+    if (g.cpt == C) {                                                                                               \
+        auto fn = plane_kernel<C>;                                                                                  \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes); \
+        if (e != hipSuccess) return e;                                                                              \
+        hipLaunchKernelGGL(fn, dim3(g.workgroups), dim3(512), g.lds_bytes, s, a, a.rowdesc, a.rle, a.chunkinfo, a.segc); \
+        return hipGetLastError();                                                                                   \
+    }
+    BGTH_PLANE_CPTS(X)
+#undef X
+    return hipErrorInvalidConfiguration;
+}
+
+hipError_t launch_count_planes(const uint64_t *h0, const uint64_t *h1, const uint32_t *chunk_desc, int32_t *raw, int64_t n_rows,
+                               int n_chunks, int G, hipStream_t s)
+{
+    if (n_rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(count_planes_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, s, h0, h1, chunk_desc, raw, n_rows, n_chunks, G);
+    return hipGetLastError();
+}
+
+}  // namespace bgth

@@ -200,7 +200,8 @@ int bgth_reader_last_timing(const bgth_reader_t *r, float out[3]);
 /* Launch geometry of the last scan: out = {threads, cols_per_thread, slices, rows_per_batch,
  * lds_bytes, workgroups}. */
 int bgth_reader_last_geometry(const bgth_reader_t *r, int out[6]);
-/* Which kernels the last scan ran: out[0] = 1 if it took the directory path (wide cohorts whose columns span several
+/* Which kernels the last scan ran: out[0] = 2 for the plane-split kernels (a sparse selection of a wide cohort: one
+ * workgroup per bit plane, two per CU, counts from the bit planes), 1 if it took the directory path (wide cohorts whose columns span several
  * workgroups: every row's {bits, ones before} directory is built once into an HBM arena by a producer kernel and the
  * column slices only walk it, pulling rows into LDS by LDS-DMA), 0 for the kernels that rebuild the row per workgroup;
  * out[1] = passes over the arena, out[2] = producer launches (0: the arena still held the rows from the previous scan

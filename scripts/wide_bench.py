@@ -43,6 +43,11 @@ def run(label, variant, reps=3):
 
 
 rd.scan(0, min(sites, 8192))
+if sub:                                               # sparse selection: team kernel against the plane-split kernels
+    ref = run("team kernel", 64 | 2048, 3)
+    a = run("plane-split kernels", 64, 3)
+    print("same counts:", np.array_equal(ref, a), rd.path())
+    sys.exit(0)
 ref = run("team kernels", 64, 2)
 a = run("directory, arena kept", None)
 b = run("directory, one-shot", 128, 2)

@@ -102,3 +102,35 @@ def test_directory_path_in_several_passes(hip, monkeypatch):
     assert np.array_equal(rd.scan(17, 299), oc[17:299])
     rd.close()
     pbf.close()
+
+
+@pytest.mark.parametrize("seed,m,rows,shift,n_sel", [(21, 700, 90, 4, 40), (22, 41000, 40, 3, 900), (23, 9000, 300, 6, 2000),
+                                                     (24, 64, 20, 2, 3), (25, 5000, 2100, 13, 1)])
+def test_plane_split_kernels(hip, monkeypatch, seed, m, rows, shift, n_sel):
+    """scan_plane.hip: one workgroup per bit plane (forced with BGTH_VARIANT=4096 on shapes the oracle decodes quickly):
+    subsets of 1 to 2,000 samples, 1 and 3 groups, genotype planes, scans that start inside a block, several sub-blocks,
+    rows of one run and noisy rows, several chunks per string and several directory trips (m = 41,000)."""
+    monkeypatch.setenv("BGTH_VARIANT", "4096")
+    rng = np.random.default_rng(seed)
+    mat = scenarios.ld_matrix(rng, rows, m, n_founders=7, switch=0.1)
+    mat[2] = 0; mat[3] = 1; mat[4] = 3
+    mat[5] = rng.integers(0, 4, m)
+    mat[rng.integers(0, rows, 50), rng.integers(0, m, 50)] = 2
+    data = orc.encode_pbf(mat, 2, shift)
+    pbf = hip.HipPbf.from_bytes(data)
+    rd = hip.HipReader(pbf)
+    smp = np.sort(rng.choice(m // 2, n_sel, replace=False))
+    cols = np.stack([2 * smp, 2 * smp + 1], 1).reshape(-1).astype(np.int32)
+    for n_groups in (1, 3):
+        group = (1 + (np.arange(n_sel) % n_groups)).astype(np.uint32) if n_groups > 1 else None
+        rd.select(cols, group=group, n_groups=n_groups)
+        oc, ogt = oracle_scan(data, 0, rows, cols=cols, group=group, n_groups=n_groups)
+        c, g = rd.scan(0, rows, want_gt=True)
+        assert rd.path()["plane_split"], (rd.path(), rd.geometry())
+        assert np.array_equal(c, oc) and np.array_equal(g, ogt), rd.geometry()
+        a, b = rows // 3, rows - 1
+        assert np.array_equal(rd.scan(a, b), oc[a:b])                  # counts only: planes in the reader's own buffers
+    monkeypatch.setenv("BGTH_VARIANT", "2048")
+    assert np.array_equal(rd.scan(0, rows), oc) and not rd.path()["plane_split"]
+    rd.close()
+    pbf.close()
