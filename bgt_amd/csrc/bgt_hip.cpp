@@ -166,6 +166,8 @@ struct bgth_pbf_s {
     int device = 0;
     int32_t m = 0, g = 0, shift = 0;
     int32_t sub_shift = 0;            // sub-checkpoints every 1 << sub_shift rows (<= shift), see derive_sub_checkpoints
+    bool wide_plane = false;          // 327,000 < m <= 650,000: a row's two bit-vectors do not fit the LDS together; every scan
+                                      // takes the directory path with one plane per workgroup (scan_plane.hip), no sub-checkpoints
     int64_t n = 0, n_blk = 0;         // n_blk: file blocks of 1 << shift rows
     int64_t n_sub = 0;                // sub-blocks of 1 << sub_shift rows: the unit the kernels work on
     // a partial image (bgth_pbf_open_rows) holds the file blocks that cover a row range: every internal index is
@@ -449,18 +451,26 @@ static bgth_pbf_t *pbf_alloc(int device, int m, int g, int shift, int64_t n)
     if (g != 2) { set_err("[E::bgth_pbf] only g=2 bit planes are supported (BGT writes 2, import.c:68); got %d", g); return nullptr; }
     if (m <= 0 || shift < 0 || shift > 30) { set_err("[E::bgth_pbf] bad header m=%d shift=%d", m, shift); return nullptr; }
     Geometry geo;
+    bool wide_plane = false;
     if (!choose_geometry(m, (m + 63) / 64, 1, 1, 0, 0, 0, &geo)) {
-        set_err("[E::bgth_pbf] m=%d columns: one row's two bit-vectors do not fit the 160 KiB LDS", m);
-        return nullptr;
+        // both bit-vectors of a row (m / 2 bytes with their rank directories) do not fit the 160 KiB LDS: one plane per
+        // workgroup does, up to m / 4 bytes = 160 KiB
+        if (!choose_walk_plane_geometry(m, (m + 63) / 64, 1, &geo)) {
+            set_err("[E::bgth_pbf] m=%d columns: one bit-vector of a row with its rank directory (m / 4 bytes) does not fit the 160 KiB LDS; "
+                    "this build reads cohorts of up to 650,000 haplotypes", m);
+            return nullptr;
+        }
+        wide_plane = true;
     }
     bgth_pbf_t *p = new bgth_pbf_s();
-    p->device = device; p->m = m; p->g = g; p->shift = shift;
+    p->device = device; p->m = m; p->g = g; p->shift = shift; p->wide_plane = wide_plane;
     // Sub-checkpoints: the file carries the permutation every 1 << shift (8192) rows; the image keeps the rank
     // form every 1 << sub_shift rows, derived once on the device.  Finer units = more workgroups per launch (a
     // whole-cohort scan of few blocks fills the GPU without slicing columns, which would repeat the per-row
     // bit-vector build) and shorter pre-rolls for region queries.  Costs rows * m / 2^(sub_shift-3) bytes of HBM.
     p->sub_shift = std::min(shift, 11);
     if (const char *e = getenv("BGTH_SUB_SHIFT")) p->sub_shift = std::max(0, std::min(shift, atoi(e)));
+    if (wide_plane) p->sub_shift = shift;                // (the pass that derives sub-checkpoints runs the two-plane kernels)
     set_rows(p, n);
     return p;
 }
@@ -1075,6 +1085,12 @@ static bgth_pbf_t *from_rle_impl(int m, int g, int shift, int64_t n_rows, const 
     if (!use_device(device)) return nullptr;
     bgth_pbf_t *p = pbf_alloc(device, m, g, shift, n_rows);
     if (!p) return nullptr;
+    if (p->wide_plane) {
+        set_err("[E::bgth_pbf_from_rle] m=%d columns: checkpoints are derived by the two-plane kernels (up to 327,000 haplotypes); "
+                "wider cohorts are read from files, which carry their 'S' records", m);
+        bgth_pbf_close(p);
+        return nullptr;
+    }
     t_building = p;
     p->n_total = n_rows;
     std::vector<uint64_t> desc((size_t)n_rows * g);
@@ -1360,6 +1376,67 @@ static bool want_dir_path(const bgth_pbf_t *p, const Geometry &classic, bool tun
     return classic.nbuf == 1 && classic.wpp > 1 && classic.slices >= 2;
 }
 
+
+// Cohorts whose two bit-vectors do not fit the LDS together (bgth_pbf_s::wide_plane): producer + one walk-only workgroup
+// per (sub-block, column slice, PLANE), the planes joined from their ballots (scan_plane.hip).  Passes over ranges of
+// sub-blocks sized so that the directory arena and, when the caller takes counts only, the passes' own bit planes fit.
+static int64_t enqueue_scan_wide_plane(bgth_reader_t *r, int64_t row0, int64_t row1, int32_t *d_fin, uint64_t *d_h0,
+                                       uint64_t *d_h1, hipStream_t s, bool timed)
+{
+    bgth_pbf_t *p = r->pbf;
+    const int64_t rows = row1 - row0;
+    const int G = r->sel.G;
+    const int64_t blk0 = row0 >> p->sub_shift, blk1 = (row1 - 1) >> p->sub_shift;
+    Geometry wg;
+    if (!choose_walk_plane_geometry(p->m, r->sel.n_chunks, (int)(blk1 - blk0 + 1), &wg)) { set_err("[E::bgth_reader_scan] no launch geometry for m=%d", p->m); return -1; }
+    r->geom = wg; r->plane_path = 1; r->dir_passes = r->dir_built = 0;
+    if (!r->raw.reserve((size_t)rows * G * 3 * 4)) { set_err("[E::bgth_reader_scan] out of HBM"); return -1; }
+    ScanArgs a;
+    { Geometry team = wg; team.wpp = 2; if (!common_scan_args(a, p, r->sel, team, s)) return -1; }
+    a.wpp = wg.wpp; a.n_slices = wg.slices;
+    a.shift = p->sub_shift;
+    a.rank0_blk_stride = (int64_t)2 * p->m;
+    a.row0 = row0; a.row1 = row1;
+    const int nwp = ((p->m + 31) / 32 + 2) & ~1;
+    const size_t plane_row = (size_t)r->sel.n_chunks * 8;
+    const size_t row_bytes = (size_t)2 * nwp * 8 + (d_h0 ? 0 : 2 * plane_row);
+    const int64_t sub_rows = (int64_t)1 << p->sub_shift;
+    const int64_t fit = (int64_t)(dir_arena_cap(p->device) / (row_bytes * (size_t)sub_rows));
+    if (fit < 1) { set_err("[E::bgth_reader_scan] the directory arena does not hold one block of m=%d", p->m); return -1; }
+    int64_t per_pass = std::min<int64_t>(blk1 - blk0 + 1, fit >= 8 ? fit / 8 * 8 : fit);
+    const int64_t pass_rows = std::min<int64_t>(per_pass * sub_rows, row1 - (blk0 << p->sub_shift));
+    if (!r->dir.reserve((size_t)pass_rows * 2 * nwp * 8) || !r->dir_n0.reserve((size_t)pass_rows * 2 * 4) ||
+        (!d_h0 && (!r->ph0.reserve((size_t)pass_rows * plane_row) || !r->ph1.reserve((size_t)pass_rows * plane_row)))) {
+        set_err("[E::bgth_reader_scan] out of HBM (directory arena of %lld rows)", (long long)pass_rows);
+        return -1;
+    }
+    r->dir_lo = r->dir_hi = 0;
+    a.dir = (uint2*)r->dir.p; a.dir_n0 = (uint32_t*)r->dir_n0.p; a.dir_nwp = nwp; a.dir_stage = wg.dir_stage;
+    if (timed) { HIP_TRY(hipEventRecord(r->ev[0], s), return -1); HIP_TRY(hipEventRecord(r->ev[1], s), return -1); }
+    for (int64_t b = blk0; b <= blk1; b += per_pass) {
+        const int64_t be = std::min(blk1 + 1, b + per_pass);
+        const int64_t lo = b << p->sub_shift, hi = std::min(row1, be << p->sub_shift), e0 = std::max(lo, row0);
+        Geometry pg = wg;
+        pg.workgroups = (int)(((be - b) + 7) / 8 * 16 * wg.slices);
+        a.blk0 = (int32_t)b; a.n_blk = (int32_t)(be - b); a.dir_row0 = lo;
+        if (d_h0) { a.h0 = d_h0; a.h1 = d_h1; a.h_row0 = row0; }
+        else { a.h0 = (uint64_t*)r->ph0.p; a.h1 = (uint64_t*)r->ph1.p; a.h_row0 = e0; }
+        if (timed && b == blk0) HIP_TRY(hipEventRecord(r->ev_dir[0], s), return -1);
+        HIP_TRY(launch_dirbuild(a, lo, hi, s), return -1);
+        if (timed && b == blk0) HIP_TRY(hipEventRecord(r->ev_dir[1], s), return -1);
+        ++r->dir_built;
+        HIP_TRY(launch_walk_plane(a, pg, s), return -1);
+        const size_t hoff = d_h0 ? (size_t)(e0 - row0) * r->sel.n_chunks : 0;
+        HIP_TRY(launch_count_planes(a.h0 + hoff, a.h1 + hoff, r->sel.d_chunk_desc, (int32_t*)r->raw.p + (size_t)(e0 - row0) * G * 3,
+                                    hi - e0, r->sel.n_chunks, G, s), return -1);
+        ++r->dir_passes;
+    }
+    if (timed) HIP_TRY(hipEventRecord(r->ev[2], s), return -1);
+    HIP_TRY(launch_finalize((const int32_t*)r->raw.p, d_fin, r->sel.d_group_haps, rows, G, s), return -1);
+    if (timed) HIP_TRY(hipEventRecord(r->ev[3], s), return -1);
+    return rows;
+}
+
 static void collect_timing(bgth_reader_t *r);
 // enqueue decode+reduce of [row0,row1) on stream s; results in d_fin (+ optional planes)
 static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_t *d_fin, uint64_t *d_h0,
@@ -1370,6 +1447,7 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
     if (row0 < 0 || row1 > p->n || row0 > row1) { set_err("[E::bgth_reader_scan] rows [%lld,%lld) outside 0..%lld", (long long)row0, (long long)row1, (long long)p->n); return -1; }
     const int64_t rows = row1 - row0;
     if (rows == 0) return 0;
+    if (p->wide_plane) return enqueue_scan_wide_plane(r, row0, row1, d_fin, d_h0, d_h1, s, timed);
     const int G = r->sel.G;
     const int64_t blk0 = row0 >> p->sub_shift, blk1 = (row1 - 1) >> p->sub_shift;      // sub-blocks
     Geometry geo;
@@ -1412,6 +1490,7 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
     a.raw_counts = (int32_t*)r->raw.p;
     a.h0 = d_h0;
     a.h1 = d_h1;
+    a.h_row0 = row0;
     a.blk0 = (int32_t)blk0;
     a.n_blk = (int32_t)(blk1 - blk0 + 1);
     a.row0 = row0;
@@ -1691,7 +1770,7 @@ extern "C" int bgth_reader_last_path(const bgth_reader_t *rc, float out[4])
     bgth_reader_t *r = const_cast<bgth_reader_t*>(rc);
     if (!r->subs.empty()) return bgth_reader_last_path(r->subs[0], out);
     if (r->t_pending) { hipSetDevice(r->pbf->device); collect_timing(r); }
-    out[0] = r->geom.dir_stage >= 0 ? 1.f : r->plane_path ? 2.f : 0.f; out[1] = (float)r->dir_passes; out[2] = (float)r->dir_built; out[3] = r->dir_build_ms;
+    out[0] = r->plane_path ? 2.f : r->geom.dir_stage >= 0 ? 1.f : 0.f; out[1] = (float)r->dir_passes; out[2] = (float)r->dir_built; out[3] = r->dir_build_ms;
     return 0;
 }
 

@@ -33,6 +33,7 @@ struct ScanArgs {
     const uint32_t *chunk_desc;  // [n_chunks]
     int32_t        *raw_counts;  // [(row1-row0)][G][3] += {n(code1), n(code2), n(code3)}
     uint64_t       *h0, *h1;     // optional [(row1-row0)][n_chunks] bit planes in slot order
+    int64_t         h_row0;      // plane-split kernels only: the row h0 / h1 start at (row0, or the first emitted row of a pass)
     int32_t        *final_rank;  // optional [2][m]: ranks by column after the last row of the launch; with final_blk_stride != 0
     int64_t         final_blk_stride;   //   one record per block of the launch: [n_blk][2][m] at final_rank + bl * stride
     int32_t        *snap;        // optional: sub-checkpoints, ranks by column BEFORE every row that is a multiple of
@@ -107,6 +108,10 @@ bool choose_plane_geometry(int m, int n_chunks, int n_blk, Geometry *g);
 hipError_t launch_plane_scan(const ScanArgs &a, const Geometry &g, hipStream_t s);
 hipError_t launch_count_planes(const uint64_t *h0, const uint64_t *h1, const uint32_t *chunk_desc, int32_t *raw, int64_t n_rows,
                                int n_chunks, int G, hipStream_t s);
+// walk-only plane kernels over the directory arena (scan_plane.hip; cohorts whose two bit-vectors do not fit the LDS together:
+// 327,000 < m <= 650,000): one workgroup per (sub-block, column slice, plane)
+bool choose_walk_plane_geometry(int m, int n_chunks, int n_blk, Geometry *g);
+hipError_t launch_walk_plane(const ScanArgs &a, const Geometry &g, hipStream_t s);
 // out[i][p][c] = table[i * table_stride][p][ via[i * via_stride][p][c] ] for n records of [2][m] ranks: the composition of rank maps
 // behind the parallel checkpoint derivation (bgt_hip.cpp: from_rle_impl, bgth_pbf_rebase)
 hipError_t launch_compose(const int32_t *table, int64_t table_stride, const int32_t *via, int64_t via_stride, int32_t *out,

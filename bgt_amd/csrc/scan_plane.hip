@@ -110,7 +110,7 @@ __global__ __launch_bounds__(512, 4) void plane_kernel(const ScanArgs a, const u
                 }
             }
             if (emit && lane < CPT && chunk0 + lane < a.n_chunks)
-                hout[(size_t)(row - a.row0) * a.n_chunks + chunk0 + lane] = keep;
+                hout[(size_t)(row - a.h_row0) * a.n_chunks + chunk0 + lane] = keep;
         }
         if (more) toggles(row + 1);
         lds_barrier();                                                   // every wave is past its walk; the toggles are complete
@@ -186,6 +186,154 @@ hipError_t launch_count_planes(const uint64_t *h0, const uint64_t *h1, const uin
     if (n_rows <= 0) return hipSuccess;
     hipLaunchKernelGGL(count_planes_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, s, h0, h1, chunk_desc, raw, n_rows, n_chunks, G);
     return hipGetLastError();
+}
+
+
+// ----------------------------------------------------------------------------------------------------
+// Cohorts too wide for both bit-vectors of a row in one LDS (327,000 < m <= 650,000 haplotypes): the walk-only kernel of
+// the directory path (scan_dir.hip), one PLANE per workgroup.  A plane-row (m / 4 bytes) comes from the arena by LDS-DMA
+// into one of two buffers when two fit (the next row lands while this one is walked: one barrier per row), else into
+// the only one; the ballots go out as bit planes and count_planes_kernel joins them.
+// ----------------------------------------------------------------------------------------------------
+template <int NT, int CPT>
+__global__ __launch_bounds__(NT) void walk_plane_kernel(const ScanArgs a, const uint32_t *__restrict__ n0tab)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NWAVE = NT / 64;
+    static_assert(CPT % 4 == 0 && CPT <= 64, "four columns per statement; lane l keeps the ballot of column l");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int S = a.n_slices;
+    const int wg = blockIdx.x;
+    const int sup = wg / (16 * S), rem = wg % (16 * S);
+    const int plane = (rem >> 3) & 1, slice = rem >> 4;
+    const int bl = sup * 8 + (rem & 7);
+    if (bl >= a.n_blk) return;
+
+    const int m = a.m, nw = a.nw, nwp = a.dir_nwp;
+    const uint32_t plane_bytes = (uint32_t)nwp * 8u;
+    const bool two = a.dir_stage & 1;
+    const uint32_t pad_rank = 32u * (uint32_t)nw;
+    const uint32_t lds0 = __builtin_amdgcn_groupstaticsize();
+    const int64_t blk = (int64_t)a.blk0 + bl;
+    const int64_t blk_beg = blk << a.shift;
+    int64_t blk_end = (blk + 1) << a.shift;
+    if (blk_end > a.row1) blk_end = a.row1;
+
+    const int chunk0 = (slice * NWAVE + wave) * CPT;
+    uint32_t rk_[CPT];
+    {
+        const int32_t *rk = a.rank0 + blk * a.rank0_blk_stride + (int64_t)plane * m;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int c = chunk0 + j;
+            const int col = c < a.n_chunks ? a.slot_col[c * 64 + lane] : -1;
+            rk_[j] = ~(col >= 0 ? (uint32_t)rk[col] : pad_rank);
+        }
+    }
+    const unsigned char *dirbase = reinterpret_cast<const unsigned char*>(a.dir);
+    const int npiece = (int)((plane_bytes + 1023u) >> 10);
+    auto dma_row = [&](int buf, int64_t row) {
+        const unsigned char *src = dirbase + (size_t)(2 * (row - a.dir_row0) + plane) * plane_bytes;
+        for (int pc = wave; pc < npiece; pc += NWAVE) {
+            const uint32_t off = (uint32_t)pc * 1024u + (uint32_t)lane * 16u;
+            if (off < plane_bytes)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off),
+                                                 (__attribute__((address_space(3))) void*)(smem + (size_t)buf * plane_bytes + (size_t)pc * 1024u),
+                                                 16, 0, 0);
+        }
+    };
+    uint64_t *hout = plane ? a.h1 : a.h0;
+    int cur = 0;
+    if (blk_beg < blk_end) dma_row(0, blk_beg);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    for (int64_t row = blk_beg; row < blk_end; ++row) {
+        const bool more = row + 1 < blk_end;
+        if (two && more) dma_row(cur ^ 1, row + 1);
+        {
+            const uint32_t base = lds0 + (uint32_t)cur * plane_bytes - 8u;
+            const uint32_t n0 = 0u - n0tab[2 * (row - a.dir_row0) + plane];
+            uint32_t ca = 0, cb = 0, cc = 0;
+            uint64_t keep = 0;
+#pragma unroll
+            for (int j = 0; j < CPT; j += 4) {
+                uint32_t q0[4] = {rk_[j], rk_[j + 1], rk_[j + 2], rk_[j + 3]};
+                uint32_t q1[4] = {0u, 0u, 0u, 0u};
+                uint64_t m0[4] = {0, 0, 0, 0}, m1[4] = {0, 0, 0, 0};
+                step4<true>(q0, q1, m0, m1, ca, cb, cc, base, 0u, n0, 0u);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    rk_[j + u] = q0[u];
+                    if (lane == j + u) keep = m0[u];
+                }
+            }
+            if (row >= a.row0 && hout && lane < CPT && chunk0 + lane < a.n_chunks)
+                hout[(size_t)(row - a.h_row0) * a.n_chunks + chunk0 + lane] = keep;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+        if (two) cur ^= 1;
+        else if (more) {
+            dma_row(0, row + 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+        }
+    }
+    if (a.final_rank) {
+        int32_t *fin = a.final_rank + (int64_t)bl * a.final_blk_stride + (int64_t)plane * m;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int c = chunk0 + j;
+            if (c < a.n_chunks) {
+                const int col = a.slot_col[c * 64 + lane];
+                if (col >= 0) fin[col] = (int32_t)~rk_[j];
+            }
+        }
+    }
+}
+
+#define BGTH_WALK_PLANE_GEOMS(X) X(1024, 16) X(1024, 32) X(1024, 64)
+
+bool choose_walk_plane_geometry(int m, int n_chunks, int n_blk, Geometry *g)
+{
+    const int nw = (m + 31) / 32, nwp = (nw + 2) & ~1;
+    if (nwp * 8 + 64 > kLdsBytesPlane || 2 * ((nw + 4) & ~3) * 4 > kLdsBytesPlane) return false;   // one plane-row / the producer's toggles
+    int best = -1; long best_key = 0;
+    static const int geoms[][2] = {
+#define X(nt, cpt) {nt, cpt},
+        BGTH_WALK_PLANE_GEOMS(X)
+#undef X
+    };
+    for (int i = 0; i < (int)(sizeof(geoms) / sizeof(geoms[0])); ++i) {
+        const int cap = geoms[i][0] / 64 * geoms[i][1];
+        const long slices = (n_chunks + cap - 1) / cap, waste = slices * cap - n_chunks;
+        const long key = slices * 1000000 + waste;
+        if (best < 0 || key < best_key) best = i, best_key = key;
+    }
+    g->threads = geoms[best][0]; g->cpt = geoms[best][1];
+    const int cap = g->threads / 64 * g->cpt;
+    g->slices = (n_chunks + cap - 1) / cap;
+    g->K = 1; g->wpp = g->threads / 64; g->nbuf = 1; g->tog_off = 0;
+    g->dir_stage = 2 * nwp * 8 + 64 <= kLdsBytesPlane ? 1 : 0;          // two plane buffers when they fit
+    g->lds_bytes = ((g->dir_stage ? 2 : 1) * nwp * 8 + 64 + 15) & ~15;
+    g->workgroups = ((n_blk + 7) / 8) * 16 * g->slices;
+    return true;
+}
+
+hipError_t launch_walk_plane(const ScanArgs &a, const Geometry &g, hipStream_t s)
+{
+#define X(NT_, C)                                                                                                   \
+    if (g.threads == NT_ && g.cpt == C) {                                                                           \
+        auto fn = walk_plane_kernel<NT_, C>;                                                                        \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes); \
+        if (e != hipSuccess) return e;                                                                              \
+        hipLaunchKernelGGL(fn, dim3(g.workgroups), dim3(NT_), g.lds_bytes, s, a, a.dir_n0);                          \
+        return hipGetLastError();                                                                                   \
+    }
+    BGTH_WALK_PLANE_GEOMS(X)
+#undef X
+    return hipErrorInvalidConfiguration;
 }
 
 }  // namespace bgth

@@ -134,3 +134,54 @@ def test_plane_split_kernels(hip, monkeypatch, seed, m, rows, shift, n_sel):
     assert np.array_equal(rd.scan(0, rows), oc) and not rd.path()["plane_split"]
     rd.close()
     pbf.close()
+
+
+def test_quarter_million_samples(hip, tmp_path):
+    """m = 500,000 haplotypes: a row's two bit-vectors (250 KB with their rank directories) do not fit the LDS together,
+    one does -- every scan runs producer + one walk-only workgroup per (sub-block, column slice, plane), the planes joined
+    from their ballots.  300 rows in three file blocks, whole cohort with genotypes, a scan that starts inside a block, a
+    subset with groups, the pull interface, the image re-saved byte for byte; bit-exact against the oracle
+    (reference pbwt.c:221-262 opens any m)."""
+    rng = np.random.default_rng(250000)
+    m, rows, shift = 500000, 300, 7
+    mat = scenarios.ld_matrix(rng, rows, m, n_founders=20, switch=0.0005)
+    mat[3] = 0; mat[4] = 1; mat[5] = 3
+    mat[6] = rng.integers(0, 4, m)                                   # ~375,000 runs per plane: every nibble boundary
+    mat[rng.integers(0, rows, 400), rng.integers(0, m, 400)] = 2
+    data = orc.encode_pbf(mat, 2, shift)
+    pbf = hip.HipPbf.from_bytes(data)
+    rd = hip.HipReader(pbf)
+    oc, ogt = oracle_scan(data, 0, rows)
+    c, g = rd.scan(0, rows, want_gt=True)
+    assert rd.path()["plane_split"] and rd.path()["producer_launches"] >= 1, (rd.path(), rd.geometry())
+    assert np.array_equal(c, oc) and np.array_equal(g, ogt), rd.geometry()
+    assert np.array_equal(unpack_gt(g, m), mat)
+    assert np.array_equal(rd.scan(130, 299), oc[130:299])            # starts inside the second block, counts only
+    out = str(tmp_path / "wide.pbf")
+    pbf.save(out)
+    assert open(out, "rb").read() == data
+    smp = np.sort(rng.choice(m // 2, 3000, replace=False))
+    cols = np.stack([2 * smp, 2 * smp + 1], 1).reshape(-1).astype(np.int32)
+    group = (1 + np.arange(3000) % 2).astype(np.uint32)
+    rd.select(cols, group=group, n_groups=2)
+    o2, og2 = oracle_scan(data, 0, rows, cols=cols, group=group, n_groups=2)
+    c2, g2 = rd.scan(0, rows, want_gt=True)
+    assert np.array_equal(c2, o2) and np.array_equal(g2, og2)
+    rd.seek(127)                                                     # pull interface across the block boundary at 128
+    for r in range(127, 131):
+        a = rd.read()
+        assert np.array_equal(a, np.stack([mat[r][cols] & 1, mat[r][cols] >> 1]))
+    rd.close()
+    pbf.close()
+
+
+def test_beyond_the_width_limit_fails_loudly(hip):
+    """One bit-vector with its rank directory must fit the LDS: 650,000 haplotypes.  Beyond that the image is refused at
+    open with a message that says so; bgth_pbf_from_rle (whose checkpoints the two-plane kernels derive) stops at 327,000."""
+    m = 700000
+    hdr = b"PBF\x01" + np.array([m, 2, 13], np.int32).tobytes()
+    empty = hdr + b"I" + np.array([0], np.int64).tobytes() + np.array([0], np.int32).tobytes() + np.array([len(hdr)], np.uint64).tobytes()
+    with pytest.raises(RuntimeError, match="650,000"):
+        hip.HipPbf.from_bytes(empty)
+    with pytest.raises(RuntimeError, match="327,000"):
+        hip.HipPbf.from_rle(400000, 13, np.zeros(0, np.uint8), np.zeros(0, np.uint32))
