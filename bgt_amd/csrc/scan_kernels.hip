@@ -376,17 +376,22 @@ hipError_t launch_fold_alleles(const uint64_t *h0_row, const uint64_t *h1_row, c
 // `/` yields a real, `//` `%` `<<` `>>` `&` `|` `^` integers, comparisons use the reals if either side is
 // real, an unbound variable fails the site.
 // ----------------------------------------------------------------------------------------------------
-struct FilterSlot { long long i; double r; bool real; };
+struct FilterSlot { long long i; double r; long long real; };   // (no padding bytes: a bool here left 7 of them per slot in memory, and the slots with them)
 
-// one unary (+ - ~ !) or binary operator on the top of the stack: p = p OP q
-__device__ __forceinline__ void filter_unop(int o, FilterSlot &p)
+// one unary (+ - ~ !) or binary operator on the top of the stack: p = p OP q.  Values in, value out (no references): the
+// four named stack slots of the SMALL kernel live in registers.  (With a `bool` in the slot its 7 padding bytes stayed in
+// memory and the compiler promoted them to LDS, 28 KB per workgroup -- and a launch that leaves the LDS allocator in that
+// state keeps the plane-split kernels, which need two 75 KB workgroups per CU, at one per CU for half their run: C3 took
+// 23.5 instead of 19.9 ms whenever the device filter ran between two scans; `make resource-usage` shows the LDS size.)
+__device__ __forceinline__ FilterSlot filter_unop(int o, FilterSlot p)
 {
     if (o == 2) { p.i = -p.i; p.r = -p.r; }
     else if (o == 3) { p.i = ~p.i; p.r = (double)p.i; p.real = false; }
     else if (o == 4) { p.i = !p.i; p.r = (double)p.i; p.real = false; }
+    return p;
 }
 
-__device__ __forceinline__ void filter_binop(int o, FilterSlot &p, const FilterSlot &q, bool &err)
+__device__ __forceinline__ FilterSlot filter_binop(int o, FilterSlot p, const FilterSlot q, bool &err)
 {
     const bool anyreal = p.real || q.real;
     bool cmp = false, iscmp = false;
@@ -414,6 +419,7 @@ __device__ __forceinline__ void filter_binop(int o, FilterSlot &p, const FilterS
     default: err = true; break;
     }
     if (iscmp) { p.i = cmp; p.r = (double)cmp; p.real = false; }
+    return p;
 }
 
 // SMALL: the program never holds more than four values and leaves exactly one (checked by launch_filter): the stack
@@ -441,8 +447,8 @@ __global__ void filter_kernel(const FilterProgram prog, const int32_t *counts, i
                     s3 = s2; s2 = s1; s1 = s0; s0 = x;
                 } else {
                     const int o = op - 16;
-                    if (o >= 1 && o <= 4) filter_unop(o, s0);
-                    else { filter_binop(o, s1, s0, err); s0 = s1; s1 = s2; s2 = s3; }
+                    if (o >= 1 && o <= 4) s0 = filter_unop(o, s0);
+                    else { s0 = filter_binop(o, s1, s0, err); s1 = s2; s2 = s3; }
                 }
             }
             pass = !err && s0.i != 0;
@@ -459,8 +465,8 @@ __global__ void filter_kernel(const FilterProgram prog, const int32_t *counts, i
                     ++top;
                 } else {
                     const int o = op - 16;
-                    if (o >= 1 && o <= 4) filter_unop(o, st[top - 1]);
-                    else { --top; filter_binop(o, st[top - 1], st[top], err); }
+                    if (o >= 1 && o <= 4) st[top - 1] = filter_unop(o, st[top - 1]);
+                    else { --top; st[top - 1] = filter_binop(o, st[top - 1], st[top], err); }
                 }
             }
             pass = !err && top >= 1 && st[0].i != 0;

@@ -30,9 +30,13 @@ __global__ __launch_bounds__(512, 4) void plane_kernel(const ScanArgs a, const u
     static_assert(CPT % 4 == 0, "columns are stepped four at a time");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // workgroup -> (sub-block, plane): the two planes of a sub-block are neighbours (same XCD round-robin slot +- 8)
-    const int plane = (blockIdx.x >> 3) & 1;
-    const int bl = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7);
+    // workgroup -> (sub-block, plane).  Workgroup ids go round-robin over the 8 XCDs; k = the index within the XCD.  Plane 0
+    // has the longer strings, so a CU should hold one workgroup of each plane, whichever way the XCD fills its 32 CUs x 2
+    // slots: neighbours in k (depth first) and ids 32 apart in k (breadth first) both get different planes.  (With plain
+    // alternation the same launch took 19.6 or 24.9 ms depending on what ran before it.)
+    const int k = blockIdx.x >> 3;
+    const int plane = (k ^ (k >> 5)) & 1;
+    const int bl = (k >> 1) * 8 + (blockIdx.x & 7);
     if (bl >= a.n_blk) return;
 
     const int m = a.m, nw = a.nw, nwp = (nw + 2) & ~1, nwt = (nw + 4) & ~3;

@@ -14,9 +14,10 @@ import bgt_amd  # noqa: E402
 samples = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 sites = int(sys.argv[2]) if len(sys.argv) > 2 else 262144
 sub = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+seed = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 m = 2 * samples
 t0 = time.time()
-rle, lens = bgt_amd.synth_rows(m, 0, sites, 2)
+rle, lens = bgt_amd.synth_rows(m, 0, sites, seed)
 pbf = bgt_amd.HipPbf.from_rle(m, 13, rle, lens)
 print("cohort m=%d sites=%d rle=%.1f MB setup %.1fs" % (m, sites, rle.size / 1e6, time.time() - t0), flush=True)
 rd = bgt_amd.HipReader(pbf)
