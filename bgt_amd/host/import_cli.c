@@ -236,19 +236,39 @@ static int read_bcf_record(reader_t *r, rec_t *c)
         p = q + (size_t)n * tv_bytes(type);
     }
     c->n_sample = (int)r->b->n_sample;
+    if (c->n_allele > 127) { fprintf(stderr, "[E::%s] %d alleles in one record: allele numbers are kept in 7 bits\n", __func__, c->n_allele); return -2; }
     if ((size_t)c->n_sample * 2 > c->m_gt) { c->m_gt = (size_t)c->n_sample * 2; c->gt = (int8_t*)realloc(c->gt, c->m_gt); }
     p = (const uint8_t*)r->b->indiv.s;
-    for (i = 0; i < (int)r->b->n_fmt; ++i) {
-        int kt, key, k;
-        bcf_dec_size(p, &q, &kt); key = tv_int(q, kt); p = q + tv_bytes(kt);
-        n = bcf_dec_size(p, &q, &type);
-        if (key == r->id_gt) {
-            if (n != 2) { fprintf(stderr, "[E::%s] only diploid genotypes can be imported\n", __func__); return -2; }
-            for (k = 0; k < 2 * c->n_sample; ++k) c->gt[k] = (int8_t)((tv_int(q + (size_t)k * tv_bytes(type), type) >> 1) - 1);
+    {
+        const uint8_t *end = p + r->b->indiv.l;                              /* the record's own lengths are not trusted */
+        for (i = 0; i < (int)r->b->n_fmt; ++i) {
+            int kt, key, k;
+            size_t bytes;
+            if (p + 2 > end) goto truncated;
+            bcf_dec_size(p, &q, &kt);
+            if (q + tv_bytes(kt) + 1 > end) goto truncated;
+            key = tv_int(q, kt); p = q + tv_bytes(kt);
+            n = bcf_dec_size(p, &q, &type);
+            bytes = (size_t)(n < 0 ? 0 : n) * (size_t)tv_bytes(type) * (size_t)c->n_sample;
+            if (n < 0 || q > end || bytes > (size_t)(end - q)) goto truncated;
+            if (key == r->id_gt) {
+                if (n != 2) { fprintf(stderr, "[E::%s] only diploid genotypes can be imported\n", __func__); return -2; }
+                for (k = 0; k < 2 * c->n_sample; ++k) {
+                    const int al = (tv_int(q + (size_t)k * tv_bytes(type), type) >> 1) - 1;      /* -1 = missing */
+                    if (al >= c->n_allele) {                                 /* (the text reader refuses it too) */
+                        fprintf(stderr, "[E::%s] a genotype names allele %d of a record with %d alleles\n", __func__, al, c->n_allele);
+                        return -2;
+                    }
+                    c->gt[k] = (int8_t)(al < 0 ? -1 : al);
+                }
+            }
+            p = q + bytes;
         }
-        p = q + (size_t)n * tv_bytes(type) * (size_t)c->n_sample;
     }
     return 0;
+truncated:
+    fprintf(stderr, "[E::%s] a record's FORMAT block is shorter than its own field sizes say\n", __func__);
+    return -2;
 }
 
 /* the next record that passes FILTER (or any, with -F) */
@@ -378,6 +398,27 @@ static int atomize(const bcf_hdr_t *h, const rec_t *c, atom_v *v)
             if (l > 0) { ks_printf(&cg, "%dI", l); rest = c->rlen - 1; }
             else { ks_printf(&cg, "%dD", -l); rest = l_alt - 1; }
             if (rest) ks_printf(&cg, "%dM", rest);
+        }
+        {   /* the walk below indexes ref[] and alt[] by what the CIGAR says: it must consume exactly the two alleles */
+            long cx = 0, cy = 0;
+            int bad = 0;
+            for (p = cg.s; *p && !bad; ++p) {
+                char *e;
+                const long l = strtol(p, &e, 10);
+                if (e == p || l < 0 || l > INT32_MAX) { bad = 1; break; }
+                p = e;
+                if (*p == 'M' || *p == '=' || *p == 'X') { cx += l; cy += l; }
+                else if (*p == 'I') cy += l;
+                else if (*p == 'D') cx += l;
+                else bad = 1;
+                if (*p == 0) break;
+            }
+            if (bad || cx != l_ref || cy != l_alt) {
+                fprintf(stderr, "[E::%s] CIGAR '%s' does not span REF (%d) and ALT (%d) at %s:%d\n", __func__, cg.s, l_ref, l_alt,
+                        h->id[BCF_DT_CTG][c->rid].key, c->pos + 1);
+                free(cg.s);
+                return -1;
+            }
         }
         for (p = cg.s; *p; ++p) {
             char *e;

@@ -572,18 +572,28 @@ static const sitetab_t *file_sites(const bgt_file_t *cbf)
 {
     bgt_file_t *bf = (bgt_file_t*)cbf;
     static const sitetab_t empty;
+    /* the global lock only guards the test and the publication: the tables of two databases of a merge load side by side
+     * (a per-file loading flag keeps a second reader of the SAME file waiting instead of loading it twice) */
     pthread_mutex_lock(&g_sites_lock);
+    while (bf->sites_loading) pthread_cond_wait(&g_sites_cond, &g_sites_lock);
     if (bf->idx == NULL) {
         char *fn = (char*)malloc(strlen(bf->prefix) + 8);
         bgzr_t *fp;
+        sitetab_t *t = NULL;
+        bf->sites_loading = 1;
+        pthread_mutex_unlock(&g_sites_lock);
         sprintf(fn, "%s.bcf", bf->prefix);
         if ((fp = bgzr_open(fn)) != NULL) {
             bcf_hdr_t *h = bcf_hdr_read_stream(fp);              /* skip the header */
-            if (h) { bf->idx = st_load(fp, bf->h0); bcf_hdr_destroy(h); }
+            if (h) { t = st_load(fp, bf->h0); bcf_hdr_destroy(h); }
             bgzr_close(fp);
         }
-        if (bf->idx == NULL) fprintf(stderr, "[E::%s] cannot read the sites of '%s'\n", __func__, fn);
+        if (t == NULL) fprintf(stderr, "[E::%s] cannot read the sites of '%s'\n", __func__, fn);
         free(fn);
+        pthread_mutex_lock(&g_sites_lock);
+        bf->idx = t;
+        bf->sites_loading = 0;
+        pthread_cond_broadcast(&g_sites_cond);
     }
     pthread_mutex_unlock(&g_sites_lock);
     return bf->idx ? (const sitetab_t*)bf->idx : &empty;

@@ -46,6 +46,7 @@ typedef struct {
     void      *gpu;                 /* appended: bgth_pbf_t*, the whole-file image in HBM        */
     int        gpu_opening;         /* appended: a reader is loading that image right now        */
     int        sites_pending;       /* appended: background loads of the site table in flight    */
+    int        sites_loading;       /* appended: a thread is reading the site table right now    */
 } bgt_file_t;
 
 /* a reader over one database */
@@ -162,7 +163,7 @@ int     bgtm_read_vcf(bgtm_t *bm, bcf1_t *b, kstring_t *s);
  * threads (BGT_THREADS, default min(cores, 16)), written in order; the bytes of the bgtm_read_vcf loop.  Only for one
  * database without genotype columns, region, BED, allele set or table; returns the records written, -1 if the query
  * needs the site-by-site path (nothing was written), -2 on a device error. */
-long    bgtm_write_vcf_bulk(bgtm_t *bm, FILE *fp, long n_rec);
+long    bgtm_write_vcf_bulk(bgtm_t *bm, FILE *fp, long n_rec);   /* one database or a merge of up to 64 */
 
 /* ---- allele sets: samples carrying all of them (-S), haplotype counts (-H) ---- */
 char         *bgtm_alcnt_print(const bgtm_t *bm);                                  /* malloc'd text, caller frees */

@@ -61,7 +61,7 @@ for label, q, va in QUERIES:
 # one pooled reader and HIP stream per query in flight)
 import random
 import threading
-for n_clients in (1, 4, 16, 64):
+for n_clients in (1, 4, 16, 64, 256):
     per = 40
     bad = []
 
