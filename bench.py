@@ -101,6 +101,15 @@ def replayed_counters(workload, sites, kernel_name):
     out = {"replayed_from": "profiles/%s (rocprofv3 --pmc passes of scripts/profile.sh on this workload; not measured in this run)" % tag,
            "profiled_kernel_ms": pj.get("avg_ms"), "hbm_bytes_per_launch": tj.get("hbm_bytes_per_launch"),
            "valu_instr_per_launch": c.get("SQ_INSTS_VALU")}
+    if tj.get("producer"):                                                         # directory path, one-shot: the producer's launch too
+        pr = tj["producer"]
+        out["producer"] = {"kernel": pr.get("kernel", "")[:60], "profiled_kernel_ms": pr.get("avg_ms"),
+                           "hbm_bytes_per_launch": pr.get("fetch_bytes", 0) + pr.get("write_bytes", 0),
+                           "hbm_write_gbs": pr.get("write_bytes", 0) / (pr.get("avg_ms", 1e9) * 1e-3) / 1e9}
+        out["hbm_bytes_per_launch_walk_only"] = out["hbm_bytes_per_launch"]
+        out["hbm_bytes_per_launch"] = out["hbm_bytes_per_launch"] + out["producer"]["hbm_bytes_per_launch"]
+        out["profiled_kernel_ms_walk_only"] = out["profiled_kernel_ms"]
+        out["profiled_kernel_ms"] = out["profiled_kernel_ms"] + (pr.get("avg_ms") or 0.0)
     if c.get("GRBM_GUI_ACTIVE") and c.get("SQ_INSTS_VALU"):
         cyc = c["GRBM_GUI_ACTIVE"] / 8.0                                           # summed over the 8 XCDs
         out["valu_instr_per_cycle_per_simd"] = c["SQ_INSTS_VALU"] / (1024.0 * cyc)
