@@ -208,6 +208,65 @@ def oracle_window(bgt_amd, np, img, m, shift, seed, abs_row, img_row, n_rows, tm
     return oc.reshape(n_rows, 1, 3), time.perf_counter() - t0
 
 
+
+def inrun_counters(n_samples, sites, seed, tmp, kernel_substr):
+    """HBM traffic of the scan kernel measured IN THIS RUN: this script starts itself twice under `rocprofv3 --pmc` (one
+    counter per pass, as MI355X_MICROARCH.md prescribes; no tracing domains) in a child mode that only builds the same
+    cohort and scans it four times, and reads the counters of the bench-size launches from the CSVs.  FETCH_SIZE counts
+    KiB at half rate on gfx950 for this kernel's 4-byte loads: the factor is the committed calibration on a 1 GiB stream
+    (profiles/*/fetch_calibration.json, 2.000)."""
+    import csv
+    import glob
+    import shutil
+    if shutil.which("rocprofv3") is None:
+        return {"error": "rocprofv3 not on PATH"}
+    out = {"source": "in-run: bench.py re-executed under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this box (child mode: same "
+                     "cohort, four scans; the three largest launches of the kernel averaged)", "kernel": kernel_substr}
+    scale = 2.0
+    try:
+        for tag in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+            fc = os.path.join(ROOT, "profiles", tag, "fetch_calibration.json")
+            if os.path.exists(fc):
+                scale = json.load(open(fc)).get("width4", {}).get("bytes_per_counted_byte", 2.0)
+                out["fetch_scale"] = {"value": scale, "from": "profiles/%s/fetch_calibration.json" % tag}
+                break
+    except Exception:
+        pass
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = os.path.join(tmp, "pmc_" + counter)
+        cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+               "--counters-child", "%d,%d,%d" % (n_samples, sites, seed)]
+        try:
+            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True,
+                           env=dict(os.environ, TMPDIR=tmp), cwd=tmp)
+        except Exception as e:
+            return {"error": "rocprofv3 pass for %s failed: %s" % (counter, repr(e)[:120])}
+        vals = []
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                    vals.append(float(r["Counter_Value"]))
+        if not vals:
+            return {"error": "no %s rows for %s" % (counter, kernel_substr)}
+        top = sorted(vals)[-3:]
+        out[counter + "_KiB_per_launch"] = sum(top) / len(top)
+    out["fetch_bytes"] = out["FETCH_SIZE_KiB_per_launch"] * 1024.0 * scale
+    out["write_bytes"] = out["WRITE_SIZE_KiB_per_launch"] * 1024.0
+    out["hbm_bytes_per_launch"] = out["fetch_bytes"] + out["write_bytes"]
+    return out
+
+
+def counters_child(spec):
+    """Child mode of inrun_counters: nothing but the cohort and four scans (no checks, no output)."""
+    import bgt_amd
+    n_samples, sites, seed = (int(x) for x in spec.split(","))
+    m = 2 * n_samples
+    rle, lens = bgt_amd.synth_rows(m, 0, sites, seed)
+    pbf = bgt_amd.HipPbf.from_rle(m, 13, rle, lens)
+    rd = bgt_amd.HipReader(pbf)
+    for _ in range(4):
+        rd.scan(0, sites)
+
 def reference_cli_baseline(n_samples, ns, seed, view_args, tmp, what, all_cores=False):
     """The compiled reference's `bgt view` on a database of the first `ns` sites of the cohort; also this repo's CLI on
     the same command (stdout compared)."""
@@ -548,7 +607,12 @@ def main():
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--cpt", type=int, default=0)
     ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--no-counters", action="store_true", help="skip the in-run rocprofv3 --pmc passes (HBM traffic of the scan kernel)")
+    ap.add_argument("--counters-child", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.counters_child:
+        counters_child(args.counters_child)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -783,6 +847,15 @@ def main():
                         out["parity_error"] = "`bgt view` stdout differs from the reference binary"
                 except Exception as e:                        # keep the port numbers, say why
                     out["cpu_baseline"]["reference_leg_error"] = repr(e)[:200]
+        if rank == 0 and world == 1 and not args.no_counters and not args.every and args.cpu_sample > 0:
+            # HBM bytes of the timed kernel, measured in this run (not replayed from profiles/)
+            kn = ("walk_kernel<%d, %d" if rd.path()["directory_path"] else "scan_kernel<%d, %d") % (geo["threads"], geo["cols_per_thread"])
+            ic = inrun_counters(n_samples, sites, seed, tmp, kn)
+            out["roofline"]["traffic_in_run"] = ic
+            if "hbm_bytes_per_launch" in ic:
+                out["roofline"]["traffic"] = ic["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = ic["source"]
+                out["roofline"]["hbm_frac_measured"] = ic["hbm_bytes_per_launch"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         if rank == 0 and world == 1 and args.workload == "c2" and args.cpu_sample > 0 and not args.every:
             try:
                 out["cli_end_to_end"] = cli_end_to_end(n_samples, sites, seed, tmp)

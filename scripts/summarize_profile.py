@@ -23,7 +23,7 @@ for f in glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")):
 stats = list(csv.DictReader(open(os.path.join(dst, "kernel_stats.csv"))))
 # the bench-size launches: scripts/profile.sh runs 1 warm-up + 3 timed steps = 4 calls (other scan_kernel
 # instances are the one-block passes that derive the synthetic cohort's checkpoints during set-up)
-scan = [r for r in stats if "scan_kernel" in r["Name"] or "walk_kernel" in r["Name"]]
+scan = [r for r in stats if "scan_kernel" in r["Name"] or "walk_kernel" in r["Name"] or "plane_kernel<" in r["Name"]]
 four = [r for r in scan if int(r["Calls"]) == 4]
 main = max(four or scan, key=lambda r: float(r["AverageNs"]))
 kname = main["Name"]
