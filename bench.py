@@ -27,7 +27,8 @@ column x one bit plane x one site: the LF-mapping step); `peak` is MEASURED LIVE
 the product's own row-step statement (8 VALU + 1 ds_read_b64 per lookup, random LDS entries) alone on every SIMD at 4
 waves per SIMD -- what the chip sustains if nothing but lookups ran; `achieved` = algorithmic lookups of the launch /
 its duration (HIP events).  `algorithmic_equiv_gbs` keeps SURVEY 8d's figure (reference-algorithm bytes / kernel time) and
-`hbm_traffic` / `valu` / `lds` the rocprofv3 PMC numbers of the same kernel, replayed from profiles/ (marked so).
+`counters` the rocprofv3 PMC numbers of the same kernel, replayed from profiles/ (marked so); `traffic` of the headline record
+is measured IN THE RUN: bench.py re-executes itself under `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` (inrun_counters).
 `peak_ideal_mix` is a ceiling that does not move with the code: the minimal row step (5 instructions of the 4-cycle
 class, 3 of the 2-cycle class) priced with class rates measured live, as if nothing else ever issued.
 `cpu_baseline` = the compiled reference (oracle/_ref/bgt) timed on this box's host cores on a bounded sample.

@@ -445,13 +445,21 @@ __device__ __forceinline__ void directory_trips_tog(uint32_t *tog, uint2 *bd, in
             const uint64_t par = __ballot((int32_t)(tq[0] ^ tq[1] ^ tq[2] ^ tq[3]) < 0);
             uint32_t cm = 0u - ((lanes_below(par) ^ (cy >> 31)) & 1u);
             uint32_t v[4], pre[4], ones = 0;
+            if ((tt[j] << 8) + 256 < nw) {                        // wave-uniform: the trip holds neither the row's last word nor
+#pragma unroll                                                    // anything behind it (all but the last trip of a row)
+                for (int k = 0; k < 4; ++k) {
+                    v[k] = tq[k] ^ cm; pre[k] = ones; ones += (uint32_t)__popc(v[k]);
+                    cm ^= (uint32_t)((int32_t)tq[k] >> 31);
+                }
+            } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                uint32_t x = tq[k] ^ cm;
-                if (i0 + k == nw - 1) x &= tail_mask;
-                if (i0 + k >= nw) x = 0u;
-                v[k] = x; pre[k] = ones; ones += (uint32_t)__popc(x);
-                cm ^= (uint32_t)((int32_t)tq[k] >> 31);
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t x = tq[k] ^ cm;
+                    if (i0 + k == nw - 1) x &= tail_mask;
+                    if (i0 + k >= nw) x = 0u;
+                    v[k] = x; pre[k] = ones; ones += (uint32_t)__popc(x);
+                    cm ^= (uint32_t)((int32_t)tq[k] >> 31);
+                }
             }
             const uint32_t incl = wave_incl_add(ones);
             const uint32_t b = (cy & 0x7fffffffu) + incl - ones;
