@@ -1401,7 +1401,7 @@ static int64_t enqueue_scan_wide_plane(bgth_reader_t *r, int64_t row0, int64_t r
     const size_t plane_row = (size_t)r->sel.n_chunks * 8;
     const size_t row_bytes = (size_t)2 * nwp * 8 + (d_h0 ? 0 : 2 * plane_row);
     const int64_t sub_rows = (int64_t)1 << p->sub_shift;
-    const int64_t fit = (int64_t)(dir_arena_cap(p->device) / (row_bytes * (size_t)sub_rows));
+    const int64_t fit = (int64_t)(dir_arena_cap(p->device) / (row_bytes * (size_t)std::min<int64_t>(sub_rows, row1 - (blk0 << p->sub_shift))));
     if (fit < 1) { set_err("[E::bgth_reader_scan] the directory arena does not hold one block of m=%d", p->m); return -1; }
     int64_t per_pass = std::min<int64_t>(blk1 - blk0 + 1, fit >= 8 ? fit / 8 * 8 : fit);
     const int64_t pass_rows = std::min<int64_t>(per_pass * sub_rows, row1 - (blk0 << p->sub_shift));
@@ -1525,7 +1525,8 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
         int64_t per_pass = blk1 - blk0 + 1;
         if (!reuse) {
             const size_t cap = dir_arena_cap(p->device);
-            const int64_t fit = (int64_t)(cap / (row_bytes * (size_t)sub_rows));
+            const int64_t blk_rows = std::min<int64_t>(sub_rows, row1 - first);     // (a short image has short sub-blocks)
+            const int64_t fit = (int64_t)(cap / (row_bytes * (size_t)blk_rows));
             if (fit < 1) { set_err("[E::bgth_reader_scan] the directory arena (%zu MB) does not hold one sub-block of m=%d", cap >> 20, p->m); return -1; }
             if (per_pass > fit) per_pass = std::max<int64_t>(8, fit / 8 * 8);     // whole XCD rounds of workgroups
             if (per_pass > fit) per_pass = fit;

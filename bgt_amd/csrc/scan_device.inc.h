@@ -420,8 +420,16 @@ __device__ __forceinline__ void directory_pass(uint2 *bd, int w0, int w1, int nw
 // which leaves the array ready for the next row.
 struct TripCarry { uint32_t cx, cnt; };
 
-// (NP = trips in flight: 2, or 1 where the registers are needed for columns)
-template <int NP>
+// (NP = trips in flight: 2, or 1 where the registers are needed for columns; STREAM: the entries go to HBM and are not read
+// again by this kernel -- the producer of scan_dir.hip -- so they are stored non-temporally)
+typedef uint32_t bgth_u32x4 __attribute__((ext_vector_type(4)));
+template <bool STREAM>
+__device__ __forceinline__ void store_entries2(uint4 *dst, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    if constexpr (STREAM) { bgth_u32x4 v = {a, b, c, d}; __builtin_nontemporal_store(v, reinterpret_cast<bgth_u32x4*>(dst)); }
+    else *dst = make_uint4(a, b, c, d);
+}
+template <int NP, bool STREAM = false>
 __device__ __forceinline__ void directory_trips_tog(uint32_t *tog, uint2 *bd, int tw, int wpp, int ntrip, int nw,
                                                     uint32_t tail_mask, uint32_t cyl, int lane)
 {
@@ -466,8 +474,8 @@ __device__ __forceinline__ void directory_trips_tog(uint32_t *tog, uint2 *bd, in
             if (on[j]) {
                 if (i0 + 3 < nw) {
                     uint4 *dst = reinterpret_cast<uint4*>(bd + i0);
-                    dst[0] = make_uint4(v[0], b, v[1], b + pre[1]);
-                    dst[1] = make_uint4(v[2], b + pre[2], v[3], b + pre[3]);
+                    store_entries2<STREAM>(dst, v[0], b, v[1], b + pre[1]);
+                    store_entries2<STREAM>(dst + 1, v[2], b + pre[2], v[3], b + pre[3]);
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) if (i0 + k < nw) bd[i0 + k] = make_uint2(v[k], b + pre[k]);

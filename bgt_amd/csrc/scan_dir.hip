@@ -67,7 +67,7 @@ __global__ __launch_bounds__(NT) void dirbuild_kernel(const ScanArgs a, const ui
         }
         lds_barrier();
         uint2 *dst = a.dir + (size_t)(sidx - 2 * a.dir_row0) * (size_t)nwp;
-        directory_trips_tog<2>(trow, dst, tw, WPP, ntrip, nw, tail_mask, cyl, lane);
+        directory_trips_tog<2>(trow, dst, tw, WPP, ntrip, nw, tail_mask, cyl, lane);      // (non-temporal stores here: 13.8 instead of 6.6 ms per 26 GB)
         if (tw == 0 && lane == 0) {
             for (int i = nw; i < nwp; ++i) dst[i] = make_uint2(0u, 0u);  // the sentinel entry padding slots read
             a.dir_n0[sidx - 2 * a.dir_row0] = (uint32_t)m - tot1;

@@ -34,7 +34,9 @@ while time.time() < t_end:
         mat[rng.integers(0, rows)] = rng.integers(0, 4); mat[rng.integers(0, rows)] = 3
     data = orc.encode_pbf(mat, 2, shift)
     os.environ.pop("BGTH_VARIANT", None)
-    flag = int(rng.choice([0, 0, 1, 2, 4, 4 | 1]))
+    # kernel variants with identical results: 1 toggles in place, 2 / 4 never / always the empty-plane kernels, 32 the
+    # directory path (producer + walk-only kernels) forced, 4096 the plane-split kernels forced, 128 no arena reuse
+    flag = int(rng.choice([0, 0, 1, 2, 4, 4 | 1, 32, 32, 32 | 128, 4096, 4096, 4096 | 2, 32 | 2]))
     if flag:
         os.environ["BGTH_VARIANT"] = str(flag)
     os.environ["BGTH_SUB_SHIFT"] = str(int(rng.integers(1, 12)))
@@ -43,6 +45,12 @@ while time.time() < t_end:
         ora = orc.Pbf(data)
         rd = bgt_amd.HipReader(pbf)
         th, cpt, K = GEOMS[int(rng.integers(0, len(GEOMS)))]
+        if flag & (32 | 4096):
+            th = cpt = K = 0                                  # (a tuned geometry names a classic kernel)
+            if rng.random() < 0.3:
+                os.environ["BGTH_DIR_ARENA_MB"] = "1"         # several passes over the arena
+            else:
+                os.environ.pop("BGTH_DIR_ARENA_MB", None)
         rd.tune(th, cpt, K)
         cols = group = None
         G = 1
@@ -57,13 +65,19 @@ while time.time() < t_end:
             ora.subset(cols)
         a = int(rng.integers(0, rows)); b = int(rng.integers(a + 1, rows + 1))
         try:
-            counts, gt = rd.scan(a, b, want_gt=True)
+            if rng.random() < 0.3:
+                counts, gt = rd.scan(a, b), None              # counts only: the plane-split kernels use their own planes
+            else:
+                counts, gt = rd.scan(a, b, want_gt=True)
         except RuntimeError as e:
-            if "no launch geometry" in str(e):
+            if "no launch geometry" in str(e) or "directory arena" in str(e):
                 continue
             raise
         oc, ogt = ora.scan(a, b, group=group, n_groups=G, want_gt=True)
-        ok = np.array_equal(counts.reshape(b - a, -1), oc.reshape(b - a, -1)) and np.array_equal(gt, ogt)
+        ok = np.array_equal(counts.reshape(b - a, -1), oc.reshape(b - a, -1)) and (gt is None or np.array_equal(gt, ogt))
+        if ok and rng.random() < 0.2:                         # the same reader again: an arena kept from the scan before
+            c2 = rd.scan(a, b)
+            ok = np.array_equal(c2.reshape(b - a, -1), oc.reshape(b - a, -1))
         n_check += 1
         if not ok:
             print("MISMATCH m=%d rows=%d shift=%d geom=%s flag=%d sub=%s range=[%d,%d) G=%d cols=%s" %
