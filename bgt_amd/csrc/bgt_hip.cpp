@@ -68,10 +68,14 @@ extern "C" const char *bgth_version(void) { return "bgt-hip 0.1 (gfx950)"; }
 // The HIP runtime takes 60-220 ms to start and the first launch loads the code objects: a process that knows it will
 // need the device starts both on a thread of their own while it parses headers, sample tables and the site side-car.
 // (Whoever touches the device first simply waits on the runtime's own initialisation lock.)
+static std::mutex g_warm_lock;
+static std::thread *g_warm_thread = nullptr;    // (on the heap and never destroyed: a caller that does not wait must not die in a destructor)
 extern "C" void bgth_runtime_warmup_async(int device)
 {
+    std::lock_guard<std::mutex> g(g_warm_lock);
+    if (g_warm_thread) return;                                           // one warm-up per process
     try {
-        std::thread([device] {
+        g_warm_thread = new std::thread([device] {
             if (hipSetDevice(device) != hipSuccess) return;
             hipFree(nullptr);
             int32_t *d = nullptr;                                                           // first launch: code object load
@@ -81,8 +85,15 @@ extern "C" void bgth_runtime_warmup_async(int device)
                 hipDeviceSynchronize();
                 hipFree(d);
             }
-        }).detach();
+        });
     } catch (...) {}
+}
+// A process that leaves before it ever touched the device (a usage error found after the warm-up was started) must not
+// run its exit handlers under a runtime that is still coming up on another thread: it waits here first.
+extern "C" void bgth_runtime_warmup_wait(void)
+{
+    std::lock_guard<std::mutex> g(g_warm_lock);
+    if (g_warm_thread && g_warm_thread->joinable()) g_warm_thread->join();
 }
 
 extern "C" int bgth_device_count(void)

@@ -12,7 +12,11 @@ int main(int argc, char *argv[])
         fprintf(stderr, "Usage: bgt <command> <arguments>\nCommands:\n  import   import VCF/BCF to BGT (PBWT encoder on MI355X)\n  view     extract from BGT (genotype-matrix read path on MI355X)\n  pbfview  decode / encode PBF <-> PIM text (the PBWT codec on MI355X)\n  version  show version\n");
         return 1;
     }
-    if (strcmp(argv[1], "view") == 0 || strcmp(argv[1], "mview") == 0) return main_view(argc - 1, argv + 1);
+    if (strcmp(argv[1], "view") == 0 || strcmp(argv[1], "mview") == 0) {
+        const int rc = main_view(argc - 1, argv + 1);          /* (a complete answer leaves through _exit inside) */
+        bgth_runtime_warmup_wait();                            /* an early error: the HIP runtime may still be starting on its thread */
+        return rc;
+    }
     if (strcmp(argv[1], "import") == 0) return main_import(argc - 1, argv + 1);
     if (strcmp(argv[1], "pbfview") == 0) return main_pbfview(argc - 1, argv + 1);   /* the codec-level tool (reference pbfview.c) */
     if (strcmp(argv[1], "synth") == 0) {                       /* bgt synth <prefix> <samples> <sites> [seed] */

@@ -37,7 +37,10 @@ const char *bgth_last_error(void);               /* thread-local, never NULL    
 int         bgth_device_count(void);
 /* Start the HIP runtime and load the kernels on a background thread (returns at once): for a process that will open an
  * image a moment later and has host-only work to do first (bgt view: headers, sample tables, the site side-car). */
-void        bgth_runtime_warmup_async(int device);             /* HIP devices visible; <0 on runtime failure     */
+void        bgth_runtime_warmup_async(int device);
+/* Wait for that thread (no-op if none was started): call before the process exits on a path that may not have opened an
+ * image -- exit handlers must not run under a runtime that is still starting. */
+void        bgth_runtime_warmup_wait(void);             /* HIP devices visible; <0 on runtime failure     */
 const char *bgth_version(void);
 
 /* ---- .pbf image in HBM  (replaces pbf_open_r / pbf_close / pbf_get_*, pbwt.c:221-286,390-393) ---- */
