@@ -123,6 +123,18 @@ def test_bad_arguments_fail_loudly():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("args,prefixes", [(["-C", "-r", "13", "-f", "AN>90"], ["ex2"]), (["-r", "13", "-u"], ["synA"]),
+                                           (["-r", "12:500-510"], ["ex2"]), (["-r", "13"], ["synB", "synA"])])
+def test_early_error_exits_cleanly_beside_the_warmup_thread(args, prefixes):
+    """A query that needs genotypes starts the HIP runtime on a thread of its own before anything else; one that then stops
+    on a usage error (a contig the database does not have: exit code 1 in the reference) must leave with that code, not die
+    in its exit handlers while the runtime is still coming up (the CLI fuzzer found rc -11 / -6 here)."""
+    for _ in range(3):
+        res = run_view(args, prefixes)
+        assert res.returncode == 1, (res.returncode, res.stderr.decode()[-300:])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(MANIFEST["views"].keys()))
 def test_cli_every_golden_view_on_gpu(name):
     """58 `bgt view` commands (VCF, BCF, `-t` tables, `-B/-e` BED filters, `-a/-S/-H/-d/-M` allele sets, failures) whose expected stdout and exit code were produced by
