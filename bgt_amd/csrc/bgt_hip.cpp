@@ -220,7 +220,8 @@ enum { kVariantNoTog = 1, kVariantNeverZP = 2, kVariantAlwaysZP = 4, kVariantNoP
        kVariantSeqCheckpoints = 512,                       // 512: bgth_pbf_from_rle derives its checkpoints block after block
        kVariantRcclSelf = 1024,                          // 1024: sharded scan_device gathers through RCCL even between shards of ONE device
                                                            //       (send / receive to self): runs the RCCL path on a one-GPU box
-       kVariantPlaneNever = 2048, kVariantPlaneAlways = 4096 };   // the plane-split kernels (sparse selections of wide cohorts)
+       kVariantPlaneNever = 2048, kVariantPlaneAlways = 4096,     // the plane-split kernels (sparse selections of wide cohorts)
+       kVariantNoWalkPrio = 16384 };                               // walk-only / team kernels without progress-based wave priorities
 static bool variant_flag(int bit) { const char *d = getenv("BGTH_VARIANT"); return d && (atoi(d) & bit); }
 
 // Builds the row index once per image; later calls only return it.  The build is enqueued on `s`, the
@@ -806,6 +807,7 @@ static bool common_scan_args(ScanArgs &a, bgth_pbf_t *p, const Selection &sel, c
     a.nbuf = geo.nbuf;
     a.n_slices = geo.slices;
     a.zp = use_zp(p) ? 1 : 0;
+    a.walk_prio = variant_flag(kVariantNoWalkPrio) ? 0 : 1;
     if (geo.wpp > 1) {                                   // team (wide-cohort) kernels read the row index
         if (!ensure_rowindex(p, s)) return false;
         a.chunkinfo = p->d_chunkinfo;
@@ -1553,6 +1555,7 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
         a.dir_n0 = (uint32_t*)r->dir_n0.p;
         a.dir_nwp = nwp;
         a.dir_stage = wgeo.dir_stage | (variant_flag(kVariantDirNoWarm) ? 0 : 2);   // bit 1: warm the L2 with the next row's plane 1
+        if (variant_flag(kVariantNoWalkPrio)) a.dir_stage |= 8;                      // bit 3: no progress-based wave priorities in the walk
         for (int64_t b = blk0; b <= blk1; b += per_pass) {
             const int64_t be = std::min(blk1 + 1, b + per_pass);
             const int64_t lo = b << p->sub_shift, hi = std::min(row1, be << p->sub_shift);
@@ -1578,7 +1581,8 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
         HIP_TRY(hipStreamSynchronize(s), return -1);
         HIP_TRY(hipMemcpy(h, d_times, 64, hipMemcpyDeviceToHost), return -1);
         hipFree(d_times);
-        const double waves = (double)geo.workgroups * ((a.debug_skip & 0x100) ? 1 : geo.threads / 64), nb = (double)rows / geo.K;
+        const Geometry &tg = dirpath ? wgeo : geo;           // (directory path: stage DMA | walk | wait | counts | plane-1 DMA | wait)
+        const double waves = (double)tg.workgroups * ((a.debug_skip & 0x100) ? 1 : tg.threads / 64), nb = (double)rows / tg.K;
         fprintf(stderr, "[bgth debug] memtime ticks per wave and batch: prefetch %.0f | clear %.0f | wait %.0f | toggles %.0f | wait %.0f | directory %.0f | wait %.0f | walk %.0f\n",
                 h[0] / waves / nb, h[1] / waves / nb, h[2] / waves / nb, h[3] / waves / nb, h[4] / waves / nb, h[5] / waves / nb, h[6] / waves / nb, h[7] / waves / nb);
     }

@@ -844,7 +844,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
             // The SIMD arbiter prefers its oldest wave: left alone, waves 0-3 race through a batch and idle at the
             // barrier while waves 12-15 finish it nearly alone (measured: walk 96 vs 189 ticks).  Rotating the user
             // priority over the rows of a batch gives the four waves of a SIMD equal progress.
-            if (!TEAM && !(BGTH_SKIP(a, 0x2000))) set_wave_priority(((wave >> 2) + k) & 3);   // (team mode: one row per barrier, no gain)
+            if (!TEAM && !(BGTH_SKIP(a, 0x2000))) set_wave_priority(((wave >> 2) + k) & 3);   // (team mode: by columns, below; a priority that falls with the rows of the batch instead measured the same)
             if (ZP && n01 == 0u - (uint32_t)m) base1 = 0u;       // plane 1 all zero: its lookups are skipped (see step2)
             if (a.snap && rb + k > blk_beg && ((rb + k) & (((int64_t)1 << a.snap_shift) - 1)) == 0) {
                 // sub-checkpoint: the ranks before this row (image-open pass only)
@@ -866,6 +866,14 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
             for (int j = 0; j < CPT; j += 4) {
                 uint64_t m0[4] = {0, 0, 0, 0}, m1[4] = {0, 0, 0, 0};
                 const int NC = (CPT - j) >= 4 ? 4 : 2;                // CPT is even: the tail is one pair
+                // team mode (one row per barrier): a wave's priority falls as it gets through its columns, so that the waves of
+                // a SIMD finish the row together instead of one after the other (scan_dir.hip: -8 % for the walk-only kernel)
+                if (TEAM && a.walk_prio) {
+                    if (j == 0) __builtin_amdgcn_s_setprio(3);
+                    else if (j == (CPT / 4 / 4) * 4) __builtin_amdgcn_s_setprio(2);
+                    else if (j == (CPT / 2 / 4) * 4) __builtin_amdgcn_s_setprio(1);
+                    else if (j == (3 * CPT / 4 / 4) * 4) __builtin_amdgcn_s_setprio(0);
+                }
                 if (NC == 4) {
                     uint32_t q0[4] = {r0[j], r0[j + 1], r0[j + 2], r0[j + 3]};
                     uint32_t q1[4] = {r1[j], r1[j + 1], r1[j + 2], r1[j + 3]};

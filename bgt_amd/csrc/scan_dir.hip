@@ -159,6 +159,9 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
         }
     };
 
+    // (profiling build only: cycles per phase -- 0 stage DMA issue, 1 walk, 2 wait + barrier, 3 counts, 4 plane-1 DMA issue,
+    //  5 its wait + barrier)
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = BGTH_TIMES(a) ? __builtin_amdgcn_s_memtime() : 0ull;
     int c0 = 0, c1 = 1, st = 2;                                          // plane buffers: current row's planes, staging
     if (blk_beg < blk_end) { dma_plane(c0, blk_beg, 0); dma_plane(c1, blk_beg, 1); }
     wait_vm0();
@@ -175,6 +178,7 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
             if (off < plane_bytes)
                 touched = *reinterpret_cast<const uint32_t*>(dirbase + (size_t)(2 * (row + 1 - a.dir_row0) + 1) * plane_bytes + off);
         }
+        BGTH_TICK(0);
         // ---- walk the row: ranks stay in registers
         {
             const uint32_t base0 = lds0 + (uint32_t)c0 * plane_bytes - 8u;
@@ -192,6 +196,15 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
             for (int j = 0; j < CPT; j += STEP) {
                 uint64_t m0[4] = {0, 0, 0, 0}, m1[4] = {0, 0, 0, 0};
                 const int NC = (CPT - j) >= STEP ? STEP : 2;              // CPT is even: the tail is one pair
+                // The SIMD arbiter prefers its oldest wave: left alone, the four waves of a SIMD finish a row one after the
+                // other and the early ones idle at the barrier while the last walks nearly alone (at 7.6 instead of 4.0 cycles
+                // per instruction).  A wave's priority falls as it gets through its columns, so the laggards catch up.
+                if (!(a.dir_stage & 8)) {
+                    if (j == 0) __builtin_amdgcn_s_setprio(3);
+                    else if (j == (CPT / 4 / STEP) * STEP) __builtin_amdgcn_s_setprio(2);
+                    else if (j == (CPT / 2 / STEP) * STEP) __builtin_amdgcn_s_setprio(1);
+                    else if (j == (3 * CPT / 4 / STEP) * STEP) __builtin_amdgcn_s_setprio(0);
+                }
                 if (NC == 4) {
                     uint32_t q0[4] = {r0[j], r0[j + 1], r0[j + 2], r0[j + 3]};
                     uint32_t q1[4] = {r1[j], r1[j + 1], r1[j + 2], r1[j + 3]};
@@ -230,9 +243,11 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
                 }
             }
         }
+        BGTH_TICK(1);
         asm volatile("" :: "v"(touched));                                // (the touch is waited for here, not before the walk)
         wait_vm0();                                                      // this wave's pieces of the staged plane have landed
         lds_barrier();                                                   // every wave is past its walk: both planes are free
+        BGTH_TICK(2);
         // ---- counts of this row and slice -> HBM
         {
             int32_t *lcb = lcnt + (int)(row & 1) * cnt_stride;
@@ -256,13 +271,19 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
                 }
             }
         }
+        BGTH_TICK(3);
         if (more) {
             if (staged) { const int nc0 = st; dma_plane(c1, row + 1, 1); st = c0; c0 = nc0; }
             else { dma_plane(c0, row + 1, 0); dma_plane(c1, row + 1, 1); }
+            BGTH_TICK(4);
             wait_vm0();
             lds_barrier();
+            BGTH_TICK(5);
         }
     }
+#ifdef BGTH_ABLATE
+    if (BGTH_TIMES(a) && lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(a.debug_times + i, tsum[i]);
+#endif
 
     if (a.final_rank) {
         int32_t *fin = a.final_rank + (int64_t)bl * a.final_blk_stride;

@@ -45,14 +45,16 @@ def run(label, variant, reps=3):
 
 rd.scan(0, min(sites, 8192))
 if sub:                                               # sparse selection: team kernel against the plane-split kernels
+    ref = run("team kernel, no prio", 64 | 2048 | 16384, 3)
     ref = run("team kernel", 64 | 2048, 3)
     a = run("plane-split kernels", 64, 3)
     print("same counts:", np.array_equal(ref, a), rd.path())
     sys.exit(0)
+run("team kernels, no prio", 64 | 16384, 2)
 ref = run("team kernels", 64, 2)
 a = run("directory, arena kept", None)
 b = run("directory, one-shot", 128, 2)
-c = run("directory, no L2 warm", 256, 3)
+c = run("directory, no priorities", 16384, 3)
 os.environ["BGTH_WALK_GEOM"] = "1024,50"
 d = run("directory 1024x50", None, 3)
 e = run("dir 1024x50, no warm", 256, 3)
