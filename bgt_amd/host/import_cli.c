@@ -547,8 +547,10 @@ int main_import(int argc, char *argv[])
     reader_t *in = NULL;
     atombuf_t *ab = NULL;
     bcf_hdr_t *h0 = NULL;
-    bgth_encoder_t *enc = NULL;
-    FILE *fp_pbf = NULL, *fp_bcf = NULL;
+    bgth_encoder_t *enc = NULL, *enc1 = NULL;             /* enc1: -1, the one-plane file prefix.pb1 (import.c:72-74) */
+    FILE *fp_pbf = NULL, *fp_bcf = NULL, *fp_pb1 = NULL;
+    uint8_t *rows1 = NULL;
+    int gen_pb1 = 0;
     bgzw_t *bz = NULL;
     csi_writer_t *ix = NULL;
     bcf1_t *b = NULL;
@@ -564,13 +566,13 @@ int main_import(int argc, char *argv[])
         case 'S': is_vcf = 1; break;
         case 't': fn_ref = optarg; is_vcf = 1; break;
         case 'F': keep_flt = 1; break;
-        case '1': fprintf(stderr, "[W::%s] -1 (.pb1) is not produced by this build (the reference marks it unused)\n", __func__); break;
+        case '1': gen_pb1 = 1; break;                                 /* also write prefix.pb1: one plane, bit = (genotype code == 1) */
         default: break;
         }
     }
     if (argc - optind < 2) {
         fprintf(stderr, "Usage: bgt import [options] <out-prefix> <in.bcf>|<in.vcf>|<in.vcf.gz>\n");
-        fprintf(stderr, "Options:\n  -S           input is VCF\n  -t FILE      list of reference names and lengths [null]\n  -F           keep filtered variants\n");
+        fprintf(stderr, "Options:\n  -S           input is VCF\n  -t FILE      list of reference names and lengths [null]\n  -F           keep filtered variants\n  -1           also write <out-prefix>.pb1 (one bit plane: the ALT allele)\n");
         return 1;
     }
     prefix = argv[optind];
@@ -593,6 +595,11 @@ int main_import(int argc, char *argv[])
             if ((enc = bgth_encoder_open(m, 2, 13, 0)) == NULL) { fprintf(stderr, "[E::%s] %s\n", __func__, bgth_encoder_last_error()); goto done; }
             sprintf(fn, "%s.pbf", prefix);
             if ((fp_pbf = fopen(fn, "wb")) == NULL) { fprintf(stderr, "[E::%s] cannot create '%s'\n", __func__, fn); goto done; }
+            if (gen_pb1) {                                            /* reference import.c:72-74: pbf_open_w(prefix.pb1, m, 1, 13) */
+                if ((enc1 = bgth_encoder_open(m, 1, 13, 0)) == NULL) { fprintf(stderr, "[E::%s] %s\n", __func__, bgth_encoder_last_error()); goto done; }
+                sprintf(fn, "%s.pb1", prefix);
+                if ((fp_pb1 = fopen(fn, "wb")) == NULL) { fprintf(stderr, "[E::%s] cannot create '%s'\n", __func__, fn); goto done; }
+            }
             sprintf(fn, "%s.bcf", prefix);
             if ((fp_bcf = fopen(fn, "wb")) == NULL) { fprintf(stderr, "[E::%s] cannot create '%s'\n", __func__, fn); goto done; }
             bz = bgzw_open(fp_bcf, clevel >= 0 && clevel <= 9 ? clevel : -1);
@@ -604,14 +611,21 @@ int main_import(int argc, char *argv[])
             ix = csi_writer_init(h0->n[BCF_DT_CTG], 14, depth, bgzw_tell(bz));
             cap_rows = ((int64_t)64 << 20) / m; if (cap_rows < 64) cap_rows = 64; if (cap_rows > 16384) cap_rows = 16384;
             rows = (uint8_t*)malloc((size_t)cap_rows * (size_t)m);
+            if (gen_pb1) rows1 = (uint8_t*)malloc((size_t)cap_rows * (size_t)m);
         } else if (2 * in->h->n[BCF_DT_SAMPLE] != m) { fprintf(stderr, "[E::%s] '%s' has a different number of samples\n", __func__, argv[j]); goto done; }
         while ((a = atombuf_read(ab)) != NULL) {
             int32_t val = (int32_t)n;
             uint64_t off0;
             if (a->n_gt != m) { fprintf(stderr, "[E::%s] internal: atom with %d genotypes\n", __func__, a->n_gt); goto done; }
             memcpy(rows + (size_t)n_buf * (size_t)m, a->gt, (size_t)m);        /* code = bit 0 plane 0, bit 1 plane 1 (import.c:96-97) */
+            if (rows1) {                                                       /* bit1[i] = (a->gt[i] == 1) (import.c:98) */
+                uint8_t *dst = rows1 + (size_t)n_buf * (size_t)m;
+                int i;
+                for (i = 0; i < m; ++i) dst[i] = a->gt[i] == 1;
+            }
             if (++n_buf == cap_rows) {
                 if (bgth_encoder_write(enc, rows, n_buf) < 0 || flush_encoder(enc, fp_pbf) < 0) { fprintf(stderr, "[E::%s] %s\n", __func__, bgth_encoder_last_error()); goto done; }
+                if (enc1 && (bgth_encoder_write(enc1, rows1, n_buf) < 0 || flush_encoder(enc1, fp_pb1) < 0)) { fprintf(stderr, "[E::%s] %s\n", __func__, bgth_encoder_last_error()); goto done; }
                 n_buf = 0;
             }
             bcf_set_site(b, a->rid, a->pos, a->rlen, a->ref, a->l_ref, a->alt, a->l_alt, a->has_multi ? "<M>" : NULL);
@@ -626,10 +640,17 @@ int main_import(int argc, char *argv[])
         reader_close(in); in = NULL;
     }
     if (n_buf > 0 && bgth_encoder_write(enc, rows, n_buf) < 0) { fprintf(stderr, "[E::%s] %s\n", __func__, bgth_encoder_last_error()); goto done; }
+    if (n_buf > 0 && enc1 && bgth_encoder_write(enc1, rows1, n_buf) < 0) { fprintf(stderr, "[E::%s] %s\n", __func__, bgth_encoder_last_error()); goto done; }
     {
         uint8_t *tail = NULL;
         const int64_t nt = bgth_encoder_finish(enc, &tail);
         if (nt < 0 || fwrite(tail, 1, (size_t)nt, fp_pbf) != (size_t)nt) { fprintf(stderr, "[E::%s] %s\n", __func__, bgth_encoder_last_error()); goto done; }
+        bgth_encoder_free_image(tail);
+    }
+    if (enc1) {
+        uint8_t *tail = NULL;
+        const int64_t nt = bgth_encoder_finish(enc1, &tail);
+        if (nt < 0 || fwrite(tail, 1, (size_t)nt, fp_pb1) != (size_t)nt) { fprintf(stderr, "[E::%s] %s\n", __func__, bgth_encoder_last_error()); goto done; }
         bgth_encoder_free_image(tail);
     }
     bgzw_close(bz); bz = NULL;
@@ -643,7 +664,10 @@ done:
     if (bz) bgzw_close(bz);
     if (fp_bcf) fclose(fp_bcf);
     if (fp_pbf) fclose(fp_pbf);
+    if (fp_pb1) fclose(fp_pb1);
     if (enc) bgth_encoder_close(enc);
+    if (enc1) bgth_encoder_close(enc1);
+    free(rows1);
     if (ix) csi_writer_destroy(ix);
     if (h0) bcf_hdr_destroy(h0);
     if (b) bcf_destroy1(b);

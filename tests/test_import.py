@@ -98,7 +98,8 @@ def random_vcf(rng, n_samples, n_records, path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed,n_samples,n_records,opts", [(1, 7, 400, []), (2, 40, 1500, ["-F"]), (3, 3, 9000, []), (4, 300, 600, ["-F"])])
+@pytest.mark.parametrize("seed,n_samples,n_records,opts", [(1, 7, 400, []), (2, 40, 1500, ["-F"]), (3, 3, 9000, []), (4, 300, 600, ["-F"]),
+                                                           (5, 60, 9500, ["-1"]), (6, 11, 300, ["-1", "-F"])])
 def test_random_vcfs_import_like_the_reference_binary(tmp_path, seed, n_samples, n_records, opts):
     ref = require_ref("bgt")
     vcf = str(tmp_path / "in.vcf")
@@ -106,7 +107,7 @@ def test_random_vcfs_import_like_the_reference_binary(tmp_path, seed, n_samples,
     mine, want = str(tmp_path / "mine"), str(tmp_path / "want")
     subprocess.check_call([BGT, "import", "-S"] + opts + [mine, vcf], timeout=600, stderr=subprocess.DEVNULL)
     subprocess.check_call([ref, "import", "-S"] + opts + [want, vcf], timeout=600, stderr=subprocess.DEVNULL)
-    for ext in ("spl", "pbf", "bcf"):
+    for ext in ("spl", "pbf", "bcf") + (("pb1",) if "-1" in opts else ()):   # -1: the one-plane file (import.c:72-74, 98-101)
         assert open(mine + "." + ext, "rb").read() == open(want + "." + ext, "rb").read(), ext
     for reg in ("11:100-400", "12", "X:60-90", "11:1,000-1,200"):       # either front end, either index: the same sites
         outs = [subprocess.run([exe, "view", "-C", "-r", reg, db], stdout=subprocess.PIPE, check=True).stdout
