@@ -1581,7 +1581,8 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
         HIP_TRY(hipStreamSynchronize(s), return -1);
         HIP_TRY(hipMemcpy(h, d_times, 64, hipMemcpyDeviceToHost), return -1);
         hipFree(d_times);
-        const Geometry &tg = dirpath ? wgeo : geo;           // (directory path: stage DMA | walk | wait | counts | plane-1 DMA | wait)
+        const Geometry &tg = dirpath ? wgeo : planepath ? pgeo : geo;   // (directory path: stage DMA | walk | wait | counts | plane-1 DMA | wait;
+                                                                        //  plane-split: walk | toggles | barrier | directory | barrier)
         const double waves = (double)tg.workgroups * ((a.debug_skip & 0x100) ? 1 : tg.threads / 64), nb = (double)rows / tg.K;
         fprintf(stderr, "[bgth debug] memtime ticks per wave and batch: prefetch %.0f | clear %.0f | wait %.0f | toggles %.0f | wait %.0f | directory %.0f | wait %.0f | walk %.0f\n",
                 h[0] / waves / nb, h[1] / waves / nb, h[2] / waves / nb, h[3] / waves / nb, h[4] / waves / nb, h[5] / waves / nb, h[6] / waves / nb, h[7] / waves / nb);

@@ -92,6 +92,8 @@ __global__ __launch_bounds__(512, 4) void plane_kernel(const ScanArgs a, const u
         }
     };
 
+    // (profiling build only: cycles per phase -- 0 walk, 1 toggles, 2 barrier, 3 directory, 4 barrier)
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = BGTH_TIMES(a) ? __builtin_amdgcn_s_memtime() : 0ull;
     // Loop (iteration -1 only prepares row blk_beg):   walk(row) + toggles(row+1) | directory(row+1) |     two barriers per row
     for (int64_t row = blk_beg - 1; row < blk_end; ++row) {
         const bool cur = row >= blk_beg, more = row + 1 < blk_end;
@@ -100,30 +102,47 @@ __global__ __launch_bounds__(512, 4) void plane_kernel(const ScanArgs a, const u
             const uint32_t n0 = 0u - n0s[row & 1];
             const bool emit = row >= a.row0;
             uint32_t ca = 0, cb = 0, cc = 0;
-            uint64_t keep = 0;                                           // lane l keeps the ballot of column l (CPT <= 64)
+            // The ballots leave straight from their SGPRs: one scalar store per column (s_store_dwordx2, written back by the
+            // s_dcache_wb at the end of the kernel) instead of moving them into lanes first (two v_cndmask per column: a
+            // quarter of this walk's VALU instructions).
+            // A scalar store reads its data registers when it EXECUTES, not when it issues: the ballots of a group stay in
+            // their SGPRs (pm) until the next statement's opening s_waitcnt lgkmcnt(0) has retired the stores.
+            uint64_t *hrow = hout + (size_t)(row - a.h_row0) * a.n_chunks + chunk0;
+            uint64_t pm[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < CPT; j += 4) {
                 uint32_t q0[4] = {rk_[j], rk_[j + 1], rk_[j + 2], rk_[j + 3]};
                 uint32_t q1[4] = {0u, 0u, 0u, 0u};                       // (plane-0 branch of the statement: untouched)
                 uint64_t m0[4] = {0, 0, 0, 0}, m1[4] = {0, 0, 0, 0};
                 step4<true>(q0, q1, m0, m1, ca, cb, cc, base, 0u, n0, 0u);
+                asm volatile("" :: "s"(pm[0]), "s"(pm[1]), "s"(pm[2]), "s"(pm[3]));
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     rk_[j + u] = q0[u];
-                    if (lane == j + u) keep = m0[u];
+                    if (emit && chunk0 + j + u < a.n_chunks)             // wave-uniform
+                        asm volatile("s_store_dwordx2 %0, %1, %2" :: "s"(m0[u]), "s"(hrow), "n"((j + u) * 8) : "memory");
+                    pm[u] = m0[u];
                 }
             }
-            if (emit && lane < CPT && chunk0 + lane < a.n_chunks)
-                hout[(size_t)(row - a.h_row0) * a.n_chunks + chunk0 + lane] = keep;
+            asm volatile("s_waitcnt lgkmcnt(0)" :: "s"(pm[0]), "s"(pm[1]), "s"(pm[2]), "s"(pm[3]) : "memory");
         }
+        BGTH_TICK(0);
         if (more) toggles(row + 1);
+        BGTH_TICK(1);
         lds_barrier();                                                   // every wave is past its walk; the toggles are complete
+        BGTH_TICK(2);
         if (more) {
             directory_trips_tog<2>(TOG, BD, tw, WPP, ntrip, nw, tail_mask, keep_cyl, lane);
             if (tid == 0) n0s[(row + 1) & 1] = (uint32_t)m - keep_tot;
         }
+        BGTH_TICK(3);
         lds_barrier();
+        BGTH_TICK(4);
     }
+    asm volatile("s_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");     // the scalar stores of the ballots reach memory
+#ifdef BGTH_ABLATE
+    if (BGTH_TIMES(a) && lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(a.debug_times + i, tsum[i]);
+#endif
 }
 
 // counts[row][g][3] += {n(code 1), n(code 2), n(code 3)} from the bit planes, one wave per row
