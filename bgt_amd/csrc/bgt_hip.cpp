@@ -176,6 +176,8 @@ struct Selection {
 struct bgth_pbf_s {
     int device = 0;
     int32_t m = 0, g = 0, shift = 0;
+    int32_t g_file = 0;               // planes of the file when that is 1 (prefix.pb1, `bgt import -1`): the image then carries an
+                                      // empty second plane, see expand_one_plane(); 0 = as g
     int32_t sub_shift = 0;            // sub-checkpoints every 1 << sub_shift rows (<= shift), see derive_sub_checkpoints
     bool wide_plane = false;          // 327,000 < m <= 650,000: a row's two bit-vectors do not fit the LDS together; every scan
                                       // takes the directory path with one plane per workgroup (scan_plane.hip), no sub-checkpoints
@@ -460,7 +462,7 @@ static void set_rows(bgth_pbf_t *p, int64_t n)
 
 static bgth_pbf_t *pbf_alloc(int device, int m, int g, int shift, int64_t n)
 {
-    if (g != 2) { set_err("[E::bgth_pbf] only g=2 bit planes are supported (BGT writes 2, import.c:68); got %d", g); return nullptr; }
+    if (g != 2) { set_err("[E::bgth_pbf] g=%d bit planes: this build holds BGT's two planes (import.c:68) and, for whole files, the one plane of a .pb1", g); return nullptr; }
     if (m <= 0 || shift < 0 || shift > 30) { set_err("[E::bgth_pbf] bad header m=%d shift=%d", m, shift); return nullptr; }
     Geometry geo;
     bool wide_plane = false;
@@ -669,12 +671,68 @@ extern "C" bgth_pbf_t *bgth_pbf_open_mem(const void *image, size_t len, int devi
     return guarded("bgth_pbf_open", (bgth_pbf_t*)nullptr, [&] { return open_mem_impl(image, len, device); });
 }
 
+// A ONE-plane file (g = 1: the prefix.pb1 that `import -1` writes, reference import.c:72-74) as the two-plane image the
+// kernels hold: every 'S' record gets the identity order for a second plane, every 'B' record a second, empty string (a
+// string that stops short leaves the rest of its row at its last bit, 0: a plane that is all zero, whose ranks never
+// move and which the empty-plane kernels do not even look up).  The footer is rebuilt for the new offsets.
+static bool expand_one_plane(const uint8_t *buf, size_t len, std::vector<uint8_t> &out)
+{
+    int32_t hdr[3];
+    memcpy(hdr, buf + 4, 12);
+    const int m = hdr[0];
+    if (m <= 0 || m > (1 << 28)) { set_err("[E::bgth_pbf_open] bad header m=%d", m); return false; }
+    out.clear();
+    out.reserve(len + len / 2 + 64);
+    hdr[1] = 2;
+    out.insert(out.end(), buf, buf + 4);
+    out.insert(out.end(), (const uint8_t*)hdr, (const uint8_t*)hdr + 12);
+    std::vector<int32_t> ident((size_t)m);
+    for (int j = 0; j < m; ++j) ident[j] = j;
+    std::vector<uint64_t> idx;
+    int64_t rows = 0;
+    size_t pos = 16;
+    const int32_t zero = 0;
+    while (pos < len && buf[pos] != 'I') {
+        if (buf[pos] == 'S') {
+            if (pos + 1 + (size_t)m * 4 > len) { set_err("[E::bgth_pbf_open] truncated 'S' record"); return false; }
+            idx.push_back((uint64_t)out.size());
+            out.insert(out.end(), buf + pos, buf + pos + 1 + (size_t)m * 4);
+            out.insert(out.end(), (const uint8_t*)ident.data(), (const uint8_t*)ident.data() + (size_t)m * 4);
+            pos += 1 + (size_t)m * 4;
+        }
+        if (pos >= len || buf[pos] != 'B' || pos + 5 > len) { set_err("[E::bgth_pbf_open] malformed record at byte %zu", pos); return false; }
+        int32_t l;
+        memcpy(&l, buf + pos + 1, 4);
+        if (l < 0 || pos + 5 + (size_t)l > len) { set_err("[E::bgth_pbf_open] truncated 'B' record"); return false; }
+        out.insert(out.end(), buf + pos, buf + pos + 5 + (size_t)l);
+        out.insert(out.end(), (const uint8_t*)&zero, (const uint8_t*)&zero + 4);
+        pos += 5 + (size_t)l;
+        ++rows;
+    }
+    if (pos >= len) { set_err("[E::bgth_pbf_open] no index footer: truncated or not a PBF image"); return false; }
+    const uint64_t off = (uint64_t)out.size();
+    const int32_t n_idx = (int32_t)idx.size();
+    out.push_back('I');
+    out.insert(out.end(), (const uint8_t*)&rows, (const uint8_t*)&rows + 8);
+    out.insert(out.end(), (const uint8_t*)&n_idx, (const uint8_t*)&n_idx + 4);
+    out.insert(out.end(), (const uint8_t*)idx.data(), (const uint8_t*)idx.data() + idx.size() * 8);
+    out.insert(out.end(), (const uint8_t*)&off, (const uint8_t*)&off + 8);
+    return true;
+}
+
 static bgth_pbf_t *open_mem_impl(const void *image, size_t len, int device)
 {
     const uint8_t *buf = (const uint8_t*)image;
     if (len < 16 || memcmp(buf, "PBF\1", 4) != 0) { set_err("[E::bgth_pbf_open] not a PBF image"); return nullptr; }
     int32_t hdr[3];
     memcpy(hdr, buf + 4, 12);
+    if (hdr[1] == 1) {                                            // one plane: held as two, the second one empty
+        std::vector<uint8_t> two;
+        if (!expand_one_plane(buf, len, two)) return nullptr;
+        bgth_pbf_t *p1 = open_mem_impl(two.data(), two.size(), device);
+        if (p1) p1->g_file = 1;
+        return p1;
+    }
     const int m = hdr[0], g = hdr[1], shift = hdr[2];
     int64_t n_footer = -1;
     size_t end = len;
@@ -1176,7 +1234,8 @@ static int64_t save_impl(const bgth_pbf_t *p, const char *path)
         if (!rle.empty()) HIP_TRY(hipMemcpy(rle.data(), p->d_rle, rle.size(), hipMemcpyDeviceToHost), goto done);
         if (!desc.empty()) HIP_TRY(hipMemcpy(desc.data(), p->d_rowdesc, desc.size() * 8, hipMemcpyDeviceToHost), goto done);
         HIP_TRY(hipMalloc((void**)&d_perm, per * 4), goto done);
-        int32_t hdr[3] = {p->m, p->g, p->shift};
+        const int gw = p->g_file ? p->g_file : 2;             // planes written (a one-plane file gets its one plane back)
+        int32_t hdr[3] = {p->m, gw, p->shift};
         fwrite("PBF\1", 1, 4, fp); fwrite(hdr, 4, 3, fp);
         for (int64_t r = 0; r < p->n; ++r) {
             if ((r & (((int64_t)1 << p->shift) - 1)) == 0) {
@@ -1185,10 +1244,10 @@ static int64_t save_impl(const bgth_pbf_t *p, const char *path)
                 HIP_TRY(hipMemcpy(perm.data(), d_perm, per * 4, hipMemcpyDeviceToHost), goto done);
                 idx.push_back((uint64_t)ftell(fp));
                 fputc('S', fp);
-                fwrite(perm.data(), 4, per, fp);
+                fwrite(perm.data(), 4, (size_t)gw * m, fp);
             }
             fputc('B', fp);
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < gw; ++k) {
                 const uint64_t d = desc[(size_t)r * 2 + k];
                 const int32_t l = (int32_t)(d >> kDescLenShift);
                 fwrite(&l, 4, 1, fp);
@@ -1209,7 +1268,7 @@ done:
 }
 
 extern "C" int bgth_pbf_get_m(const bgth_pbf_t *p) { return p->m; }
-extern "C" int bgth_pbf_get_g(const bgth_pbf_t *p) { return p->g; }
+extern "C" int bgth_pbf_get_g(const bgth_pbf_t *p) { return p->g_file ? p->g_file : p->g; }
 extern "C" int bgth_pbf_get_shift(const bgth_pbf_t *p) { return p->shift; }
 extern "C" int64_t bgth_pbf_get_n(const bgth_pbf_t *p) { return p->n_total; }
 extern "C" int64_t bgth_pbf_rle_bytes(const bgth_pbf_t *p) { return p->rle_bytes; }

@@ -109,6 +109,11 @@ def test_random_vcfs_import_like_the_reference_binary(tmp_path, seed, n_samples,
     subprocess.check_call([ref, "import", "-S"] + opts + [want, vcf], timeout=600, stderr=subprocess.DEVNULL)
     for ext in ("spl", "pbf", "bcf") + (("pb1",) if "-1" in opts else ()):   # -1: the one-plane file (import.c:72-74, 98-101)
         assert open(mine + "." + ext, "rb").read() == open(want + "." + ext, "rb").read(), ext
+    if "-1" in opts:                                                    # and the one-plane file decodes (as a two-plane image whose
+        ref_pv = require_ref("pbfview")                                  # second plane is empty) like the reference's codec tool reads it
+        a = subprocess.run([BGT, "pbfview", mine + ".pb1"], stdout=subprocess.PIPE, check=True).stdout
+        b = subprocess.run([ref_pv, want + ".pb1"], stdout=subprocess.PIPE, check=True).stdout
+        assert a == b and a.count(b"\n") > 100
     for reg in ("11:100-400", "12", "X:60-90", "11:1,000-1,200"):       # either front end, either index: the same sites
         outs = [subprocess.run([exe, "view", "-C", "-r", reg, db], stdout=subprocess.PIPE, check=True).stdout
                 for exe in (BGT, ref) for db in (mine, want)]
