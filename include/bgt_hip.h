@@ -40,10 +40,13 @@ int         bgth_device_count(void);
 void        bgth_runtime_warmup_async(int device);
 /* Wait for that thread (no-op if none was started): call before the process exits on a path that may not have opened an
  * image -- exit handlers must not run under a runtime that is still starting. */
-void        bgth_runtime_warmup_wait(void);             /* HIP devices visible; <0 on runtime failure     */
+void        bgth_runtime_warmup_wait(void);
 const char *bgth_version(void);
 
-/* ---- .pbf image in HBM  (replaces pbf_open_r / pbf_close / pbf_get_*, pbwt.c:221-286,390-393) ---- */
+/* ---- .pbf image in HBM  (replaces pbf_open_r / pbf_close / pbf_get_*, pbwt.c:221-286,390-393) ----
+ * Widths: up to 650,000 columns (haplotypes).  Planes: BGT's two (import.c:68); a whole ONE-plane file (prefix.pb1 of
+ * `import -1`) opens too, held with an empty second plane (bgth_pbf_get_g says 1, bgth_pbf_save writes one plane back);
+ * more planes are refused. */
 bgth_pbf_t *bgth_pbf_open(const char *path, int device);
 bgth_pbf_t *bgth_pbf_open_mem(const void *image, size_t len, int device);
 /* Partial image: only the 1<<shift-row blocks of the file that cover rows [row0,row1) are read (through the
