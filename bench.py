@@ -210,7 +210,7 @@ def oracle_window(bgt_amd, np, img, m, shift, seed, abs_row, img_row, n_rows, tm
 
 
 
-def inrun_counters(n_samples, sites, seed, tmp, kernel_substr):
+def inrun_counters(n_samples, sites, seed, tmp, kernel_substr, producer_substr=None, child_env=None):
     """HBM traffic of the scan kernel measured IN THIS RUN: this script starts itself twice under `rocprofv3 --pmc` (one
     counter per pass, as MI355X_MICROARCH.md prescribes; no tracing domains) in a child mode that only builds the same
     cohort and scans it four times, and reads the counters of the bench-size launches from the CSVs.  FETCH_SIZE counts
@@ -234,26 +234,39 @@ def inrun_counters(n_samples, sites, seed, tmp, kernel_substr):
     except Exception:
         pass
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        d = os.path.join(tmp, "pmc_" + counter)
+        d = os.path.join(tmp, "pmc_%s_%d" % (counter, n_samples))
         cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
                "--counters-child", "%d,%d,%d" % (n_samples, sites, seed)]
         try:
-            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True,
-                           env=dict(os.environ, TMPDIR=tmp), cwd=tmp)
+            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600, check=True,
+                           env=dict(os.environ, TMPDIR=tmp, **(child_env or {})), cwd=tmp)
         except Exception as e:
             return {"error": "rocprofv3 pass for %s failed: %s" % (counter, repr(e)[:120])}
-        vals = []
+        vals, pvals = [], []
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
-                if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                if r["Counter_Name"] != counter:
+                    continue
+                if kernel_substr in r["Kernel_Name"]:
                     vals.append(float(r["Counter_Value"]))
+                elif producer_substr and producer_substr in r["Kernel_Name"]:
+                    pvals.append(float(r["Counter_Value"]))
         if not vals:
             return {"error": "no %s rows for %s" % (counter, kernel_substr)}
         top = sorted(vals)[-3:]
         out[counter + "_KiB_per_launch"] = sum(top) / len(top)
+        if pvals:
+            top = sorted(pvals)[-3:]
+            out.setdefault("producer", {"kernel": producer_substr})[counter + "_KiB_per_launch"] = sum(top) / len(top)
     out["fetch_bytes"] = out["FETCH_SIZE_KiB_per_launch"] * 1024.0 * scale
     out["write_bytes"] = out["WRITE_SIZE_KiB_per_launch"] * 1024.0
     out["hbm_bytes_per_launch"] = out["fetch_bytes"] + out["write_bytes"]
+    pr = out.get("producer")
+    if pr and "FETCH_SIZE_KiB_per_launch" in pr and "WRITE_SIZE_KiB_per_launch" in pr:     # directory path, one-shot: + the producer
+        pr["fetch_bytes"] = pr["FETCH_SIZE_KiB_per_launch"] * 1024.0 * scale
+        pr["write_bytes"] = pr["WRITE_SIZE_KiB_per_launch"] * 1024.0
+        out["hbm_bytes_per_launch_walk_only"] = out["hbm_bytes_per_launch"]
+        out["hbm_bytes_per_launch"] += pr["fetch_bytes"] + pr["write_bytes"]
     return out
 
 
@@ -515,7 +528,7 @@ class Pipeline:
 
 
 def secondary_record(torch, bgt_amd, np, peak, name, what, n_samples, sites, seed, every, steps, warmup, dev, local, tmp,
-                     cpu_sites, counters_workload):
+                     cpu_sites, counters_workload, inrun=True):
     m = 2 * n_samples
     t0 = time.time()
     rle, lens = bgt_amd.synth_rows(m, 0, sites, seed)
@@ -588,6 +601,18 @@ def secondary_record(torch, bgt_amd, np, peak, name, what, n_samples, sites, see
     del pipe
     rd.close()
     pbf.close()
+    if path["directory_path"] and every <= 1 and inrun:
+        # HBM bytes of the one-shot scan measured in this run: walk-only kernel + producer (the arena rebuilt by every scan);
+        # after this process has given its image and arena back, so that the child's scan is one pass like the timed one
+        kn = "walk_kernel<%d, %d" % (geo["threads"], geo["cols_per_thread"])
+        ic = inrun_counters(n_samples, sites, seed, tmp, kn, "dirbuild_kernel", {"BGTH_VARIANT": "128"})
+        rec["roofline"]["traffic_in_run"] = ic
+        if "hbm_bytes_per_launch" in ic:
+            rec["roofline"]["traffic"] = ic["hbm_bytes_per_launch"]
+            rec["roofline"]["traffic_source"] = ic["source"]
+            rec["roofline"]["hbm_frac_measured"] = ic["hbm_bytes_per_launch"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            if ic.get("producer", {}).get("write_bytes") and path.get("producer_ms"):
+                rec["roofline"]["producer_hbm_write_gbs"] = ic["producer"]["write_bytes"] / (path["producer_ms"] * 1e-3) / 1e9
     return rec
 
 
@@ -884,7 +909,8 @@ def main():
                                  "configuration), whole cohort, -G -f'AC>0'", 153 * 8192, 4, 0, "c4shard")):
                 try:
                     rec = secondary_record(torch, bgt_amd, np, peak, name, what, 100000, s_sites, s_seed, s_every,
-                                           args.secondary_steps, 1, dev, local, tmp, 8192 + 2048, cw)   # (past the second 'S' record)
+                                           args.secondary_steps, 1, dev, local, tmp, 8192 + 2048, cw,   # (past the second 'S' record)
+                                           inrun=not args.no_counters)
                     rec["name"] = name
                     out["secondary"].append(rec)
                     if rec.get("parity_error"):
