@@ -181,6 +181,7 @@ struct bgth_pbf_s {
     int32_t sub_shift = 0;            // sub-checkpoints every 1 << sub_shift rows (<= shift), see derive_sub_checkpoints
     bool wide_plane = false;          // 327,000 < m <= 650,000: a row's two bit-vectors do not fit the LDS together; every scan
                                       // takes the directory path with one plane per workgroup (scan_plane.hip), no sub-checkpoints
+    bool one_shot = false;            // opened with BGTH_OPEN_HINT=walk: no sub-checkpoints, arena passes of one round of workgroups
     int64_t n = 0, n_blk = 0;         // n_blk: file blocks of 1 << shift rows
     int64_t n_sub = 0;                // sub-blocks of 1 << sub_shift rows: the unit the kernels work on
     // a partial image (bgth_pbf_open_rows) holds the file blocks that cover a row range: every internal index is
@@ -571,7 +572,8 @@ static BlockScan scan_block(const uint8_t *buf, size_t beg, size_t end, int m, i
                 dst_desc[r.rows * g + k] = (base_off + r.packed) | (uint64_t)l << kDescLenShift;
                 memcpy(dst_rle + r.packed, buf + pos, (size_t)l);
                 for (size_t z = (size_t)l; z < pad; ++z) dst_rle[r.packed + z] = 0;
-            } else if (k == 1 && string_is_all_zero(buf + pos, (size_t)l)) ++r.empty1;
+                if (k == 1 && string_is_all_zero(buf + pos, (size_t)l)) ++r.empty1;    // (the pass that reads the bytes anyway)
+            }
             r.packed += pad; r.payload += l;
             pos += (size_t)l;
         }
@@ -583,7 +585,17 @@ static BlockScan scan_block(const uint8_t *buf, size_t beg, size_t end, int m, i
 
 // The footer's block index makes the blocks of a file independent: sizes first, then every block copied to its place, on
 // several host threads.  false = no usable index (the caller then walks the records in order and reports what is wrong).
-static bool parse_blocks_parallel(const uint8_t *buf, size_t end, size_t len, int m, int g, int shift, int64_t n_rows, Parsed &out)
+// With an Upload the packed strings and the 'S' records never exist as one host copy: every host thread packs a block into
+// its own buffer and copies it to its place in HBM, while the others pack (one C4 shard, 2.4 GB: parse 222 + upload 101 +
+// freeing the host copy 257 ms become one stage).
+struct Upload {
+    int device = 0;
+    uint8_t *d_rle = nullptr;          // rle_n + 256 bytes (kernels may read whole dwords past the last string)
+    int32_t *d_perm = nullptr;         // the 'S' records, in file order
+    bool failed = false;               // a HIP call failed (the error is set): do not try the sequential parser
+};
+static bool parse_blocks_parallel(const uint8_t *buf, size_t end, size_t len, int m, int g, int shift, int64_t n_rows, Parsed &out,
+                                  Upload *up = nullptr)
 {
     if (end + 13 > len || n_rows <= 0 || m <= 0 || g != 2) return false;
     int32_t n_idx;
@@ -600,25 +612,61 @@ static bool parse_blocks_parallel(const uint8_t *buf, size_t end, size_t len, in
     auto run = [&](auto fn) {
         std::vector<std::thread> th;
         std::atomic<int> next(0);
-        for (int t = 0; t < nt; ++t) th.emplace_back([&] { for (int b; (b = next.fetch_add(1)) < n_idx;) fn(b); });
+        for (int t = 0; t < nt; ++t) th.emplace_back([&, t] { for (int b; (b = next.fetch_add(1)) < n_idx;) fn(b, t); });
         for (std::thread &t : th) t.join();
     };
-    run([&](int b) { info[b] = scan_block(buf, idx[b], idx[b + 1], m, g, nullptr, nullptr, 0, nullptr); });
+    run([&](int b, int) { info[b] = scan_block(buf, idx[b], idx[b + 1], m, g, nullptr, nullptr, 0, nullptr); });
     std::vector<uint64_t> off((size_t)n_idx + 1, 0);
     std::vector<int64_t> row0((size_t)n_idx + 1, 0);
     for (int b = 0; b < n_idx; ++b) {
         if (!info[b].ok || info[b].rows != (b + 1 < n_idx ? blk_rows : n_rows - (int64_t)b * blk_rows)) return false;
         off[b + 1] = off[b] + info[b].packed; row0[b + 1] = row0[b] + info[b].rows;
-        out.payload += info[b].payload; out.n_empty1 += info[b].empty1;
+        out.payload += info[b].payload;
     }
     if (off[n_idx] >= ((uint64_t)1 << kDescLenShift)) return false;
     out.rows = n_rows;
     out.rle_n = off[n_idx]; out.n_desc = (size_t)n_rows * g; out.n_perm = (size_t)n_idx * g * m;
-    out.rle = (uint8_t*)malloc(std::max<size_t>(out.rle_n, 1));
     out.desc = (uint64_t*)malloc(out.n_desc * 8);
-    out.perms = (int32_t*)malloc(out.n_perm * 4);
-    if (!out.rle || !out.desc || !out.perms) throw std::bad_alloc();
-    run([&](int b) { scan_block(buf, idx[b], idx[b + 1], m, g, out.rle + off[b], out.desc + (size_t)row0[b] * g, off[b], out.perms + (size_t)b * g * m); });
+    if (!out.desc) throw std::bad_alloc();
+    std::atomic<int64_t> empty1(0);
+    if (!up) {
+        out.rle = (uint8_t*)malloc(std::max<size_t>(out.rle_n, 1));
+        out.perms = (int32_t*)malloc(out.n_perm * 4);
+        if (!out.rle || !out.perms) throw std::bad_alloc();
+        run([&](int b, int) {
+            empty1 += scan_block(buf, idx[b], idx[b + 1], m, g, out.rle + off[b], out.desc + (size_t)row0[b] * g, off[b], out.perms + (size_t)b * g * m).empty1;
+        });
+        out.n_empty1 = empty1;
+        return true;
+    }
+    const size_t pad = 256, sbytes = (size_t)g * m * 4;
+    size_t widest = 0;
+    for (int b = 0; b < n_idx; ++b) widest = std::max(widest, info[b].packed);
+    up->failed = true;
+    if (!use_device(up->device)) return false;
+    HIP_TRY(hipMalloc((void**)&up->d_rle, out.rle_n + pad), return false);
+    HIP_TRY(hipMemset(up->d_rle + out.rle_n, 0, pad), return false);
+    HIP_TRY(hipMalloc((void**)&up->d_perm, out.n_perm * 4), return false);
+    std::vector<uint8_t*> mine((size_t)nt, nullptr);
+    std::atomic<int> hip_err((int)hipSuccess), no_mem(0);
+    run([&](int b, int t) {
+        if (hip_err.load() != (int)hipSuccess || no_mem.load()) return;
+        if (!mine[t]) {
+            mine[t] = (uint8_t*)malloc(widest + sbytes);
+            if (!mine[t]) { no_mem = 1; return; }
+            hipError_t e = hipSetDevice(up->device);
+            if (e != hipSuccess) { hip_err = (int)e; return; }
+        }
+        empty1 += scan_block(buf, idx[b], idx[b + 1], m, g, mine[t], out.desc + (size_t)row0[b] * g, off[b], (int32_t*)(mine[t] + widest)).empty1;
+        hipError_t e = info[b].packed ? hipMemcpy(up->d_rle + off[b], mine[t], info[b].packed, hipMemcpyHostToDevice) : hipSuccess;
+        if (e == hipSuccess) e = hipMemcpy(up->d_perm + (size_t)b * g * m, mine[t] + widest, sbytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) hip_err = (int)e;
+    });
+    for (uint8_t *q : mine) free(q);
+    if (no_mem.load()) throw std::bad_alloc();
+    if (hip_err.load() != (int)hipSuccess) { set_err("[E::bgth_pbf_open] copying the strings to the device: %s", hipGetErrorString((hipError_t)hip_err.load())); return false; }
+    out.n_empty1 = empty1;
+    up->failed = false;
     return true;
 }
 
@@ -751,7 +799,15 @@ static bgth_pbf_t *open_mem_impl(const void *image, size_t len, int device)
     t_building = p;
 
     Parsed ps;
-    if (!parse_blocks_parallel(buf, end, len, m, g, shift, n_footer, ps) && !parse_sequential(buf, end, m, g, shift, ps)) goto fail;
+    Upload up;
+    up.device = device;
+    if (!parse_blocks_parallel(buf, end, len, m, g, shift, n_footer, ps, &up)) {
+        p->d_rle = up.d_rle;                                     // (freed with the image)
+        if (up.d_perm) hipFree(up.d_perm);
+        up.d_rle = nullptr; up.d_perm = nullptr;
+        if (up.failed || !parse_sequential(buf, end, m, g, shift, ps)) goto fail;
+        p->d_rle = nullptr;
+    }
     p->n_empty1 = ps.n_empty1;
     {
     const int64_t row = ps.rows, payload = ps.payload;
@@ -762,14 +818,30 @@ static bgth_pbf_t *open_mem_impl(const void *image, size_t len, int device)
     if (rle.size() >= ((size_t)1 << kDescLenShift)) { set_err("[E::bgth_pbf_open] RLE payload too large"); goto fail; }
     set_rows(p, row);
     p->n_total = row;
+    // BGTH_OPEN_HINT=walk (set by `bgt view` for a one-shot walk of the whole file): when the file blocks alone fill the
+    // chip -- blocks x column slices >= two workgroups per CU -- the pass that derives sub-checkpoints costs as much as the
+    // walk it is meant to spread, so it is skipped (one C4 shard: 319 of 1,460 ms).  A resident process wants them: they
+    // cut the pre-roll of a region query from <= 8191 to <= 2047 rows.
+    if (const char *hint = getenv("BGTH_OPEN_HINT")) {
+        Geometry wg;
+        if (strcmp(hint, "walk") == 0 && !p->wide_plane && p->sub_shift < p->shift &&
+            choose_walk_geometry(m, (m + 63) / 64, 1, (int)p->n_blk, 0, 0, &wg) && p->n_blk * wg.slices >= 512) {
+            p->sub_shift = p->shift;
+            p->one_shot = true;
+            set_rows(p, row);
+        }
+    }
     tr.lap("parse records");
     p->rle_bytes = payload;
     p->packed_bytes = (int64_t)rle.size();
     {
         const size_t pad = 256;    // kernels may read whole dwords past the last string
-        HIP_TRY(hipMalloc((void**)&p->d_rle, rle.size() + pad), goto fail);
-        HIP_TRY(hipMemset(p->d_rle + rle.size(), 0, pad), goto fail);
-        if (!rle.empty()) HIP_TRY(hipMemcpy(p->d_rle, rle.data(), rle.size(), hipMemcpyHostToDevice), goto fail);
+        if (up.d_rle) p->d_rle = up.d_rle;                      // the parser put the strings in place
+        else {
+            HIP_TRY(hipMalloc((void**)&p->d_rle, rle.size() + pad), goto fail);
+            HIP_TRY(hipMemset(p->d_rle + rle.size(), 0, pad), goto fail);
+            if (!rle.empty()) HIP_TRY(hipMemcpy(p->d_rle, rle.data(), rle.size(), hipMemcpyHostToDevice), goto fail);
+        }
         HIP_TRY(hipMalloc((void**)&p->d_rowdesc, std::max<size_t>(desc.size(), 1) * 8), goto fail);
         if (!desc.empty()) HIP_TRY(hipMemcpy(p->d_rowdesc, desc.data(), desc.size() * 8, hipMemcpyHostToDevice), goto fail);
         tr.lap("upload strings");
@@ -778,13 +850,14 @@ static bgth_pbf_t *open_mem_impl(const void *image, size_t len, int device)
         const size_t np = perms.size(), per = (size_t)2 * m;
         if (np) {
             const int d = p->shift - p->sub_shift;
-            int32_t *d_perm = nullptr;
+            int32_t *d_perm = up.d_perm;
             int *d_bad = nullptr, bad = 0;
-            HIP_TRY(hipMalloc((void**)&d_perm, np * 4), goto fail);
+            up.d_perm = nullptr;
+            if (!d_perm) HIP_TRY(hipMalloc((void**)&d_perm, np * 4), goto fail);
             HIP_TRY(hipMalloc((void**)&d_bad, 4), { hipFree(d_perm); goto fail; });
             HIP_TRY(hipMemset(d_bad, 0, 4), { hipFree(d_perm); hipFree(d_bad); goto fail; });
             HIP_TRY(hipMalloc((void**)&p->d_rank0, std::max<int64_t>(p->n_sub, 1) * per * 4), { hipFree(d_perm); hipFree(d_bad); goto fail; });
-            HIP_TRY(hipMemcpy(d_perm, perms.data(), np * 4, hipMemcpyHostToDevice), { hipFree(d_perm); hipFree(d_bad); goto fail; });
+            if (perms.data()) HIP_TRY(hipMemcpy(d_perm, perms.data(), np * 4, hipMemcpyHostToDevice), { hipFree(d_perm); hipFree(d_bad); goto fail; });
             for (size_t b = 0; b < np / per; ++b)                 // validated: the records come from a file
                 HIP_TRY(launch_invert(d_perm + b * per, p->d_rank0 + ((size_t)b << d) * per, m, 2, nullptr, d_bad), { hipFree(d_perm); hipFree(d_bad); goto fail; });
             HIP_TRY(hipDeviceSynchronize(), { hipFree(d_perm); hipFree(d_bad); goto fail; });
@@ -804,6 +877,7 @@ static bgth_pbf_t *open_mem_impl(const void *image, size_t len, int device)
     return p;
 fail:
     t_building = nullptr;
+    if (up.d_perm) hipFree(up.d_perm);
     bgth_pbf_close(p);
     return nullptr;
 }
@@ -825,7 +899,9 @@ extern "C" bgth_pbf_t *bgth_pbf_open(const char *path, int device)
     madvise(map, (size_t)st.st_size, MADV_SEQUENTIAL);       // (advice values are enumerators, not flags: one call each)
     madvise(map, (size_t)st.st_size, MADV_WILLNEED);
     bgth_pbf_t *p = bgth_pbf_open_mem(map, (size_t)st.st_size, device);
+    Trace tr;
     munmap(map, (size_t)st.st_size);
+    tr.lap("unmap the file");
     return p;
 }
 
@@ -1270,6 +1346,7 @@ done:
 extern "C" int bgth_pbf_get_m(const bgth_pbf_t *p) { return p->m; }
 extern "C" int bgth_pbf_get_g(const bgth_pbf_t *p) { return p->g_file ? p->g_file : p->g; }
 extern "C" int bgth_pbf_get_shift(const bgth_pbf_t *p) { return p->shift; }
+extern "C" int64_t bgth_pbf_unit_rows(const bgth_pbf_t *p) { const bgth_pbf_t *q = p->shards.empty() ? p : p->shards[0]; return (int64_t)1 << q->sub_shift; }
 extern "C" int64_t bgth_pbf_get_n(const bgth_pbf_t *p) { return p->n_total; }
 extern "C" int64_t bgth_pbf_rle_bytes(const bgth_pbf_t *p) { return p->rle_bytes; }
 extern "C" int64_t bgth_pbf_hbm_bytes(const bgth_pbf_t *p)
@@ -1600,9 +1677,19 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
             const int64_t blk_rows = std::min<int64_t>(sub_rows, row1 - first);     // (a short image has short sub-blocks)
             const int64_t fit = (int64_t)(cap / (row_bytes * (size_t)blk_rows));
             if (fit < 1) { set_err("[E::bgth_reader_scan] the directory arena (%zu MB) does not hold one sub-block of m=%d", cap >> 20, p->m); return -1; }
+            if (p->one_shot) {
+                // A walk that will not come back (BGTH_OPEN_HINT=walk) has nothing to gain from an arena of the whole file:
+                // the walk-only kernel runs one workgroup per CU, so passes of one ROUND of workgroups each take the same
+                // time as one launch of all of them -- with a third of the HBM (one C4 shard: 42 GB instead of 125 GB),
+                // which the driver wipes when the process ends, at the expense of whoever allocates next.
+                const int64_t rounds = ((blk1 - blk0 + 1) * wgeo.slices + 255) / 256;
+                per_pass = std::min(per_pass, (blk1 - blk0 + rounds) / rounds);
+            }
             if (per_pass > fit) per_pass = std::max<int64_t>(8, fit / 8 * 8);     // whole XCD rounds of workgroups
             if (per_pass > fit) per_pass = fit;
             const int64_t arena_rows = std::min<int64_t>(per_pass * sub_rows, row1 - first);
+            Trace tr;
+            struct Lap { Trace &t; ~Lap() { t.lap("directory arena (hipMalloc)"); } } lap_arena{tr};
             if (!r->dir.reserve((size_t)arena_rows * row_bytes) || !r->dir_n0.reserve((size_t)arena_rows * 2 * 4)) {
                 r->dir_lo = r->dir_hi = 0;
                 set_err("[E::bgth_reader_scan] out of HBM (directory arena of %lld rows)", (long long)arena_rows);

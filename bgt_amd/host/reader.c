@@ -631,6 +631,15 @@ static int needed_rows(const bgt_t *bgt, int64_t *r0, int64_t *r1)
     return 1;
 }
 
+/* BGT_TRACE=1: wall-clock of the stages of getting a database ready, on stderr (tuning aid) */
+static double rd_now_ms(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+static void rd_lap(double *t0, const char *what)
+{
+    const double t1 = rd_now_ms();
+    if (getenv("BGT_TRACE")) fprintf(stderr, "[bgt trace]   %-32s %8.2f ms\n", what, t1 - *t0);
+    *t0 = t1;
+}
+
 static int ensure_device(bgt_t *bgt)
 {
     bgt_file_t *wf = (bgt_file_t*)bgt->f;
@@ -638,6 +647,7 @@ static int ensure_device(bgt_t *bgt)
     char *fn;
     int64_t r0 = 0, r1 = 0;
     int partial;
+    double t_lap = rd_now_ms();
     if (dv->rd) return 0;
     fn = (char*)malloc(strlen(wf->prefix) + 8);
     sprintf(fn, "%s.pbf", wf->prefix);
@@ -656,12 +666,14 @@ static int ensure_device(bgt_t *bgt)
             wf->gpu_opening = 1;
             pthread_mutex_unlock(&g_open_lock);
             img = open_whole_image(fn);                          /* the whole file */
+            rd_lap(&t_lap, "image open");
             pthread_mutex_lock(&g_open_lock);
             wf->gpu = img; wf->gpu_opening = 0;
             pthread_cond_broadcast(&g_open_cond);
         }
         pthread_mutex_unlock(&g_open_lock);
         if (wf->gpu) dv->rd = bgth_reader_create((bgth_pbf_t*)wf->gpu);
+        rd_lap(&t_lap, "reader create");
     }
     free(fn);
     if (dv->rd == NULL) { fprintf(stderr, "[E::%s] %s\n", __func__, bgth_last_error()); return -1; }
@@ -779,7 +791,11 @@ static int prepare_one(bgt_t *bgt, int n_groups_total, int need_device)
     for (i = 0, bgt->n_out = 0; i < f->n_rows; ++i)
         if (bgt->gtag[i] > 0) { bgt->group[bgt->n_out] = bgt->gtag[i]; bgt->out[bgt->n_out++] = i; }
     dv->n_groups_total = n_groups_total;
-    if (bgt->n_out > 0 && dv->rd && apply_selection(bgt) < 0) rc = -1;
+    {
+        double t_lap = rd_now_ms();
+        if (bgt->n_out > 0 && dv->rd && apply_selection(bgt) < 0) rc = -1;
+        rd_lap(&t_lap, "selection");
+    }
     dv->site = -1;
     bgt->b0->shared.l = 0;
     return rc;
@@ -1953,7 +1969,14 @@ long bgtm_write_vcf_bulk(bgtm_t *bm, FILE *fp, long n_rec)
             if (row_max < 0) { k.row_min[d] = 0; continue; }
             k.row_min[d] = row_min;
             scan[d].rd = ((devrd_t*)bm->bgt[d]->pb)->rd; scan[d].r0 = row_min; scan[d].r1 = row_max + 1;
-            scan[d].piece = 131072; scan[d].cstride = k.cstride; scan[d].lock = &k.lock; scan[d].cond = &k.cond; scan[d].failed = &k.failed;
+            /* pieces of 256 decoding units (sub-blocks of 2048 rows, or file blocks of an image without sub-checkpoints): a
+             * piece must fill the chip by itself -- 64 units were a quarter of it, four times the device time */
+            {
+                const devrd_t *dvd = (const devrd_t*)bm->bgt[d]->pb;
+                const bgth_pbf_t *img = dvd->own_img ? dvd->own_img : (const bgth_pbf_t*)bm->bgt[d]->f->gpu;
+                scan[d].piece = img ? 256 * bgth_pbf_unit_rows(img) : 524288;
+            }
+            scan[d].cstride = k.cstride; scan[d].lock = &k.lock; scan[d].cond = &k.cond; scan[d].failed = &k.failed;
             scan[d].counts = (int32_t*)malloc((size_t)(row_max - row_min + 1) * (size_t)k.cstride * 4);
             if (scan[d].counts == NULL) { failed = 1; break; }
             k.counts[d] = scan[d].counts;

@@ -91,6 +91,9 @@ int main_view(int argc, char *argv[])
         bgth_runtime_warmup_async(gp && gp[0] >= '0' && gp[0] <= '9' && strchr(gp, ',') ? atoi(gp) : 0);
     }
 
+    /* a plain walk of the whole file(s), counts only: the image may skip the sub-checkpoints a long-lived reader wants */
+    if ((flag & BGT_F_NO_GT) && !reg && !bed && !aexpr && seekn <= 0 && !fmt) setenv("BGTH_OPEN_HINT", "walk", 0);
+
     n_files = argc - optind;
     files = (bgt_file_t**)calloc((size_t)n_files, sizeof(bgt_file_t*));
     for (i = 0; i < n_files; ++i)

@@ -69,6 +69,9 @@ bgth_pbf_t *bgth_pbf_open_sharded(const char *path, int n_shards, const int *dev
 int         bgth_pbf_n_shards(const bgth_pbf_t *p);      /* 0 for a single-device image                    */
 /* ranges[2 i], ranges[2 i + 1] = rows [row0,row1) of shard i: ceil(blocks / n_shards) whole blocks each          */
 void        bgth_shard_ranges(int64_t n_rows, int shift, int n_shards, int64_t *ranges);
+/* rows between two checkpoints the image can start decoding from (2048, or the file's 1 << shift when it keeps no
+ * sub-checkpoints): the unit of work of a scan -- a caller that scans in pieces gives each piece >= 256 of them */
+int64_t     bgth_pbf_unit_rows(const bgth_pbf_t *p);
 int64_t     bgth_pbf_first_row(const bgth_pbf_t *p);     /* first loaded row (0 for a full image)        */
 int64_t     bgth_pbf_loaded_rows(const bgth_pbf_t *p);   /* number of loaded rows                         */
 /* Build an image from bare RLE strings (row-major, plane-minor: row0/plane0,row0/plane1,row1/plane0..)
