@@ -17,7 +17,9 @@
 //   A  every unit and plane at once, from the identity order and without emitting: the order L the unit's own rows
 //      produce; then which neighbours in L are identical over the whole unit (classes), on a bit-transposed copy
 //   B  unit after unit (cheap): the columns in the order before unit k, sorted stably by their class in L_k, are the
-//      order after it   [rocPRIM radix sort, 16-bit keys]; all orders turned into ranks by one kernel at the end
+//      order after it -- ONE launch for the whole chain (order_chain_kernel: a workgroup per plane, the order resident in
+//      LDS, a block radix sort per unit); above 32768 columns the order does not fit and a rocPRIM sort per unit does it;
+//      all orders turned into ranks by one kernel at the end
 //   C  every unit and plane at once, from its true start order: scatter / directory / emit / step as above.
 // A call with one unit is phase C alone.  Above 32768 columns (encode_wide_kernel) the ranks live in memory.
 #include <hip/hip_runtime.h>
@@ -359,15 +361,23 @@ __global__ __launch_bounds__(kThreads) void encode_wide_kernel(EncodeArgs a)
         const bool more = r + 1 < r_end;
         const uint8_t *nsrc = a.codes + (size_t)(more ? r + 1 : r) * a.stride;
         char *other_m8 = reinterpret_cast<char*>(other) - 8;
-        for (int c0 = tid; c0 < m; c0 += 8 * kThreads) {
-            int32_t q[8];
-            uint32_t nb8[8];
+        // (software-pipelined: the ranks and next-row codes of batch k + 1 are in flight while batch k takes its step --
+        // 16 loads per thread outstanding instead of 8, and no load waits behind the stores of its own batch)
+        int32_t q[8];
+        uint32_t nb8[8];
+        auto fetch = [&](int c0, int32_t (&fq)[8], uint32_t (&fn)[8]) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int c = c0 + j * kThreads;
-                q[j] = c < m ? Qg[c] : -1;
-                nb8[j] = (c < m && more) ? nsrc[c] : 0u;
+                fq[j] = c < m ? Qg[c] : -1;
+                fn[j] = (c < m && more) ? nsrc[c] : 0u;
             }
+        };
+        fetch(tid, q, nb8);
+        for (int c0 = tid; c0 < m; c0 += 8 * kThreads) {
+            int32_t q2[8];
+            uint32_t nb2[8];
+            if (c0 + 8 * kThreads < m) fetch(c0 + 8 * kThreads, q2, nb2);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int c = c0 + j * kThreads;
@@ -380,6 +390,8 @@ __global__ __launch_bounds__(kThreads) void encode_wide_kernel(EncodeArgs a)
                     if ((nb8[j] >> plane) & 1u) atomicOr(reinterpret_cast<uint32_t*>(other_m8 - 8 * (qn >> 5)), 0x80000000u >> (qn & 31));
                 }
             }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { q[j] = q2[j]; nb8[j] = nb2[j]; }
         }
     }
     for (int c = tid; c < m; c += kThreads) {
@@ -466,6 +478,105 @@ __global__ __launch_bounds__(256) void class_keys_kernel(int m, int g, int bits,
     key[i] = (uint32_t)plane << bits | (uint32_t)cid_u[(size_t)plane * m + local_u[(size_t)plane * m + col]];
 }
 
+// ---- phase B on one workgroup per plane (m <= 32768) --------------------------------------------------------------
+// ccls[u][plane][col] = class of the column in unit u's own order, for every unit at once (16 bits: a class number is
+// below m <= 32768)
+__global__ __launch_bounds__(256) void column_class_kernel(int m, int64_t n_total, const int32_t *cid, const int32_t *local, uint16_t *ccls)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_total) return;
+    const int64_t base = i / m * m;
+    ccls[i] = (uint16_t)cid[base + local[i]];
+}
+
+// The chain of phase B in ONE launch: a workgroup per plane keeps the order (position -> column) in LDS and, unit after
+// unit, sorts it stably by the columns' class in that unit -- an LSD radix sort over the 15 bits of a class number,
+// DIGIT bits a pass, the elements {class << 16 | column} blocked EPT to a thread: digits counted in registers (packed
+// bytes), one scan over the [bucket][thread] counts, scatter in place.  Every unit's order goes out as it is found
+// (perms[u + 1]).  Positions m .. 1024 EPT - 1 hold sentinels that sort last in every pass.  (128 units at m = 20,000:
+// 128 x 7 launches of a library sort, 5.1 ms, become one launch of 4.5 ms -- 35 us a unit, four passes of five barriers
+// each on one CU; BGTH_ENC_LIBSORT=1 takes the library path for comparison.)
+template <int EPT, int DIGIT>
+__global__ __launch_bounds__(kThreads) void order_chain_kernel(int m, int g, int n_units, const uint16_t *ccls, int32_t *perms)
+{
+    constexpr int NB = 1 << DIGIT, PASSES = (15 + DIGIT - 1) / DIGIT;
+    extern __shared__ uint32_t chain_lds[];                // [1024 EPT] elements, then [NB][1024] 16-bit counts
+    __shared__ uint32_t agg[16];
+    uint32_t *data = chain_lds;
+    uint16_t *cnt = reinterpret_cast<uint16_t*>(chain_lds + kThreads * EPT);
+    const int tid = threadIdx.x, lane = tid & 63, plane = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t gm = (size_t)g * m;
+    uint32_t el[EPT];
+    {
+        const int32_t *src = perms + (size_t)plane * m;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) { const int p = tid * EPT + i; el[i] = p < m ? (uint32_t)src[p] : 0xffffffffu; }
+    }
+    for (int u = 0; u < n_units; ++u) {
+        const uint16_t *cls = ccls + (size_t)u * gm + (size_t)plane * m;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const bool real = el[i] != 0xffffffffu;
+            const uint32_t col = real ? el[i] & 0xffffu : 0u, c = cls[col];
+            el[i] = real ? c << 16 | col : 0xffffffffu;
+        }
+#pragma unroll 1
+        for (int pass = 0; pass < PASSES; ++pass) {
+            const int sh = 16 + pass * DIGIT;
+            // this thread's count per digit, in its own column of the [bucket][thread] table; an element's number among its
+            // thread's elements of the same digit is the count it finds (a byte each in rk[])
+            uint32_t rk[EPT / 4];
+#pragma unroll
+            for (int i = 0; i < EPT / 4; ++i) rk[i] = 0u;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) cnt[b * kThreads + tid] = 0;
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) {
+                const uint32_t d = (el[i] >> sh) & (NB - 1);
+                uint16_t *c = cnt + d * kThreads + tid;
+                const uint32_t r = *c;
+                *c = (uint16_t)(r + 1u);
+                rk[i >> 2] |= r << (8 * (i & 3));
+            }
+            lds_barrier();
+            // exclusive scan over the counts in [bucket][thread] order: this thread's NB consecutive entries
+            uint32_t *cw = reinterpret_cast<uint32_t*>(cnt + tid * NB);
+            uint32_t total = 0;
+#pragma unroll
+            for (int b = 0; b < NB; b += 2) { const uint32_t w = cw[b >> 1]; total += (w & 0xffffu) + (w >> 16); }
+            const uint32_t incl = wave_incl_add(total);
+            if (lane == 63) agg[wave] = incl;
+            lds_barrier();
+            {
+                const uint32_t va = lane < 16 ? agg[lane] : 0u;
+                const uint32_t sa = wave_incl_add(va);
+                uint32_t base = (wave ? lane_value(sa, wave - 1) : 0u) + incl - total;
+#pragma unroll
+                for (int b = 0; b < NB; b += 2) {                // (read again rather than kept across the barrier: registers)
+                    const uint32_t w = cw[b >> 1], b0 = base, b1 = base + (w & 0xffffu);
+                    base = b1 + (w >> 16);
+                    cw[b >> 1] = b0 | b1 << 16;
+                }
+            }
+            lds_barrier();
+            int sh2 = sh;
+            asm volatile("" : "+s"(sh2));                       // (the digits are computed again, not kept in registers since the count)
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) {
+                const uint32_t d = (el[i] >> sh2) & (NB - 1);
+                data[(uint32_t)cnt[d * kThreads + tid] + ((rk[i >> 2] >> (8 * (i & 3))) & 255u)] = el[i];
+            }
+            lds_barrier();
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) el[i] = data[tid * EPT + i];
+            lds_barrier();                                  // (the next pass's scatter, or the next unit's, must not overtake these reads)
+        }
+        int32_t *dst = perms + (size_t)(u + 1) * gm + (size_t)plane * m;
+        for (int p = tid; p < m; p += kThreads) dst[p] = (int32_t)(data[p] & 0xffffu);
+    }
+}
+
 // position -> column  <->  column -> position, for n consecutive (unit, plane) arrays of m entries
 __global__ __launch_bounds__(256) void invert_kernel(int m, int64_t n_total, const int32_t *src, int32_t *dst)
 {
@@ -542,6 +653,7 @@ struct bgth_encoder_s {
     int32_t *d_row_len = nullptr, *d_snap = nullptr, *d_snap_base = nullptr, *d_status = nullptr;
     int32_t *d_perms = nullptr;                      // [units + 1][g][m] true order before every unit as position -> column
     uint32_t *d_key[2] = {nullptr, nullptr};
+    uint16_t *d_ccls = nullptr;                      // [units][g][m] class of every column in every unit's own order (narrow cohorts)
     int32_t wpt = 0;                                 // > 0: the wide kernel with this many directory words per thread
     void *d_temp = nullptr;
     size_t temp_bytes = 0;
@@ -560,8 +672,9 @@ extern "C" const char *bgth_encoder_last_error(void) { return g_enc_err; }
 static void free_batch_buffers(bgth_encoder_t *e)
 {
     hipFree(e->d_codes); hipFree(e->d_out); hipFree(e->d_flag); hipFree(e->d_true); hipFree(e->d_perms); hipFree(e->d_local); hipFree(e->d_perm);
-    hipFree(e->d_cid); hipFree(e->d_row_len); hipFree(e->d_snap); hipFree(e->d_snap_base); hipFree(e->d_out_len);
+    hipFree(e->d_cid); hipFree(e->d_row_len); hipFree(e->d_snap); hipFree(e->d_snap_base); hipFree(e->d_out_len); hipFree(e->d_ccls);
     e->d_codes = e->d_out = e->d_flag = nullptr;
+    e->d_ccls = nullptr;
     e->d_perms = nullptr;
     e->d_true = e->d_local = e->d_perm = e->d_cid = e->d_row_len = e->d_snap = e->d_snap_base = nullptr;
     e->d_out_len = nullptr;
@@ -645,6 +758,7 @@ static int ensure_capacity(bgth_encoder_t *e, int64_t rows, int32_t n_units, int
     ENC_TRY(hipMalloc(&e->d_local, ugm * 4), return -1);
     ENC_TRY(hipMalloc(&e->d_perm, ugm * 4), return -1);
     ENC_TRY(hipMalloc(&e->d_cid, ugm * 4), return -1);
+    if (!e->wpt) ENC_TRY(hipMalloc(&e->d_ccls, ugm * 2), return -1);
     ENC_TRY(hipMalloc(&e->d_row_len, (size_t)g * rows * 4), return -1);
     ENC_TRY(hipMalloc(&e->d_snap, ((size_t)g * n_snap * m + 1) * 4), return -1);
     ENC_TRY(hipMalloc(&e->d_snap_base, (size_t)n_units * 4), return -1);
@@ -750,14 +864,45 @@ static int encode_batch(bgth_encoder_t *e, const uint8_t *codes, int64_t rows, b
                            e->d_colbits, wpu, m, g, e->d_perm, e->d_flag);
         hipLaunchKernelGGL(class_ids_kernel, dim3((unsigned)(n_units * g)), dim3(kThreads), 0, e->stream, m, e->d_flag, e->d_cid);
         // B: the true order before every unit: one stable sort by class per unit, then all orders turned into ranks
+        hipEvent_t evb0 = nullptr, evb1 = nullptr;
+        if (trace && hipEventCreate(&evb0) == hipSuccess && hipEventCreate(&evb1) == hipSuccess) hipEventRecord(evb0, e->stream);
         const unsigned nk = (unsigned)gm, kb = (nk + 255) / 256;
         const int cbits = e->wpt ? 18 : 15;                 // bits of a class number
         hipLaunchKernelGGL(invert_kernel, dim3(kb), dim3(256), 0, e->stream, m, (int64_t)gm, e->d_state, e->d_perms);
-        for (int32_t k = 0; k < n_units; ++k) {
+        if (!e->wpt && !getenv("BGTH_ENC_LIBSORT")) {
+            // one launch for the whole chain: a workgroup per plane, the order resident in LDS (order_chain_kernel)
+            const int64_t n_cls = (int64_t)n_units * (int64_t)gm;
+            hipLaunchKernelGGL(column_class_kernel, dim3((unsigned)((n_cls + 255) / 256)), dim3(256), 0, e->stream, m, n_cls, e->d_cid, e->d_local, e->d_ccls);
+            const int digit = e->cpt == 32 ? 3 : 4;
+            const size_t lds = (size_t)kThreads * e->cpt * 4 + ((size_t)2 << digit) * kThreads;
+            const dim3 cgrid((unsigned)g), cblock(kThreads);
+            if (e->cpt == 4) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&order_chain_kernel<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL((order_chain_kernel<4, 4>), cgrid, cblock, lds, e->stream, m, g, n_units, e->d_ccls, e->d_perms);
+            } else if (e->cpt == 8) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&order_chain_kernel<8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL((order_chain_kernel<8, 4>), cgrid, cblock, lds, e->stream, m, g, n_units, e->d_ccls, e->d_perms);
+            } else if (e->cpt == 20) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&order_chain_kernel<20, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL((order_chain_kernel<20, 4>), cgrid, cblock, lds, e->stream, m, g, n_units, e->d_ccls, e->d_perms);
+            } else {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&order_chain_kernel<32, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL((order_chain_kernel<32, 3>), cgrid, cblock, lds, e->stream, m, g, n_units, e->d_ccls, e->d_perms);
+            }
+        } else
+        for (int32_t k = 0; k < n_units; ++k) {                 // wide cohorts (the order does not fit the LDS): a library sort per unit
             hipLaunchKernelGGL(class_keys_kernel, dim3(kb), dim3(256), 0, e->stream, m, g, cbits, e->d_cid + (size_t)k * gm,
                                e->d_local + (size_t)k * gm, e->d_perms + (size_t)k * gm, e->d_key[0]);
             ENC_TRY(rocprim::radix_sort_pairs(e->d_temp, e->temp_bytes, e->d_key[0], e->d_key[1], e->d_perms + (size_t)k * gm,
                                               e->d_perms + (size_t)(k + 1) * gm, nk, 0, (unsigned)(cbits + (g > 1 ? 1 : 0)), e->stream), return -1);
+        }
+        if (evb1) {
+            hipEventRecord(evb1, e->stream);
+            hipEventSynchronize(evb1);
+            float msb = 0.f;
+            hipEventElapsedTime(&msb, evb0, evb1);
+            fprintf(stderr, "[bgth_encoder] phase B (the chain of %d units): %.2f ms\n", n_units, (double)msb);
+            hipEventDestroy(evb0); hipEventDestroy(evb1);
         }
         {
             const int64_t n_total = (int64_t)(n_units + 1) * (int64_t)gm;

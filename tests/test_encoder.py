@@ -155,6 +155,28 @@ def test_encoder_parallel_units_match_oracle(small_units, m, rows, shift, founde
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("m,rows,founders", [(4096, 90, 2), (4097, 90, 5), (8192, 70, 3), (8193, 50, 4), (20480, 60, 3), (20481, 40, 2),
+                                             (32767, 50, 2), (32768, 40, 50)])
+def test_encoder_order_chain_kernel(small_units, monkeypatch, m, rows, founders):
+    """phase B in one launch (order_chain_kernel: a workgroup per plane sorts the order resident in LDS, unit after unit) at
+    the edges of its four shapes -- 4 / 8 / 20 / 32 elements a thread, with and without sentinel positions, 4- and 3-bit
+    digits -- against the oracle writer, and against the library sort it replaced (BGTH_ENC_LIBSORT=1)."""
+    import bgt_amd
+    rng = np.random.default_rng(3 * m + rows)
+    mat = scenarios.ld_matrix(rng, rows, m, n_founders=founders, switch=0.0005)
+    mat[20:36] = 0                                   # a whole unit of constant rows: one class of m columns
+    mat[36:40, : m // 2] = 1
+    enc = bgt_amd.HipEncoder(m, 2, 4)
+    enc.write(mat)
+    image = enc.finish()
+    assert image == orc.encode_pbf(mat, 2, 4)
+    monkeypatch.setenv("BGTH_ENC_LIBSORT", "1")
+    lib = bgt_amd.HipEncoder(m, 2, 4)
+    lib.write(mat)
+    assert lib.finish() == image
+
+
+@pytest.mark.gpu
 def test_encoder_parallel_units_over_several_calls(small_units):
     import bgt_amd
     rng = np.random.default_rng(77)
