@@ -361,23 +361,15 @@ __global__ __launch_bounds__(kThreads) void encode_wide_kernel(EncodeArgs a)
         const bool more = r + 1 < r_end;
         const uint8_t *nsrc = a.codes + (size_t)(more ? r + 1 : r) * a.stride;
         char *other_m8 = reinterpret_cast<char*>(other) - 8;
-        // (software-pipelined: the ranks and next-row codes of batch k + 1 are in flight while batch k takes its step --
-        // 16 loads per thread outstanding instead of 8, and no load waits behind the stores of its own batch)
-        int32_t q[8];
-        uint32_t nb8[8];
-        auto fetch = [&](int c0, int32_t (&fq)[8], uint32_t (&fn)[8]) {
+        for (int c0 = tid; c0 < m; c0 += 8 * kThreads) {
+            int32_t q[8];
+            uint32_t nb8[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int c = c0 + j * kThreads;
-                fq[j] = c < m ? Qg[c] : -1;
-                fn[j] = (c < m && more) ? nsrc[c] : 0u;
+                q[j] = c < m ? Qg[c] : -1;
+                nb8[j] = (c < m && more) ? nsrc[c] : 0u;
             }
-        };
-        fetch(tid, q, nb8);
-        for (int c0 = tid; c0 < m; c0 += 8 * kThreads) {
-            int32_t q2[8];
-            uint32_t nb2[8];
-            if (c0 + 8 * kThreads < m) fetch(c0 + 8 * kThreads, q2, nb2);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int c = c0 + j * kThreads;
@@ -390,8 +382,6 @@ __global__ __launch_bounds__(kThreads) void encode_wide_kernel(EncodeArgs a)
                     if ((nb8[j] >> plane) & 1u) atomicOr(reinterpret_cast<uint32_t*>(other_m8 - 8 * (qn >> 5)), 0x80000000u >> (qn & 31));
                 }
             }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { q[j] = q2[j]; nb8[j] = nb2[j]; }
         }
     }
     for (int c = tid; c < m; c += kThreads) {
