@@ -825,9 +825,11 @@ static bgth_pbf_t *open_mem_impl(const void *image, size_t len, int device)
     if (const char *hint = getenv("BGTH_OPEN_HINT")) {
         Geometry wg;
         if (strcmp(hint, "walk") == 0 && !p->wide_plane && p->sub_shift < p->shift &&
-            choose_walk_geometry(m, (m + 63) / 64, 1, (int)p->n_blk, 0, 0, &wg) && p->n_blk * wg.slices >= 512) {
+            choose_walk_geometry(m, (m + 63) / 64, 1, (int)p->n_blk, 0, 0, &wg) &&
+            p->n_blk * wg.slices >= (getenv("BGTH_OPEN_HINT_MIN") ? atoll(getenv("BGTH_OPEN_HINT_MIN")) : 512)) {   // (the variable: tests)
             p->sub_shift = p->shift;
             p->one_shot = true;
+            if (getenv("BGTH_TRACE")) fprintf(stderr, "[bgth trace] one-shot walk: %lld file blocks x %d column slices, no sub-checkpoints\n", (long long)p->n_blk, wg.slices);
             set_rows(p, row);
         }
     }

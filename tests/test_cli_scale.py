@@ -134,3 +134,29 @@ def test_wide_cohort_subset_like_config3(tmp_path):
         ref = md5_of([REF, "view"] + args + [db])
         assert mine[0] == ref[0] == 0, (args, mine, ref)
         assert mine[2] > 0 and mine[1:3] == ref[1:3], (args, mine, ref)
+
+
+def test_one_shot_walk_of_a_wide_cohort(tmp_path, monkeypatch):
+    """`bgt view -G -f` over a whole wide database opens its image with BGTH_OPEN_HINT=walk: no sub-checkpoints, a directory
+    arena of one round of workgroups walked in several passes, the strings streamed to HBM while the host parses.  The
+    hint only applies when file blocks x column slices fill the chip (one C4 shard: 153 x 4); BGTH_OPEN_HINT_MIN lowers that
+    bar so that 100,000 samples x 12,000 sites (2 blocks) take the same code path.  Same bytes as the compiled reference, as
+    without the hint, and as with an arena too small for one pass."""
+    import bgt_amd
+    bgt_amd.build_library()
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bgt_amd", "host")])
+    db = str(tmp_path / "w")
+    subprocess.check_call([BGT, "synth", db, "100000", "12000", "4"], timeout=600)
+    args = ["-G", "-f", "AC>0"]
+    ref = md5_of([REF, "view"] + args + [db])
+    plain = md5_of([BGT, "view"] + args + [db])
+    monkeypatch.setenv("BGTH_OPEN_HINT_MIN", "1")
+    monkeypatch.setenv("BGTH_TRACE", "1")
+    hinted = md5_of([BGT, "view"] + args + [db])
+    err = subprocess.run([BGT, "view"] + args + [db], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300).stderr.decode()
+    assert "one-shot walk: 2 file blocks x 4 column slices" in err and "directory arena" in err, err
+    monkeypatch.setenv("BGTH_DIR_ARENA_MB", "1000")                   # 8192-row units of 100 KB rows: one unit a pass
+    small = md5_of([BGT, "view"] + args + [db])
+    assert ref[0] == plain[0] == hinted[0] == small[0] == 0, (ref, plain, hinted, small)
+    assert ref[2] > 0 and plain[1:3] == ref[1:3] and hinted[1:3] == ref[1:3] and small[1:3] == ref[1:3], (ref, plain, hinted, small)
+
