@@ -31,7 +31,11 @@ static double view_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC
 static void view_lap(double *t0, const char *what)
 {
     const double t1 = view_now();
-    if (getenv("BGT_TRACE")) fprintf(stderr, "[bgt trace] %-34s %8.2f ms\n", what, t1 - *t0);
+    if (getenv("BGT_TRACE")) {
+        struct timespec ts;
+        clock_gettime(CLOCK_REALTIME, &ts);                      /* (epoch ms: lines up with a `date +%s%N` around the process) */
+        fprintf(stderr, "[bgt trace] %-34s %8.2f ms   @%lld\n", what, t1 - *t0, (long long)ts.tv_sec * 1000 + ts.tv_nsec / 1000000);
+    }
     *t0 = t1;
 }
 
