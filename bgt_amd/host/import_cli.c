@@ -18,6 +18,8 @@
 #include <string.h>
 #include <unistd.h>
 #include <zlib.h>
+#include <pthread.h>
+#include <stdarg.h>
 #include "../../include/bgt_reader.h"
 #include "../../include/bgt_hip.h"
 #include "csi_writer.h"
@@ -33,6 +35,9 @@ typedef struct {
     kstring_t pool;
 } rec_t;
 
+typedef struct prefetch_s prefetch_t;
+static void pf_destroy(prefetch_t *pf);
+
 typedef struct {
     int is_bcf, keep_flt;
     gzFile tf; bgzr_t *bf;
@@ -40,6 +45,7 @@ typedef struct {
     kstring_t line;
     bcf1_t *b;
     int id_gt, id_cigar, id_end;
+    prefetch_t *pf;                           /* text input: lines parsed ahead on several threads */
 } reader_t;
 
 static int gz_getline(gzFile f, kstring_t *s)
@@ -94,7 +100,7 @@ static reader_t *reader_open(const char *fn, int is_bcf, const char *fn_ref, int
         if ((r->bf = bgzr_open(fn)) != NULL) r->h = bcf_hdr_read_stream(r->bf);
         r->b = bcf_init1();
     } else {
-        if ((r->tf = gzopen(strcmp(fn, "-") ? fn : "/dev/stdin", "r")) != NULL) r->h = read_text_header(r->tf, fn_ref, &r->line);
+        if ((r->tf = gzopen(strcmp(fn, "-") ? fn : "/dev/stdin", "r")) != NULL) { gzbuffer(r->tf, 1 << 20); r->h = read_text_header(r->tf, fn_ref, &r->line); }
     }
     if (r->h == NULL) { fprintf(stderr, "[E::%s] cannot read a %s header from '%s'\n", __func__, is_bcf ? "BCF" : "VCF", fn); return NULL; }
     r->id_gt = bcf_id2int(r->h, BCF_DT_ID, "GT");
@@ -106,6 +112,7 @@ static reader_t *reader_open(const char *fn, int is_bcf, const char *fn_ref, int
 static void reader_close(reader_t *r)
 {
     if (!r) return;
+    pf_destroy(r->pf);
     if (r->tf) gzclose(r->tf);
     if (r->bf) bgzr_close(r->bf);
     if (r->b) bcf_destroy1(r->b);
@@ -119,20 +126,29 @@ static void rec_set_alleles(rec_t *c, int n)
     c->n_allele = n;
 }
 
-/* text record -> rec_t.  Returns 0, -1 at EOF, <-1 on a record this importer cannot take. */
-static int read_text_record(reader_t *r, rec_t *c)
+/* a record's complaint, kept with the record: lines are parsed ahead of their turn and out of order */
+static void rec_err(char *err, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err, 256, fmt, ap);
+    va_end(ap);
+}
+
+/* one text line (modified in place) -> rec_t.  Returns 0, or <-1 on a record this importer cannot take (message in err).
+ * Reads the header only: lines are parsed side by side. */
+static int parse_text_line(const reader_t *r, char *line, rec_t *c, char *err)
 {
     char *f[10], *p, *q;
     int i, nf = 0, gt_idx = -1, ns = 0;
-    if (gz_getline(r->tf, &r->line) < 0) return -1;
-    for (p = r->line.s; nf < 9; ++nf) {                            /* the eight fixed columns and FORMAT */
+    for (p = line; nf < 9; ++nf) {                                 /* the eight fixed columns and FORMAT */
         f[nf] = p;
         if ((q = strchr(p, '\t')) == NULL) { ++nf; p = NULL; break; }
         *q = 0; p = q + 1;
     }
-    if (nf < 8) { fprintf(stderr, "[E::%s] fewer than 8 columns\n", __func__); return -2; }
+    if (nf < 8) { rec_err(err, "[E::%s] fewer than 8 columns\n", "read_text_record"); return -2; }
     if ((c->rid = bcf_id2int(r->h, BCF_DT_CTG, f[0])) < 0) {
-        fprintf(stderr, "[E::%s] contig '%s' is not in the header (declare it, or give the contig list with -t)\n", __func__, f[0]);
+        rec_err(err, "[E::%s] contig '%s' is not in the header (declare it, or give the contig list with -t)\n", "read_text_record", f[0]);
         return -2;
     }
     c->pos = atoi(f[1]) - 1;
@@ -175,27 +191,130 @@ static int read_text_record(reader_t *r, rec_t *c)
     if (nf >= 9 && p) {
         char *save = NULL, *t;
         for (t = strtok_r(f[8], ":", &save), i = 0; t; t = strtok_r(NULL, ":", &save), ++i) if (strcmp(t, "GT") == 0) gt_idx = i;
-        if (gt_idx < 0) { fprintf(stderr, "[E::%s] no GT in FORMAT\n", __func__); return -2; }
+        if (gt_idx < 0) { rec_err(err, "[E::%s] no GT in FORMAT\n", "read_text_record"); return -2; }
         ns = r->h->n[BCF_DT_SAMPLE];
         if ((size_t)ns * 2 > c->m_gt) { c->m_gt = (size_t)ns * 2; c->gt = (int8_t*)realloc(c->gt, c->m_gt); }
         for (i = 0; i < ns; ++i) {
             int k, g;
-            if (p == NULL) { fprintf(stderr, "[E::%s] fewer sample columns than the header names\n", __func__); return -2; }
+            if (p == NULL) { rec_err(err, "[E::%s] fewer sample columns than the header names\n", "read_text_record"); return -2; }
             if ((q = strchr(p, '\t')) != NULL) *q = 0;
             for (k = 0; k < gt_idx && p; ++k) { p = strchr(p, ':'); if (p) ++p; }      /* the gt_idx-th sub-field */
             for (g = 0; p && *p && *p != ':'; ++g) {
                 int a;
-                if (g >= 2) { fprintf(stderr, "[E::%s] only diploid genotypes can be imported\n", __func__); return -2; }
+                if (g >= 2) { rec_err(err, "[E::%s] only diploid genotypes can be imported\n", "read_text_record"); return -2; }
                 if (*p == '.') { a = -1; ++p; } else a = (int)strtol(p, &p, 10);
-                if (a >= c->n_allele) { fprintf(stderr, "[E::%s] genotype refers to allele %d of %d\n", __func__, a, c->n_allele); return -2; }
+                if (a >= c->n_allele) { rec_err(err, "[E::%s] genotype refers to allele %d of %d\n", "read_text_record", a, c->n_allele); return -2; }
                 c->gt[2 * i + g] = (int8_t)a;
                 if (*p == '/' || *p == '|') ++p;
             }
-            if (g != 2) { fprintf(stderr, "[E::%s] only diploid genotypes can be imported\n", __func__); return -2; }
+            if (g != 2) { rec_err(err, "[E::%s] only diploid genotypes can be imported\n", "read_text_record"); return -2; }
             p = q ? q + 1 : NULL;
         }
         c->n_sample = ns;
     }
+    return 0;
+}
+
+/* ---- text lines parsed ahead: while the importer works through one batch of records, a filler thread reads the lines of
+ * the next (the only serial part: gzgets) and parses them on several threads -- splitting a line into 2 x n_sample allele
+ * numbers is most of what `bgt import` does on the host.  Records, and their complaints, are handed over in file order. */
+typedef struct { kstring_t line; rec_t rec; int ret; char err[256]; } pf_slot_t;
+struct prefetch_s {
+    reader_t *r;
+    pf_slot_t *slot[2];
+    int n[2], cap, cur, at, n_threads;
+    int eof;                                  /* the filler met the end of the file */
+    int started;                              /* a filler thread is running on batch cur ^ 1 */
+    pthread_t filler;
+    int fill_batch, next;                     /* the parse workers' shared cursor (a batch at a time) */
+    pthread_mutex_t lock;
+};
+
+static void *pf_parse_worker(void *p)
+{
+    prefetch_t *pf = (prefetch_t*)p;
+    pf_slot_t *b = pf->slot[pf->fill_batch];
+    const int n = pf->n[pf->fill_batch];
+    for (;;) {
+        int i;
+        pthread_mutex_lock(&pf->lock);
+        i = pf->next; pf->next += 4;
+        pthread_mutex_unlock(&pf->lock);
+        if (i >= n) break;
+        for (int k = i; k < i + 4 && k < n; ++k) { b[k].err[0] = 0; b[k].ret = parse_text_line(pf->r, b[k].line.s, &b[k].rec, b[k].err); }
+    }
+    return NULL;
+}
+
+static void *pf_fill(void *p)
+{
+    prefetch_t *pf = (prefetch_t*)p;
+    const int w = pf->fill_batch;
+    pf_slot_t *b = pf->slot[w];
+    size_t bytes = 0;
+    int n = 0, t, n_started = 0;
+    pthread_t th[64];
+    while (n < pf->cap && bytes < ((size_t)32 << 20)) {
+        if (gz_getline(pf->r->tf, &b[n].line) < 0) { pf->eof = 1; break; }
+        bytes += b[n].line.l;
+        ++n;
+    }
+    pf->n[w] = n;
+    pf->next = 0;
+    for (t = 1; t < pf->n_threads && t * 8 < n; ++t) if (pthread_create(&th[n_started], NULL, pf_parse_worker, pf) == 0) ++n_started;
+    pf_parse_worker(pf);
+    for (t = 0; t < n_started; ++t) pthread_join(th[t], NULL);
+    return NULL;
+}
+
+static prefetch_t *pf_init(reader_t *r)
+{
+    prefetch_t *pf = (prefetch_t*)calloc(1, sizeof(*pf));
+    const char *e = getenv("BGT_THREADS");
+    long nt = e ? atol(e) : sysconf(_SC_NPROCESSORS_ONLN);
+    pf->r = r; pf->cap = 1024;
+    pf->n_threads = nt < 1 ? 1 : nt > 16 ? 16 : (int)nt;
+    pf->slot[0] = (pf_slot_t*)calloc((size_t)pf->cap, sizeof(pf_slot_t));
+    pf->slot[1] = (pf_slot_t*)calloc((size_t)pf->cap, sizeof(pf_slot_t));
+    pthread_mutex_init(&pf->lock, NULL);
+    return pf;
+}
+
+static void pf_destroy(prefetch_t *pf)
+{
+    int w, i;
+    if (!pf) return;
+    if (pf->started) pthread_join(pf->filler, NULL);
+    for (w = 0; w < 2; ++w) {
+        for (i = 0; i < pf->cap; ++i) {
+            pf_slot_t *s = &pf->slot[w][i];
+            free(s->line.s); free(s->rec.allele); free(s->rec.cigar.s); free(s->rec.gt); free(s->rec.pool.s);
+        }
+        free(pf->slot[w]);
+    }
+    pthread_mutex_destroy(&pf->lock);
+    free(pf);
+}
+
+/* text record -> rec_t.  Returns 0, -1 at EOF, <-1 on a record this importer cannot take. */
+static int read_text_record(reader_t *r, rec_t *c)
+{
+    prefetch_t *pf = r->pf;
+    pf_slot_t *s;
+    if (pf == NULL) pf = r->pf = pf_init(r);
+    while (pf->at == pf->n[pf->cur]) {                            /* this batch is used up: take the one filled meanwhile */
+        if (pf->started) { pthread_join(pf->filler, NULL); pf->started = 0; }
+        else if (pf->eof) return -1;
+        else { pf->fill_batch = pf->cur ^ 1; pf_fill(pf); }         /* the first batch (or no thread to be had): nothing to overlap with */
+        pf->cur ^= 1; pf->at = 0;
+        if (!pf->eof) {                                             /* have the next one filled while this one is used */
+            pf->fill_batch = pf->cur ^ 1;
+            if (pthread_create(&pf->filler, NULL, pf_fill, pf) == 0) pf->started = 1;
+        }
+    }
+    s = &pf->slot[pf->cur][pf->at++];
+    if (s->ret < -1) { fputs(s->err, stderr); return s->ret; }
+    { rec_t tmp = *c; *c = s->rec; s->rec = tmp; }                /* the record changes hands; its old storage is reused by the slot */
     return 0;
 }
 
