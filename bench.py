@@ -125,10 +125,13 @@ def make_roofline(peak, T, sites, k_ms, rle_bytes_per_site, geo, workload, count
     lookups = 2.0 * T * sites                                                      # tracked columns x 2 planes x sites
     achieved = lookups / (k_ms * 1e-3) / 1e9
     alg_bytes_per_site = 16.0 * T + rle_bytes_per_site + 12.0
-    kname = ("walk_kernel<%d, %d" if path and path.get("directory_path") else "scan_kernel<%d, %d") % (geo["threads"], geo["cols_per_thread"])
+    if path and path.get("plane_split") and not path.get("directory_path"):
+        kname = "plane_kernel<%d" % geo["cols_per_thread"]                        # scan_plane.hip: a workgroup per (sub-block, plane)
+    else:
+        kname = ("walk_kernel<%d, %d" if path and path.get("directory_path") else "scan_kernel<%d, %d") % (geo["threads"], geo["cols_per_thread"])
     r = {"bound": "valu_issue", "achieved": achieved, "peak": peak["g_lookups_per_s"], "unit": "G rank-lookups/s",
          "frac": achieved / peak["g_lookups_per_s"], "traffic": None,
-         "kernel": kname + ", ...>", "kernel_ms": k_ms, "lookups_per_launch": lookups,
+         "kernel": kname + (">" if kname.startswith("plane_kernel") else ", ...>"), "kernel_ms": k_ms, "lookups_per_launch": lookups,
          "peak_source": peak["source"], "peak_cycles_per_valu_instr": peak["cycles_per_valu_instr"],
          "peak_clock_ghz": peak["clock_ghz"],
          "peak_ideal_mix": peak["ideal_mix_g_lookups_per_s"], "frac_of_ideal_mix": achieved / peak["ideal_mix_g_lookups_per_s"],
@@ -150,6 +153,10 @@ def make_roofline(peak, T, sites, k_ms, rle_bytes_per_site, geo, workload, count
             r["hbm_frac_measured"] = rc["hbm_bytes_per_launch"] / (rc["profiled_kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
         if rc.get("valu_instr_per_cycle_per_simd"):
             r["valu_issue_frac_profiled"] = rc["valu_instr_per_cycle_per_simd"] / peak["valu_instr_per_cycle_per_simd"]
+        if rc.get("valu_instr_per_launch"):
+            # share of the kernel's VALU instructions that are the lookups' 8-instruction steps: the rest builds the rows'
+            # rank directories, which a sparse selection of a wide cohort cannot amortise (C3: 10,000 of 200,000 columns)
+            r["lookup_share_of_valu_instr"] = lookups * 8.0 / 64.0 / rc["valu_instr_per_launch"]
     return r
 
 
