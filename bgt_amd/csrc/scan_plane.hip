@@ -71,33 +71,71 @@ __global__ __launch_bounds__(512, 4) void plane_kernel(const ScanArgs a, const u
     uint64_t *hout = plane ? a.h1 : a.h0;
     const int tw = wave;
 
-    // toggles of row `row` into TOG (the array is clean: the directory pass clears what it reads)
-    uint32_t keep_cyl = 0, keep_tot = 0;
-    auto toggles = [&](int64_t row) {
+    // What the toggles of a row need from memory -- its descriptor, this wave's first chunk of the string with that chunk's
+    // row-index record, the carries of this wave's directory trips and the row's number of ones -- is fetched a row AHEAD,
+    // behind the walk (the descriptor two rows ahead, so that nothing waits for an address either).  Everything goes through
+    // vector loads, uniform addresses included: scalar loads would count in lgkmcnt, and the walk's every statement opens with
+    // s_waitcnt lgkmcnt(0).  (Before: descriptor -> string -> decode as a chain inside the toggles phase, 1.8 k of a row's
+    // 8.6 k cycles.)
+    auto vidx = [](uint64_t i) { uint32_t lo = (uint32_t)i, hi = (uint32_t)(i >> 32); asm volatile("" : "+v"(lo), "+v"(hi)); return (uint64_t)hi << 32 | lo; };
+    auto load_desc = [&](int64_t row) -> uint64_t { return row < blk_end ? rowdesc[vidx((uint64_t)(2 * row + plane))] : 0ull; };
+    struct Ahead { uint32_t w, ci, cyl; };
+    auto load_ahead = [&](int64_t row, uint64_t d) -> Ahead {       // d = the row's descriptor (already here)
+        Ahead p = {0u, 0u, 0u};
+        if (row >= blk_end) return p;
         const int64_t sidx = 2 * row + plane;
-        const uint64_t d = rowdesc[sidx];
         const uint32_t slen = (uint32_t)(d >> kDescLenShift);
         const uint64_t off = d & kDescOffMask;
         const uint32_t *sc = segc + (size_t)sidx * (size_t)(a.S8 + 1);
-        const int t = tw + lane * WPP;
-        keep_cyl = t < ntrip ? sc[t] : 0u;
-        keep_tot = sc[a.S8];
+        const int t = tw + lane * WPP;                                  // (ntrip <= 40: lane 63 has no trip and carries the row's ones)
+        if (t < ntrip || lane == 63) p.cyl = sc[lane == 63 ? a.S8 : t];
+        const uint32_t k0 = (uint32_t)tw * 256u + 4u * (uint32_t)lane;
+        if (k0 < slen) p.w = reinterpret_cast<const uint32_t*>(rle + off)[tw * 64 + lane];
+        if ((uint32_t)tw * 256u < slen) p.ci = chunkinfo[vidx(((off + (uint64_t)tw * 256u) >> 8) + (uint64_t)sidx)];
+        return p;
+    };
+
+    // toggles of row `row` into TOG (the array is clean: the directory pass clears what it reads)
+    uint32_t keep_cyl = 0, keep_tot = 0;
+    auto toggles = [&](int64_t row, uint64_t d, const Ahead &p) {
+        const int64_t sidx = 2 * row + plane;
+        const uint32_t slen = (uint32_t)(d >> kDescLenShift);
+        const uint64_t off = d & kDescOffMask;
+        keep_cyl = lane == 63 ? 0u : p.cyl;
+        keep_tot = (uint32_t)__builtin_amdgcn_readlane((int)p.cyl, 63);
         for (int c = tw; (uint32_t)c * 256u < slen; c += WPP) {
             const uint32_t k0 = (uint32_t)c * 256u + 4u * (uint32_t)lane;
-            const uint32_t w = k0 < slen ? reinterpret_cast<const uint32_t*>(rle + off)[c * 64 + lane] : 0u;
-            const uint32_t ci = chunkinfo[((off + (uint64_t)c * 256u) >> 8) + (uint64_t)sidx];
+            uint32_t w, ci;
+            if (c == tw) { w = p.w; ci = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.ci); }
+            else {
+                w = k0 < slen ? reinterpret_cast<const uint32_t*>(rle + off)[c * 64 + lane] : 0u;
+                ci = chunkinfo[((off + (uint64_t)c * 256u) >> 8) + (uint64_t)sidx];
+            }
             if (ci & kChunkDead) break;
             const ChunkDecode cd = decode_chunk(w, k0, slen, lane);
             chunk_toggles(a, TOG, 1, cd, ci & kChunkPosMask, ci >> 31, lane);
         }
     };
+    // cur: row + 1 of the loop below (fetched an iteration ago); d_next: descriptor of row + 2
+    uint64_t d_cur, d_next;
+    Ahead cur;
+    {
+        const uint64_t d0 = load_desc(blk_beg);
+        d_next = load_desc(blk_beg + 1);
+        d_cur = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(d0 >> 32)) << 32 | (uint32_t)__builtin_amdgcn_readfirstlane((int)d0);
+        cur = load_ahead(blk_beg, d_cur);
+    }
 
     // (profiling build only: cycles per phase -- 0 walk, 1 toggles, 2 barrier, 3 directory, 4 barrier)
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = BGTH_TIMES(a) ? __builtin_amdgcn_s_memtime() : 0ull;
     // Loop (iteration -1 only prepares row blk_beg):   walk(row) + toggles(row+1) | directory(row+1) |     two barriers per row
     for (int64_t row = blk_beg - 1; row < blk_end; ++row) {
-        const bool cur = row >= blk_beg, more = row + 1 < blk_end;
-        if (cur) {
+        const bool walking = row >= blk_beg, more = row + 1 < blk_end;
+        // row + 2: its descriptor came an iteration ago; its data and the descriptor of row + 3 travel behind this walk
+        const uint64_t d_ahead = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(d_next >> 32)) << 32 | (uint32_t)__builtin_amdgcn_readfirstlane((int)d_next);
+        const Ahead ahead = load_ahead(row + 2, d_ahead);
+        d_next = load_desc(row + 3);
+        if (walking) {
             const uint32_t base = lds0 - 8u;
             const uint32_t n0 = 0u - n0s[row & 1];
             const bool emit = row >= a.row0;
@@ -127,7 +165,11 @@ __global__ __launch_bounds__(512, 4) void plane_kernel(const ScanArgs a, const u
             asm volatile("s_waitcnt lgkmcnt(0)" :: "s"(pm[0]), "s"(pm[1]), "s"(pm[2]), "s"(pm[3]) : "memory");
         }
         BGTH_TICK(0);
-        if (more) toggles(row + 1);
+        // The build of the next row is a latency chain of few instructions (decode, LDS atomics, prefix scans, two barriers):
+        // it goes ahead of the walk of the CU's other workgroup, which fills the issue slots it leaves.
+        if (a.walk_prio) __builtin_amdgcn_s_setprio(3);
+        if (more) toggles(row + 1, d_cur, cur);
+        d_cur = d_ahead; cur = ahead;
         BGTH_TICK(1);
         lds_barrier();                                                   // every wave is past its walk; the toggles are complete
         BGTH_TICK(2);
@@ -137,6 +179,7 @@ __global__ __launch_bounds__(512, 4) void plane_kernel(const ScanArgs a, const u
         }
         BGTH_TICK(3);
         lds_barrier();
+        if (a.walk_prio) __builtin_amdgcn_s_setprio(0);
         BGTH_TICK(4);
     }
     asm volatile("s_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");     // the scalar stores of the ballots reach memory

@@ -47,6 +47,7 @@ rd.scan(0, min(sites, 8192))
 if sub:                                               # sparse selection: team kernel against the plane-split kernels
     ref = run("team kernel, no prio", 64 | 2048 | 16384, 3)
     ref = run("team kernel", 64 | 2048, 3)
+    run("plane-split, no prio", 64 | 16384, 3)
     a = run("plane-split kernels", 64, 3)
     print("same counts:", np.array_equal(ref, a), rd.path())
     sys.exit(0)
