@@ -45,22 +45,45 @@ __global__ __launch_bounds__(NT) void dirbuild_kernel(const ScanArgs a, const ui
     int64_t s1 = s0 + per_wg;
     if (s1 > str_hi) s1 = str_hi;
 
+    // What a plane-row's toggles read from memory -- this wave's first chunk of the string, that chunk's row-index record, the
+    // carries of its directory trips and the row's ones (lane 63) -- is fetched a plane-row ahead, its descriptor two ahead:
+    // the directory stores of the row before then cover the latency instead of a chain descriptor -> string -> decode.
+    struct Ahead { uint32_t w, ci, cyl; };
+    auto load_ahead = [&](int64_t sidx, uint64_t d) -> Ahead {
+        Ahead p = {0u, 0u, 0u};
+        if (sidx >= s1) return p;
+        const uint32_t slen = (uint32_t)(d >> kDescLenShift);
+        const uint64_t off = d & kDescOffMask;
+        const uint32_t *sc = segc + (size_t)sidx * (size_t)(a.S8 + 1);
+        const int t = tw + lane * WPP;                                  // (ntrip <= 40 < 63 WPP: lane 63 has no trip)
+        if (t < ntrip || lane == 63) p.cyl = sc[lane == 63 ? a.S8 : t];
+        const uint32_t k0 = (uint32_t)tw * 256u + 4u * (uint32_t)lane;
+        if (k0 < slen) p.w = reinterpret_cast<const uint32_t*>(rle + off)[tw * 64 + lane];
+        if ((uint32_t)tw * 256u < slen) p.ci = chunkinfo[((off + (uint64_t)tw * 256u) >> 8) + (uint64_t)sidx];
+        return p;
+    };
     uint64_t desc = s0 < s1 ? rowdesc[s0] : 0ull;
+    uint64_t desc1 = s0 + 1 < s1 ? rowdesc[s0 + 1] : 0ull;
+    Ahead cur = load_ahead(s0, desc);
     for (int64_t sidx = s0; sidx < s1; ++sidx) {
         uint32_t *trow = TOG + (size_t)((sidx - s0) & 1) * nwt;
         const uint64_t cd0 = desc;
-        if (sidx + 1 < s1) desc = rowdesc[sidx + 1];
+        const Ahead here = cur;
+        desc = desc1;
+        cur = load_ahead(sidx + 1, desc);
+        desc1 = sidx + 2 < s1 ? rowdesc[sidx + 2] : 0ull;
         const uint32_t slen = (uint32_t)(cd0 >> kDescLenShift);
         const uint64_t off = cd0 & kDescOffMask;
-        // carries of this wave's directory trips (lane u <-> trip tw + u * WPP) and the row's number of ones
-        const uint32_t *sc = segc + (size_t)sidx * (size_t)(a.S8 + 1);
-        const int t = tw + lane * WPP;
-        const uint32_t cyl = t < ntrip ? sc[t] : 0u;
-        const uint32_t tot1 = sc[a.S8];
+        const uint32_t cyl = lane == 63 ? 0u : here.cyl;
+        const uint32_t tot1 = (uint32_t)__builtin_amdgcn_readlane((int)here.cyl, 63);
         for (int c = tw; (uint32_t)c * 256u < slen; c += WPP) {
             const uint32_t k0 = (uint32_t)c * 256u + 4u * (uint32_t)lane;
-            const uint32_t w = k0 < slen ? reinterpret_cast<const uint32_t*>(rle + off)[c * 64 + lane] : 0u;
-            const uint32_t ci = chunkinfo[((off + (uint64_t)c * 256u) >> 8) + (uint64_t)sidx];
+            uint32_t w, ci;
+            if (c == tw) { w = here.w; ci = here.ci; }
+            else {
+                w = k0 < slen ? reinterpret_cast<const uint32_t*>(rle + off)[c * 64 + lane] : 0u;
+                ci = chunkinfo[((off + (uint64_t)c * 256u) >> 8) + (uint64_t)sidx];
+            }
             if (ci & kChunkDead) break;                                  // behind a terminating zero byte
             const ChunkDecode cd = decode_chunk(w, k0, slen, lane);
             chunk_toggles(a, trow, 1, cd, ci & kChunkPosMask, ci >> 31, lane);
