@@ -728,7 +728,17 @@ def main():
 
     peak = lookup_peak(bgt_amd, local) if rank == 0 else None
     pipe = Pipeline(torch, bgt_amd, rd, 0, sites, dev, local, world, rank, dist)
-    dt, k_ms, last = pipe.run(args.steps, args.warmup)
+    # Every timed step does ALL the work of a pass: on the directory path (wide cohorts: C4) the rows are built again by every
+    # step instead of being walked from the arena the step before left behind (BGTH_VARIANT bit 128; no effect on the other
+    # kernels).  The arena-kept rate is reported by the C4-shard secondary record, labelled.
+    one_shot_forced = "BGTH_VARIANT" not in os.environ
+    if one_shot_forced:
+        os.environ["BGTH_VARIANT"] = "128"
+    try:
+        dt, k_ms, last = pipe.run(args.steps, args.warmup)
+    finally:
+        if one_shot_forced:
+            os.environ.pop("BGTH_VARIANT")
     n_pass = int(pipe.host_n_pass[last].item()) if rank == 0 else 0
     if rank == 0:
         host = pipe.host[last]
@@ -820,6 +830,7 @@ def main():
             out["config"]["one_database"] = ("every shard built from the identity order, then re-based onto the composition of "
                                              "the earlier shards' final ranks (bgth_pbf_final_ranks / bgth_pbf_rebase)")
             out["config"]["kernel_path"] = rd.path()
+            out["config"]["rows_rebuilt_by_every_step"] = bool(one_shot_forced)       # (no directory arena carried from step to step)
             if not parity["parity_ok"]:
                 out["parity_error"] = "gathered counts fail the on-box checks: %s" % json.dumps(parity)
             if strong:
