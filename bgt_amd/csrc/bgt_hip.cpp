@@ -615,7 +615,9 @@ static bool parse_blocks_parallel(const uint8_t *buf, size_t end, size_t len, in
         for (int t = 0; t < nt; ++t) th.emplace_back([&, t] { for (int b; (b = next.fetch_add(1)) < n_idx;) fn(b, t); });
         for (std::thread &t : th) t.join();
     };
+    Trace tr;
     run([&](int b, int) { info[b] = scan_block(buf, idx[b], idx[b + 1], m, g, nullptr, nullptr, 0, nullptr); });
+    tr.lap("  blocks sized");
     std::vector<uint64_t> off((size_t)n_idx + 1, 0);
     std::vector<int64_t> row0((size_t)n_idx + 1, 0);
     for (int b = 0; b < n_idx; ++b) {
@@ -663,6 +665,7 @@ static bool parse_blocks_parallel(const uint8_t *buf, size_t end, size_t len, in
         if (e != hipSuccess) hip_err = (int)e;
     });
     for (uint8_t *q : mine) free(q);
+    tr.lap("  blocks packed + copied");
     if (no_mem.load()) throw std::bad_alloc();
     if (hip_err.load() != (int)hipSuccess) { set_err("[E::bgth_pbf_open] copying the strings to the device: %s", hipGetErrorString((hipError_t)hip_err.load())); return false; }
     out.n_empty1 = empty1;
@@ -902,7 +905,7 @@ extern "C" bgth_pbf_t *bgth_pbf_open(const char *path, int device)
     madvise(map, (size_t)st.st_size, MADV_WILLNEED);
     bgth_pbf_t *p = bgth_pbf_open_mem(map, (size_t)st.st_size, device);
     Trace tr;
-    munmap(map, (size_t)st.st_size);
+    munmap(map, (size_t)st.st_size);                          // (leaving it to the process's exit costs the same there: measured)
     tr.lap("unmap the file");
     return p;
 }
