@@ -6,6 +6,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
+#include <errno.h>
+#include <signal.h>
+#include <sys/wait.h>
 #include "../../include/bgt_reader.h"
 #include "../../include/bgt_hip.h"
 
@@ -37,6 +40,36 @@ static void view_lap(double *t0, const char *what)
         fprintf(stderr, "[bgt trace] %-34s %8.2f ms   @%lld\n", what, t1 - *t0, (long long)ts.tv_sec * 1000 + ts.tv_nsec / 1000000);
     }
     *t0 = t1;
+}
+
+/* A query that uses the device leaves HBM allocations, queues and a runtime behind whose tear-down costs the process 70-180 ms
+ * AFTER its last byte is written (measured: scripts/region_trace.sh, scripts/cli_time_c4shard.sh) -- time the caller's shell
+ * would wait for nothing.  So the work runs in a child: the process the shell started only waits for one byte, the exit
+ * status, which the child sends after it has flushed and closed stdout and stderr, and leaves with it; the child finishes its
+ * tear-down on its own.  A child that ends any other way (an error return, BGT_CLEAN_EXIT=1, a signal) is waited for and its
+ * status or signal handed on unchanged.  Forked before the first thread and before the HIP runtime exists.  BGT_NO_FORK=1:
+ * one process as before. */
+static int g_done_fd = -1;
+static void work_in_a_child(void)
+{
+    int fd[2];
+    pid_t pid;
+    if (getenv("BGT_NO_FORK") || pipe(fd) != 0) return;
+    fflush(stdout); fflush(stderr);
+    if ((pid = fork()) < 0) { close(fd[0]); close(fd[1]); return; }
+    if (pid == 0) { close(fd[0]); g_done_fd = fd[1]; return; }
+    {
+        unsigned char code = 0;
+        ssize_t n;
+        int st = 0;
+        close(fd[1]);
+        do n = read(fd[0], &code, 1); while (n < 0 && errno == EINTR);
+        if (n == 1) _exit(code);                                   /* the answer is complete and out */
+        while (waitpid(pid, &st, 0) < 0 && errno == EINTR) {}
+        if (WIFEXITED(st)) _exit(WEXITSTATUS(st));
+        if (WIFSIGNALED(st)) { signal(WTERMSIG(st), SIG_DFL); kill(getpid(), WTERMSIG(st)); }
+        _exit(1);
+    }
 }
 
 int main_view(int argc, char *argv[])
@@ -92,6 +125,7 @@ int main_view(int argc, char *argv[])
      * (headers, sample tables, group expressions, the site side-car); `view -G` without counts never opens it */
     if (!(flag & BGT_F_NO_GT) || (flag & BGT_F_SET_AC) || site_flt) {
         const char *gp = getenv("BGT_GPUS");
+        work_in_a_child();
         bgth_runtime_warmup_async(gp && gp[0] >= '0' && gp[0] <= '9' && strchr(gp, ',') ? atoi(gp) : 0);
     }
 
@@ -184,6 +218,11 @@ int main_view(int argc, char *argv[])
          * that nobody waits for (the driver reclaims the process's memory); BGT_CLEAN_EXIT=1 keeps the orderly path */
         view_lap(&t_lap, "done (fast exit)");
         fflush(stderr);
+        if (g_done_fd >= 0) {                                       /* the waiting parent leaves with the status; see work_in_a_child */
+            const unsigned char ok = 0;
+            close(1); close(2);
+            if (write(g_done_fd, &ok, 1) != 1) {}
+        }
         _exit(0);
     }
     free(line.s);
