@@ -37,6 +37,7 @@ import argparse
 import hashlib
 import json
 import os
+import re
 import subprocess
 import sys
 import tempfile
@@ -352,9 +353,9 @@ def cli_end_to_end(n_samples, sites, seed, tmp):
             lines = pr.stdout.count(b"\n")
             stages = {}
             for ln in pr.stderr.decode().splitlines():
-                if ln.startswith("[bgt trace]") or ln.startswith("[bgth trace]"):
-                    name, ms = ln.split("]", 1)[1].rsplit(None, 2)[0].strip(), float(ln.split()[-2])
-                    stages[name] = round(stages.get(name, 0.0) + ms, 2)
+                mt = re.match(r"^\[bgth? trace\]\s+(.*?)\s+([0-9.]+) ms\b", ln)     # (other trace lines carry no time; an epoch stamp may follow)
+                if mt:
+                    stages[mt.group(1).strip()] = round(stages.get(mt.group(1).strip(), 0.0) + float(mt.group(2)), 2)
     return {"command": "bgt view -G -f 'AC>0' <prefix> (stdout to a pipe)", "sites": sites, "samples": n_samples,
             "wall_s": round(best, 3), "sites_per_s": sites / best, "output_lines": lines, "stages_ms": stages,
             "database_written_in_s": round(t_synth, 2),
