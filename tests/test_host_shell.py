@@ -135,6 +135,24 @@ def test_early_error_exits_cleanly_beside_the_warmup_thread(args, prefixes):
 
 
 @pytest.mark.gpu
+def test_device_work_in_a_child_keeps_the_contract(monkeypatch):
+    """A `bgt view` that uses the device does its work in a child and leaves as soon as the answer is out and the status is
+    known (view_cli.c: work_in_a_child); the child tears the GPU context down on its own.  Same bytes and exit codes as one
+    process (BGT_NO_FORK=1); stdout reaches end-of-file for a reader of the pipe without waiting for the child; a consumer
+    that stops reading ends the pipeline promptly (SIGPIPE travels through the parent)."""
+    import time
+    for args, prefixes in ((["-C"], ["synA"]), (["-G", "-f", "AC>0"], ["synA", "synB"]), (["-C", "-r", "13"], ["ex2"])):
+        forked = run_view(args, prefixes)
+        monkeypatch.setenv("BGT_NO_FORK", "1")
+        single = run_view(args, prefixes)
+        monkeypatch.delenv("BGT_NO_FORK")
+        assert forked.returncode == single.returncode and forked.stdout == single.stdout, (args, forked.returncode, single.returncode)
+    t0 = time.time()
+    p = subprocess.run("%s view -C synA | head -n 3" % BGT, shell=True, cwd=GOLD, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode == 0 and p.stdout.count(b"\n") == 3 and time.time() - t0 < 60, (p.returncode, p.stderr.decode()[-300:])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(MANIFEST["views"].keys()))
 def test_cli_every_golden_view_on_gpu(name):
     """58 `bgt view` commands (VCF, BCF, `-t` tables, `-B/-e` BED filters, `-a/-S/-H/-d/-M` allele sets, failures) whose expected stdout and exit code were produced by
