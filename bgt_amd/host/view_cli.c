@@ -9,6 +9,7 @@
 #include <errno.h>
 #include <signal.h>
 #include <sys/wait.h>
+#include <sys/prctl.h>
 #include "../../include/bgt_reader.h"
 #include "../../include/bgt_hip.h"
 
@@ -47,7 +48,7 @@ static void view_lap(double *t0, const char *what)
  * would wait for nothing.  So the work runs in a child: the process the shell started only waits for one byte, the exit
  * status, which the child sends after it has flushed and closed stdout and stderr, and leaves with it; the child finishes its
  * tear-down on its own.  A child that ends any other way (an error return, BGT_CLEAN_EXIT=1, a signal) is waited for and its
- * status or signal handed on unchanged.  Forked before the first thread and before the HIP runtime exists.  BGT_NO_FORK=1:
+ * status or signal handed on unchanged; a parent that is killed takes the child with it (PR_SET_PDEATHSIG).  Forked before the first thread and before the HIP runtime exists.  BGT_NO_FORK=1:
  * one process as before. */
 static int g_done_fd = -1;
 static void work_in_a_child(void)
@@ -57,7 +58,15 @@ static void work_in_a_child(void)
     if (getenv("BGT_NO_FORK") || pipe(fd) != 0) return;
     fflush(stdout); fflush(stderr);
     if ((pid = fork()) < 0) { close(fd[0]); close(fd[1]); return; }
-    if (pid == 0) { close(fd[0]); g_done_fd = fd[1]; return; }
+    if (pid == 0) {
+        /* a parent that is killed (a `timeout`, a closed terminal) takes the child with it; on the normal path the signal
+         * arrives when the child has nothing left to do but release the device, which the kernel then does for it */
+        const pid_t parent = getppid();
+        prctl(PR_SET_PDEATHSIG, SIGKILL);
+        if (getppid() != parent) _exit(1);                         /* (it died in between) */
+        close(fd[0]); g_done_fd = fd[1];
+        return;
+    }
     {
         unsigned char code = 0;
         ssize_t n;
