@@ -14,6 +14,7 @@
  * test links this same file with the compiled reference library and compares the two bodies.
  *
  * Only what the handler needs of HTTP is here: GET, the query string, `Connection: close`. */
+#define _GNU_SOURCE
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -26,6 +27,10 @@
 #include <strings.h>
 #include <sys/time.h>
 #include <sys/socket.h>
+#include <sys/un.h>
+#include <sys/stat.h>
+#include <limits.h>
+#include <sched.h>
 #include <netinet/in.h>
 #include <arpa/inet.h>
 #include "../../include/bgt_reader.h"
@@ -263,6 +268,7 @@ static void query_stream(query_t *q, FILE *w)
     for (;;) {
         int rc;
         if (n_read > q->max_read || bm->n_gt_read > g_max_gt) break;
+        if (ferror(w)) break;                                        /* the client is gone or stopped reading (send timeout): free the worker */
         if ((rc = bgtm_read(bm, b)) < 0) {
             /* -1 is the end of the data; anything below is a failure (a device error): the status line left long ago, so the
              * body says it -- a 200 that silently stops short would pass for a complete answer */
@@ -338,17 +344,31 @@ static void *serve_connection(void *arg)
     char *req = (char*)malloc(65536), *q, *sp, *host = NULL, *line;
     size_t n = 0;
     FILE *w;
-    struct timeval tv = {10, 0};                                     /* a client that never finishes its request does not keep the worker */
-    struct timeval tvs = {30, 0};                                    /* nor one that stops reading its answer */
-    setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+    struct timeval tvs = {30, 0};                                    /* a client that stops reading its answer: see below */
+    const long long deadline = now_ns() + 10LL * 1000000000LL;       /* the whole request within 10 s, however it trickles in */
+    int complete = 0;
     setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tvs, sizeof(tvs));
     while (n < 65535) {
-        const ssize_t k = read(fd, req + n, 65535 - n);
-        if (k <= 0) break;
+        const long long left = deadline - now_ns();
+        struct timeval tv;
+        ssize_t k;
+        if (left <= 0) { complete = -1; break; }
+        tv.tv_sec = (time_t)(left / 1000000000LL); tv.tv_usec = (suseconds_t)(left % 1000000000LL / 1000);
+        if (tv.tv_sec == 0 && tv.tv_usec == 0) tv.tv_usec = 1;
+        setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+        k = read(fd, req + n, 65535 - n);
+        if (k < 0 && (errno == EAGAIN || errno == EWOULDBLOCK)) { complete = -1; break; }   /* the deadline passed */
+        if (k <= 0) break;                                           /* the client closed its side: take what is there */
         n += (size_t)k; req[n] = 0;
-        if (strstr(req, "\r\n\r\n") || strstr(req, "\n\n")) break;
+        if (strstr(req, "\r\n\r\n") || strstr(req, "\n\n")) { complete = 1; break; }
     }
     req[n] = 0;
+    if (complete < 0) {                 /* never finished its request: no query is run for it */
+        static const char late[] = "HTTP/1.1 408 Request Timeout\r\nConnection: close\r\n\r\n";
+        ssize_t wr = send(fd, late, sizeof(late) - 1, MSG_NOSIGNAL | MSG_DONTWAIT);
+        (void)wr; close(fd); free(req);
+        return NULL;
+    }
     w = fdopen(fd, "w");
     if (w == NULL) { close(fd); free(req); return NULL; }
     if (strncmp(req, "GET ", 4) != 0) {
@@ -368,6 +388,9 @@ static void *serve_connection(void *arg)
         q = strchr(q, '?');
         answer(q ? q + 1 : "", host ? host : "localhost", w, 1);
     }
+    /* a send that timed out leaves the stream in error: every later flush would block for the timeout again (glibc retries
+     * the write), so the socket is shut down first -- the final flush inside fclose() then fails at once */
+    if (ferror(w)) shutdown(fd, SHUT_RDWR);
     fclose(w);                                                        /* closes fd */
     free(req);
     return NULL;
@@ -387,6 +410,155 @@ static void *worker_main(void *arg)
     return NULL;
 }
 
+#ifndef BGS_REFERENCE_LIB
+/* ------------------------------------------------------------------------------------------------
+ * -u SOCKET: a resident host for `bgt view` command lines (include/bgt_reader.h: view_run).  A `bgt view` process
+ * started with BGT_SERVER=SOCKET sends its arguments, its working directory and its own stdout / stderr as file
+ * descriptors; the query runs here, on images that are already in HBM, writes straight into the client's descriptors
+ * and the answer on the socket is the exit status -- the bytes are those of a local run, the HIP start-up and the
+ * image build (140-270 ms per process) are paid once per database.  Databases are opened on first
+ * use (any prefix a client names, resolved in ITS working directory) and stay open; the ones on this command line are
+ * opened at start.  This mode serves the user who started it (a unix socket with that user's permissions): arguments
+ * may name files, so bgt_no_file stays 0 and no HTTP port is opened beside it.
+ * ------------------------------------------------------------------------------------------------ */
+#define BGS_CACHE_MAX 256
+typedef struct { char *path; bgt_file_t *bf; struct timespec mtime; } cache_ent_t;
+static cache_ent_t g_cache[BGS_CACHE_MAX];
+static int g_n_cache;
+static pthread_mutex_t g_cache_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static bgt_file_t *cache_open(const char *prefix, void *ctx)
+{
+    char full[PATH_MAX], pbf[PATH_MAX + 8];
+    struct stat st;
+    bgt_file_t *bf = NULL;
+    int i;
+    (void)ctx;
+    snprintf(pbf, sizeof(pbf), "%s.pbf", prefix);
+    if (realpath(pbf, full) == NULL || stat(full, &st) != 0) return NULL;   /* (the thread's own working directory: see unix_worker) */
+    pthread_mutex_lock(&g_cache_lock);
+    for (i = 0; i < g_n_cache; ++i)
+        if (strcmp(g_cache[i].path, full) == 0) {
+            /* a database that was rewritten since it was opened is opened again (the old image stays with its readers) */
+            if (g_cache[i].mtime.tv_sec == st.st_mtim.tv_sec && g_cache[i].mtime.tv_nsec == st.st_mtim.tv_nsec) bf = g_cache[i].bf;
+            break;
+        }
+    if (bf == NULL && (i < g_n_cache || g_n_cache < BGS_CACHE_MAX)) {
+        full[strlen(full) - 4] = 0;                                  /* back to the prefix */
+        if ((bf = bgt_open(full)) != NULL) {
+            if (bgt_file_preload(bf) < 0) fprintf(stderr, "[W::%s] '%s' is not resident yet; the first query will load it\n", __func__, full);
+            strcat(full, ".pbf");
+            if (i == g_n_cache) { g_cache[i].path = strdup(full); ++g_n_cache; }
+            g_cache[i].bf = bf; g_cache[i].mtime = st.st_mtim;
+        }
+    }
+    pthread_mutex_unlock(&g_cache_lock);
+    return bf;
+}
+static void cache_close(bgt_file_t *bf, void *ctx) { (void)bf; (void)ctx; }   /* stays resident */
+
+static int recv_all(int fd, void *buf, size_t len)
+{
+    size_t k = 0;
+    while (k < len) {
+        const ssize_t n = recv(fd, (char*)buf + k, len - k, 0);
+        if (n <= 0) { if (n < 0 && errno == EINTR) continue; return -1; }
+        k += (size_t)n;
+    }
+    return 0;
+}
+
+static void *unix_worker(void *arg)
+{
+    const int fd = (int)(intptr_t)arg;
+    struct msghdr mh;
+    struct iovec iov;
+    union { struct cmsghdr h; char buf[CMSG_SPACE(2 * sizeof(int))]; } cm;
+    struct cmsghdr *c;
+    uint32_t body = 0;
+    int fds[2] = {-1, -1}, argc = 0, i, rc = 1;
+    char *req = NULL, *p, *end, **argv = NULL;
+    unsigned char status[2] = {'S', 1};
+    FILE *out = NULL, *err = NULL;
+    struct timeval tv = {10, 0};
+    ssize_t n;
+    static const bgt_view_host_t host = {cache_open, cache_close, NULL};
+    setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+    memset(&mh, 0, sizeof(mh)); memset(&cm, 0, sizeof(cm));
+    iov.iov_base = &body; iov.iov_len = 4;
+    mh.msg_iov = &iov; mh.msg_iovlen = 1; mh.msg_control = cm.buf; mh.msg_controllen = sizeof(cm.buf);
+    n = recvmsg(fd, &mh, MSG_CMSG_CLOEXEC);                           /* the descriptors arrive with the first bytes */
+    if (n <= 0) goto done;
+    for (c = CMSG_FIRSTHDR(&mh); c; c = CMSG_NXTHDR(&mh, c))
+        if (c->cmsg_level == SOL_SOCKET && c->cmsg_type == SCM_RIGHTS && c->cmsg_len == CMSG_LEN(sizeof(fds))) memcpy(fds, CMSG_DATA(c), sizeof(fds));
+    if (n < 4 && recv_all(fd, (char*)&body + n, 4 - (size_t)n) < 0) goto done;
+    if (fds[0] < 0 || fds[1] < 0 || body < 8 || body > (1u << 24)) goto done;
+    req = (char*)malloc((size_t)body + 1);
+    if (recv_all(fd, req, body) < 0) goto done;
+    req[body] = 0; end = req + body;
+    if (strcmp(req, "BGTV1") != 0) goto done;
+    out = fdopen(fds[0], "w"); err = fdopen(fds[1], "w");
+    if (!out || !err) goto done;
+    setvbuf(err, NULL, _IONBF, 0);
+    p = req + 6;
+    /* this thread has a working directory of its own (unshare(CLONE_FS) when it started): relative paths in the
+     * arguments -- databases, -B / -d / -s / -a files -- mean what they mean to the client */
+    if (chdir(p) != 0) { fprintf(err, "[E::main_view] the server cannot enter '%s'\n", p); goto done; }
+    p += strlen(p) + 1;
+    if (p >= end) goto done;
+    argc = atoi(p); p += strlen(p) + 1;
+    if (argc < 1 || argc > 4096) goto done;
+    argv = (char**)calloc((size_t)argc + 1, sizeof(char*));
+    for (i = 0; i < argc && p < end; ++i) { argv[i] = p; p += strlen(p) + 1; }
+    if (i < argc) goto done;
+    {
+        const long long t0 = now_ns();
+        rc = view_run(argc, argv, out, err, &host);
+        if (getenv("BGS_TRACE")) fprintf(stderr, "[bgs trace] view query: %.2f ms, status %d\n", (now_ns() - t0) * 1e-6, rc);
+    }
+    status[1] = (unsigned char)rc;
+done:
+    if (out) fclose(out); else if (fds[0] >= 0) close(fds[0]);        /* everything is written before the status leaves */
+    if (err) fclose(err); else if (fds[1] >= 0) close(fds[1]);
+    n = send(fd, status, 2, MSG_NOSIGNAL);
+    (void)n;
+    close(fd);
+    free(argv); free(req);
+    return NULL;
+}
+
+static void *unix_thread_main(void *arg)
+{
+    /* a private working directory per thread: chdir() in one query must not move the others */
+    if (unshare(CLONE_FS) != 0) fprintf(stderr, "[W::%s] unshare(CLONE_FS) failed (%s): relative paths of clients resolve in the server's directory\n", __func__, strerror(errno));
+    return unix_worker(arg);
+}
+
+static int serve_unix(const char *path)
+{
+    struct sockaddr_un sa;
+    int srv;
+    if (strlen(path) >= sizeof(sa.sun_path)) { fprintf(stderr, "[E::%s] socket path too long\n", __func__); return 1; }
+    signal(SIGPIPE, SIG_IGN);
+    srv = socket(AF_UNIX, SOCK_STREAM, 0);
+    memset(&sa, 0, sizeof(sa)); sa.sun_family = AF_UNIX; strcpy(sa.sun_path, path);
+    unlink(path);
+    if (srv < 0 || bind(srv, (struct sockaddr*)&sa, sizeof(sa)) < 0 || listen(srv, 128) < 0) {
+        fprintf(stderr, "[E::%s] cannot listen on '%s': %s\n", __func__, path, strerror(errno));
+        return 1;
+    }
+    fprintf(stderr, "[%lld] launched at socket %s\n", now_ns(), path);
+    for (;;) {
+        const int fd = accept(srv, NULL, NULL);
+        pthread_t th;
+        if (fd < 0) { if (errno == EINTR) continue; break; }
+        if (pthread_create(&th, NULL, unix_thread_main, (void*)(intptr_t)fd) == 0) pthread_detach(th);
+        else close(fd);
+    }
+    return 0;
+}
+#endif
+
 static int usage(const char *port)
 {
     fprintf(stderr, "Usage: bgt-server [options] <bgt.pre1> [...]\n");
@@ -396,21 +568,35 @@ static int usage(const char *port)
     fprintf(stderr, "  -d FILE   variant annotations in the FMF format []\n");
     fprintf(stderr, "  -g INT    minimal sample group size (force -G if positive) [0]\n");
     fprintf(stderr, "  -q STR    answer this one query string on stdout and exit (no socket)\n");
+#ifndef BGS_REFERENCE_LIB
+    fprintf(stderr, "  -u PATH   serve `bgt view` command lines on this unix socket instead of HTTP (clients: BGT_SERVER=PATH bgt view ...)\n");
+#endif
     return 1;
 }
 
 int main(int argc, char **argv)
 {
-    const char *port = getenv("PORT") && *getenv("PORT") ? getenv("PORT") : "8000", *one_query = NULL;
+    const char *port = getenv("PORT") && *getenv("PORT") ? getenv("PORT") : "8000", *one_query = NULL, *unix_path = NULL;
     int c, i, srv, on = 1;
     struct sockaddr_in addr;
-    while ((c = getopt(argc, argv, "d:p:m:g:q:")) >= 0) {
+    while ((c = getopt(argc, argv, "d:p:m:g:q:u:")) >= 0) {
         if (c == 'p') port = optarg;
         else if (c == 'm') g_max_gt = strtoull(optarg, NULL, 10);
         else if (c == 'd') g_vardb = fmf_read(optarg);
         else if (c == 'g') g_min_group = atoi(optarg);
         else if (c == 'q') one_query = optarg;
+        else if (c == 'u') unix_path = optarg;
     }
+#ifndef BGS_REFERENCE_LIB
+    if (unix_path) {                                                  /* a host for `bgt view` clients; databases named here are made resident now */
+        char cwd[PATH_MAX];
+        if (getcwd(cwd, sizeof(cwd)) == NULL) cwd[0] = 0;
+        for (i = optind; i < argc; ++i)
+            if (cache_open(argv[i], NULL) == NULL) { fprintf(stderr, "[E::%s] failed to open '%s'\n", __func__, argv[i]); return 1; }
+        return serve_unix(unix_path);
+    }
+#endif
+    (void)unix_path;
     if (optind == argc) return usage(port);
     bgt_no_file = 1;                                                  /* bgt-server.go:416: arguments are never file names */
     if (argc - optind > BGS_MAX_FILES) { fprintf(stderr, "[E::%s] %d databases given, at most %d are served\n", __func__, argc - optind, BGS_MAX_FILES); return 1; }

@@ -10,23 +10,26 @@
 #include <signal.h>
 #include <sys/wait.h>
 #include <sys/prctl.h>
+#include <sys/socket.h>
+#include <sys/un.h>
+#include <pthread.h>
 #include "../../include/bgt_reader.h"
 #include "../../include/bgt_hip.h"
 
-static int usage(const char *cmd)
+static int usage(const char *cmd, FILE *e)
 {
-    fprintf(stderr, "Usage: bgt %s [options] <bgt-prefix> [...]\n", cmd);
-    fprintf(stderr, "Options:\n");
-    fprintf(stderr, "  -s EXPR   sample group: ,name1,name2 | file | expression on .spl metadata (repeatable)\n");
-    fprintf(stderr, "  -r STR    region chr[:beg-end]\n");
-    fprintf(stderr, "  -i INT    start from the INT-th site (1-based)      -n INT   emit at most INT sites\n");
-    fprintf(stderr, "  -f STR    site filter on AC, AN, AC#, AN# (e.g. 'AC>0', 'AC1/AN1>=0.1&&AC2==0')\n");
-    fprintf(stderr, "  -G        no sample genotypes     -C   write AC/AN (implied by -f or several -s)\n");
-    fprintf(stderr, "  -b        BCF output   -l INT   compression level   -u   uncompressed BCF\n");
-    fprintf(stderr, "  -B FILE   sites overlapping the BED intervals   -e   ... not overlapping\n");
-    fprintf(stderr, "  -a EXPR   allele set: ,chr:pos:rlen:alt,... | ,chr:pos:REF:ALT | file   -S   samples carrying all of them\n");
-    fprintf(stderr, "  -d FILE   variant annotations (FMF): -a EXPR then selects its rows by metadata   -M   load FILE in memory\n");
-    fprintf(stderr, "  -H        haplotype counts over the allele set   -t STR   table of comma-separated expressions\n");
+    fprintf(e, "Usage: bgt %s [options] <bgt-prefix> [...]\n", cmd);
+    fprintf(e, "Options:\n");
+    fprintf(e, "  -s EXPR   sample group: ,name1,name2 | file | expression on .spl metadata (repeatable)\n");
+    fprintf(e, "  -r STR    region chr[:beg-end]\n");
+    fprintf(e, "  -i INT    start from the INT-th site (1-based)      -n INT   emit at most INT sites\n");
+    fprintf(e, "  -f STR    site filter on AC, AN, AC#, AN# (e.g. 'AC>0', 'AC1/AN1>=0.1&&AC2==0')\n");
+    fprintf(e, "  -G        no sample genotypes     -C   write AC/AN (implied by -f or several -s)\n");
+    fprintf(e, "  -b        BCF output   -l INT   compression level   -u   uncompressed BCF\n");
+    fprintf(e, "  -B FILE   sites overlapping the BED intervals   -e   ... not overlapping\n");
+    fprintf(e, "  -a EXPR   allele set: ,chr:pos:rlen:alt,... | ,chr:pos:REF:ALT | file   -S   samples carrying all of them\n");
+    fprintf(e, "  -d FILE   variant annotations (FMF): -a EXPR then selects its rows by metadata   -M   load FILE in memory\n");
+    fprintf(e, "  -H        haplotype counts over the allele set   -t STR   table of comma-separated expressions\n");
     return 1;
 }
 
@@ -81,7 +84,80 @@ static void work_in_a_child(void)
     }
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * BGT_SERVER=<unix socket>: hand the query to a resident `bgt-server -u <socket>` instead of starting a HIP runtime and
+ * building the images in this process (140-270 ms against the reference's 7 ms for a small query).
+ * The request carries this process's stdout and stderr AS FILE DESCRIPTORS (SCM_RIGHTS), its working directory and
+ * its arguments; the server runs the same view_run() on its resident images and writes straight into those descriptors,
+ * so the bytes are those of a local run; the answer on the socket is the exit status.  No server there: run locally.
+ * ------------------------------------------------------------------------------------------------ */
+static int view_via_server(const char *path, int argc, char *argv[])
+{
+    struct sockaddr_un sa;
+    struct msghdr mh;
+    struct iovec iov;
+    union { struct cmsghdr h; char buf[CMSG_SPACE(2 * sizeof(int))]; } cm;
+    struct cmsghdr *c;
+    char cwd[PATH_MAX], *req;
+    size_t len = 0, cap, k;
+    int fd, i, fds[2] = {1, 2};
+    unsigned char status[2];
+    ssize_t n;
+    if (strlen(path) >= sizeof(sa.sun_path) || getcwd(cwd, sizeof(cwd)) == NULL) return -1;
+    if ((fd = socket(AF_UNIX, SOCK_STREAM, 0)) < 0) return -1;
+    memset(&sa, 0, sizeof(sa));
+    sa.sun_family = AF_UNIX; strcpy(sa.sun_path, path);
+    if (connect(fd, (struct sockaddr*)&sa, sizeof(sa)) < 0) { close(fd); return -1; }
+    /* request: "BGTV1\0" cwd "\0" argc (decimal) "\0" argv[0] "\0" ... , preceded by its length (uint32) */
+    cap = strlen(cwd) + 64;
+    for (i = 0; i < argc; ++i) cap += strlen(argv[i]) + 1;
+    req = (char*)malloc(cap + 4);
+    len = 4;
+    len += (size_t)sprintf(req + len, "BGTV1") + 1;
+    len += (size_t)sprintf(req + len, "%s", cwd) + 1;
+    len += (size_t)sprintf(req + len, "%d", argc) + 1;
+    for (i = 0; i < argc; ++i) { k = strlen(argv[i]) + 1; memcpy(req + len, argv[i], k); len += k; }
+    { const uint32_t body = (uint32_t)(len - 4); memcpy(req, &body, 4); }
+    fflush(stdout); fflush(stderr);
+    memset(&mh, 0, sizeof(mh)); memset(&cm, 0, sizeof(cm));
+    iov.iov_base = req; iov.iov_len = len;
+    mh.msg_iov = &iov; mh.msg_iovlen = 1;
+    mh.msg_control = cm.buf; mh.msg_controllen = sizeof(cm.buf);
+    c = CMSG_FIRSTHDR(&mh);
+    c->cmsg_level = SOL_SOCKET; c->cmsg_type = SCM_RIGHTS; c->cmsg_len = CMSG_LEN(sizeof(fds));
+    memcpy(CMSG_DATA(c), fds, sizeof(fds));
+    n = sendmsg(fd, &mh, MSG_NOSIGNAL);                             /* the descriptors travel with the first byte */
+    if (n < 0) { free(req); close(fd); return -1; }
+    for (k = (size_t)n; k < len; k += (size_t)n)
+        if ((n = send(fd, req + k, len - k, MSG_NOSIGNAL)) <= 0) { free(req); close(fd); return 1; }
+    free(req);
+    for (k = 0; k < 2; k += (size_t)n) {                            /* {'S', status}: anything else is a lost server */
+        do n = read(fd, status + k, 2 - k); while (n < 0 && errno == EINTR);
+        if (n <= 0) break;
+    }
+    close(fd);
+    if (k != 2 || status[0] != 'S') { fprintf(stderr, "[E::main_view] the server at '%s' went away before it answered.\n", path); return 1; }
+    return status[1];
+}
+
+#define VIEW_FAIL(code) do { rc = (code); goto done; } while (0)
+static pthread_mutex_t g_getopt_lock = PTHREAD_MUTEX_INITIALIZER;   /* getopt's state is global; a resident host runs queries on threads */
+
 int main_view(int argc, char *argv[])
+{
+    const char *srv = getenv("BGT_SERVER");
+    if (srv && *srv) {
+        const int rc = view_via_server(srv, argc, argv);
+        if (rc >= 0) return rc;
+        if (getenv("BGT_TRACE")) fprintf(stderr, "[bgt trace] no server at '%s': running locally\n", srv);
+    }
+    return view_run(argc, argv, stdout, stderr, NULL);
+}
+
+/* `bgt view` proper.  host == NULL: the command-line process (device work in a child, fast exit).  host != NULL: a resident
+ * process runs the query on one of its threads -- databases come from (and go back to) the host's cache, out / err are the
+ * client's, nothing process-wide is touched and everything is released in order. */
+int view_run(int argc, char *argv[], FILE *out, FILE *err, const bgt_view_host_t *host)
 {
     double t_lap = view_now();
     int i, c, n_files, out_bcf = 0, clevel = -1, flag = 0, u_set = 0, n_groups = 0, not_vcf = 0, excl = 0, in_mem = 0;
@@ -90,12 +166,15 @@ int main_view(int argc, char *argv[])
     long seekn = -1, n_rec = LONG_MAX, n_read = 0;
     int rd_ret = -1;
     char *reg = NULL, *site_flt = NULL, *fmt = NULL, *aexpr = NULL, *dbfn = NULL, *gexpr[BGT_MAX_GROUPS];
-    bgt_file_t **files;
-    bgtm_t *bm;
+    bgt_file_t **files = NULL;
+    bgtm_t *bm = NULL;
     bcf1_t *b;
+    int rc = 0, n_open = 0;
     bgzw_t *bz = NULL;
     kstring_t line = {0, 0, 0};
 
+    int first_file;
+    pthread_mutex_lock(&g_getopt_lock);
     optind = 1;
     while ((c = getopt(argc, argv, "ubs:r:l:CMGB:ef:g:a:i:n:SHt:d:")) >= 0) {
         switch (c) {
@@ -120,65 +199,68 @@ int main_view(int argc, char *argv[])
         default: break;
         }
     }
-    if (n_rec < 0) { fprintf(stderr, "[E::%s] option -n must be at least 0.\n", __func__); return 1; }
+    first_file = optind;
+    pthread_mutex_unlock(&g_getopt_lock);
+    n_files = 0;
+    if (n_rec < 0) { fprintf(err, "[E::%s] option -n must be at least 0.\n", "main_view"); VIEW_FAIL(1); }
     if (clevel > 9) clevel = 9;
     if (u_set) { clevel = 0; out_bcf = 1; }
     if (n_groups > 1) flag |= BGT_F_SET_AC;
-    if (argc - optind < 1) return usage(argv[0]);
+    if (argc - first_file < 1) VIEW_FAIL(usage(argv[0], err));
     if ((flag & (BGT_F_CNT_AL | BGT_F_CNT_HAP)) && aexpr == NULL) {  /* ref view.c:93-96 */
-        fprintf(stderr, "[E::%s] -a must be specified when -S/-H is in use.\n", __func__);
-        return 1;
+        fprintf(err, "[E::%s] -a must be specified when -S/-H is in use.\n", "main_view");
+        VIEW_FAIL(1);
     }
 
     /* a query that will touch genotypes needs the device: start the HIP runtime now, beside the host-only work below
      * (headers, sample tables, group expressions, the site side-car); `view -G` without counts never opens it */
-    if (!(flag & BGT_F_NO_GT) || (flag & BGT_F_SET_AC) || site_flt) {
+    if (!host && (!(flag & BGT_F_NO_GT) || (flag & BGT_F_SET_AC) || site_flt)) {
         const char *gp = getenv("BGT_GPUS");
         work_in_a_child();
         bgth_runtime_warmup_async(gp && gp[0] >= '0' && gp[0] <= '9' && strchr(gp, ',') ? atoi(gp) : 0);
     }
 
     /* a plain walk of the whole file(s), counts only: the image may skip the sub-checkpoints a long-lived reader wants */
-    if ((flag & BGT_F_NO_GT) && !reg && !bed && !aexpr && seekn <= 0 && !fmt) setenv("BGTH_OPEN_HINT", "walk", 0);
+    if (!host && (flag & BGT_F_NO_GT) && !reg && !bed && !aexpr && seekn <= 0 && !fmt) setenv("BGTH_OPEN_HINT", "walk", 0);
 
-    n_files = argc - optind;
+    n_files = argc - first_file;
     files = (bgt_file_t**)calloc((size_t)n_files, sizeof(bgt_file_t*));
     for (i = 0; i < n_files; ++i)
-        if ((files[i] = bgt_open(argv[optind + i])) == NULL) {
-            fprintf(stderr, "[E::%s] failed to open BGT with prefix '%s'\n", __func__, argv[optind + i]);
-            return 1;
-        }
+        if ((files[i] = host ? host->open(argv[first_file + i], host->ctx) : bgt_open(argv[first_file + i])) == NULL) {
+            fprintf(err, "[E::%s] failed to open BGT with prefix '%s'\n", "main_view", argv[first_file + i]);
+            VIEW_FAIL(1);
+        } else n_open = i + 1;
     view_lap(&t_lap, "open databases (header, samples)");
     bm = bgtm_reader_init(n_files, files);
     bgtm_set_flag(bm, flag);
     if (site_flt && bgtm_set_flt_site(bm, site_flt) != 0) {
-        fprintf(stderr, "[E::%s] failed to set frequency filters. Syntax error?\n", __func__);
-        return 1;
+        fprintf(err, "[E::%s] failed to set frequency filters. Syntax error?\n", "main_view");
+        VIEW_FAIL(1);
     }
     if (reg && bgtm_set_region(bm, reg) < 0) {
-        fprintf(stderr, "[E::%s] failed to set region. Region format error?\n", __func__);
-        return 1;
+        fprintf(err, "[E::%s] failed to set region. Region format error?\n", "main_view");
+        VIEW_FAIL(1);
     }
     if (bed) bgtm_set_bed(bm, bed, excl);
     if (fmt && bgtm_set_table(bm, fmt) < 0) {
-        fprintf(stderr, "[E::%s] failed to set tabular output.\n", __func__);
-        return 1;
+        fprintf(err, "[E::%s] failed to set tabular output.\n", "main_view");
+        VIEW_FAIL(1);
     }
     if (seekn > 0) bgtm_set_start(bm, seekn);
     if (aexpr) {                                                    /* ref view.c:125-133 */
         int n_al;
         if (dbfn && in_mem) vardb = fmf_read(dbfn);                 /* ref view.c:76-84 */
         n_al = bgtm_set_alleles(bm, aexpr, vardb, in_mem ? NULL : dbfn);
-        if (n_al < 0) { fprintf(stderr, "[E::%s] failed to set alleles.\n", __func__); return 1; }
-        if (n_al == 0) fprintf(stderr, "[W::%s] no alleles selected.\n", __func__);
+        if (n_al < 0) { fprintf(err, "[E::%s] failed to set alleles.\n", "main_view"); VIEW_FAIL(1); }
+        if (n_al == 0) fprintf(err, "[W::%s] no alleles selected.\n", "main_view");
     }
     for (i = 0; i < n_groups; ++i)
         if (bgtm_add_group(bm, gexpr[i]) < 0) {
-            fprintf(stderr, "[E::%s] failed to add sample group '%s'.\n", __func__, gexpr[i]);
-            return 1;
+            fprintf(err, "[E::%s] failed to add sample group '%s'.\n", "main_view", gexpr[i]);
+            VIEW_FAIL(1);
         }
     if (!out_bcf && !not_vcf) bgtm_want_vcf_text(bm);
-    if (bgtm_prepare(bm) < 0) { fprintf(stderr, "[E::%s] failed to prepare the readers.\n", __func__); return 1; }
+    if (bgtm_prepare(bm) < 0) { fprintf(err, "[E::%s] failed to prepare the readers.\n", "main_view"); VIEW_FAIL(1); }
     view_lap(&t_lap, "prepare (.pbf image -> HBM)");
 
     /* the reference builds the mode string "wb%d" and takes its first digit as the level, so the default
@@ -186,22 +268,22 @@ int main_view(int argc, char *argv[])
     if (not_vcf) out_bcf = 0;
     else if (out_bcf) {
         long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
-        bz = bgzw_open(stdout, clevel < 0 ? 1 : clevel);
+        bz = bgzw_open(out, clevel < 0 ? 1 : clevel);
         bgzw_threads(bz, ncpu > 8 ? 8 : (int)ncpu);                 /* blocks are independent: same bytes, deflated in parallel */
         bcf_hdr_write_stream(bz, bm->h_out);
     }
-    else vcf_hdr_write_text(stdout, bm->h_out);
+    else vcf_hdr_write_text(out, bm->h_out);
 
     b = bcf_init1();
     if (!bz && !not_vcf && !getenv("BGT_NO_BULK")) {                /* the whole walk at once where the query allows it */
-        const long nb = bgtm_write_vcf_bulk(bm, stdout, n_rec);
+        const long nb = bgtm_write_vcf_bulk(bm, out, n_rec);
         if (nb >= 0) n_read += nb;
         else if (nb < -1) rd_ret = -2;
     }
-    while (rd_ret >= -1 && (rd_ret = ((bz || not_vcf) ? bgtm_read(bm, b) : bgtm_read_vcf(bm, b, &line))) >= 0 && n_read < n_rec) {
+    while (rd_ret >= -1 && !ferror(out) && (rd_ret = ((bz || not_vcf) ? bgtm_read(bm, b) : bgtm_read_vcf(bm, b, &line))) >= 0 && n_read < n_rec) {
         if (bz) bcf_write1_stream(bz, b);
-        else if (!not_vcf) { fwrite(line.s, 1, line.l, stdout); fputc('\n', stdout); }
-        if (fmt && bm->n_fields > 0) puts(bm->tbl_line.s);
+        else if (!not_vcf) { fwrite(line.s, 1, line.l, out); fputc('\n', out); }
+        if (fmt && bm->n_fields > 0) { fputs(bm->tbl_line.s, out); fputc('\n', out); }
         ++n_read;
     }
     bcf_destroy1(b);
@@ -211,22 +293,22 @@ int main_view(int argc, char *argv[])
             int n_hap;
             bgt_hapcnt_t *hc = bgtm_hapcnt(bm, &n_hap);
             char *s = bgtm_hapcnt_print_destroy(bm, n_hap, hc);
-            if (s) fputs(s, stdout);
+            if (s) fputs(s, out);
             free(s);
         }
         if (bm->flag & BGT_F_CNT_AL) {
             char *s = bgtm_alcnt_print(bm);
-            if (s) fputs(s, stdout);
+            if (s) fputs(s, out);
             free(s);
         }
     }
     if (bz) bgzw_close(bz);
-    fflush(stdout);
-    if (rd_ret >= -1 && !getenv("BGT_CLEAN_EXIT")) {
+    fflush(out);
+    if (!host && rd_ret >= -1 && !getenv("BGT_CLEAN_EXIT")) {
         /* everything is written: freeing the images in HBM one by one and tearing the HIP runtime down costs 20-60 ms
          * that nobody waits for (the driver reclaims the process's memory); BGT_CLEAN_EXIT=1 keeps the orderly path */
         view_lap(&t_lap, "done (fast exit)");
-        fflush(stderr);
+        fflush(err);
         if (g_done_fd >= 0) {                                       /* the waiting parent leaves with the status; see work_in_a_child */
             const unsigned char ok = 0;
             close(1); close(2);
@@ -234,16 +316,17 @@ int main_view(int argc, char *argv[])
         }
         _exit(0);
     }
+    if (rd_ret < -1) {                                              /* -1 is the end of the data; anything below is a failure */
+        fprintf(err, "[E::%s] reading stopped on an error (%d): the output is incomplete.\n", "main_view", rd_ret);
+        rc = 1;
+    }
+done:
     free(line.s);
-    bgtm_reader_destroy(bm);
+    if (bm) bgtm_reader_destroy(bm);
     if (bed) bed_destroy(bed);
     if (vardb) fmf_destroy(vardb);
-    for (i = 0; i < n_files; ++i) bgt_close(files[i]);
+    for (i = 0; i < n_open; ++i) { if (host) host->close(files[i], host->ctx); else bgt_close(files[i]); }
     free(files);
     view_lap(&t_lap, "close");
-    if (rd_ret < -1) {                                              /* -1 is the end of the data; anything below is a failure */
-        fprintf(stderr, "[E::%s] reading stopped on an error (%d): the output is incomplete.\n", __func__, rd_ret);
-        return 1;
-    }
-    return 0;
+    return rc;
 }

@@ -180,6 +180,17 @@ void  bed_destroy(void *bed);
 
 /* ---- command line front ends: `bgt view` (reference view.c:14-183), `bgt import` (import.c:8-120) ---- */
 int main_view(int argc, char *argv[]);
+/* `bgt view` for a RESIDENT host (extension; `bgt-server -u SOCKET` is the one in this repo): the same query on the
+ * caller's thread, written to out / err, with the databases taken from and given back to the host (open / close are
+ * called with ctx) instead of being opened and closed per query; nothing process-wide is touched.  host == NULL is what
+ * main_view runs in a command-line process.  With BGT_SERVER=<socket> in its environment main_view hands the query --
+ * arguments, working directory and its own stdout / stderr descriptors -- to such a host and leaves with its status. */
+typedef struct {
+    bgt_file_t *(*open)(const char *prefix, void *ctx);
+    void        (*close)(bgt_file_t *bgt, void *ctx);
+    void         *ctx;
+} bgt_view_host_t;
+int view_run(int argc, char *argv[], FILE *out, FILE *err, const bgt_view_host_t *host);
 int main_pbfview(int argc, char **argv);   /* `bgt pbfview` (reference pbfview.c) */
 int main_import(int argc, char *argv[]);
 
