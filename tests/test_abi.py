@@ -67,7 +67,7 @@ def test_measurement_tools_live_in_their_own_library(libpath):
     bench = os.path.join(os.path.dirname(libpath), "libbgt_hip_bench.so")
     assert os.path.exists(bench)
     out = subprocess.check_output(["nm", "-D", "--defined-only", bench]).decode()
-    assert sorted(set(re.findall(r" T (bgth_[a-z0-9_]+)", out))) == declared and len(declared) == 4
+    assert sorted(set(re.findall(r" T (bgth_[a-z0-9_]+)", out))) == declared and len(declared) == 8
     prod = subprocess.check_output(["nm", "-D", "--defined-only", libpath]).decode()
     assert "issue_rate" not in prod and "op_rate" not in prod
 
