@@ -155,6 +155,7 @@ static Rccl &rccl()
 // ----------------------------------------------------------------------------------------------------
 struct Selection {
     int width = 0, n_chunks = 0, G = 1;
+    bool whole = false;                // every column of the cohort exactly once (no subset list)
     std::vector<int32_t> slot_col, slot_of_out, group_haps;
     std::vector<uint32_t> chunk_desc;
     int32_t *d_slot_col = nullptr, *d_slot_of_out = nullptr, *d_group_haps = nullptr;
@@ -224,7 +225,8 @@ enum { kVariantNoTog = 1, kVariantNeverZP = 2, kVariantAlwaysZP = 4, kVariantNoP
        kVariantRcclSelf = 1024,                          // 1024: sharded scan_device gathers through RCCL even between shards of ONE device
                                                            //       (send / receive to self): runs the RCCL path on a one-GPU box
        kVariantPlaneNever = 2048, kVariantPlaneAlways = 4096,     // the plane-split kernels (sparse selections of wide cohorts)
-       kVariantNoWalkPrio = 16384 };                               // walk-only / team kernels without progress-based wave priorities
+       kVariantNoWalkPrio = 16384,
+       kVariantNoCC = 65536 };                                     // narrow kernels: never the ballot-free row step (scan_step_cc.inc.h)                               // walk-only / team kernels without progress-based wave priorities
 static bool variant_flag(int bit) { const char *d = getenv("BGTH_VARIANT"); return d && (atoi(d) & bit); }
 
 // Builds the row index once per image; later calls only return it.  The build is enqueued on `s`, the
@@ -400,7 +402,7 @@ static bool build_selection(Selection &s, int m, int n_sub, const int32_t *sub, 
     if (n_sub <= 0 || n_sub >= m || sub == nullptr) { n_sub = m; sub = nullptr; }   // ref pbwt.c:377
     if (G < 1 || G > 32) { set_err("[E::bgth_reader_select] n_groups %d out of 1..32", G); return false; }
     if (group == nullptr) G = 1;
-    s.width = n_sub; s.G = G;
+    s.width = n_sub; s.G = G; s.whole = sub == nullptr;
     std::vector<std::vector<int32_t>> by_group(G);
     for (int i = 0; i < n_sub; ++i) {
         const int col = sub ? sub[i] : i;
@@ -947,6 +949,7 @@ static bool common_scan_args(ScanArgs &a, bgth_pbf_t *p, const Selection &sel, c
     a.n_slices = geo.slices;
     a.zp = use_zp(p) ? 1 : 0;
     a.walk_prio = variant_flag(kVariantNoWalkPrio) ? 0 : 1;
+    a.cc_step = sel.whole && sel.G == 1 && !variant_flag(kVariantNoCC) ? 1 : 0;
     if (geo.wpp > 1) {                                   // team (wide-cohort) kernels read the row index
         if (!ensure_rowindex(p, s)) return false;
         a.chunkinfo = p->d_chunkinfo;

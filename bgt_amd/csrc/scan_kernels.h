@@ -42,6 +42,8 @@ struct ScanArgs {
     const uint32_t *segc;
     int32_t  m, nw, shift, n_chunks, G, K, wpp, nbuf, S8;
     int32_t  zp;                 // use the kernels with the all-zero-plane-1 shortcut (the image has such rows)
+    int32_t  cc_step;            // the selection is the whole cohort in ONE group and no bit planes are wanted: the narrow kernels may
+                                 // count n(code 3) per lane and take the per-plane counts from the strings (BGTH_VARIANT 65536 forbids it)
     int32_t  walk_prio;          // team kernels: progress-based wave priorities in the walk (BGTH_VARIANT 16384 switches them off)
     int32_t  tog_off;            // team mode: byte offset in LDS of the separate toggle array [2K][(nw+4)&~3], 0 = toggles in place
     int32_t  blk0, n_blk, n_slices;

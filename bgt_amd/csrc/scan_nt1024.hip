@@ -6,10 +6,10 @@ namespace bgth {
 
 static const int kLdsBytesLocal = 160 * 1024;
 
-template <int NT, int CPT, bool MULTI, bool GT, bool TEAM, bool ZP>
+template <int NT, int CPT, bool MULTI, bool GT, bool TEAM, bool ZP, bool CC = false>
 static hipError_t launch_one(const ScanArgs &a, const Geometry &g, hipStream_t s)
 {
-    auto fn = scan_kernel<NT, CPT, MULTI, GT, TEAM, ZP>;
+    auto fn = scan_kernel<NT, CPT, MULTI, GT, TEAM, ZP, CC>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes);
     if (e != hipSuccess) return e;
@@ -22,6 +22,12 @@ template <int NT, int CPT, bool ZP>
 static hipError_t launch_variant(const ScanArgs &a, const Geometry &g, hipStream_t s)
 {
     const int v = (a.G > 1 ? 4 : 0) | (a.h0 ? 2 : 0) | (g.wpp > 1 ? 1 : 0);
+#ifdef BGTH_CC_FORM
+    // EXPERIMENT builds only (make ccform N=..; profiles/r04_issue/): one group, counts only, every column of the cohort tracked,
+    // pipelined narrow mode, no empty-plane shortcut -> the ballot-free instruction-major row step of scan_step_cc.inc.h.  It is
+    // bit-exact and SLOWER in the kernel (11.4-12.3 ms against 10.9 ms on C2) although faster in isolation, so it does not ship.
+    if constexpr (!ZP) if (v == 0 && a.cc_step && g.nbuf == 2) return launch_one<NT, CPT, false, false, false, false, true>(a, g, s);
+#endif
     switch (v) {
     case 0: return launch_one<NT, CPT, false, false, false, ZP>(a, g, s);
     case 1: return launch_one<NT, CPT, false, false, true, ZP>(a, g, s);

@@ -295,9 +295,13 @@ def tail_ops(kind):
 
 
 # the sign mask register is chosen per lookup so that the select's three sources sit in three different banks
+SG_BASE = [72]          # first sign register: behind the entry pairs (v30 .. v30 + 2 nl - 1), a multiple of 4
+
+
 def sgb(s):
-    r = 72 + 2 * s          # entry pair v30+2s / v31+2s: banks {2,3} for even s, {0,1} for odd s; v72+2s: bank 0 / 2
-    assert r % 4 not in ((30 + 2 * s) % 4, (31 + 2 * s) % 4)
+    # entry pair v30+2s / v31+2s: banks {2,3} for even s, {0,1} for odd s -> sign in bank 0/1 for even s, 2/3 for odd s
+    r = SG_BASE[0] + (s & ~3) + {0: 0, 1: 2, 2: 1, 3: 3}[s & 3]
+    assert r % 4 not in ((30 + 2 * s) % 4, (31 + 2 * s) % 4) and r < 94, (s, r)
     return "v%d" % r
 
 
@@ -322,10 +326,10 @@ def step(nl, addr, tail, layout, joint=None, counts=False, waits="all"):
                 L.append(t(s))
         for s in range(0, nl, 2):
             if joint == "and_sub":
-                L += ["v_and_b32 %s, %s, %s" % (elo(s), sg(s), sg(s + 1)), "v_sub_u32 v%d, v%d, %s" % (90 + (s // 2) % 4, 90 + (s // 2) % 4, elo(s))]
+                L += ["v_and_b32 %s, %s, %s" % (elo(s), sg(s), sg(s + 1)), "v_sub_u32 v%d, v%d, %s" % (100 + (s // 2) % 4, 100 + (s // 2) % 4, elo(s))]
             if joint == "three":
-                L += ["v_sub_u32 v90, v90, %s" % sg(s), "v_sub_u32 v91, v91, %s" % sg(s + 1),
-                      "v_and_b32 %s, %s, %s" % (elo(s), sg(s), sg(s + 1)), "v_sub_u32 v92, v92, %s" % elo(s)]
+                L += ["v_sub_u32 v100, v100, %s" % sg(s), "v_sub_u32 v101, v101, %s" % sg(s + 1),
+                      "v_and_b32 %s, %s, %s" % (elo(s), sg(s), sg(s + 1)), "v_sub_u32 v102, v102, %s" % elo(s)]
             if counts:
                 L += [c.replace("{M0}", mk(s)).replace("{M1}", mk(s + 1)) for c in COUNT3]
     else:
@@ -334,10 +338,10 @@ def step(nl, addr, tail, layout, joint=None, counts=False, waits="all"):
             for t in T:
                 L.append(t(s)); L.append(t(s + 1))
             if joint == "and_sub":
-                L += ["v_and_b32 %s, %s, %s" % (elo(s), sg(s), sg(s + 1)), "v_sub_u32 v%d, v%d, %s" % (90 + (s // 2) % 4, 90 + (s // 2) % 4, elo(s))]
+                L += ["v_and_b32 %s, %s, %s" % (elo(s), sg(s), sg(s + 1)), "v_sub_u32 v%d, v%d, %s" % (100 + (s // 2) % 4, 100 + (s // 2) % 4, elo(s))]
             if joint == "three":
-                L += ["v_sub_u32 v90, v90, %s" % sg(s), "v_sub_u32 v91, v91, %s" % sg(s + 1),
-                      "v_and_b32 %s, %s, %s" % (elo(s), sg(s), sg(s + 1)), "v_sub_u32 v92, v92, %s" % elo(s)]
+                L += ["v_sub_u32 v100, v100, %s" % sg(s), "v_sub_u32 v101, v101, %s" % sg(s + 1),
+                      "v_and_b32 %s, %s, %s" % (elo(s), sg(s), sg(s + 1)), "v_sub_u32 v102, v102, %s" % elo(s)]
             if counts:
                 L += [c.replace("{M0}", mk(s)).replace("{M1}", mk(s + 1)) for c in COUNT3]
     return L
@@ -369,10 +373,97 @@ for nl in (8, 16):
          step(nl, addr_folded, "sign", "instr", joint="three"), "10 VALU per lookup", nl, True)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# 8. pass 3: what exactly breaks the fast rate?  31 fast instructions + ONE instruction X per 32 (all independent)
+# ---------------------------------------------------------------------------------------------------------------
+F4 = ["v_add_u32 {A}, {B}, {A}", "v_sub_u32 {C}, {D}, {C}", "v_ashrrev_i32 {E}, 31, {E}", "v_and_b32 {F}, {D}, {F}"]
+for nm, x in [("nothing (32 fast)", "v_add_u32 {A}, {B}, {A}"), ("v_bcnt_u32_b32", "v_bcnt_u32_b32 {A}, {B}, {A}"), ("v_lshlrev_b32 vgpr", "v_lshlrev_b32 {C}, {D}, {C}"),
+              ("v_max_i32", "v_max_i32 {E}, {B}, {E}"), ("v_mul_i32_i24", "v_mul_i32_i24 {F}, {D}, {F}"), ("v_cmp_gt_i32_e64", "v_cmp_gt_i32_e64 {M}, 0, {A}"),
+              ("v_cndmask_b32_e64", "v_cndmask_b32_e64 {A}, {B}, {A}, s[22:23]"), ("v_mad_i32_i24", "v_mad_i32_i24 {A}, {A}, -8, {B}"),
+              ("v_add_u32 with an SGPR source", "v_add_u32 {A}, s20, {A}"), ("v_readlane_b32", "v_readlane_b32 s24, {A}, 3"),
+              ("v_mov_b32 dpp", "v_mov_b32_dpp {A}, {B} row_shr:1 row_mask:0xf bank_mask:0xf"), ("s_add_u32 (SALU)", "s_add_u32 s24, s24, s25"),
+              ("ds_read_b32 (+ wait)", "ds_read_b32 {A}, {B}\n\ts_waitcnt lgkmcnt(0)")]:
+    lines = []
+    for r in range(4):
+        for k in range(31):
+            lines.append(fmt(F4[k % 4], (r + k) % 8))
+        lines += fmt(x, r % 8).split("\n\t")
+    add("8 31 fast + 1 x %s" % nm, lines, "per 32")
+S2 = ["v_lshlrev_b32 {A}, {B}, {A}", "v_bcnt_u32_b32 {C}, {D}, {C}"]
+for n in (1, 4, 16, 64):
+    lines, k = [], 0
+    while len(lines) < 128:
+        for i_ in range(n):
+            lines.append(fmt(F4[(k + i_) % 4], (k + i_) % 8))
+        for i_ in range(n):
+            lines.append(fmt(S2[(k + i_) % 2], (k + i_) % 8))
+        k += n
+    add("8 blocks of %d fast then %d of {lshl, bcnt}" % (n, n), lines, "1 fast : 1 slow")
+
 # VALU-only timing of the two 2-instruction address forms (pass 1 ran the bitop3 with one register as all three sources)
 add("4 address: v_ashrrev 2 + v_bitop3 (~a & -8), third source an inline constant", body(["v_ashrrev_i32 {D}, 2, {A}", "v_bitop3_b32 {D}, {D}, -8, 0 bitop3:0x0c"], "slot", 4), "2 per lookup")
 add("4 address: v_ashrrev 2 + v_and_b32 -8 (descending table)", body(["v_ashrrev_i32 {D}, 2, {A}", "v_and_b32 {D}, -8, {D}"], "slot", 4), "2 per lookup")
 add("4 select: v_bitop3 a ? b : c, sources in three banks", ["v_bitop3_b32 v%d, v%d, v%d, v%d bitop3:0xca" % (10 + (i % 8), 72 + 2 * (i % 8), 30 + 2 * (i % 8), 31 + 2 * (i % 8)) for i in range(64)], "1")
+
+
+# ---- pass 3: more forms of the ballot-free step on the real directory
+def step3(nl, form, halves=False):
+    SG_BASE[0] = 72
+    if nl > 20: raise ValueError("more than 20 lookups do not fit this register map (pairs v30.., signs v72.., accumulators v90..)")
+    """form: 'joint' (9 VALU), 'bits' (per-lane bit accumulators of both planes: acc = 2 acc - sign, 10 VALU),
+    'and' (address by v_and on a descending table, joint), 'lshr' (words bit-reversed: variable shift right is a fast
+    instruction; mask = 0 - (t & 1)), 'cmpsel' (cmp + cndmask, no SALU counts)"""
+    L = ["s_waitcnt lgkmcnt(0)"]
+    for s_ in range(nl):
+        L.append("v_ashrrev_i32 %s, 2, %s" % (elo(s_), q(s_)))
+    for s_ in range(nl):
+        if form == "and":
+            L.append("v_and_b32 %s, -8, %s" % (elo(s_), elo(s_)))
+        else:
+            L.append("v_bitop3_b32 %s, %s, -8, 0 bitop3:0x0c" % (elo(s_), elo(s_)))
+    for s_ in range(nl):
+        L += rd(s_)
+    groups = [range(0, nl // 2), range(nl // 2, nl)] if halves else [range(nl)]
+    for gi, g in enumerate(groups):
+        L.append("s_waitcnt lgkmcnt(%d)" % (nl - g[-1] - 1))
+        if form == "lshr":
+            for s_ in g: L.append("v_lshrrev_b32 %s, %s, %s" % (elo(s_), q(s_), elo(s_)))
+            for s_ in g: L.append("v_bcnt_u32_b32 %s, %s, %s" % (ehi(s_), elo(s_), ehi(s_)))
+            for s_ in g: L.append("v_and_b32 %s, 1, %s" % (sg(s_), elo(s_)))
+            for s_ in g: L.append("v_sub_u32 %s, 0, %s" % (sg(s_), sg(s_)))
+        else:
+            for s_ in g: L.append("v_lshlrev_b32 %s, %s, %s" % (elo(s_), q(s_), elo(s_)))
+            for s_ in g: L.append("v_bcnt_u32_b32 %s, %s, %s" % (ehi(s_), elo(s_), ehi(s_)))
+            if form == "cmpsel":
+                for s_ in g: L.append("v_cmp_gt_i32_e64 %s, 0, %s" % (mk(s_), elo(s_)))
+            else:
+                for s_ in g: L.append("v_ashrrev_i32 %s, 31, %s" % (sg(s_), elo(s_)))
+        for s_ in g: L.append("v_sub_u32 %s, v94, %s" % (elo(s_), ehi(s_)))
+        for s_ in g: L.append("v_add_u32 %s, %s, %s" % (ehi(s_), q(s_), ehi(s_)))
+        if form == "cmpsel":
+            for s_ in g: L.append("v_cndmask_b32_e64 %s, %s, %s, %s" % (q(s_), ehi(s_), elo(s_), mk(s_)))
+        else:
+            for s_ in g: L.append("v_bitop3_b32 %s, %s, %s, %s bitop3:0xca" % (q(s_), sg(s_), elo(s_), ehi(s_)))
+        if form == "bits":
+            for s_ in g: L.append("v_add_u32 v%d, v%d, v%d" % (100 + s_ % 2, 100 + s_ % 2, 100 + s_ % 2))
+            for s_ in g: L.append("v_sub_u32 v%d, v%d, %s" % (100 + s_ % 2, 100 + s_ % 2, sg(s_)))
+        elif form != "cmpsel":
+            for s_ in g:
+                if s_ % 2 == 0: L.append("v_and_b32 %s, %s, %s" % (elo(s_), sg(s_), sg(s_ + 1)))
+            for s_ in g:
+                if s_ % 2 == 0: L.append("v_sub_u32 v%d, v%d, %s" % (100 + (s_ // 2) % 4, 100 + (s_ // 2) % 4, elo(s_)))
+    return L
+
+
+for nl in (16, 20):
+    addl("9 ballot-free, joint count, instruction-major over %d" % nl, step3(nl, "joint"), "9 VALU per lookup", nl, "fold")
+    addl("9 ballot-free, per-lane bit accumulators of both planes (acc = 2 acc - sign), instruction-major over %d" % nl, step3(nl, "bits"), "10 VALU per lookup", nl, "fold")
+addl("9 ballot-free, joint count, two halves of 8 (second half's reads in flight during the first half's tails)", step3(16, "joint", halves=True), "9 VALU per lookup", 16, "fold")
+addl("9 ballot-free, joint count, 12 lookups in flight", step3(12, "joint"), "9 VALU per lookup", 12, "fold")
+addl("9 ballot-free, per-lane bit accumulators, two halves of 8", step3(16, "bits", halves=True), "10 VALU per lookup", 16, "fold")
+addl("9 ballot-free, joint count, address by v_and on a descending table, instruction-major over 16", step3(16, "and"), "9 VALU per lookup", 16, "desc")
+addl("9 ballot-free, bit-reversed words + v_lshrrev (fast) + mask = 0 - (t & 1), joint count, instruction-major over 16", step3(16, "lshr"), "10 VALU per lookup", 16, "foldrev")
+addl("9 v_cmp + v_cndmask (ballot kept) but NO SALU counts, folded address, instruction-major over 16", step3(16, "cmpsel"), "8 VALU per lookup", 16, "fold")
 
 
 def emit():
@@ -451,17 +542,23 @@ def emit():
         w("    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];")
         w("    uint2 *tab = reinterpret_cast<uint2*>(smem);")
         w("    constexpr int NE = 4096;                          // 32 KB of {bits, ones before}: a row of 131,072 columns")
-        w("    for (int i = threadIdx.x; i < NE; i += blockDim.x) tab[i] = make_uint2(0x9e3779b9u * (uint32_t)(i + 1) * (uint32_t)(i + 7), 0u);")
+        mode = {True: "fold", False: "plain"}.get(folded, folded)
+        desc = mode == "desc"
+        w("    // word w of the row sits in entry %s" % ("NE - 1 - w (descending table)" if desc else "w"))
+        w("    for (int i = threadIdx.x; i < NE; i += blockDim.x) tab[%s] = make_uint2(0x9e3779b9u * (uint32_t)(i + 1) * (uint32_t)(i + 7), 0u);" % ("NE - 1 - i" if desc else "i"))
         w("    __syncthreads();")
         w("    if (threadIdx.x == 0) {")
         w("        uint32_t run = 0;")
-        w("        for (int i = 0; i < NE; ++i) { tab[i].y = run; run += (uint32_t)__popc(tab[i].x); }")
+        w("        for (int i = 0; i < NE; ++i) { uint2 &e = tab[%s]; e.y = run; run += (uint32_t)__popc(e.x); %s }" % ("NE - 1 - i" if desc else "i", "e.x = __brev(e.x);" if mode == "foldrev" else ""))
         w("        tab[NE] = make_uint2((uint32_t)NE * 32u - run, 0u);")
         w("    }")
         w("    __syncthreads();")
         w("    const uint32_t rowaddr = __builtin_amdgcn_groupstaticsize();")
         w("    const uint32_t n0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tab[NE].x);")
-        w("    const uint32_t c = %s;" % ("4u * rowaddr" if folded else "0u"))
+        if desc:      # entry of word w at TOP - 8 w, TOP = rowaddr + 8 (NE - 1); the registers hold q + c', c' = 4 (TOP + 8)
+            w("    const uint32_t c = 0u - 4u * (rowaddr + 8u * (uint32_t)NE);")
+        else:
+            w("    const uint32_t c = %s;" % ("0u" if mode == "plain" else "4u * rowaddr"))
         w("    uint32_t qv[%d];" % nl)
         w("    for (int s = 0; s < %d; ++s) qv[s] = ~(((((uint32_t)(threadIdx.x * %d + s) * 2654435761u) ^ seed) %% (NE * 32u)) + c);" % (nl, nl))
         w("    ib_setup();")
@@ -469,7 +566,7 @@ def emit():
         for s_ in range(nl):
             w('        "v_mov_b32 v%d, %%%d\\n\\t"' % (10 + s_, s_))
         w('        "s_mov_b32 s20, %%%d\\n\\ts_mov_b32 s21, %%%d\\n\\tv_mov_b32 v94, %%%d\\n\\t"' % (nl, nl + 1, nl + 2))
-        w('        "v_mov_b32 v90, 0\\n\\tv_mov_b32 v91, 0\\n\\tv_mov_b32 v92, 0\\n\\tv_mov_b32 v93, 0\\n\\ts_mov_b32 s24, 0\\n\\ts_mov_b32 s25, 0\\n\\ts_mov_b32 s26, 0\\n\\t"')
+        w('        "v_mov_b32 v100, 0\\n\\tv_mov_b32 v101, 0\\n\\tv_mov_b32 v102, 0\\n\\tv_mov_b32 v103, 0\\n\\ts_mov_b32 s24, 0\\n\\ts_mov_b32 s25, 0\\n\\ts_mov_b32 s26, 0\\n\\t"')
         w("        :: " + ", ".join('"v"(qv[%d])' % s_ for s_ in range(nl)) + ', "s"(rowaddr - 8u), "s"(0u - n0), "v"(0u - n0 - c)')
         w("        : BGTH_IB_CLOBBER);")
         w("    const unsigned long long t0 = __builtin_amdgcn_s_memtime();")
