@@ -159,6 +159,9 @@ struct Selection {
     std::vector<int32_t> slot_col, slot_of_out, group_haps;
     std::vector<uint32_t> chunk_desc;
     int32_t *d_slot_col = nullptr, *d_slot_of_out = nullptr, *d_group_haps = nullptr;
+    int32_t *d_slot_of_col = nullptr;  // [m]: slot of a column, -1 = not selected (made on first use: the sparse plane-1 tracker)
+    size_t cap_soc = 0;
+    bool dup_cols = false;             // a column selected twice (one slot cannot stand for both: no tracker)
     uint32_t *d_chunk_desc = nullptr;
     size_t cap[4] = {0, 0, 0, 0};      // bytes behind the four device tables: a reader that is selected again (a pooled
                                        // reader serves query after query) allocates only when a table grows
@@ -168,6 +171,8 @@ struct Selection {
         if (d_slot_of_out) hipFree(d_slot_of_out);
         if (d_group_haps) hipFree(d_group_haps);
         if (d_chunk_desc) hipFree(d_chunk_desc);
+        if (d_slot_of_col) hipFree(d_slot_of_col);
+        d_slot_of_col = nullptr; cap_soc = 0;
         d_slot_col = d_slot_of_out = d_group_haps = nullptr;
         d_chunk_desc = nullptr;
         cap[0] = cap[1] = cap[2] = cap[3] = 0;
@@ -185,6 +190,8 @@ struct bgth_pbf_s {
     bool one_shot = false;            // opened with BGTH_OPEN_HINT=walk: no sub-checkpoints, arena passes of one round of workgroups
     int64_t n = 0, n_blk = 0;         // n_blk: file blocks of 1 << shift rows
     int64_t n_sub = 0;                // sub-blocks of 1 << sub_shift rows: the unit the kernels work on
+    bool n1_known = false;            // plane-1 statistics (ensure_plane1_stats): most ones in a row, ones in all rows
+    int64_t n1_max = 0, n1_sum = 0;
     // a partial image (bgth_pbf_open_rows) holds the file blocks that cover a row range: every internal index is
     // relative to row_off (a multiple of 1 << shift), the C ABI speaks file rows
     int64_t row_off = 0, n_total = 0;
@@ -226,8 +233,10 @@ enum { kVariantNoTog = 1, kVariantNeverZP = 2, kVariantAlwaysZP = 4, kVariantNoP
                                                            //       (send / receive to self): runs the RCCL path on a one-GPU box
        kVariantPlaneNever = 2048, kVariantPlaneAlways = 4096,     // the plane-split kernels (sparse selections of wide cohorts)
        kVariantNoWalkPrio = 16384,
-       kVariantNoCC = 65536 };                                     // narrow kernels: never the ballot-free row step (scan_step_cc.inc.h)                               // walk-only / team kernels without progress-based wave priorities
+       kVariantNoCC = 65536,
+       kVariantSparseNever = 131072, kVariantSparseAlways = 262144 }; // plane 1 by the sparse tracker (scan_sparse.hip): never / whenever it is possible                                     // narrow kernels: never the ballot-free row step (scan_step_cc.inc.h)                               // walk-only / team kernels without progress-based wave priorities
 static bool variant_flag(int bit) { const char *d = getenv("BGTH_VARIANT"); return d && (atoi(d) & bit); }
+static bool ensure_plane1_stats(bgth_pbf_t *p, hipStream_t s);
 
 // Builds the row index once per image; later calls only return it.  The build is enqueued on `s`, the
 // stream of the scan that needs it, and waited for, so that other streams may use the index afterwards.
@@ -246,6 +255,24 @@ static bool ensure_rowindex(bgth_pbf_t *p, hipStream_t s)
     HIP_TRY(hipStreamSynchronize(s), { hipFree(ci); hipFree(sc); return false; });
     p->d_chunkinfo = ci; p->d_segc = sc; p->S8 = S8;
     p->rowindex_bytes = (int64_t)(n_ci + n_sc) * 4;
+    return true;
+}
+
+// Ones per plane-1 row (counted once per image, on the stream of the first scan that asks): what decides whether plane 1
+// is walked by the sparse tracker (scan_sparse.hip) -- work proportional to the ones -- or densely like plane 0.
+static bool ensure_plane1_stats(bgth_pbf_t *p, hipStream_t s)
+{
+    std::lock_guard<std::mutex> guard(p->rowindex_lock);
+    if (p->n1_known) return true;
+    unsigned long long *d_st = nullptr, h[2] = {0, 0};
+    int32_t *d_n1 = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_st, 16), return false);
+    HIP_TRY(hipMalloc((void**)&d_n1, (size_t)std::max<int64_t>(p->n, 1) * 4), { hipFree(d_st); return false; });
+    bool ok = hipMemsetAsync(d_st, 0, 16, s) == hipSuccess && launch_plane1_ones(p->d_rowdesc, p->d_rle, p->n, p->m, d_n1, d_st, s) == hipSuccess &&
+              hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h, d_st, 16, hipMemcpyDeviceToHost) == hipSuccess;
+    hipFree(d_st); hipFree(d_n1);
+    if (!ok) { set_err("[E::bgth] plane-1 statistics: %s", hipGetErrorString(hipGetLastError())); return false; }
+    p->n1_max = (int64_t)h[0]; p->n1_sum = (int64_t)h[1]; p->n1_known = true;
     return true;
 }
 
@@ -352,6 +379,10 @@ struct bgth_reader_s {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     DevBuf raw, fin, h0, h1, gt;      // scratch of every scan; results of bgth_reader_scan
     DevBuf ph0, ph1;                  // bit planes of the plane-split kernels when the caller wants counts only
+    DevBuf sp_e2s, sp_tail;           // sparse plane-1 tracker: epoch tables and tail references per sub-block of a launch
+    bool sparse1 = false;             // the last scan walked plane 1 with the tracker
+    hipStream_t stream2 = nullptr;    // the tracker's stream (beside the scan kernel's)
+    hipEvent_t ev_sp[2] = {nullptr, nullptr};
     int plane_path = 0;               // the last scan ran the plane-split kernels
     // directory path: the arena of {bits, ones before} rows and their zero counts; [dir_lo, dir_hi) = image rows it holds
     // from the last producer pass (a later scan inside that range only walks), dir_passes/dir_built = what the last scan did
@@ -436,6 +467,19 @@ static bool build_selection(Selection &s, int m, int n_sub, const int32_t *sub, 
     s.n_chunks = (int)s.chunk_desc.size();
     if (s.n_chunks == 0) { set_err("[E::bgth_reader_select] empty selection"); return false; }
     const size_t nslot = s.slot_col.size();
+    {
+        std::vector<int32_t> soc((size_t)m, -1);
+        s.dup_cols = false;
+        for (size_t i = 0; i < nslot; ++i)
+            if (s.slot_col[i] >= 0) { if (soc[s.slot_col[i]] >= 0) s.dup_cols = true; soc[s.slot_col[i]] = (int32_t)i; }
+        if (s.cap_soc < (size_t)m * 4) {
+            if (s.d_slot_of_col) hipFree(s.d_slot_of_col);
+            s.d_slot_of_col = nullptr; s.cap_soc = 0;
+            HIP_TRY(hipMalloc((void**)&s.d_slot_of_col, (size_t)m * 4), return false);
+            s.cap_soc = (size_t)m * 4;
+        }
+        HIP_TRY(hipMemcpy(s.d_slot_of_col, soc.data(), (size_t)m * 4, hipMemcpyHostToDevice), return false);
+    }
     auto grow = [&](void **ptr, size_t &have, size_t need) -> bool {
         if (need <= have) return true;
         if (*ptr) hipFree(*ptr);
@@ -1377,10 +1421,13 @@ static void reader_free(bgth_reader_t *r)
     r->win[0].release(); r->win[1].release();
     r->dir.release(); r->dir_n0.release();
     r->ph0.release(); r->ph1.release();
+    r->sp_e2s.release(); r->sp_tail.release();
     for (int i = 0; i < 4; ++i) if (r->ev[i]) hipEventDestroy(r->ev[i]);
     for (int i = 0; i < 2; ++i) if (r->ev_dir[i]) hipEventDestroy(r->ev_dir[i]);
     if (r->ev_gather) hipEventDestroy(r->ev_gather);
     if (r->stream) hipStreamDestroy(r->stream);
+    if (r->stream2) hipStreamDestroy(r->stream2);
+    for (hipEvent_t e : r->ev_sp) if (e) hipEventDestroy(e);
     delete r;
 }
 
@@ -1594,6 +1641,36 @@ static int64_t enqueue_scan_wide_plane(bgth_reader_t *r, int64_t row0, int64_t r
     return rows;
 }
 
+// Decides whether plane 1 of this scan is walked by the sparse tracker and, if so, fills its arguments (a.blk0 / a.n_blk /
+// a.shift / a.rank0* are set): the image's plane 1 must be sparse (a row's ones cost the tracker about what 64 of them cost
+// a dense lookup pass), no column selected twice, its LDS and scratch must fit.  BGTH_VARIANT 131072 / 262144: never / whenever possible.
+static bool sparse_plane1_setup(bgth_reader_t *r, ScanArgs &a, hipStream_t s)
+{
+    bgth_pbf_t *p = r->pbf;
+    if (variant_flag(kVariantSparseNever) || r->sel.dup_cols || p->g_file == 1) return false;
+    if (!ensure_plane1_stats(p, s)) return false;
+    // EXPERIMENTAL, opt-in (BGTH_VARIANT 262144): bit-exact (tests/test_dir_path.py::test_sparse_plane1_tracker) but not yet a
+    // gain -- C2: the tracker alone takes 6.9 ms per 1 M rows (a chain of ~8 k cycles per row and sub-block), the plane-0-only scan
+    // kernel 10.5 ms with its ballots written out, 18.8 ms together against 11.0 ms for the dense kernel (profiles/r04_sparse/).
+    const bool force = variant_flag(kVariantSparseAlways);
+    if (!force) return false;
+    if (p->n1_max > 8192) return false;
+    const int icap = (int)std::max<int64_t>(64, (p->n1_max + 63) / 64 * 64);
+    int tcap = p->m > 65536 ? 131072 : 32768;
+    while (tcap < 8 * icap) tcap *= 2;
+    if (force && getenv("BGTH_SPARSE_TCAP"))                         // (tests: a small tail, so that epochs turn over)
+        tcap = std::max(std::max(4096, atoi(getenv("BGTH_SPARSE_TCAP")) / 4096 * 4096), (icap + 4095) / 4096 * 4096);
+    if (sparse_lds_bytes(p->m, tcap, icap) > 160 * 1024) return false;
+    const size_t mpad = (size_t)32 * ((((size_t)p->m + 31) / 32 + 127) & ~(size_t)127);
+    if (!r->sp_e2s.reserve((size_t)a.n_blk * 2 * mpad * 4) || !r->sp_tail.reserve((size_t)a.n_blk * (size_t)tcap * 4)) return false;
+    a.sp_e2s = (int32_t*)r->sp_e2s.p;
+    a.sp_tail = (int32_t*)r->sp_tail.p;
+    a.sp_slot_of_col = r->sel.d_slot_of_col;
+    a.sp_tcap = tcap;
+    a.sp_icap = icap;
+    return true;
+}
+
 static void collect_timing(bgth_reader_t *r);
 // enqueue decode+reduce of [row0,row1) on stream s; results in d_fin (+ optional planes)
 static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_t *d_fin, uint64_t *d_h0,
@@ -1665,12 +1742,55 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
     if (!planepath && (G > 1 || r->geom.slices > 1))         // a single-group, single-slice launch stores its counts
         HIP_TRY(hipMemsetAsync(r->raw.p, 0, (size_t)rows * G * 3 * 4, s), return -1);
     if (timed) HIP_TRY(hipEventRecord(r->ev[1], s), return -1);
+    r->sparse1 = false;
     if (planepath) {
         a.h0 = p_h0; a.h1 = p_h1;
+        // Plane 1 by the sparse tracker (scan_sparse.hip) when its rows are nearly empty: the plane kernels then run plane 0
+        // alone, the tracker sets the bits of h1 (zeroed first), count_planes joins them as before.
+        if (sparse_plane1_setup(r, a, s)) {
+            HIP_TRY(hipMemsetAsync(p_h1, 0, (size_t)rows * r->sel.n_chunks * 8, s), return -1);
+            a.skip1 = 1;
+            r->sparse1 = true;
+        }
         HIP_TRY(launch_plane_scan(a, pgeo, s), return -1);
+        if (a.skip1) HIP_TRY(launch_sparse_plane1(a, s), return -1);
         HIP_TRY(launch_count_planes(p_h0, p_h1, r->sel.d_chunk_desc, (int32_t*)r->raw.p, rows, r->sel.n_chunks, G, s), return -1);
     }
-    else if (!dirpath) HIP_TRY(launch_scan(a, geo, s), return -1);
+    else if (!dirpath) {
+        // Narrow cohorts with a sparse plane 1: the scan kernel walks plane 0 alone and writes its ballots, the tracker sets the
+        // bits of plane 1 on a stream of its own beside it, count_planes joins the two.
+        uint64_t *n_h0 = d_h0, *n_h1 = d_h1;
+        bool sp = geo.nbuf == 2 && geo.slices == 1 && !(r->tune_threads || r->tune_cpt || r->tune_K) && !a.snap;
+        if (sp && !d_h0) {
+            const size_t pl = (size_t)rows * r->sel.n_chunks * 8;
+            if (!r->ph0.reserve(pl) || !r->ph1.reserve(pl)) sp = false;
+            else { n_h0 = (uint64_t*)r->ph0.p; n_h1 = (uint64_t*)r->ph1.p; }
+        }
+        // (half the rows per batch: the kernel builds no plane-1 rows, and the LDS it leaves lets the tracker's workgroups share its CUs)
+        Geometry sgeo;
+        // (the smallest batch that keeps the pipelined narrow mode: more than a quarter of the waves in rows)
+        const int sK = getenv("BGTH_SPARSE_K") ? atoi(getenv("BGTH_SPARSE_K")) : std::min(geo.K, geo.threads / 256 + 1);
+        sp = sp && choose_geometry(p->m, r->sel.n_chunks, 1, (int)(blk1 - blk0 + 1), geo.threads, geo.cpt, sK, &sgeo, false) &&
+             sgeo.nbuf == 2 && sgeo.slices == 1;
+        if (sp && sparse_plane1_setup(r, a, s)) {
+            a.K = sgeo.K; a.wpp = sgeo.wpp; a.nbuf = sgeo.nbuf; a.n_slices = sgeo.slices; a.G = 1;
+            r->geom = sgeo;
+            if (!r->stream2) HIP_TRY(hipStreamCreateWithFlags(&r->stream2, hipStreamNonBlocking), return -1);
+            if (!r->ev_sp[0]) { HIP_TRY(hipEventCreateWithFlags(&r->ev_sp[0], hipEventDisableTiming), return -1); HIP_TRY(hipEventCreateWithFlags(&r->ev_sp[1], hipEventDisableTiming), return -1); }
+            a.h0 = n_h0; a.h1 = n_h1; a.h_row0 = row0;
+            HIP_TRY(hipMemsetAsync(n_h1, 0, (size_t)rows * r->sel.n_chunks * 8, s), return -1);
+            HIP_TRY(hipEventRecord(r->ev_sp[0], s), return -1);
+            HIP_TRY(hipStreamWaitEvent(r->stream2, r->ev_sp[0], 0), return -1);
+            if (!getenv("BGTH_SPARSE_NOTRACK")) HIP_TRY(launch_sparse_plane1(a, r->stream2), return -1);   // (timing experiments only)
+            HIP_TRY(hipEventRecord(r->ev_sp[1], r->stream2), return -1);
+            a.skip1 = 1; a.zp = 1;
+            HIP_TRY(launch_scan(a, sgeo, s), return -1);
+            HIP_TRY(hipStreamWaitEvent(s, r->ev_sp[1], 0), return -1);
+            HIP_TRY(launch_count_planes(n_h0, n_h1, r->sel.d_chunk_desc, (int32_t*)r->raw.p, rows, r->sel.n_chunks, G, s), return -1);
+            r->sparse1 = true;
+        }
+        else HIP_TRY(launch_scan(a, geo, s), return -1);
+    }
     else {
         // Passes over ranges of sub-blocks whose rows fit the arena: producer, then the walk-only kernel.  An arena that
         // already holds the rows of this scan (the previous scan of this reader covered them in one pass) is walked as is.
@@ -1941,7 +2061,7 @@ extern "C" int bgth_reader_last_path(const bgth_reader_t *rc, float out[4])
     bgth_reader_t *r = const_cast<bgth_reader_t*>(rc);
     if (!r->subs.empty()) return bgth_reader_last_path(r->subs[0], out);
     if (r->t_pending) { hipSetDevice(r->pbf->device); collect_timing(r); }
-    out[0] = r->plane_path ? 2.f : r->geom.dir_stage >= 0 ? 1.f : 0.f; out[1] = (float)r->dir_passes; out[2] = (float)r->dir_built; out[3] = r->dir_build_ms;
+    out[0] = (r->plane_path ? 2.f : r->geom.dir_stage >= 0 ? 1.f : 0.f) + (r->sparse1 ? 4.f : 0.f); out[1] = (float)r->dir_passes; out[2] = (float)r->dir_built; out[3] = r->dir_build_ms;
     return 0;
 }
 

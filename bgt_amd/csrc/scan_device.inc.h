@@ -102,6 +102,18 @@ __device__ __forceinline__ uint32_t rle_len(uint32_t byte)
 // inside the statement; a lookup needs two of them: the low one is first the LDS address, then the shifted
 // word, then the candidate for bit = 1.  BASE operands are (LDS address of the plane-row) - 8, N0 operands are -n0.
 // ----------------------------------------------------------------------------------------------------
+#ifdef BGTH_CMPX_STEP
+// EXPERIMENT (make ccform N=.. CMPX=1): seven VALU per lookup -- q + oi goes to ALL lanes, then v_cmpx leaves only the lanes whose
+// bit is 1 active (it also writes the ballot), they take -n0 - oi, and the scalar unit re-opens the wave (every lane of these
+// kernels is active in the walk).
+#define BGTH_TAIL(Q, ELO, EHI, T, MASK, N0)            \
+    "v_lshlrev_b32 " ELO ", " Q ", " ELO "\n\t"        \
+    "v_bcnt_u32_b32 " EHI ", " ELO ", " EHI "\n\t"     \
+    "v_add_u32 " Q ", " Q ", " EHI "\n\t"              \
+    "v_cmpx_gt_i32_e64 " MASK ", 0, " ELO "\n\t"       \
+    "v_sub_u32 " Q ", " N0 ", " EHI "\n\t"             \
+    "s_mov_b64 exec, -1\n\t"
+#else
 #define BGTH_TAIL(Q, ELO, EHI, T, MASK, N0)            \
     "v_lshlrev_b32 " ELO ", " Q ", " ELO "\n\t"        \
     "v_bcnt_u32_b32 " EHI ", " ELO ", " EHI "\n\t"     \
@@ -109,6 +121,7 @@ __device__ __forceinline__ uint32_t rle_len(uint32_t byte)
     "v_sub_u32 " T ", " N0 ", " EHI "\n\t"             \
     "v_add_u32 " EHI ", " Q ", " EHI "\n\t"            \
     "v_cndmask_b32_e64 " Q ", " EHI ", " T ", " MASK "\n\t"
+#endif
 #define BGTH_ADDR(T, Q, BASE)                          \
     "v_ashrrev_i32 " T ", 5, " Q "\n\t"                \
     "v_mad_i32_i24 " T ", " T ", -8, " BASE "\n\t"
@@ -116,6 +129,21 @@ __device__ __forceinline__ uint32_t rle_len(uint32_t byte)
 // Two lookups with their dependent chains interleaved: a wave that shares its SIMD with only one other (the wide-cohort
 // kernels: 2 waves per SIMD) issues 8 % more lookups per cycle this way, four waves per SIMD are indifferent
 // (profiles/r02a_calibration: 4.56 vs 4.94 cycles per instruction at 2 waves, 3.99 vs 4.02 at 4).
+#ifdef BGTH_CMPX_STEP
+#define BGTH_TAIL2(QA, ELA, EHA, MA, N0A, QB, ELB, EHB, MB, N0B)  \
+    "v_lshlrev_b32 " ELA ", " QA ", " ELA "\n\t"                  \
+    "v_lshlrev_b32 " ELB ", " QB ", " ELB "\n\t"                  \
+    "v_bcnt_u32_b32 " EHA ", " ELA ", " EHA "\n\t"                \
+    "v_bcnt_u32_b32 " EHB ", " ELB ", " EHB "\n\t"                \
+    "v_add_u32 " QA ", " QA ", " EHA "\n\t"                       \
+    "v_add_u32 " QB ", " QB ", " EHB "\n\t"                       \
+    "v_cmpx_gt_i32_e64 " MA ", 0, " ELA "\n\t"                    \
+    "v_sub_u32 " QA ", " N0A ", " EHA "\n\t"                      \
+    "s_mov_b64 exec, -1\n\t"                                      \
+    "v_cmpx_gt_i32_e64 " MB ", 0, " ELB "\n\t"                    \
+    "v_sub_u32 " QB ", " N0B ", " EHB "\n\t"                      \
+    "s_mov_b64 exec, -1\n\t"
+#else
 #define BGTH_TAIL2(QA, ELA, EHA, MA, N0A, QB, ELB, EHB, MB, N0B)  \
     "v_lshlrev_b32 " ELA ", " QA ", " ELA "\n\t"                  \
     "v_lshlrev_b32 " ELB ", " QB ", " ELB "\n\t"                  \
@@ -129,6 +157,7 @@ __device__ __forceinline__ uint32_t rle_len(uint32_t byte)
     "v_add_u32 " EHB ", " QB ", " EHB "\n\t"                      \
     "v_cndmask_b32_e64 " QA ", " EHA ", " ELA ", " MA "\n\t"      \
     "v_cndmask_b32_e64 " QB ", " EHB ", " ELB ", " MB "\n\t"
+#endif
 #define BGTH_ASHR(T, Q)        "v_ashrrev_i32 " T ", 5, " Q "\n\t"
 #define BGTH_MAD(T, BASE)      "v_mad_i32_i24 " T ", " T ", -8, " BASE "\n\t"
 
@@ -762,7 +791,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int p = build_slot + i * NWAVE;
-                if (p < 2 * Kc)
+                if (p < 2 * Kc && !(ZP && a.skip1 && (p & 1)))           // (skip1: plane 1 belongs to the sparse tracker, scan_sparse.hip)
                     build_plane_row(a, rle, BDb + (size_t)p * nwp, n0b + p, cdsc[i], cpre[i][0], cpre[i][1], lane, tail_mask,
                                     CC ? fold_of(buf * 2 * K + p) - fold_of(next_slot(buf * 2 * K + p)) : 0u);
             }
@@ -926,7 +955,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
             // barrier while waves 12-15 finish it nearly alone (measured: walk 96 vs 189 ticks).  Rotating the user
             // priority over the rows of a batch gives the four waves of a SIMD equal progress.
             if (!TEAM && !(BGTH_SKIP(a, 0x2000))) set_wave_priority(((wave >> 2) + k) & 3);   // (team mode: by columns, below; a priority that falls with the rows of the batch instead measured the same)
-            if (ZP && n01 == 0u - (uint32_t)m) base1 = 0u;       // plane 1 all zero: its lookups are skipped (see step2)
+            if (ZP && (a.skip1 || n01 == 0u - (uint32_t)m)) base1 = 0u;   // plane 1 all zero (or not this kernel's): its lookups are skipped (see step2)
             if (a.snap && rb + k > blk_beg && ((rb + k) & (((int64_t)1 << a.snap_shift) - 1)) == 0) {
                 // sub-checkpoint: the ranks before this row (image-open pass only)
                 int32_t *dst = a.snap + ((rb + k) >> a.snap_shift) * (int64_t)(2 * m);
@@ -988,7 +1017,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
                     if (c < CPT && chunk0 + c < a.n_chunks) {
                         const size_t at = (size_t)(rb + k - a.row0) * a.n_chunks + chunk0 + c;
                         a.h0[at] = keep0[q];
-                        a.h1[at] = keep1[q];
+                        if (!(ZP && a.skip1)) a.h1[at] = keep1[q];
                     }
                 }
             }

@@ -21,8 +21,9 @@ static hipError_t launch_one(const ScanArgs &a, const Geometry &g, hipStream_t s
 template <int NT, int CPT, bool ZP>
 static hipError_t launch_variant(const ScanArgs &a, const Geometry &g, hipStream_t s)
 {
-    const int v = (a.G > 1 ? 4 : 0) | (a.h0 ? 2 : 0) | (g.wpp > 1 ? 1 : 0);
-#ifdef BGTH_CC_FORM
+    // (skip1: plane 0 alone, its ballots to h0 -- the counts come from count_planes, whatever the groups)
+    const int v = a.skip1 ? 2 : (a.G > 1 ? 4 : 0) | (a.h0 ? 2 : 0) | (g.wpp > 1 ? 1 : 0);
+#ifdef BGTH_CC_EXPERIMENT
     // EXPERIMENT builds only (make ccform N=..; profiles/r04_issue/): one group, counts only, every column of the cohort tracked,
     // pipelined narrow mode, no empty-plane shortcut -> the ballot-free instruction-major row step of scan_step_cc.inc.h.  It is
     // bit-exact and SLOWER in the kernel (11.4-12.3 ms against 10.9 ms on C2) although faster in isolation, so it does not ship.

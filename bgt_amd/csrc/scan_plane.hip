@@ -34,9 +34,10 @@ __global__ __launch_bounds__(512, 4) void plane_kernel(const ScanArgs a, const u
     // has the longer strings, so a CU should hold one workgroup of each plane, whichever way the XCD fills its 32 CUs x 2
     // slots: neighbours in k (depth first) and ids 32 apart in k (breadth first) both get different planes.  (With plain
     // alternation the same launch took 19.6 or 24.9 ms depending on what ran before it.)
+    // (a.skip1: plane 1 is walked by the sparse tracker, scan_sparse.hip: every workgroup here is a plane-0 one)
     const int k = blockIdx.x >> 3;
-    const int plane = (k ^ (k >> 5)) & 1;
-    const int bl = (k >> 1) * 8 + (blockIdx.x & 7);
+    const int plane = __builtin_amdgcn_readfirstlane(a.skip1 ? 0 : (k ^ (k >> 5)) & 1);
+    const int bl = __builtin_amdgcn_readfirstlane(a.skip1 ? (int)blockIdx.x : (k >> 1) * 8 + (int)(blockIdx.x & 7));
     if (bl >= a.n_blk) return;
 
     const int m = a.m, nw = a.nw, nwp = (nw + 2) & ~1, nwt = (nw + 4) & ~3;
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(512, 4) void plane_kernel(const ScanArgs a, const u
     }
     asm volatile("s_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");     // the scalar stores of the ballots reach memory
 #ifdef BGTH_ABLATE
-    if (BGTH_TIMES(a) && lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(a.debug_times + i, tsum[i]);
+    if (BGTH_TIMES(a) && lane == 0 && !a.skip1) for (int i = 0; i < 8; ++i) atomicAdd(a.debug_times + i, tsum[i]);   // (skip1: the tracker reports)
 #endif
 }
 
@@ -247,7 +248,7 @@ hipError_t launch_plane_scan(const ScanArgs &a, const Geometry &g, hipStream_t s
         auto fn = plane_kernel<C>;                                                                                  \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes); \
         if (e != hipSuccess) return e;                                                                              \
-        hipLaunchKernelGGL(fn, dim3(g.workgroups), dim3(512), g.lds_bytes, s, a, a.rowdesc, a.rle, a.chunkinfo, a.segc); \
+        hipLaunchKernelGGL(fn, dim3(a.skip1 ? (unsigned)((a.n_blk + 7) / 8 * 8) : (unsigned)g.workgroups), dim3(512), g.lds_bytes, s, a, a.rowdesc, a.rle, a.chunkinfo, a.segc); \
         return hipGetLastError();                                                                                   \
     }
     BGTH_PLANE_CPTS(X)

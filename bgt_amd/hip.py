@@ -392,8 +392,8 @@ class HipReader:
     def path(self):
         t = (C.c_float * 4)()
         lib().bgth_reader_last_path(self.h, t)
-        return {"directory_path": int(t[0]) == 1, "plane_split": int(t[0]) == 2, "passes": int(t[1]), "producer_launches": int(t[2]),
-                "producer_ms": t[3]}
+        return {"directory_path": (int(t[0]) & 3) == 1, "plane_split": (int(t[0]) & 3) == 2, "sparse_plane1": bool(int(t[0]) & 4),
+                "passes": int(t[1]), "producer_launches": int(t[2]), "producer_ms": t[3]}
 
     def geometry(self):
         g = (C.c_int * 6)()

@@ -213,6 +213,8 @@ int bgth_reader_last_geometry(const bgth_reader_t *r, int out[6]);
  * workgroup per bit plane, two per CU, counts from the bit planes), 1 if it took the directory path (wide cohorts whose columns span several
  * workgroups: every row's {bits, ones before} directory is built once into an HBM arena by a producer kernel and the
  * column slices only walk it, pulling rows into LDS by LDS-DMA), 0 for the kernels that rebuild the row per workgroup;
+ * + 4 when plane 1 was walked by the sparse tracker (its rows nearly empty: work proportional to the ones; the kernels above
+ * then ran plane 0 alone);
  * out[1] = passes over the arena, out[2] = producer launches (0: the arena still held the rows from the previous scan
  * of this reader), out[3] = milliseconds of the first producer launch.  BGTH_DIR_ARENA_MB bounds the arena
  * (default: 60 % of the HBM free at first use). */

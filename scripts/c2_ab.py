@@ -19,7 +19,7 @@ pbf = bgt_amd.HipPbf.from_rle(m, 13, rle, lens)
 print("cohort m=%d sites=%d setup %.1fs" % (m, sites, time.time() - t0), flush=True)
 rd = bgt_amd.HipReader(pbf)
 res = {}
-for label, var in (("ballot step (BGTH_VARIANT=65536)", "65536"), ("ballot-free instruction-major step", None), ("ballot step again", "65536"), ("ballot-free again", None)):
+for label, var in (("both planes dense", None), ("plane 1 by the sparse tracker (BGTH_VARIANT=262144)", "262144"), ("dense again", None), ("tracker again", "262144")):
     if var is None:
         os.environ.pop("BGTH_VARIANT", None)
     else:
@@ -31,6 +31,6 @@ for label, var in (("ballot step (BGTH_VARIANT=65536)", "65536"), ("ballot-free 
         best = min(best, rd.timing()["scan_ms"])
     res[label] = counts
     g = rd.geometry()
-    print("%-40s %4d thr x %2d cols x %d slices K %d : %8.3f ms  %7.2f M sites/s" % (label, g["threads"], g["cols_per_thread"], g["slices"], g["rows_per_batch"], best, sites / best / 1e3), flush=True)
+    print("%-40s %4d thr x %2d cols x %d slices K %d sparse %s: %8.3f ms  %7.2f M sites/s" % (label, g["threads"], g["cols_per_thread"], g["slices"], g["rows_per_batch"], rd.path()["sparse_plane1"], best, sites / best / 1e3), flush=True)
 keys = list(res)
 print("same counts:", all(np.array_equal(res[keys[0]], res[k]) for k in keys[1:]))

@@ -136,6 +136,44 @@ def test_plane_split_kernels(hip, monkeypatch, seed, m, rows, shift, n_sel):
     pbf.close()
 
 
+@pytest.mark.parametrize("seed,m,rows,shift,n_sel,pm,tcap", [(31, 700, 90, 4, 40, 0.02, "4096"), (32, 5000, 300, 6, 300, 0.004, None),
+                                                             (33, 41000, 40, 3, 900, 0.001, None), (34, 5000, 2100, 13, 1, 0.002, "4096"),
+                                                             (35, 6000, 260, 5, 2999, 0.01, "4096")])
+def test_sparse_plane1_tracker(hip, monkeypatch, seed, m, rows, shift, n_sel, pm, tcap):
+    """scan_sparse.hip (opt-in, BGTH_VARIANT 262144): plane 1 walked as an ordered set -- select / delete / append per one, epochs
+    compacted when the tail fills (a tail of 4,096 slots makes them turn over), rows of more than 64 ones (several waves), a row
+    that is all ones / all missing -- under the plane-split kernels (4096) and under the pipelined narrow kernel (plane 0 alone,
+    the tracker beside it on a second stream); 1 and 3 groups, genotype planes, scans that start inside a block."""
+    rng = np.random.default_rng(seed)
+    mat = scenarios.ld_matrix(rng, rows, m, n_founders=7, switch=0.1, p_missing=pm, p_multi=pm)
+    mat[2] = 0; mat[3] = 1; mat[5] = rng.integers(0, 2, m)
+    mat[7, rng.integers(0, m, 100)] = 3
+    data = orc.encode_pbf(mat, 2, shift)
+    pbf = hip.HipPbf.from_bytes(data)
+    rd = hip.HipReader(pbf)
+    smp = np.sort(rng.choice(m // 2, n_sel, replace=False))
+    cols = np.stack([2 * smp, 2 * smp + 1], 1).reshape(-1).astype(np.int32)
+    if tcap:
+        monkeypatch.setenv("BGTH_SPARSE_TCAP", tcap)
+    for variant in (4096 + 262144, 262144):
+        monkeypatch.setenv("BGTH_VARIANT", str(variant))
+        for n_groups in (1, 3):
+            group = (1 + (np.arange(n_sel) % n_groups)).astype(np.uint32) if n_groups > 1 else None
+            rd.select(cols, group=group, n_groups=n_groups)
+            oc, ogt = oracle_scan(data, 0, rows, cols=cols, group=group, n_groups=n_groups)
+            c, g = rd.scan(0, rows, want_gt=True)
+            used = rd.path()["sparse_plane1"]
+            assert np.array_equal(c, oc) and np.array_equal(g, ogt), (variant, rd.path(), rd.geometry())
+            a, b = rows // 3, rows - 1
+            assert np.array_equal(rd.scan(a, b), oc[a:b])
+            assert used or rd.path()["sparse_plane1"] or variant == 262144, rd.path()      # (the narrow form needs the pipelined geometry)
+        rd.select(None)
+        oc, _ = oracle_scan(data, 0, rows)
+        assert np.array_equal(rd.scan(0, rows), oc)
+    rd.close()
+    pbf.close()
+
+
 def test_quarter_million_samples(hip, tmp_path):
     """m = 500,000 haplotypes: a row's two bit-vectors (250 KB with their rank directories) do not fit the LDS together,
     one does -- every scan runs producer + one walk-only workgroup per (sub-block, column slice, plane), the planes joined
