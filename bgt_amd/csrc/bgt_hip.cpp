@@ -190,6 +190,7 @@ struct bgth_pbf_s {
     bool one_shot = false;            // opened with BGTH_OPEN_HINT=walk: no sub-checkpoints, arena passes of one round of workgroups
     int64_t n = 0, n_blk = 0;         // n_blk: file blocks of 1 << shift rows
     int64_t n_sub = 0;                // sub-blocks of 1 << sub_shift rows: the unit the kernels work on
+    int arena_share = 1;              // shards of one sharded image on this device (the directory arena is cap / arena_share)
     bool n1_known = false;            // plane-1 statistics (ensure_plane1_stats): most ones in a row, ones in all rows
     int64_t n1_max = 0, n1_sum = 0;
     // a partial image (bgth_pbf_open_rows) holds the file blocks that cover a row range: every internal index is
@@ -1110,6 +1111,15 @@ extern "C" bgth_pbf_t *bgth_pbf_open_sharded(const char *path, int n_shards, con
         int32_t hdr[3]; int64_t n_total = 0;
         if (n_shards < 1 || n_shards > 64 || !devices) { set_err("[E::bgth_pbf_open_sharded] 1..64 shards, one device each"); return nullptr; }
         if (!read_pbf_geometry(path, hdr, &n_total) || n_total < 0 || hdr[2] < 0 || hdr[2] > 30) { set_err("[E::bgth_pbf_open_sharded] '%s': no PBF header / index footer", path); return nullptr; }
+        {   // every device named must exist BEFORE anything is read or allocated: a clean refusal, not a half-opened image
+            int n_dev = 0;
+            if (hipGetDeviceCount(&n_dev) != hipSuccess) n_dev = 0;
+            for (int i = 0; i < n_shards; ++i)
+                if (devices[i] < 0 || devices[i] >= n_dev) {
+                    set_err("[E::bgth_pbf_open_sharded] shard %d names device %d, this process sees %d device(s)", i, devices[i], n_dev);
+                    return nullptr;
+                }
+        }
         if (!use_device(devices[0])) return nullptr;
         bgth_pbf_t *p = pbf_alloc(devices[0], hdr[0], hdr[1], hdr[2], n_total);
         if (!p) return nullptr;
@@ -1131,7 +1141,13 @@ extern "C" bgth_pbf_t *bgth_pbf_open_sharded(const char *path, int n_shards, con
         bool ok = true;
         for (int i = 0; i < n_shards; ++i) {
             if (!errs[i].empty()) { set_err("%s", errs[i].c_str()); ok = false; }
-            if (parts[i]) p->shards.push_back(parts[i]);
+            if (parts[i]) {
+                // shards that share a device share its HBM: each one's directory arena is capped at its share of the free memory
+                int same = 0;
+                for (int j = 0; j < n_shards; ++j) same += parts[j] && devices[j] == devices[i] ? 1 : 0;
+                parts[i]->arena_share = std::max(1, same);
+                p->shards.push_back(parts[i]);
+            }
         }
         if (!ok || (p->shards.empty() && n_total > 0)) { bgth_pbf_close(p); return nullptr; }
         return p;
@@ -1605,7 +1621,7 @@ static int64_t enqueue_scan_wide_plane(bgth_reader_t *r, int64_t row0, int64_t r
     const size_t plane_row = (size_t)r->sel.n_chunks * 8;
     const size_t row_bytes = (size_t)2 * nwp * 8 + (d_h0 ? 0 : 2 * plane_row);
     const int64_t sub_rows = (int64_t)1 << p->sub_shift;
-    const int64_t fit = (int64_t)(dir_arena_cap(p->device) / (row_bytes * (size_t)std::min<int64_t>(sub_rows, row1 - (blk0 << p->sub_shift))));
+    const int64_t fit = (int64_t)((dir_arena_cap(p->device) / (size_t)p->arena_share) / (row_bytes * (size_t)std::min<int64_t>(sub_rows, row1 - (blk0 << p->sub_shift))));
     if (fit < 1) { set_err("[E::bgth_reader_scan] the directory arena does not hold one block of m=%d", p->m); return -1; }
     int64_t per_pass = std::min<int64_t>(blk1 - blk0 + 1, fit >= 8 ? fit / 8 * 8 : fit);
     const int64_t pass_rows = std::min<int64_t>(per_pass * sub_rows, row1 - (blk0 << p->sub_shift));
@@ -1801,7 +1817,7 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
         const bool reuse = !variant_flag(kVariantDirNoReuse) && r->dir.p && r->dir_stream == s && r->dir_lo <= first && row1 <= r->dir_hi;
         int64_t per_pass = blk1 - blk0 + 1;
         if (!reuse) {
-            const size_t cap = dir_arena_cap(p->device);
+            const size_t cap = dir_arena_cap(p->device) / (size_t)p->arena_share;
             const int64_t blk_rows = std::min<int64_t>(sub_rows, row1 - first);     // (a short image has short sub-blocks)
             const int64_t fit = (int64_t)(cap / (row_bytes * (size_t)blk_rows));
             if (fit < 1) { set_err("[E::bgth_reader_scan] the directory arena (%zu MB) does not hold one sub-block of m=%d", cap >> 20, p->m); return -1; }
@@ -1940,7 +1956,11 @@ static int64_t scan_device_sharded(bgth_reader_t *r, int64_t row0, int64_t row1,
         char *dst = (char*)d_counts + (size_t)(q.a0 - row0) * cstride;
         const size_t bytes = (size_t)(q.a1 - q.a0) * cstride;
         if (sr->pbf->device == root_dev && !self) {
-            if (hipSetDevice(root_dev) != hipSuccess || hipMemcpyAsync(dst, sr->fin.p, bytes, hipMemcpyDeviceToDevice, sr->stream) != hipSuccess) { failed = true; break; }
+            // the copy runs on the CALLER's stream, behind the shard's scan (event): work the caller enqueued earlier that still
+            // reads d_counts -- a filter over the previous scan's counts -- is then ordered before this overwrite
+            if (hipSetDevice(root_dev) != hipSuccess) { failed = true; break; }
+            if (sr->stream != root_s && (hipEventRecord(sr->ev_gather, sr->stream) != hipSuccess || hipStreamWaitEvent(root_s, sr->ev_gather, 0) != hipSuccess)) { failed = true; break; }
+            if (hipMemcpyAsync(dst, sr->fin.p, bytes, hipMemcpyDeviceToDevice, root_s) != hipSuccess) { failed = true; break; }
         } else if (sr->pbf->device == root_dev) {                        // (test knob: the same bytes through RCCL, rank to itself)
             const int root = comm_rank(p, root_dev);
             if (hipSetDevice(root_dev) != hipSuccess || rccl().Send(sr->fin.p, bytes, 0, root, p->comm[root], sr->stream) != 0 ||

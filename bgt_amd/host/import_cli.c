@@ -192,6 +192,7 @@ static int parse_text_line(const reader_t *r, char *line, rec_t *c, char *err)
         char *save = NULL, *t;
         for (t = strtok_r(f[8], ":", &save), i = 0; t; t = strtok_r(NULL, ":", &save), ++i) if (strcmp(t, "GT") == 0) gt_idx = i;
         if (gt_idx < 0) { rec_err(err, "[E::%s] no GT in FORMAT\n", "read_text_record"); return -2; }
+        if (c->n_allele > 127) { rec_err(err, "[E::%s] %d alleles in one record: allele numbers are kept in 7 bits\n", "read_text_record", c->n_allele); return -2; }   /* (the BCF reader refuses the same) */
         ns = r->h->n[BCF_DT_SAMPLE];
         if ((size_t)ns * 2 > c->m_gt) { c->m_gt = (size_t)ns * 2; c->gt = (int8_t*)realloc(c->gt, c->m_gt); }
         for (i = 0; i < ns; ++i) {
@@ -202,7 +203,13 @@ static int parse_text_line(const reader_t *r, char *line, rec_t *c, char *err)
             for (g = 0; p && *p && *p != ':'; ++g) {
                 int a;
                 if (g >= 2) { rec_err(err, "[E::%s] only diploid genotypes can be imported\n", "read_text_record"); return -2; }
-                if (*p == '.') { a = -1; ++p; } else a = (int)strtol(p, &p, 10);
+                if (*p == '.') { a = -1; ++p; }
+                else {
+                    char *e;
+                    a = (int)strtol(p, &e, 10);
+                    if (e == p || a < 0) { rec_err(err, "[E::%s] malformed genotype '%.8s'\n", "read_text_record", p); return -2; }   /* (as the BCF reader: -3 is no allele) */
+                    p = e;
+                }
                 if (a >= c->n_allele) { rec_err(err, "[E::%s] genotype refers to allele %d of %d\n", "read_text_record", a, c->n_allele); return -2; }
                 c->gt[2 * i + g] = (int8_t)a;
                 if (*p == '/' || *p == '|') ++p;

@@ -2012,8 +2012,7 @@ long bgtm_write_vcf_bulk(bgtm_t *bm, FILE *fp, long n_rec)
         pthread_mutex_lock(&k.lock);
         while (!k.done[i]) pthread_cond_wait(&k.cond, &k.lock);
         pthread_mutex_unlock(&k.lock);
-        if (k.out[i].l && !k.failed) fwrite(k.out[i].s, 1, k.out[i].l, fp);
-        written += (long)k.n_lines[i];
+        if (k.out[i].l && !k.failed) { fwrite(k.out[i].s, 1, k.out[i].l, fp); written += (long)k.n_lines[i]; }   /* (only what left) */
         free(k.out[i].s); k.out[i].s = NULL;
     }
     for (j = 0; j < n_started; ++j) pthread_join(th[j], NULL);

@@ -162,7 +162,9 @@ int     bgtm_read_vcf(bgtm_t *bm, bcf1_t *b, kstring_t *s);
 /* every remaining site as VCF text in one call -- one device scan for all counts, the lines formatted on several host
  * threads (BGT_THREADS, default min(cores, 16)), written in order; the bytes of the bgtm_read_vcf loop.  Only for one
  * database without genotype columns, region, BED, allele set or table; returns the records written, -1 if the query
- * needs the site-by-site path (nothing was written), -2 on a device error. */
+ * needs the site-by-site path (nothing was written), -2 on a device error.  Blocks are streamed out as they become ready, so
+ * a -2 may FOLLOW part of the body (whole lines, in order, nothing after the failure): a caller must not take the output
+ * for complete -- `bgt view` prints "[E::main_view] reading stopped on an error ...: the output is incomplete." and exits 1. */
 long    bgtm_write_vcf_bulk(bgtm_t *bm, FILE *fp, long n_rec);   /* one database or a merge of up to 64 */
 
 /* ---- allele sets: samples carrying all of them (-S), haplotype counts (-H) ---- */
