@@ -201,7 +201,7 @@ def popcount_identity(np, counts, ones, m):
     return bool(np.array_equal(c[:, 1] + c[:, 2], ones[:, 0]) and np.array_equal((m - c[:, 0]) + c[:, 2], ones[:, 1]))
 
 
-def oracle_window(bgt_amd, np, img, m, shift, seed, abs_row, img_row, n_rows, tmp, device, cols=None):
+def oracle_window(bgt_amd, np, img, m, shift, seed, abs_row, img_row, n_rows, tmp, device, cols=None, group=None, n_groups=1):
     """CPU-oracle counts of cohort rows [abs_row, abs_row + n_rows): the strings are drawn again (the generator is
     addressable by row), built into a small image from the identity order, re-based onto the ranks the big image `img`
     holds before its row img_row (= the same cohort row), saved as a .pbf and decoded by the oracle from that 'S' record
@@ -226,8 +226,8 @@ def oracle_window(bgt_amd, np, img, m, shift, seed, abs_row, img_row, n_rows, tm
     if cols is not None:
         ora.subset(cols)
     t0 = time.perf_counter()
-    oc = ora.scan(lead, lead + n_rows)
-    return oc.reshape(n_rows, 1, 3), time.perf_counter() - t0
+    oc = ora.scan(lead, lead + n_rows, group=group, n_groups=n_groups)
+    return oc.reshape(n_rows, -1, 3), time.perf_counter() - t0
 
 
 

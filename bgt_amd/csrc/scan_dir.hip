@@ -324,7 +324,7 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
 // ----------------------------------------------------------------------------------------------------
 // geometry and launch
 // ----------------------------------------------------------------------------------------------------
-#define BGTH_WALK_GEOMS(X) X(512, 64) X(512, 80) X(512, 98) X(1024, 50)
+#define BGTH_WALK_GEOMS(X) X(512, 64) X(512, 80) X(512, 98) X(1024, 50) X(1024, 44) X(1024, 40) X(1024, 36) X(1024, 32) X(1024, 26)
 
 static int walk_lds_need(int nw, int G, int threads, int nplane)
 {
@@ -351,10 +351,16 @@ bool choose_walk_geometry(int m, int n_chunks, int G, int n_blk, int want_thread
         const int cap = nt / 64 * cpt;
         const long slices = (n_chunks + cap - 1) / cap;
         const long waste = slices * cap - n_chunks;
-        // fewest slices (every slice pulls the whole row into its LDS); then four waves per SIMD rather than two (the row
-        // step issues at 4.0 instead of 4.6 cycles per instruction and the DMA waits hide better: m = 200,000, 262,144
-        // sites, 28.1 ms with 1024 x 50 against 30.7 ms with 512 x 98); then least idle slots
-        const long key = slices * 10000000 + (nt == 1024 ? 0 : 1000000) + waste;
+        // Time of the launch ~ rounds of workgroups over the 256 CUs (one walk-only workgroup per CU) x the time of one: a
+        // row costs a workgroup its columns' lookups plus a fixed part (stage DMA, two barriers: about 9 columns' worth at four waves per SIMD,
+        // profiles/r03_c4shard).  A long scan thus wants the least slices x (columns + 9) -- idle slots of a half-empty last
+        // slice are lookups like any other (m = 65,000: 2 x 32 columns instead of 2 x 50) --, a short one (fewer workgroups
+        // than CUs) the fewest columns that still fit the chip in one round.  512 threads: two waves per SIMD issue the row
+        // step ~15 % slower (28.1 ms with 1024 x 50 against 30.7 ms with 512 x 98 at m = 200,000).
+        const long wgs = slices * (long)n_blk;
+        const long rounds256 = wgs <= 256 ? 256 : wgs;                       // (in 1/256 rounds)
+        const long per_simd = (long)cpt * (nt / 256);                        // lookups (x 2 planes) a SIMD issues per row
+        const long key = rounds256 * (per_simd + 36) * (nt == 1024 ? 100 : 115) * 64 + waste;
         if (best < 0 || key < best_key) best = i, best_key = key;
     }
     if (best < 0) return false;

@@ -66,6 +66,41 @@ def test_plane_popcounts_match_counts_everywhere(n_samples, sites, seed):
     assert np.array_equal(oc, counts[w0:w1])
 
 
+@pytest.mark.parametrize("name,n_samples,sites,seed,every", [("C3", 100000, 262144, 3, 20), ("C4 shard", 100000, 153 * 8192, 4, 7), ("C2", 10000, 1000000, 2, 3)])
+def test_subsets_and_groups_at_width_against_the_oracle(name, n_samples, sites, seed, every, tmp_path):
+    """Subsets and sample groups AT WIDTH against the CPU oracle, not against themselves: a window of 2,560 rows that
+    starts 2,048 rows before a block boundary in the middle of the image (the strings are drawn again, built into a small image,
+    re-based onto the ranks the big image holds there -- bench.oracle_window -- and decoded by the oracle sequentially across the
+    boundary).  C3: every 20th of 100,000 samples (the plane-split kernels), one and three groups; one C4 shard (153 file blocks,
+    1,253,376 sites): a subset with three groups and the whole cohort in three groups (directory path); C2: the same at 10,000."""
+    import bgt_amd
+    import bench
+    m = 2 * n_samples
+    rle, lens = bgt_amd.synth_rows(m, 0, sites, seed)
+    pbf = bgt_amd.HipPbf.from_rle(m, 13, rle, lens)
+    del rle
+    rd = bgt_amd.HipReader(pbf)
+    mid = (sites // 2) // 8192 * 8192
+    back, ahead = (2048, 512) if m > 20000 else (8192, 1024)
+    lo, hi = mid - back, mid + ahead
+    sel = np.arange(0, n_samples, every)
+    cols = np.stack([2 * sel, 2 * sel + 1], 1).reshape(-1).astype(np.int32)
+    for n_groups in (1, 3):
+        group = (1 + (np.arange(sel.size) % n_groups)).astype(np.uint32) if n_groups > 1 else None
+        rd.select(cols, group=group, n_groups=n_groups)
+        got = rd.scan(lo, hi)
+        oc, _ = bench.oracle_window(bgt_amd, np, pbf, m, 13, seed, lo, lo, hi - lo, str(tmp_path), 0, cols, group, n_groups)
+        assert np.array_equal(got, oc), (name, n_groups, rd.path(), rd.geometry())
+    # the whole cohort in three groups
+    group = (1 + (np.arange(n_samples) % 3)).astype(np.uint32)
+    rd.select(np.arange(m, dtype=np.int32), group=group, n_groups=3)
+    got = rd.scan(lo, hi)
+    oc, _ = bench.oracle_window(bgt_amd, np, pbf, m, 13, seed, lo, lo, hi - lo, str(tmp_path), 0, None, group, 3)
+    assert np.array_equal(got, oc), (name, "whole cohort, 3 groups", rd.path(), rd.geometry())
+    rd.close()
+    pbf.close()
+
+
 @pytest.mark.parametrize("n_samples,sites,seed", [(10000, 131072, 2), (2504, 100000, 1), (100000, 6000, 3)])
 def test_decode_encode_round_trip_at_scale(n_samples, sites, seed, tmp_path):
     """decode -> encode -> decode: the synthetic cohort's run-length strings come from the CPU generator; scanning them
