@@ -50,7 +50,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-SAMPLES = {"c2": 10000, "c3": 100000, "c4": 100000, "small": 2504}
+SAMPLES = {"c2": 10000, "c3": 100000, "c4": 100000, "small": 2504, "hrc": 32488}   # hrc: the width of the reference's published numbers (HRC r1)
 HBM_PEAK_GBS = 8000.0                      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 REF_BIN = os.path.join(ROOT, "oracle", "_ref", "bgt")
 MY_BIN = os.path.join(ROOT, "bgt_amd", "bin", "bgt")
