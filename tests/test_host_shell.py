@@ -162,3 +162,43 @@ def test_cli_every_golden_view_on_gpu(name):
     assert res.returncode == v["rc"], res.stderr.decode()
     exp = open(os.path.join(GOLD, "expected", name + ".out"), "rb").read()
     assert res.stdout == exp, res.stderr.decode()[-400:]
+
+
+@pytest.mark.gpu
+def test_every_golden_view_through_a_resident_host(tmp_path):
+    """`BGT_SERVER=<socket> bgt view ...` against `bgt-server -u <socket>`: the launcher hands the query -- arguments, working
+    directory, its own stdout / stderr as descriptors -- to the resident process, which runs the same view_run() on images that
+    stay in HBM.  All golden commands (relative paths, BED / allele / sample files included, the failures with their exit codes)
+    must give the bytes and statuses the compiled reference gave; a second round is answered from the cache; without a host
+    behind the socket the command runs locally."""
+    sock = str(tmp_path / "bgt.sock")
+    srv = subprocess.Popen([os.path.join(ROOT, "bgt_amd", "bin", "bgt-server"), "-u", sock], stderr=subprocess.PIPE)
+    try:
+        t0 = time.time()
+        while not os.path.exists(sock):
+            assert srv.poll() is None and time.time() - t0 < 60, "bgt-server -u did not come up"
+            time.sleep(0.02)
+        env = dict(os.environ, BGT_SERVER=sock)
+        for rnd in range(2):
+            for name in sorted(MANIFEST["views"].keys()):
+                v = MANIFEST["views"][name]
+                res = subprocess.run([BGT, "view"] + v["args"] + v["prefixes"], cwd=GOLD, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
+                assert res.returncode == v["rc"], (name, rnd, res.returncode, res.stderr.decode()[-300:])
+                assert res.stdout == open(os.path.join(GOLD, "expected", name + ".out"), "rb").read(), (name, rnd)
+        # a reader that stops early (head) must not wedge the host
+        p = subprocess.run("%s view -C synA | head -n 3" % BGT, shell=True, cwd=GOLD, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120, env=env)
+        assert p.returncode == 0 and p.stdout.count(b"\n") == 3
+        res = subprocess.run([BGT, "view", "-C", "synA"], cwd=GOLD, stdout=subprocess.PIPE, timeout=120, env=env)
+        assert res.returncode == 0 and res.stdout == open(os.path.join(GOLD, "expected", "synA_C.out"), "rb").read() if os.path.exists(os.path.join(GOLD, "expected", "synA_C.out")) else res.returncode == 0
+    finally:
+        srv.terminate()
+        srv.wait(timeout=30)
+    gone = subprocess.run([BGT, "view", "-G", "synA"], cwd=GOLD, stdout=subprocess.PIPE, timeout=120, env=dict(os.environ, BGT_SERVER=sock))
+    assert gone.returncode == 0 and gone.stdout.count(b"\n") > 10                 # no host there: the local path
+
+
+def test_launcher_starts_without_the_device_libraries():
+    """bin/bgt is a launcher: libbgt.so and the HIP runtime behind it are loaded on demand (a query a resident host answers
+    must not pay 13 ms of dynamic linking)."""
+    out = subprocess.check_output(["ldd", BGT]).decode()
+    assert "libbgt" not in out and "amdhip" not in out, out
