@@ -761,7 +761,7 @@ def main():
     n_samples = SAMPLES[args.workload]
     m = 2 * n_samples
     shift = 13
-    seed = args.seed or {"c2": 2, "c3": 3, "c4": 4, "small": 1}[args.workload]
+    seed = args.seed or {"c2": 2, "c3": 3, "c4": 4, "small": 1, "hrc": 7}[args.workload]
     strong = args.workload == "c4"
     if strong:                                                # configs[3]: one database, block-aligned shards
         total = args.sites or 10000000

@@ -1664,12 +1664,12 @@ static bool sparse_plane1_setup(bgth_reader_t *r, ScanArgs &a, hipStream_t s)
 {
     bgth_pbf_t *p = r->pbf;
     if (variant_flag(kVariantSparseNever) || r->sel.dup_cols || p->g_file == 1) return false;
-    if (!ensure_plane1_stats(p, s)) return false;
     // EXPERIMENTAL, opt-in (BGTH_VARIANT 262144): bit-exact (tests/test_dir_path.py::test_sparse_plane1_tracker) but not yet a
     // gain -- C2: the tracker alone takes 6.9 ms per 1 M rows (a chain of ~8 k cycles per row and sub-block), the plane-0-only scan
     // kernel 10.5 ms with its ballots written out, 18.8 ms together against 11.0 ms for the dense kernel (profiles/r04_sparse/).
     const bool force = variant_flag(kVariantSparseAlways);
     if (!force) return false;
+    if (!ensure_plane1_stats(p, s)) return false;
     if (p->n1_max > 8192) return false;
     const int icap = (int)std::max<int64_t>(64, (p->n1_max + 63) / 64 * 64);
     int tcap = p->m > 65536 ? 131072 : 32768;

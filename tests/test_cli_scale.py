@@ -154,7 +154,8 @@ def test_one_shot_walk_of_a_wide_cohort(tmp_path, monkeypatch):
     monkeypatch.setenv("BGTH_TRACE", "1")
     hinted = md5_of([BGT, "view"] + args + [db])
     err = subprocess.run([BGT, "view"] + args + [db], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300).stderr.decode()
-    assert "one-shot walk: 2 file blocks x 4 column slices" in err and "directory arena" in err, err
+    import re                                                     # (a short image takes more, narrower column slices to fill the chip)
+    assert re.search(r"one-shot walk: 2 file blocks x \d+ column slices", err) and "directory arena" in err, err
     monkeypatch.setenv("BGTH_DIR_ARENA_MB", "1000")                   # 8192-row units of 100 KB rows: one unit a pass
     small = md5_of([BGT, "view"] + args + [db])
     assert ref[0] == plain[0] == hinted[0] == small[0] == 0, (ref, plain, hinted, small)
