@@ -1587,13 +1587,15 @@ static size_t dir_arena_cap(int device)
 
 // Should this scan build its rows once into the arena and walk them from there?  Yes for a wide cohort whose columns
 // span several workgroups (every slice of the team kernels rebuilds the row); BGTH_VARIANT 32 / 64 force / forbid it.
-static bool want_dir_path(const bgth_pbf_t *p, const Geometry &classic, bool tuned)
+// (round 4: also for ONE column slice when most of the cohort is selected -- m = 34,000: 11.7 ms against the team kernels' 13.2 ms per
+// 524,288 sites; the producer's arena is small there and the walk-only workgroup has no build phases to idle through)
+static bool want_dir_path(const bgth_pbf_t *p, const Geometry &classic, bool tuned, int width = 0)
 {
     if (variant_flag(kVariantDirNever)) return false;
     if (variant_flag(kVariantDirAlways)) return true;
     if (use_zp(p)) return false;                         // (the walk-only kernel has no empty-plane shortcut: it looks plane 1 up)
     if (tuned) return false;                             // bgth_reader_tune names a classic geometry
-    return classic.nbuf == 1 && classic.wpp > 1 && classic.slices >= 2;
+    return classic.nbuf == 1 && classic.wpp > 1 && (classic.slices >= 2 || 2 * (int64_t)width >= p->m);
 }
 
 
@@ -1705,7 +1707,7 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
         set_err("[E::bgth_reader_scan] no launch geometry for m=%d (threads=%d cpt=%d)", p->m, r->tune_threads, r->tune_cpt);
         return -1;
     }
-    bool dirpath = want_dir_path(p, geo, r->tune_threads || r->tune_cpt || r->tune_K);
+    bool dirpath = want_dir_path(p, geo, r->tune_threads || r->tune_cpt || r->tune_K, r->sel.width);
     Geometry wgeo;
     if (dirpath) {
         int wt = 0, wc = 0;                              // BGTH_WALK_GEOM=threads,cols: tuning knob of the walk-only kernel
@@ -1713,7 +1715,7 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
         if (!choose_walk_geometry(p->m, r->sel.n_chunks, G, (int)(blk1 - blk0 + 1), wt, wc, &wgeo)) dirpath = false;
         // the team kernels also slice the columns of a SHORT scan to fill the chip; the directory path is for selections whose
         // columns do not fit one workgroup (every slice then repeats the build), not for those
-        else if (wgeo.slices < 2 && !variant_flag(kVariantDirAlways)) dirpath = false;
+        else if (wgeo.slices < 2 && 2 * (int64_t)r->sel.width < p->m && !variant_flag(kVariantDirAlways)) dirpath = false;
     }
     // Plane-split kernels: a selection of few columns of a WIDE cohort (the team kernels would run one workgroup per CU,
     // mostly building): one workgroup per plane, two per CU.  BGTH_VARIANT 2048 / 4096 forbid / force them.

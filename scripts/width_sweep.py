@@ -24,7 +24,7 @@ for n in widths:
     pbf = bgt_amd.HipPbf.from_rle(m, 13, rle, lens)
     del rle
     rd = bgt_amd.HipReader(pbf)
-    os.environ["BGTH_VARIANT"] = "128"                       # every scan builds its rows (no arena carried over)
+    os.environ["BGTH_VARIANT"] = str(128 + int(os.environ.get("SWEEP_VARIANT", "0")))   # 128: every scan builds its rows (no arena carried over)
     rd.scan(0, min(sites, 16384))
     best = 1e9
     for _ in range(3):

@@ -5,6 +5,7 @@ import ctypes as C
 import json
 import os
 import subprocess
+import time
 
 import pytest
 
