@@ -508,6 +508,35 @@ static void set_rows(bgth_pbf_t *p, int64_t n)
     p->n_sub = (n + ((int64_t)1 << p->sub_shift) - 1) >> p->sub_shift;
 }
 
+// Sub-checkpoint spacing of an image of n rows.  A workgroup decodes one sub-block x column slice, so a SHORT image at the
+// default spacing of 2048 rows leaves most of the 256 CUs idle (142,000 rows = 70 sub-blocks) or makes the kernels slice its
+// columns, each slice repeating the row build.  The spacing that minimises
+//        (1 + 10 / rows per sub-block)  x  (workgroups rounded up to whole rounds of what the chip holds) / workgroups
+// -- ~10 rows' worth of start-up per workgroup against the idle tail of the last round -- is taken, the default unless a finer
+// one is >= 2 % better: 1 M rows keep 2048 (scripts/subshift_ab.py: 10.9 ms at 2048, 11.2 ms at 256), the HRC-shaped 142,000 x
+// 64,976 takes 128 (8.7 -> 6.5 ms), 50,000 x 5,008 takes 128 (2.3 -> 0.24 ms).  Costs rows * m / 2^(sub_shift-3) bytes.
+static void fit_sub_shift(bgth_pbf_t *p, int64_t n)
+{
+    if (getenv("BGTH_SUB_SHIFT") || p->wide_plane || n <= 0) return;
+    const int top = std::min(p->shift, 11), chunks = (p->m + 63) / 64;
+    int slices = 1;                                      // column slices of a long whole-cohort scan
+    int64_t slots = 256;                                 // workgroups the chip holds at a time
+    Geometry g, w;
+    if (choose_geometry(p->m, chunks, 1, 4096, 0, 0, 0, &g)) {
+        slices = g.slices;
+        if (g.nbuf == 1 && g.wpp > 1 && choose_walk_geometry(p->m, chunks, 1, 4096, 0, 0, &w)) slices = w.slices;
+        else slots = 256 * (int64_t)std::max(1, std::min(2048 / g.threads, (160 * 1024) / std::max(1, g.lds_bytes)));
+    }
+    double best = 1e30;
+    int pick = top;
+    for (int s = top; s >= std::min(top, 7); --s) {
+        const int64_t wgs = ((n + ((int64_t)1 << s) - 1) >> s) * slices;
+        const double t = (1.0 + 10.0 / (double)((int64_t)1 << s)) * (double)((wgs + slots - 1) / slots * slots) / (double)wgs;
+        if (t < best * 0.98) { best = t; pick = s; }
+    }
+    p->sub_shift = pick;
+}
+
 static bgth_pbf_t *pbf_alloc(int device, int m, int g, int shift, int64_t n)
 {
     if (g != 2) { set_err("[E::bgth_pbf] g=%d bit planes: this build holds BGT's two planes (import.c:68) and, for whole files, the one plane of a .pb1", g); return nullptr; }
@@ -533,6 +562,7 @@ static bgth_pbf_t *pbf_alloc(int device, int m, int g, int shift, int64_t n)
     p->sub_shift = std::min(shift, 11);
     if (const char *e = getenv("BGTH_SUB_SHIFT")) p->sub_shift = std::max(0, std::min(shift, atoi(e)));
     if (wide_plane) p->sub_shift = shift;                // (the pass that derives sub-checkpoints runs the two-plane kernels)
+    fit_sub_shift(p, n);
     set_rows(p, n);
     return p;
 }
@@ -866,6 +896,7 @@ static bgth_pbf_t *open_mem_impl(const void *image, size_t len, int device)
     struct { const Parsed &q; size_t size() const { return q.n_perm; } const int32_t *data() const { return q.perms; } } perms = {ps};
     if (n_footer >= 0 && n_footer != row) { set_err("[E::bgth_pbf_open] footer says %lld rows, stream has %lld", (long long)n_footer, (long long)row); goto fail; }
     if (rle.size() >= ((size_t)1 << kDescLenShift)) { set_err("[E::bgth_pbf_open] RLE payload too large"); goto fail; }
+    fit_sub_shift(p, row);
     set_rows(p, row);
     p->n_total = row;
     // BGTH_OPEN_HINT=walk (set by `bgt view` for a one-shot walk of the whole file): when the file blocks alone fill the

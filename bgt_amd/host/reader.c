@@ -1970,11 +1970,13 @@ long bgtm_write_vcf_bulk(bgtm_t *bm, FILE *fp, long n_rec)
             k.row_min[d] = row_min;
             scan[d].rd = ((devrd_t*)bm->bgt[d]->pb)->rd; scan[d].r0 = row_min; scan[d].r1 = row_max + 1;
             /* pieces of 256 decoding units (sub-blocks of 2048 rows, or file blocks of an image without sub-checkpoints): a
-             * piece must fill the chip by itself -- 64 units were a quarter of it, four times the device time */
+             * piece must fill the chip by itself -- 64 units were a quarter of it, four times the device time.  A short image
+             * has finer units (bgt_hip.cpp fit_sub_shift): at least 262,144 rows then, several rounds of workgroups */
             {
                 const devrd_t *dvd = (const devrd_t*)bm->bgt[d]->pb;
                 const bgth_pbf_t *img = dvd->own_img ? dvd->own_img : (const bgth_pbf_t*)bm->bgt[d]->f->gpu;
                 scan[d].piece = img ? 256 * bgth_pbf_unit_rows(img) : 524288;
+                if (scan[d].piece < 262144) scan[d].piece = 262144;
             }
             scan[d].cstride = k.cstride; scan[d].lock = &k.lock; scan[d].cond = &k.cond; scan[d].failed = &k.failed;
             scan[d].counts = (int32_t*)malloc((size_t)(row_max - row_min + 1) * (size_t)k.cstride * 4);
