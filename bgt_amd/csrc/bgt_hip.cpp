@@ -521,17 +521,20 @@ static void fit_sub_shift(bgth_pbf_t *p, int64_t n)
     const int top = std::min(p->shift, 11), chunks = (p->m + 63) / 64;
     int slices = 1;                                      // column slices of a long whole-cohort scan
     int64_t slots = 256;                                 // workgroups the chip holds at a time
-    Geometry g, w;
+    bool plane = false;                                  // sample subsets of this width go to the plane-split kernels:
+    Geometry g, w;                                       //   one workgroup per sub-block and plane, two per CU
     if (choose_geometry(p->m, chunks, 1, 4096, 0, 0, 0, &g)) {
         slices = g.slices;
-        if (g.nbuf == 1 && g.wpp > 1 && choose_walk_geometry(p->m, chunks, 1, 4096, 0, 0, &w)) slices = w.slices;
+        if (g.nbuf == 1 && g.wpp > 1 && choose_walk_geometry(p->m, chunks, 1, 4096, 0, 0, &w)) { slices = w.slices; plane = true; }
         else slots = 256 * (int64_t)std::max(1, std::min(2048 / g.threads, (160 * 1024) / std::max(1, g.lds_bytes)));
     }
     double best = 1e30;
     int pick = top;
     for (int s = top; s >= std::min(top, 7); --s) {
-        const int64_t wgs = ((n + ((int64_t)1 << s) - 1) >> s) * slices;
-        const double t = (1.0 + 10.0 / (double)((int64_t)1 << s)) * (double)((wgs + slots - 1) / slots * slots) / (double)wgs;
+        const int64_t subs = (n + ((int64_t)1 << s) - 1) >> s, wgs = subs * slices;
+        const double start = 1.0 + 10.0 / (double)((int64_t)1 << s);
+        double t = start * (double)((wgs + slots - 1) / slots * slots) / (double)wgs;
+        if (plane) t += start * (double)((2 * subs + 511) / 512 * 512) / (double)(2 * subs);
         if (t < best * 0.98) { best = t; pick = s; }
     }
     p->sub_shift = pick;
@@ -1749,10 +1752,12 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
         else if (wgeo.slices < 2 && 2 * (int64_t)r->sel.width < p->m && !variant_flag(kVariantDirAlways)) dirpath = false;
     }
     // Plane-split kernels: a selection of few columns of a WIDE cohort (the team kernels would run one workgroup per CU,
-    // mostly building): one workgroup per plane, two per CU.  BGTH_VARIANT 2048 / 4096 forbid / force them.
+    // mostly building): one workgroup per plane, two per CU.  BGTH_VARIANT 2048 / 4096 forbid / force them.  Team kernels that
+    // batch rows (K > 1: m = 40,000 ... 100,000) keep selections of more than a sixth of the cohort (scripts/subset_ab.py:
+    // every 13th of 64,976 columns 1.59 against 1.90 ms, every 10th of 100,000 5.7 against 7.7 ms, every 4th of 64,976 2.68 against 2.44 ms).
     Geometry pgeo;
     bool planepath = !dirpath && !variant_flag(kVariantPlaneNever) && !(r->tune_threads || r->tune_cpt || r->tune_K) &&
-                     ((geo.nbuf == 1 && geo.wpp > 1 && geo.K == 1) || variant_flag(kVariantPlaneAlways)) &&
+                     ((geo.nbuf == 1 && geo.wpp > 1 && (geo.K == 1 || 6 * (int64_t)r->sel.width <= p->m)) || variant_flag(kVariantPlaneAlways)) &&
                      choose_plane_geometry(p->m, r->sel.n_chunks, (int)(blk1 - blk0 + 1), &pgeo);
     uint64_t *p_h0 = d_h0, *p_h1 = d_h1;
     if (planepath && !d_h0) {
