@@ -685,7 +685,7 @@ int main_import(int argc, char *argv[])
     int m = 0;
     const atom_t *a;
 
-    optind = 1;
+    optind = 0;
     while ((c = getopt(argc, argv, "1l:SFt:")) >= 0) {
         switch (c) {
         case 'l': clevel = atoi(optarg); break;

@@ -120,7 +120,7 @@ int view_run(int argc, char *argv[], FILE *out, FILE *err, const bgt_view_host_t
 
     int first_file;
     pthread_mutex_lock(&g_getopt_lock);
-    optind = 1;
+    optind = 0;                                                     /* glibc: 0 re-initialises the scanner -- it keeps a pointer INTO the argv of the call before (freed by a resident host) */
     while ((c = getopt(argc, argv, "ubs:r:l:CMGB:ef:g:a:i:n:SHt:d:")) >= 0) {
         switch (c) {
         case 'b': out_bcf = 1; break;

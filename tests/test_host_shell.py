@@ -203,3 +203,27 @@ def test_launcher_starts_without_the_device_libraries():
     must not pay 13 ms of dynamic linking)."""
     out = subprocess.check_output(["ldd", BGT]).decode()
     assert "libbgt" not in out and "amdhip" not in out, out
+
+
+def test_resident_host_parses_every_query_afresh(tmp_path):
+    """A resident host runs view_run() many times in one process: getopt's scanner must start over for every query (glibc keeps
+    the permutation state of the call before unless optind is set to 0).  Queries whose databases do not exist fail at the
+    open, naming the prefix -- the right one, whatever was parsed before.  No device needed."""
+    sock = str(tmp_path / "bgt.sock")
+    srv = subprocess.Popen([os.path.join(ROOT, "bgt_amd", "bin", "bgt-server"), "-u", sock], stderr=subprocess.PIPE)
+    try:
+        t0 = time.time()
+        while not os.path.exists(sock):
+            assert srv.poll() is None and time.time() - t0 < 60, "bgt-server -u did not come up"
+            time.sleep(0.02)
+        env = dict(os.environ, BGT_SERVER=sock)
+        seq = [(["-C", "-G"], ["none1"]), ([], ["none2", "other2"]), (["-C", "-G"], ["none3"]), (["-B", "points.bed", "-s", 'pop=="X"'], ["none4"]),
+               (["-GC", "-f", "AC>0"], ["none5", "other5", "third5"]), ([], ["none6"]), (["-B", "points.bed"], ["none7"]),
+               (["-G", "-t", "CHROM,POS"], ["none8"])]
+        for rnd in range(2):
+            for args, prefixes in seq:
+                res = subprocess.run([BGT, "view"] + args + prefixes, cwd=GOLD, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60, env=env)
+                assert res.returncode == 1 and ("prefix '%s'" % prefixes[0]) in res.stderr.decode(), (args, prefixes, res.stderr.decode()[-200:])
+    finally:
+        srv.terminate()
+        srv.wait(timeout=30)
