@@ -10,14 +10,17 @@ strings, row directory, checkpoints) are resident in HBM before the timed region
           then `secondary` records at 100,000 samples (the north-star width): C3 (1,000,000 sites, every 20th sample =
           10,000 tracked columns) and one C4 shard (153 file blocks = 1,253,376 sites, whole cohort), each with its own
           roofline and a CPU baseline from the compiled reference on the first sites of the same database.
-  N > 1   default --workload c4 = BASELINE configs[3] itself, strong scaling: the 1,221 file blocks of ONE database of
-          100,000 samples x 10,000,000 sites split over the N ranks (153 blocks per rank at N = 8; site-range sharding, no
-          data-path collective), then an all_gather over RCCL/xGMI of the per-shard counts and flags.  Every rank builds
-          its shard from the identity order, the shards' final ranks are exchanged and each shard is re-based onto the
-          composition of the earlier ones (bgth_pbf_rebase), so the gathered counts are those of the one database.  Rank 0
-          checks them after the timed region: the plane-popcount identity on every site of every shard and a CPU-oracle
-          window that runs across the boundary between shard 0 and shard 1 (`parity_ok`).  (The N = 1 point of this
-          workload: `bench.py --workload c4`.)  --workload c2: weak scaling, rank r scans sites [r*1M, (r+1)*1M).
+  N > 1   headline: the SAME per-GPU workload, weak scaling (the driver compares this value with the N = 1 value): rank r holds
+          sites [r, r+1) x 1,000,000 of ONE C2-width database of N x 1,000,000 sites (site-range sharding, no data-path
+          collective), then an all_gather over RCCL/xGMI of the per-shard counts and flags.  Every rank builds its shard
+          from the identity order, the shards' final ranks are exchanged and each shard is re-based onto the composition
+          of the earlier ones (bgth_pbf_rebase), so the gathered counts are those of the one database.  Rank 0 checks them
+          after the timed region: the plane-popcount identity on every site of every shard and a CPU-oracle window that
+          runs across the boundary between shard 0 and shard 1 (`parity_ok`).
+          secondary "C4-sharded" (same run, same checks): BASELINE configs[3] itself, strong scaling -- the 1,221 file
+          blocks of ONE database of 100,000 samples x 10,000,000 sites split over the N ranks (153 blocks per rank at
+          N = 8).  `--workload c4` makes it the headline (its N = 1 point: `bench.py --workload c4`).
+          On failure the failing rank prints one JSON line with the error, its rank and device.
 
 Prints one JSON line (rank 0).
 
@@ -38,6 +41,7 @@ passing line) with the image resident in a `bgt-server -u` host; `cli_end_to_end
 `cpu_baseline` = the compiled reference (oracle/_ref/bgt) timed on this box's host cores on a bounded sample.
 """
 import argparse
+import datetime
 import hashlib
 import json
 import os
@@ -46,6 +50,7 @@ import subprocess
 import sys
 import tempfile
 import time
+import types
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -708,68 +713,24 @@ def secondary_record(torch, bgt_amd, np, peak, name, what, n_samples, sites, see
     return rec
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default=None, choices=sorted(SAMPLES),
-                    help="default: c2 on one GPU, c4 (BASELINE configs[3], strong scaling over one database) on several")
-    ap.add_argument("--sites", type=int, default=0, help="sites per GPU (default 1,000,000; c4: all 10,000,000 split over the GPUs)")
-    ap.add_argument("--every", type=int, default=0, help="select every N-th sample only (C3: --workload c3 --every 20)")
-    ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--cpu-sample", type=int, default=262144, help="sites for the CPU baseline (0 = skip)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the 100,000-sample secondary records (N = 1)")
-    ap.add_argument("--secondary-steps", type=int, default=3)
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo = dry run through host copies)")
-    ap.add_argument("--threads", type=int, default=0)
-    ap.add_argument("--cpt", type=int, default=0)
-    ap.add_argument("--batch", type=int, default=0)
-    ap.add_argument("--no-counters", action="store_true", help="skip the in-run rocprofv3 --pmc passes (HBM traffic of the scan kernel)")
-    ap.add_argument("--counters-child", default=None, help=argparse.SUPPRESS)
-    args = ap.parse_args()
-    if args.counters_child:
-        counters_child(args.counters_child)
-        return
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if args.gpus != 1 and world == 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run" % args.gpus)
-
-    import numpy as np
-    import torch
-    import bgt_amd
-    from bgt_amd.shard import block_shards
-
-    if os.environ.get("BENCH_ALL_RANKS_ON_DEVICE0"):         # dry run of N > 1 on a one-GPU box (with --backend gloo)
-        local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
-        else:
-            dist.init_process_group(args.backend)
-
-    if args.workload is None:
-        args.workload = "c2" if world == 1 else "c4"
-    n_samples = SAMPLES[args.workload]
+def sharded_run(args, ctx, workload, steps, warmup, sites_arg):
+    """One timed run of the hot path over this rank's shard: synthetic rows -> image in HBM -> (N > 1: chained onto the shards
+    before it) -> `steps` x (scan + device filter + gather + copy to rank 0's pinned memory) -> rank 0's on-box parity checks
+    of the gathered result.  Returns a namespace with the record (rank 0: .out) and what the N = 1 follow-ups use."""
+    torch, bgt_amd, np, dist, rank, world, local, dev, block_shards = (ctx.torch, ctx.bgt_amd, ctx.np, ctx.dist, ctx.rank, ctx.world,
+                                                                        ctx.local, ctx.dev, ctx.block_shards)
+    n_samples = SAMPLES[workload]
     m = 2 * n_samples
     shift = 13
-    seed = args.seed or {"c2": 2, "c3": 3, "c4": 4, "small": 1, "hrc": 7}[args.workload]
-    strong = args.workload == "c4"
+    seed = args.seed or {"c2": 2, "c3": 3, "c4": 4, "small": 1, "hrc": 7}[workload]
+    strong = workload == "c4"
     if strong:                                                # configs[3]: one database, block-aligned shards (SURVEY 8e)
-        total = args.sites or 10000000
+        total = sites_arg or 10000000
         shards = block_shards(total, shift, world)
         row_lo, row_hi = shards[rank]
         sites = shards[0][1] - shards[0][0]                   # every rank's buffers are sized for the longest shard
     else:
-        sites = args.sites or 1000000
+        sites = sites_arg or 1000000
         total = world * sites
         row_lo, row_hi = rank * sites, (rank + 1) * sites
 
@@ -811,7 +772,9 @@ def main():
     rd.tune(args.threads, args.cpt, args.batch)
     T = rd.width
 
-    peak = lookup_peak(bgt_amd, local) if rank == 0 else None
+    if rank == 0 and ctx.peak is None:
+        ctx.peak = lookup_peak(bgt_amd, local)
+    peak = ctx.peak
     pipe = Pipeline(torch, bgt_amd, rd, 0, sites, dev, local, world, rank, dist)
     # Every timed step does ALL the work of a pass: on the directory path (wide cohorts: C4) the rows are built again by every
     # step instead of being walked from the arena the step before left behind (BGTH_VARIANT bit 128; no effect on the other
@@ -820,7 +783,7 @@ def main():
     if one_shot_forced:
         os.environ["BGTH_VARIANT"] = "128"
     try:
-        dt, k_ms, last = pipe.run(args.steps, args.warmup)
+        dt, k_ms, last = pipe.run(steps, warmup)
     finally:
         if one_shot_forced:
             os.environ.pop("BGTH_VARIANT")
@@ -842,6 +805,9 @@ def main():
         ks = [torch.zeros(1, dtype=torch.float64, device=cdev) for _ in range(world)]
         dist.all_gather(ks, torch.tensor([k_ms], dtype=torch.float64, device=cdev))
         rank_kernel_ms = [float(k.item()) for k in ks]
+        dv = [torch.zeros(1, dtype=torch.float64, device=cdev) for _ in range(world)]
+        dist.all_gather(dv, torch.tensor([float(torch.cuda.current_device())], dtype=torch.float64, device=cdev))
+        rank_devices = [int(x.item()) for x in dv]
         # ---- parity of the gathered result, after the timed region.  (1) every rank counts the ones of its strings; rank 0
         # holds the gathered counts and checks the plane-popcount identity on every site of every shard
         real = row_hi - row_lo
@@ -873,23 +839,23 @@ def main():
                                            "matches": bool(np.array_equal(oc, got)), "oracle_s": round(t_or, 2)}
             parity["parity_ok"] = bool(parity["oracle_window"]["matches"] and parity["popcount_identity_ok"] is not False)
 
-    ms_per_step = dt / args.steps * 1e3
-    value = total / (dt / args.steps)
+    ms_per_step = dt / steps * 1e3
+    value = total / (dt / steps)
     geo = rd.geometry()
 
     out = None
     if rank == 0:
-        if args.workload == "c2":
+        if workload == "c2":
             wl = "C2: synthetic %d samples x %d sites per GPU, whole cohort, -G -f'AC>0'" % (n_samples, sites)
         elif strong:
             wl = "C4: synthetic %d samples x %d sites, whole cohort, -G -f'AC>0', %d file blocks sharded over %d GPU(s)" % (
                 n_samples, total, (total + 8191) // 8192, world)
         else:
-            wl = "%s: %d samples x %d sites per GPU%s" % (args.workload, n_samples, sites,
+            wl = "%s: %d samples x %d sites per GPU%s" % (workload, n_samples, sites,
                                                           ", every %d-th sample selected" % args.every if args.every > 1 else "")
         out = {
             "metric": "sites/sec `bgt view -G -f'AC>0'` whole-cohort scan",
-            "value": value, "unit": "sites/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "sites/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": ("strong" if strong else "weak") if world > 1 else None,      # (one GPU: nothing scales)
             "vs_baseline": None,
@@ -906,7 +872,7 @@ def main():
                        "filter": "AC>0 evaluated on the device (bgth_filter_apply_device); counts + flags copied "
                                  "to pinned host memory, the copy of step i overlapping the scan of step i+1",
                        "launch": geo},
-            "roofline": make_roofline(peak, T, sites, k_ms, rle_bytes_per_site, geo, args.workload, sites, rd.path()),
+            "roofline": make_roofline(peak, T, sites, k_ms, rle_bytes_per_site, geo, workload, sites, rd.path()),
             "setup": {"generate_s": round(t_gen, 2), "upload_and_checkpoints_s": round(t_load, 2),
                       "hbm_resident_bytes": pbf.hbm_bytes},
         }
@@ -914,6 +880,8 @@ def main():
             out["parity_ok"] = parity["parity_ok"]
             out["parity"] = parity
             out["per_rank_kernel_ms"] = rank_kernel_ms
+            out["ranks"] = {"world_size": world, "backend": dist.get_backend(), "device_of_rank": rank_devices,
+                            "devices_visible": torch.cuda.device_count()}
             out["gather_ms"] = pipe.gather_ms
             out["setup"]["chain_shards_s"] = round(t_chain, 2)
             out["config"]["one_database"] = ("every shard built from the identity order, then re-based onto the composition of "
@@ -924,6 +892,101 @@ def main():
                 out["parity_error"] = "gathered counts fail the on-box checks: %s" % json.dumps(parity)
             if strong:
                 out["config"]["n1_point"] = "python bench.py --workload c4 (the same database on one GPU)"
+
+    R = types.SimpleNamespace(out=out, rle=rle, lens=lens, pbf=pbf, rd=rd, pipe=pipe, sites=sites, total=total, m=m, shift=shift, seed=seed,
+                              row_lo=row_lo, n_samples=n_samples, geo=geo, k_ms=k_ms, T=T,
+                              host=pipe.host[last] if rank == 0 else None, host_flags=pipe.host_flags[last] if rank == 0 else None)
+
+    def release():
+        R.pipe = R.host = R.host_flags = R.rle = R.lens = None
+        R.rd.close()
+        R.pbf.close()
+        torch.cuda.empty_cache()
+    R.release = release
+    return R
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default=None, choices=sorted(SAMPLES),
+                    help="default: c2 on one GPU, c4 (BASELINE configs[3], strong scaling over one database) on several")
+    ap.add_argument("--sites", type=int, default=0, help="sites per GPU (default 1,000,000; c4: all 10,000,000 split over the GPUs)")
+    ap.add_argument("--every", type=int, default=0, help="select every N-th sample only (C3: --workload c3 --every 20)")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--cpu-sample", type=int, default=262144, help="sites for the CPU baseline (0 = skip)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the 100,000-sample secondary records (N = 1)")
+    ap.add_argument("--secondary-steps", type=int, default=3)
+    ap.add_argument("--secondary-sites", type=int, default=0, help="N > 1: total sites of the C4-sharded secondary record (default 10,000,000)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo = dry run through host copies)")
+    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--cpt", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--no-counters", action="store_true", help="skip the in-run rocprofv3 --pmc passes (HBM traffic of the scan kernel)")
+    ap.add_argument("--counters-child", default=None, help=argparse.SUPPRESS)
+    args = ap.parse_args()
+    if args.counters_child:
+        counters_child(args.counters_child)
+        return
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if args.gpus != 1 and world == 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run" % args.gpus)
+
+    import numpy as np
+    import torch
+    import bgt_amd
+    from bgt_amd.shard import block_shards
+
+    if os.environ.get("BENCH_ALL_RANKS_ON_DEVICE0"):         # dry run of N > 1 on a one-GPU box (with --backend gloo)
+        local = 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        if args.backend == "nccl":
+            # ("nccl" is RCCL on ROCm.)  A rank that fails alone leaves the others in a collective: five minutes, not the default ten+
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=5))
+        else:
+            dist.init_process_group(args.backend, timeout=datetime.timedelta(minutes=5))
+
+    ctx = types.SimpleNamespace(torch=torch, bgt_amd=bgt_amd, np=np, dist=dist, rank=rank, world=world, local=local, dev=dev,
+                                block_shards=block_shards, peak=None)
+    # One GPU: C2, the configuration the metric is quoted on.  Several GPUs: the SAME per-GPU workload, weak scaling -- rank r
+    # holds sites [r, r+1) x 1,000,000 of ONE database of N x 1,000,000 sites (a per-N value the N = 1 value compares with) --
+    # and, as a secondary record of the same run, BASELINE configs[3]: the 10,000,000-site x 100,000-sample database
+    # block-sharded over the N GPUs (strong scaling; `--workload c4` makes it the headline).
+    headline_wl = args.workload or "c2"
+    R = sharded_run(args, ctx, headline_wl, args.steps, args.warmup, args.sites)
+    out = R.out
+    (rle, lens, pbf, rd, pipe, sites, total, m, shift, seed, row_lo, n_samples, geo, k_ms, peak, T) = (
+        R.rle, R.lens, R.pbf, R.rd, R.pipe, R.sites, R.total, R.m, R.shift, R.seed, R.row_lo, R.n_samples, R.geo, R.k_ms, ctx.peak, R.T)
+    host, host_flags = R.host, R.host_flags
+    args.workload = headline_wl
+    if world > 1 and headline_wl == "c2" and not args.no_secondary and not args.every:
+        del pipe, rd, pbf, rle, lens, host, host_flags
+        R.release()
+        try:
+            R4 = sharded_run(args, ctx, "c4", args.secondary_steps, 1, args.secondary_sites)
+            if rank == 0:
+                rec = R4.out
+                rec["name"] = "C4-sharded"
+                for k in ("metric", "unit", "higher_is_better", "vs_baseline", "vs_baseline_note", "value_scope", "dtype", "data"):
+                    rec.pop(k, None)
+                out["secondary"] = [rec]
+                if rec.get("parity_error"):
+                    out["parity_error"] = "C4-sharded: " + rec["parity_error"]
+            R4.release()
+        except Exception as e:                                    # the headline stands; the record says what happened
+            if rank == 0:
+                out["secondary"] = [{"name": "C4-sharded", "error": repr(e)[:400]}]
+        rle = lens = pbf = rd = pipe = host = host_flags = None
 
     # ---- CPU baseline + on-box parity check (rank 0, N=1 only) on a bounded sample of the same cohort:
     # the first `cpu_sample` sites.  The COMPILED REFERENCE (oracle/_ref/bgt, built from /root/reference in the build
@@ -1054,4 +1117,14 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as exc:                                   # one line a first multi-GPU run can be diagnosed from
+        import traceback
+        print(json.dumps({"metric": "sites/sec `bgt view -G -f'AC>0'` whole-cohort scan", "value": None, "unit": "sites/s",
+                          "n_gpus": int(os.environ.get("WORLD_SIZE", "1")), "error": repr(exc)[:600],
+                          "failed_rank": int(os.environ.get("RANK", "0")), "failed_local_rank": int(os.environ.get("LOCAL_RANK", "0")),
+                          "traceback_tail": traceback.format_exc().splitlines()[-6:]}), flush=True)
+        raise

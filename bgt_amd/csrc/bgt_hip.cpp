@@ -51,6 +51,23 @@ static void set_err(const char *fmt, ...)
 
 extern "C" const char *bgth_last_error(void) { return g_err; }
 
+// Device memory of a process that ended a moment ago (the child `bgt view` leaves behind, view_cli.c: work_in_a_child) comes
+// back asynchronously: an allocation that fails for lack of memory is tried again for up to BGTH_OOM_WAIT_MS (default 300 ms,
+// 0 = fail at once) before it is an error.  Every hipMalloc of this file goes through here.
+static hipError_t dev_malloc_retry(void **p, size_t n)
+{
+    hipError_t e = (hipMalloc)(p, n);
+    if (e != hipErrorOutOfMemory) return e;
+    static const int wait_ms = [] { const char *v = getenv("BGTH_OOM_WAIT_MS"); const int w = v ? atoi(v) : 300; return w < 0 ? 0 : (w > 10000 ? 10000 : w); }();
+    for (int waited = 0; waited < wait_ms && e == hipErrorOutOfMemory; waited += 25) {
+        (void)hipGetLastError();                                         // (the failed call's sticky status)
+        std::this_thread::sleep_for(std::chrono::milliseconds(25));
+        e = (hipMalloc)(p, n);
+    }
+    return e;
+}
+#define hipMalloc(p, n) dev_malloc_retry((void**)(p), (n))
+
 // Nothing C++ may cross the C ABI: entry points that build host-side vectors run under this guard.  An image under
 // construction is registered in t_building so that an exception does not leak its device memory.
 static thread_local bgth_pbf_t *t_building = nullptr;

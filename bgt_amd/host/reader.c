@@ -1879,6 +1879,13 @@ static void *bulk_worker(void *arg)
     return NULL;
 }
 
+/* BGT_TRACE=1: the timeline of a bulk walk, ms since its start (tuning aid) */
+static double g_bulk_t0;
+static void bulk_mark(const char *what, long n)
+{
+    if (getenv("BGT_TRACE")) fprintf(stderr, "[bgt trace]   bulk +%7.2f ms  %s %ld\n", rd_now_ms() - g_bulk_t0, what, n);
+}
+
 static void *bulk_scan_worker(void *arg)
 {
     bulk_scan_t *q = (bulk_scan_t*)arg;
@@ -1891,6 +1898,7 @@ static void *bulk_scan_worker(void *arg)
             q->rc = -1;
             strncpy(q->err, bgth_last_error(), sizeof(q->err) - 1); q->err[sizeof(q->err) - 1] = 0;
         }
+        bulk_mark("device piece done, rows", (long)(a1 - q->r0));
         pthread_mutex_lock(q->lock);
         if (q->rc == 0) q->ready = a1 - q->r0; else *q->failed = 1;
         pthread_cond_broadcast(q->cond);
@@ -1909,6 +1917,7 @@ long bgtm_write_vcf_bulk(bgtm_t *bm, FILE *fp, long n_rec)
     int64_t i, lo[BULK_MAX_DB], hi[BULK_MAX_DB], cur[BULK_MAX_DB], total = 0, cap = 0;
     long written = 0;
     int n_threads, j, d, failed = 0;
+    g_bulk_t0 = rd_now_ms();
     if (bm->h_out == NULL && bgtm_prepare(bm) < 0) return -2;
     if (bm->n_bgt < 1 || bm->n_bgt > BULK_MAX_DB || !(bm->flag & BGT_F_NO_GT) || (bm->flag & (BGT_F_CNT_AL | BGT_F_CNT_HAP)) || bm->h_al || bm->n_fields > 0) return -1;
     memset(&k, 0, sizeof(k));
@@ -1928,34 +1937,9 @@ long bgtm_write_vcf_bulk(bgtm_t *bm, FILE *fp, long n_rec)
     }
     if (total == 0) return 0;
     if (n_rec < total) return -1;                                /* -n counts EMITTED records: site by site */
-    /* the merged order, exactly as read_core finds it: the smallest look-ahead site, every database at that site consumed */
-    for (d = 0; d < k.n_db; ++d) { cur[d] = lo[d]; k.idx[d] = NULL; }
-    cap = k.n_db == 1 ? total : total / 2 + 1024;
-    for (d = 0; d < k.n_db; ++d) k.idx[d] = (int32_t*)malloc((size_t)cap * 4);
-    k.lead = (uint8_t*)malloc((size_t)cap);
-    for (;;) {
-        int best = -1;
-        for (d = 0; d < k.n_db; ++d) {
-            if (cur[d] >= hi[d]) continue;
-            if (best < 0 || st_cmp(k.t[best], cur[best], k.t[d], cur[d]) > 0) best = d;
-        }
-        if (best < 0) break;
-        if (k.n_sites == cap) {
-            cap += cap / 2 + 1024;
-            for (d = 0; d < k.n_db; ++d) k.idx[d] = (int32_t*)realloc(k.idx[d], (size_t)cap * 4);
-            k.lead = (uint8_t*)realloc(k.lead, (size_t)cap);
-        }
-        k.lead[k.n_sites] = (uint8_t)best;
-        {
-            const int64_t at = cur[best];                         /* (compare the others with the chosen head before it moves) */
-            for (d = 0; d < k.n_db; ++d) {
-                if (d != best && cur[d] < hi[d] && st_cmp(k.t[best], at, k.t[d], cur[d]) == 0) k.idx[d][k.n_sites] = (int32_t)cur[d]++;
-                else if (d != best) k.idx[d][k.n_sites] = -1;
-            }
-            k.idx[best][k.n_sites] = (int32_t)cur[best]++;
-        }
-        ++k.n_sites;
-    }
+    /* the merged order, exactly as read_core finds it: the smallest look-ahead site, every database at that site consumed.
+     * (Built AFTER the device passes below have been started: it is ~5 ns x sites of one thread's time the device does not
+     * have to wait for; one database = its own order.) */
     /* counts: one device pass per database over the rows its sites use, the databases side by side and each in pieces, so
      * that the formatters below work on the sites of piece k while the device scans piece k+1 */
     memset(scan, 0, sizeof(scan));
@@ -1992,7 +1976,43 @@ long bgtm_write_vcf_bulk(bgtm_t *bm, FILE *fp, long n_rec)
         for (d = 0; d < k.n_db; ++d)
             if (scan[d].rd && pthread_create(&scan[d].th, NULL, bulk_scan_worker, &scan[d]) == 0) scan[d].started = 1;
     }
-    k.blk_sites = 8192;
+    bulk_mark("device passes started, databases", (long)k.n_db);
+    if (k.n_db == 1) {                                            /* one database: site j of the output is its site lo + j */
+        k.idx[0] = (int32_t*)malloc((size_t)total * 4);
+        k.lead = (uint8_t*)calloc((size_t)total, 1);
+        for (i = 0; i < total; ++i) k.idx[0][i] = (int32_t)(lo[0] + i);
+        k.n_sites = total;
+    } else {
+        for (d = 0; d < k.n_db; ++d) { cur[d] = lo[d]; k.idx[d] = NULL; }
+        cap = k.n_db == 1 ? total : total / 2 + 1024;
+        for (d = 0; d < k.n_db; ++d) k.idx[d] = (int32_t*)malloc((size_t)cap * 4);
+        k.lead = (uint8_t*)malloc((size_t)cap);
+        for (;;) {
+            int best = -1;
+            for (d = 0; d < k.n_db; ++d) {
+                if (cur[d] >= hi[d]) continue;
+                if (best < 0 || st_cmp(k.t[best], cur[best], k.t[d], cur[d]) > 0) best = d;
+            }
+            if (best < 0) break;
+            if (k.n_sites == cap) {
+                cap += cap / 2 + 1024;
+                for (d = 0; d < k.n_db; ++d) k.idx[d] = (int32_t*)realloc(k.idx[d], (size_t)cap * 4);
+                k.lead = (uint8_t*)realloc(k.lead, (size_t)cap);
+            }
+            k.lead[k.n_sites] = (uint8_t)best;
+            {
+                const int64_t at = cur[best];                         /* (compare the others with the chosen head before it moves) */
+                for (d = 0; d < k.n_db; ++d) {
+                    if (d != best && cur[d] < hi[d] && st_cmp(k.t[best], at, k.t[d], cur[d]) == 0) k.idx[d][k.n_sites] = (int32_t)cur[d]++;
+                    else if (d != best) k.idx[d][k.n_sites] = -1;
+                }
+                k.idx[best][k.n_sites] = (int32_t)cur[best]++;
+            }
+            ++k.n_sites;
+        }
+    }
+    bulk_mark("merged order built, sites", (long)k.n_sites);
+    k.blk_sites = 4096;
     k.n_blocks = (k.n_sites + k.blk_sites - 1) / k.blk_sites;
     k.out = (kstring_t*)calloc((size_t)k.n_blocks, sizeof(kstring_t));
     k.n_lines = (int64_t*)calloc((size_t)k.n_blocks, 8);
@@ -2009,14 +2029,17 @@ long bgtm_write_vcf_bulk(bgtm_t *bm, FILE *fp, long n_rec)
     for (d = 0; d < k.n_db; ++d) if (scan[d].rd && !scan[d].started) {   /* no thread for it: the device pass runs here */
         bulk_scan_worker(&scan[d]);
     }
+    bulk_mark("formatter threads started", (long)n_started);
     if (n_started == 0) bulk_worker(&k);                          /* no formatter thread could be started: format here */
     for (i = 0; i < k.n_blocks; ++i) {                            /* blocks leave in order, as soon as they are ready */
         pthread_mutex_lock(&k.lock);
         while (!k.done[i]) pthread_cond_wait(&k.cond, &k.lock);
         pthread_mutex_unlock(&k.lock);
+        if (i == 0 || i == k.n_blocks / 2) bulk_mark("block ready to leave", (long)i);
         if (k.out[i].l && !k.failed) { fwrite(k.out[i].s, 1, k.out[i].l, fp); written += (long)k.n_lines[i]; }   /* (only what left) */
         free(k.out[i].s); k.out[i].s = NULL;
     }
+    bulk_mark("last block written, lines", written);
     for (j = 0; j < n_started; ++j) pthread_join(th[j], NULL);
     for (d = 0; d < k.n_db; ++d) {
         if (scan[d].started) pthread_join(scan[d].th, NULL);

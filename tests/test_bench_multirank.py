@@ -17,12 +17,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("workload,sites,extra", [("c4", 6 * 8192 - 1000, []), ("c2", 40000, [])])
+@pytest.mark.parametrize("workload,sites,extra", [("c4", 6 * 8192 - 1000, []), ("c2", 40000, ["--no-secondary"])])
 def test_two_ranks_on_one_device(workload, sites, extra):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--backend", "gloo", "--sites", str(sites)] + (["--workload", workload] if workload != "c4" else []) + extra
+           "--backend", "gloo", "--sites", str(sites)] + ["--workload", workload] + extra
     env = dict(os.environ, BENCH_ALL_RANKS_ON_DEVICE0="1", BGTH_DIR_ARENA_MB="6000")
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=1200, cwd=ROOT)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
@@ -36,3 +36,23 @@ def test_two_ranks_on_one_device(workload, sites, extra):
     assert out["parity"]["popcount_identity_ok"] is True and out["parity"]["oracle_window"]["matches"] is True
     assert out["parity"]["sites_checked_popcount_identity"] == out["config"]["sites_total"]
     assert len(out["per_rank_kernel_ms"]) == 2 and "parity_error" not in out
+
+
+def test_default_run_of_two_ranks_carries_the_sharded_c4_record():
+    """The driver's command without --workload: the headline is the per-GPU C2 workload (weak scaling: a value the N = 1 value
+    compares with), BASELINE configs[3] block-sharded over the ranks rides along as secondary record, both checked on the box."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--backend", "gloo", "--sites", "40000", "--secondary-sites", str(6 * 8192 - 1000), "--secondary-steps", "1"]
+    env = dict(os.environ, BENCH_ALL_RANKS_ON_DEVICE0="1", BGTH_DIR_ARENA_MB="6000")
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=1200, cwd=ROOT)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    out = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["haplotypes"] == 20000 and out["parity_ok"] is True
+    assert out["ranks"]["world_size"] == 2 and out["ranks"]["device_of_rank"] == [0, 0]
+    sec = out["secondary"][0]
+    assert sec["name"] == "C4-sharded" and "error" not in sec, sec
+    assert sec["scaling"] == "strong" and sec["config"]["haplotypes"] == 200000 and sec["value"] > 0
+    assert sec["parity_ok"] is True and sec["parity"]["sites_checked_popcount_identity"] == sec["config"]["sites_total"]
+    assert "parity_error" not in out
