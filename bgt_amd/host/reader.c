@@ -1803,17 +1803,82 @@ typedef struct {
     const sitetab_t *t[BULK_MAX_DB]; int64_t row_min[BULK_MAX_DB]; const int32_t *counts[BULK_MAX_DB];
     /* the merged walk: site j of the output is site idx[d][j] of database d (-1: that database lacks it); lead[j] = the
      * database whose record describes the site (the smallest look-ahead, first of equals: read_core's `best`) */
-    int64_t n_sites; int32_t *idx[BULK_MAX_DB]; uint8_t *lead;
+    int64_t n_sites; int32_t *idx[BULK_MAX_DB]; uint8_t *lead;   /* one database: both NULL = its own order from site lo0 on */
+    int64_t lo0;
     int64_t n_blocks, blk_sites;
     kstring_t *out; int64_t *n_lines; volatile int *done;
     int64_t next_block;
+    double wall_ms, cpu_ms;                                       /* BGT_TRACE: formatting time over all blocks, wall and thread CPU */
+    int via_record;
     pthread_mutex_t lock; pthread_cond_t cond;
 } bulk_t;
+
+#define BULK_IDX(k, d, j) ((k)->idx[d] ? (int64_t)(k)->idx[d][j] : (k)->lo0 + (j))
+#define BULK_LEAD(k, j)   ((k)->lead ? (k)->lead[j] : 0)
+
+/* Buffers that outlive a walk.  A formatted block is ~200 KB and the counts of a database are 12 bytes per row: fresh
+ * allocations of that size are mmap'ed and page-faulted by 64 threads at once, all through one address-space lock (measured
+ * at C2 scale in a resident host: a block of 4,096 sites took 8 ms to format instead of 1.8, and the device pass's copy
+ * to the host stalled behind the faults for up to 50 ms).  So blocks are formatted into buffers taken from -- and returned
+ * to -- a process-wide pool, and the counts buffer of the last walk is kept for the next one. */
+#define BULK_POOL_MAX 512
+static struct { pthread_mutex_t lock; char *s[BULK_POOL_MAX]; size_t m[BULK_POOL_MAX]; int n; int32_t *counts; size_t counts_bytes; } g_bulk_pool =
+    { PTHREAD_MUTEX_INITIALIZER, {0}, {0}, 0, NULL, 0 };
+static void bulk_buf_get(kstring_t *o, size_t want)
+{
+    o->l = 0; o->m = 0; o->s = NULL;
+    pthread_mutex_lock(&g_bulk_pool.lock);
+    if (g_bulk_pool.n > 0) { --g_bulk_pool.n; o->s = g_bulk_pool.s[g_bulk_pool.n]; o->m = g_bulk_pool.m[g_bulk_pool.n]; }
+    pthread_mutex_unlock(&g_bulk_pool.lock);
+    if (o->s == NULL) { o->s = (char*)malloc(want); o->m = o->s ? want : 0; }
+}
+static void bulk_buf_put(kstring_t *o)
+{
+    if (o->s == NULL) return;
+    pthread_mutex_lock(&g_bulk_pool.lock);
+    if (g_bulk_pool.n < BULK_POOL_MAX && o->m <= (4u << 20)) { g_bulk_pool.s[g_bulk_pool.n] = o->s; g_bulk_pool.m[g_bulk_pool.n] = o->m; ++g_bulk_pool.n; o->s = NULL; }
+    pthread_mutex_unlock(&g_bulk_pool.lock);
+    free(o->s);
+    o->s = NULL; o->l = o->m = 0;
+}
+static int32_t *bulk_counts_get(size_t bytes)
+{
+    int32_t *p = NULL;
+    pthread_mutex_lock(&g_bulk_pool.lock);
+    if (g_bulk_pool.counts && g_bulk_pool.counts_bytes >= bytes) { p = g_bulk_pool.counts; g_bulk_pool.counts = NULL; }
+    pthread_mutex_unlock(&g_bulk_pool.lock);
+    return p ? p : (int32_t*)malloc(bytes);
+}
+static void bulk_counts_put(int32_t *p, size_t bytes)
+{
+    int32_t *old = NULL;
+    if (p == NULL) return;
+    pthread_mutex_lock(&g_bulk_pool.lock);
+    if (bytes <= ((size_t)1 << 30) && (g_bulk_pool.counts == NULL || g_bulk_pool.counts_bytes < bytes)) {
+        old = g_bulk_pool.counts; g_bulk_pool.counts = p; g_bulk_pool.counts_bytes = bytes; p = NULL;
+    }
+    pthread_mutex_unlock(&g_bulk_pool.lock);
+    free(old); free(p);
+}
+
+static inline char *put_dec(char *p, int64_t v)                 /* decimal digits of v at p; returns the end */
+{
+    char tmp[24];
+    int n = 0;
+    uint64_t u = v < 0 ? (uint64_t)0 - (uint64_t)v : (uint64_t)v;
+    if (v < 0) *p++ = '-';
+    do { tmp[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+    while (n) *p++ = tmp[--n];
+    return p;
+}
 
 static void *bulk_worker(void *arg)
 {
     bulk_t *k = (bulk_t*)arg;
     bgtm_t *bm = k->bm;
+    int last_rid = -1;
+    const char *chrom = NULL;
+    size_t l_chrom = 0;
     kexpr_t *flt = ke_clone(bm->site_flt);
     bcf1_t *b = bcf_init1();
     kstring_t line = {0, 0, 0};
@@ -1825,13 +1890,14 @@ static void *bulk_worker(void *arg)
         pthread_mutex_unlock(&k->lock);
         if (blk >= k->n_blocks) break;
         o = &k->out[blk];
+        bulk_buf_get(o, (size_t)k->blk_sites * 64);
         j0 = blk * k->blk_sites; j1 = j0 + k->blk_sites < k->n_sites ? j0 + k->blk_sites : k->n_sites;
         if (k->need_counts) {                                     /* wait for the pieces that hold this block's rows */
             int d;
             for (d = 0; d < k->n_db; ++d) {
                 int64_t need = -1;
                 if (k->scan[d].rd == NULL) continue;
-                for (j = j0; j < j1; ++j) if (k->idx[d][j] >= 0 && k->t[d]->row[k->idx[d][j]] > need) need = k->t[d]->row[k->idx[d][j]];
+                for (j = j0; j < j1; ++j) if (BULK_IDX(k, d, j) >= 0 && k->t[d]->row[BULK_IDX(k, d, j)] > need) need = k->t[d]->row[BULK_IDX(k, d, j)];
                 if (need < 0) continue;
                 pthread_mutex_lock(&k->lock);
                 while (!k->failed && k->scan[d].ready <= need - k->scan[d].r0) pthread_cond_wait(&k->cond, &k->lock);
@@ -1839,36 +1905,80 @@ static void *bulk_worker(void *arg)
             }
         }
         if (k->failed) j1 = j0;                                   /* a device pass failed: nothing more is formatted */
+        const double w0 = rd_now_ms();
+        struct timespec c0; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &c0);
         for (j = j0; j < j1; ++j) {                               /* what read_core does for one merged site without genotypes */
-            const sitetab_t *t = k->t[k->lead[j]];
-            const int64_t i = k->idx[k->lead[j]][j];
+            const sitetab_t *t = k->t[BULK_LEAD(k, j)];
+            const int64_t i = BULK_IDX(k, BULK_LEAD(k, j), j);
             int d, max_allele = 0;
             for (d = 0; d < k->n_db; ++d)
-                if (k->idx[d][j] >= 0 && k->t[d]->n_allele[k->idx[d][j]] > max_allele) max_allele = k->t[d]->n_allele[k->idx[d][j]];
-            bcf_set_site(b, t->rid[i], t->pos[i], t->rlen[i], t->pool + t->ref_off[i], (int)t->ref_len[i],
-                         t->pool + t->alt_off[i], (int)t->alt_len[i], max_allele > 2 ? "<M>" : NULL);
-            if ((int)t->ref_len[i] != b->rlen) { int32_t val = b->pos + b->rlen; bcf_append_info_ints(bm->h_out, b, "END", 1, &val); }
+                if (BULK_IDX(k, d, j) >= 0 && k->t[d]->n_allele[BULK_IDX(k, d, j)] > max_allele) max_allele = k->t[d]->n_allele[BULK_IDX(k, d, j)];
+            bgt_info_t ss;
             if (k->need_counts) {
-                bgt_info_t ss;
                 int g;
                 memset(&ss, 0, sizeof(ss));
                 ss.n_groups = bm->n_groups;
                 for (d = 0; d < k->n_db; ++d) {                   /* the databases that carry the site add their counts */
                     const int32_t *c;
-                    if (k->idx[d][j] < 0) continue;
-                    c = k->counts[d] + (size_t)(k->t[d]->row[k->idx[d][j]] - k->row_min[d]) * (size_t)k->cstride;
+                    if (BULK_IDX(k, d, j) < 0) continue;
+                    c = k->counts[d] + (size_t)(k->t[d]->row[BULK_IDX(k, d, j)] - k->row_min[d]) * (size_t)k->cstride;
                     ss.an += c[0]; ss.ac[0] += c[1]; ss.ac[1] += c[2];
                     if (bm->n_groups > 1)
                         for (g = 0; g < bm->n_groups; ++g) { ss.gan[g] += c[3 * (1 + g)]; ss.gac[g][0] += c[3 * (1 + g) + 1]; ss.gac[g][1] += c[3 * (1 + g) + 2]; }
                 }
-                fill_info(bm->h_out, &ss, b);
                 if (!pass_site_flt(&ss, flt)) continue;
             }
-            vcf_format1(bm->h_out, b, &line);
-            ks_putn(o, line.s, line.l); ks_putc(o, '\n');
+            if (k->via_record) {                                  /* BGT_BULK_VIA_RECORD=1: through a BCF record, as bgtm_read_vcf does */
+                bcf_set_site(b, t->rid[i], t->pos[i], t->rlen[i], t->pool + t->ref_off[i], (int)t->ref_len[i],
+                             t->pool + t->alt_off[i], (int)t->alt_len[i], max_allele > 2 ? "<M>" : NULL);
+                if ((int)t->ref_len[i] != b->rlen) { int32_t val = b->pos + b->rlen; bcf_append_info_ints(bm->h_out, b, "END", 1, &val); }
+                if (k->need_counts) fill_info(bm->h_out, &ss, b);
+                vcf_format1(bm->h_out, b, &line);
+                ks_putn(o, line.s, line.l); ks_putc(o, '\n');
+            } else {
+                /* The same bytes written directly (vcf_format1 over the record bcf_set_site / fill_info would build: ID and FILTER
+                 * are '.', QUAL is 0, INFO = [END] AN AC [AN<g> AC<g> ...] with one AC value per ALT allele): encoding a record and
+                 * decoding it again cost 0.5 us of CPU per site, the bound of a resident query (16 formatter cores: 32 of 44 ms). */
+                const int three = max_allele > 2, l_ref = (int)t->ref_len[i], l_alt = (int)t->alt_len[i];
+                char *q;
+                if (t->rid[i] != last_rid) { last_rid = t->rid[i]; chrom = bm->h_out->id[BCF_DT_CTG][last_rid].key; l_chrom = strlen(chrom); }
+                ks_need(o, l_chrom + (size_t)l_ref + (size_t)l_alt + 128 + (k->need_counts && bm->n_groups > 1 ? (size_t)bm->n_groups * 48 : 0));
+                q = o->s + o->l;
+                memcpy(q, chrom, l_chrom); q += l_chrom;
+                *q++ = '\t'; q = put_dec(q, (int64_t)t->pos[i] + 1);
+                *q++ = '\t'; *q++ = '.'; *q++ = '\t';
+                memcpy(q, t->pool + t->ref_off[i], (size_t)l_ref); q += l_ref;
+                *q++ = '\t';
+                memcpy(q, t->pool + t->alt_off[i], (size_t)l_alt); q += l_alt;
+                if (three) { memcpy(q, ",<M>", 4); q += 4; }
+                memcpy(q, "\t0\t.\t", 5); q += 5;                    /* (QUAL of a record bcf_set_site makes is 0, not missing) */
+                if ((int)t->ref_len[i] != t->rlen[i]) {
+                    memcpy(q, "END=", 4); q = put_dec(q + 4, (int64_t)t->pos[i] + t->rlen[i]);
+                    if (k->need_counts) *q++ = ';';
+                } else if (!k->need_counts) *q++ = '.';
+                if (k->need_counts) {
+                    int g;
+                    memcpy(q, "AN=", 3); q = put_dec(q + 3, ss.an);
+                    memcpy(q, ";AC=", 4); q = put_dec(q + 4, ss.ac[0]);
+                    if (three) { *q++ = ','; q = put_dec(q, ss.ac[1]); }
+                    if (bm->n_groups > 1)
+                        for (g = 0; g < bm->n_groups; ++g) {
+                            char key[5];
+                            size_t lk;
+                            *q++ = ';'; group_key(key, 'N', g); lk = strlen(key); memcpy(q, key, lk); q += lk; *q++ = '='; q = put_dec(q, ss.gan[g]);
+                            *q++ = ';'; group_key(key, 'C', g); memcpy(q, key, lk); q += lk; *q++ = '='; q = put_dec(q, ss.gac[g][0]);
+                            if (three) { *q++ = ','; q = put_dec(q, ss.gac[g][1]); }
+                        }
+                }
+                *q++ = '\n';
+                o->l = (size_t)(q - o->s);
+            }
             ++n;
         }
+        struct timespec c1; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &c1);
+        const double w1 = rd_now_ms();
         pthread_mutex_lock(&k->lock);
+        k->wall_ms += w1 - w0; k->cpu_ms += (c1.tv_sec - c0.tv_sec) * 1e3 + (c1.tv_nsec - c0.tv_nsec) * 1e-6;
         k->n_lines[blk] = n; k->done[blk] = 1;
         pthread_cond_broadcast(&k->cond);
         pthread_mutex_unlock(&k->lock);
@@ -1922,6 +2032,7 @@ long bgtm_write_vcf_bulk(bgtm_t *bm, FILE *fp, long n_rec)
     if (bm->n_bgt < 1 || bm->n_bgt > BULK_MAX_DB || !(bm->flag & BGT_F_NO_GT) || (bm->flag & (BGT_F_CNT_AL | BGT_F_CNT_HAP)) || bm->h_al || bm->n_fields > 0) return -1;
     memset(&k, 0, sizeof(k));
     k.bm = bm; k.n_db = bm->n_bgt;
+    k.via_record = getenv("BGT_BULK_VIA_RECORD") != NULL;
     k.need_counts = (bm->flag & BGT_F_SET_AC) || bm->site_flt || bm->n_groups > 1;
     k.cstride = 3 * (1 + (bm->n_groups > 1 ? bm->n_groups : 0));
     for (d = 0; d < k.n_db; ++d) {                                /* every database: a plain walk from its cursor to its end */
@@ -1963,7 +2074,8 @@ long bgtm_write_vcf_bulk(bgtm_t *bm, FILE *fp, long n_rec)
                 if (scan[d].piece < 262144) scan[d].piece = 262144;
             }
             scan[d].cstride = k.cstride; scan[d].lock = &k.lock; scan[d].cond = &k.cond; scan[d].failed = &k.failed;
-            scan[d].counts = (int32_t*)malloc((size_t)(row_max - row_min + 1) * (size_t)k.cstride * 4);
+            scan[d].counts = k.n_db == 1 ? bulk_counts_get((size_t)(row_max - row_min + 1) * (size_t)k.cstride * 4)
+                                         : (int32_t*)malloc((size_t)(row_max - row_min + 1) * (size_t)k.cstride * 4);
             if (scan[d].counts == NULL) { failed = 1; break; }
             k.counts[d] = scan[d].counts;
         }
@@ -1978,9 +2090,7 @@ long bgtm_write_vcf_bulk(bgtm_t *bm, FILE *fp, long n_rec)
     }
     bulk_mark("device passes started, databases", (long)k.n_db);
     if (k.n_db == 1) {                                            /* one database: site j of the output is its site lo + j */
-        k.idx[0] = (int32_t*)malloc((size_t)total * 4);
-        k.lead = (uint8_t*)calloc((size_t)total, 1);
-        for (i = 0; i < total; ++i) k.idx[0][i] = (int32_t)(lo[0] + i);
+        k.idx[0] = NULL; k.lead = NULL; k.lo0 = lo[0];
         k.n_sites = total;
     } else {
         for (d = 0; d < k.n_db; ++d) { cur[d] = lo[d]; k.idx[d] = NULL; }
@@ -2037,9 +2147,11 @@ long bgtm_write_vcf_bulk(bgtm_t *bm, FILE *fp, long n_rec)
         pthread_mutex_unlock(&k.lock);
         if (i == 0 || i == k.n_blocks / 2) bulk_mark("block ready to leave", (long)i);
         if (k.out[i].l && !k.failed) { fwrite(k.out[i].s, 1, k.out[i].l, fp); written += (long)k.n_lines[i]; }   /* (only what left) */
-        free(k.out[i].s); k.out[i].s = NULL;
+        bulk_buf_put(&k.out[i]);
     }
     bulk_mark("last block written, lines", written);
+    bulk_mark("formatting, sum over blocks: wall us", (long)(k.wall_ms * 1e3));
+    bulk_mark("formatting, sum over blocks: thread CPU us", (long)(k.cpu_ms * 1e3));
     for (j = 0; j < n_started; ++j) pthread_join(th[j], NULL);
     for (d = 0; d < k.n_db; ++d) {
         if (scan[d].started) pthread_join(scan[d].th, NULL);
@@ -2049,7 +2161,9 @@ long bgtm_write_vcf_bulk(bgtm_t *bm, FILE *fp, long n_rec)
     for (d = 0; d < k.n_db; ++d) {
         bm->n_gt_read += (uint64_t)(hi[d] - lo[d]) * (uint64_t)bm->bgt[d]->n_out;
         ((cursor_t*)bm->bgt[d]->bcf)->next = hi[d];
-        free(scan[d].counts); free(k.idx[d]);
+        if (k.n_db == 1 && scan[d].counts) bulk_counts_put(scan[d].counts, (size_t)(scan[d].r1 - scan[d].r0) * (size_t)k.cstride * 4);
+        else free(scan[d].counts);
+        free(k.idx[d]);
     }
     free(k.lead);
     free(k.out); free(k.n_lines); free((void*)k.done);

@@ -227,3 +227,18 @@ def test_resident_host_parses_every_query_afresh(tmp_path):
     finally:
         srv.terminate()
         srv.wait(timeout=30)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args,prefixes", [(["-G", "-C"], ["synA"]), (["-G", "-f", "AC>0"], ["synA", "synB"]),
+                                           (["-G", "-s", 'pop=="X"', "-s", 'pop=="Y"'], ["synA"]),
+                                           (["-G", "-s", 'pop=="X"', "-s", 'pop=="Y"', "-f", "AC1>0&&AC2==0"], ["synA", "synB"]),
+                                           (["-G", "-C"], ["ex2"]), (["-G", "-C"], ["ex3"])])
+def test_bulk_walk_writes_the_bytes_of_the_record_path(args, prefixes):
+    """The bulk walk formats its lines directly; BGT_BULK_VIA_RECORD=1 builds a BCF record per site and formats that (what
+    bgtm_read_vcf does); BGT_NO_BULK=1 is the site-by-site loop itself.  Same bytes, with counts, groups, several
+    databases, multi-allelic sites and END."""
+    runs = [subprocess.run([BGT, "view"] + args + prefixes, cwd=GOLD, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300,
+                           env=dict(os.environ, **env)) for env in ({}, {"BGT_BULK_VIA_RECORD": "1"}, {"BGT_NO_BULK": "1"})]
+    assert all(r.returncode == 0 for r in runs), [r.stderr.decode()[-200:] for r in runs]
+    assert runs[0].stdout == runs[1].stdout == runs[2].stdout and runs[0].stdout.count(b"\n") > 10
