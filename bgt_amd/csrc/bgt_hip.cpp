@@ -86,6 +86,7 @@ extern "C" const char *bgth_version(void) { return "bgt-hip 0.1 (gfx950)"; }
 // need the device starts both on a thread of their own while it parses headers, sample tables and the site side-car.
 // (Whoever touches the device first simply waits on the runtime's own initialisation lock.)
 static std::mutex g_warm_lock;
+static std::atomic<bool> g_runtime_ready{false};   // a HIP call has returned in this process: the runtime is up (nobody waits for it any more)
 static std::thread *g_warm_thread = nullptr;    // (on the heap and never destroyed: a caller that does not wait must not die in a destructor)
 extern "C" void bgth_runtime_warmup_async(int device)
 {
@@ -102,6 +103,7 @@ extern "C" void bgth_runtime_warmup_async(int device)
                 hipDeviceSynchronize();
                 hipFree(d);
             }
+            g_runtime_ready = true;
         });
     } catch (...) {}
 }
@@ -437,6 +439,7 @@ static bool use_device(int device)
 {
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) { set_err("[E::bgth] hipSetDevice(%d): %s", device, hipGetErrorString(e)); return false; }
+    g_runtime_ready = true;
     return true;
 }
 
@@ -892,8 +895,15 @@ static bgth_pbf_t *open_mem_impl(const void *image, size_t len, int device)
     // the reference reader finds everything through the footer (pbwt.c:228-235); an image without one is truncated
     if (n_footer < 0) { set_err("[E::bgth_pbf_open] no index footer: truncated or not a PBF image"); return nullptr; }
     Trace tr;
-    if (!use_device(device)) return nullptr;
-    tr.lap("device init");
+    // A cold process is still starting the HIP runtime on its warm-up thread (60-220 ms): then everything the host can do
+    // alone comes first -- both passes of the block parser, the strings packed into host memory and uploaded in one piece --
+    // instead of waiting for the runtime and copying block by block (C2 database, cold `bgt view`: ~45 ms of 230).  With the
+    // runtime up (a resident host, a second database) the blocks go to the device as they are packed.
+    const bool beside_init = !g_runtime_ready.load() && !getenv("BGTH_OPEN_WAIT_FIRST");
+    if (!beside_init) {
+        if (!use_device(device)) return nullptr;
+        tr.lap("device init");
+    }
     bgth_pbf_t *p = pbf_alloc(device, m, g, shift, 0);
     if (!p) return nullptr;
     t_building = p;
@@ -901,12 +911,17 @@ static bgth_pbf_t *open_mem_impl(const void *image, size_t len, int device)
     Parsed ps;
     Upload up;
     up.device = device;
-    if (!parse_blocks_parallel(buf, end, len, m, g, shift, n_footer, ps, &up)) {
+    if (!parse_blocks_parallel(buf, end, len, m, g, shift, n_footer, ps, beside_init ? nullptr : &up)) {
         p->d_rle = up.d_rle;                                     // (freed with the image)
         if (up.d_perm) hipFree(up.d_perm);
         up.d_rle = nullptr; up.d_perm = nullptr;
         if (up.failed || !parse_sequential(buf, end, m, g, shift, ps)) goto fail;
         p->d_rle = nullptr;
+    }
+    if (beside_init) {
+        tr.lap("parse records (beside the runtime's start)");
+        if (!use_device(device)) goto fail;
+        tr.lap("device init (what was left of it)");
     }
     p->n_empty1 = ps.n_empty1;
     {
@@ -943,7 +958,7 @@ static bgth_pbf_t *open_mem_impl(const void *image, size_t len, int device)
         else {
             HIP_TRY(hipMalloc((void**)&p->d_rle, rle.size() + pad), goto fail);
             HIP_TRY(hipMemset(p->d_rle + rle.size(), 0, pad), goto fail);
-            if (!rle.empty()) HIP_TRY(hipMemcpy(p->d_rle, rle.data(), rle.size(), hipMemcpyHostToDevice), goto fail);
+            if (!rle.empty()) HIP_TRY(hipMemcpy(p->d_rle, rle.data(), rle.size(), hipMemcpyHostToDevice), goto fail);   // (one copy: eight threads copying pieces were slower, 48-97 vs 35-40 ms for 331 MB)
         }
         HIP_TRY(hipMalloc((void**)&p->d_rowdesc, std::max<size_t>(desc.size(), 1) * 8), goto fail);
         if (!desc.empty()) HIP_TRY(hipMemcpy(p->d_rowdesc, desc.data(), desc.size() * 8, hipMemcpyHostToDevice), goto fail);

@@ -6,6 +6,7 @@
  * Reference behaviour restated: bgt.c:40-81 (open), :89-246 (single reader), :272-356 (site pull),
  * :364-676 (multi reader set-up), :692-757 (INFO and filter), :797-888 (merge loop).
  */
+#define _GNU_SOURCE                                            /* F_SETPIPE_SZ */
 #include <assert.h>
 #include <ctype.h>
 #include <limits.h>
@@ -13,6 +14,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
+#include <fcntl.h>
+#include <sys/stat.h>
 #include <pthread.h>
 #include <zlib.h>
 #include "../../include/bgt_reader.h"
@@ -2140,6 +2143,11 @@ long bgtm_write_vcf_bulk(bgtm_t *bm, FILE *fp, long n_rec)
         bulk_scan_worker(&scan[d]);
     }
     bulk_mark("formatter threads started", (long)n_started);
+    {   /* tens of MB through a pipe: 64 KB of buffer is a context switch per 64 KB; ask for the 1 MB an unprivileged process may have */
+        struct stat st;
+        const int fd = fileno(fp);
+        if (fd >= 0 && total > 65536 && fstat(fd, &st) == 0 && S_ISFIFO(st.st_mode)) (void)fcntl(fd, F_SETPIPE_SZ, 1 << 20);
+    }
     if (n_started == 0) bulk_worker(&k);                          /* no formatter thread could be started: format here */
     for (i = 0; i < k.n_blocks; ++i) {                            /* blocks leave in order, as soon as they are ready */
         pthread_mutex_lock(&k.lock);
