@@ -1824,7 +1824,7 @@ typedef struct {
  * at C2 scale in a resident host: a block of 4,096 sites took 8 ms to format instead of 1.8, and the device pass's copy
  * to the host stalled behind the faults for up to 50 ms).  So blocks are formatted into buffers taken from -- and returned
  * to -- a process-wide pool, and the counts buffer of the last walk is kept for the next one. */
-#define BULK_POOL_MAX 512
+#define BULK_POOL_MAX 256
 static struct { pthread_mutex_t lock; char *s[BULK_POOL_MAX]; size_t m[BULK_POOL_MAX]; int n; int32_t *counts; size_t counts_bytes; } g_bulk_pool =
     { PTHREAD_MUTEX_INITIALIZER, {0}, {0}, 0, NULL, 0 };
 static void bulk_buf_get(kstring_t *o, size_t want)
@@ -1839,7 +1839,7 @@ static void bulk_buf_put(kstring_t *o)
 {
     if (o->s == NULL) return;
     pthread_mutex_lock(&g_bulk_pool.lock);
-    if (g_bulk_pool.n < BULK_POOL_MAX && o->m <= (4u << 20)) { g_bulk_pool.s[g_bulk_pool.n] = o->s; g_bulk_pool.m[g_bulk_pool.n] = o->m; ++g_bulk_pool.n; o->s = NULL; }
+    if (g_bulk_pool.n < BULK_POOL_MAX && o->m <= (1u << 20)) { g_bulk_pool.s[g_bulk_pool.n] = o->s; g_bulk_pool.m[g_bulk_pool.n] = o->m; ++g_bulk_pool.n; o->s = NULL; }
     pthread_mutex_unlock(&g_bulk_pool.lock);
     free(o->s);
     o->s = NULL; o->l = o->m = 0;
