@@ -554,7 +554,7 @@ static void fit_sub_shift(bgth_pbf_t *p, int64_t n)
         const int64_t subs = (n + ((int64_t)1 << s) - 1) >> s, wgs = subs * slices;
         const double start = 1.0 + 10.0 / (double)((int64_t)1 << s);
         double t = start * (double)((wgs + slots - 1) / slots * slots) / (double)wgs;
-        if (plane) t += start * (double)((2 * subs + 511) / 512 * 512) / (double)(2 * subs);
+        if (plane) { const int64_t ps = 256 * (int64_t)plane_slots_per_cu(p->m); t += start * (double)((2 * subs + ps - 1) / ps * ps) / (double)(2 * subs); }
         if (t < best * 0.98) { best = t; pick = s; }
     }
     p->sub_shift = pick;
@@ -1785,11 +1785,12 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
     }
     // Plane-split kernels: a selection of few columns of a WIDE cohort (the team kernels would run one workgroup per CU,
     // mostly building): one workgroup per plane, two per CU.  BGTH_VARIANT 2048 / 4096 forbid / force them.  Team kernels that
-    // batch rows (K > 1: m = 40,000 ... 100,000) keep selections of more than a sixth of the cohort (scripts/subset_ab.py:
-    // every 13th of 64,976 columns 1.59 against 1.90 ms, every 10th of 100,000 5.7 against 7.7 ms, every 4th of 64,976 2.68 against 2.44 ms).
+    // batch rows (K > 1: m = 40,000 ... 100,000) keep selections of more than a quarter of the cohort (scripts/subset_ab.py, with
+    // three workgroups per CU: every 13th of 64,976 columns 1.15 against 1.90 ms, every 6th 1.95 against 2.13, every 4th 1.99
+    // against 2.41; every 10th of 100,000 5.7 against 8.4 ms; every 4th of 40,000 4.91 against 5.05).
     Geometry pgeo;
     bool planepath = !dirpath && !variant_flag(kVariantPlaneNever) && !(r->tune_threads || r->tune_cpt || r->tune_K) &&
-                     ((geo.nbuf == 1 && geo.wpp > 1 && (geo.K == 1 || 6 * (int64_t)r->sel.width <= p->m)) || variant_flag(kVariantPlaneAlways)) &&
+                     ((geo.nbuf == 1 && geo.wpp > 1 && (geo.K == 1 || 4 * (int64_t)r->sel.width <= p->m)) || variant_flag(kVariantPlaneAlways)) &&
                      choose_plane_geometry(p->m, r->sel.n_chunks, (int)(blk1 - blk0 + 1), &pgeo);
     uint64_t *p_h0 = d_h0, *p_h1 = d_h1;
     if (planepath && !d_h0) {

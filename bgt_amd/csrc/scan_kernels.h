@@ -91,7 +91,7 @@ struct ScanArgs {
 // workgroup hold, so that few column slices repeat the per-row bit-vector build)
 #define BGTH_CPT_512_WIDE(X) X(64) X(80) X(98)
 
-struct Geometry { int threads, cpt, slices, K, lds_bytes, workgroups, wpp, nbuf, tog_off; int dir_stage = -1; };   // dir_stage >= 0: directory path
+struct Geometry { int threads, cpt, slices, K, lds_bytes, workgroups, wpp, nbuf, tog_off; int dir_stage = -1; int low = 0; };   // dir_stage >= 0: directory path; low: the plane-split kernels at <= 80 VGPRs (six waves per SIMD)
 
 // Picks threads/columns-per-thread/slices/K for a selection of n_chunks*64 slots over n_blk blocks.
 // Returns false if the row bit-vectors of this m cannot fit in LDS.
@@ -116,6 +116,7 @@ hipError_t launch_invert(const int32_t *perm, int32_t *inv, int m, int64_t n_per
 // plane-split kernels (scan_plane.hip; sparse selections of wide cohorts): one workgroup per (sub-block, plane), two per CU;
 // the planes meet in count_planes (raw[row][g][3] = the three popcounts per group from the bit planes h0 / h1)
 bool choose_plane_geometry(int m, int n_chunks, int n_blk, Geometry *g);
+int plane_slots_per_cu(int m);   // workgroups of the plane-split kernels a CU holds (2 or 3)
 hipError_t launch_plane_scan(const ScanArgs &a, const Geometry &g, hipStream_t s);
 hipError_t launch_count_planes(const uint64_t *h0, const uint64_t *h1, const uint32_t *chunk_desc, int32_t *raw, int64_t n_rows,
                                int n_chunks, int G, hipStream_t s);

@@ -20,13 +20,20 @@ namespace bgth {
 
 static const int kLdsBytesPlane = 160 * 1024;
 
-template <int CPT>
-__global__ __launch_bounds__(512, 4) void plane_kernel(const ScanArgs a, const uint64_t *__restrict__ rowdesc,
+// LOW: the <= 80-VGPR statement, six waves per SIMD: THREE workgroups of 512 threads share a CU where their LDS allows
+// (m <= 139,000), else TWO of 768 (twelve waves each).  Measured against two of 512 at 120 VGPRs, every 20th sample,
+// 1.5 M sites: m = 100,000 16.0 -> 12.4 ms, m = 131,072 19.7 -> 16.0 ms; HRC shape, every 13th: 1.58 -> 1.15 ms.
+// (Tried and dropped: a third workgroup of 512 threads at m = 140,000 ... 212,000 by keeping the toggles in the .x of the
+// entries themselves -- four barriers per row, nothing of the build beside the workgroup's own walk: 55.5 against 68.0 M sites/s at C3.)
+// (Eight waves per SIMD -- four workgroups of 512 or two of 1024 threads at 64 VGPRs -- gain nothing over six: m = 64,976
+// 1.27 against 1.15 ms, m = 100,000 equal, C3 with 2 x 1024 16.8 against 14.7 ms with 2 x 768.)
+template <int CPT, int LOW = 0, int NT = 512>                        // LOW 1: <= 80 VGPRs (six waves per SIMD)
+__global__ __launch_bounds__(NT, LOW == 1 ? 6 : 4) void plane_kernel(const ScanArgs a, const uint64_t *__restrict__ rowdesc,
                                                        const uint8_t *__restrict__ rle, const uint32_t *__restrict__ chunkinfo,
                                                        const uint32_t *__restrict__ segc)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NT = 512, WPP = 8;                                    // 8 waves: one team on the plane-row
+    constexpr int WPP = NT / 64;                                        // all waves: one team on the plane-row
     static_assert(CPT % 4 == 0, "columns are stepped four at a time");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -162,7 +169,8 @@ __global__ __launch_bounds__(512, 4) void plane_kernel(const ScanArgs a, const u
                 uint32_t q0[4] = {rk_[j], rk_[j + 1], rk_[j + 2], rk_[j + 3]};
                 uint32_t q1[4] = {0u, 0u, 0u, 0u};                       // (plane-0 branch of the statement: untouched)
                 uint64_t m0[4] = {0, 0, 0, 0}, m1[4] = {0, 0, 0, 0};
-                step4<true>(q0, q1, m0, m1, ca, cb, cc, base, 0u, n0, 0u);
+                if constexpr (LOW == 1) step4_plane_low(q0, m0, ca, base, n0);
+                else step4<true>(q0, q1, m0, m1, ca, cb, cc, base, 0u, n0, 0u);
                 asm volatile("" :: "s"(pm[0]), "s"(pm[1]), "s"(pm[2]), "s"(pm[3]));
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -223,19 +231,43 @@ __global__ __launch_bounds__(256) void count_planes_kernel(const uint64_t *__res
 }
 
 #define BGTH_PLANE_CPTS(X) X(4) X(8) X(12) X(20) X(32)
+#define BGTH_PLANE_CPTS_768(X) X(4) X(8) X(12) X(16) X(20)
+
+// g->low: the register budget of the kernel (0: 120 VGPRs, 1: 80) = how many waves a SIMD holds (4 / 6).
+// BGTH_PLANE_LOW=0: the round-3 shape (two workgroups of 512 threads at 120 VGPRs) for A/B runs.
+static int plane_knob(const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; }
+static int plane_lds(int m) { const int nw = (m + 31) / 32, nwp = (nw + 2) & ~1, nwt = (nw + 4) & ~3; return ((nwp * 8 + nwt * 4 + 16) + 15) & ~15; }
+// workgroups of the plane-split kernels a CU holds: three of 512 threads where their LDS allows (m <= 139,000), else two
+int plane_slots_per_cu(int m)
+{
+    static const int low_knob = plane_knob("BGTH_PLANE_LOW", 1);
+    return low_knob && 3 * plane_lds(m) <= kLdsBytesPlane ? 3 : 2;
+}
 
 bool choose_plane_geometry(int m, int n_chunks, int n_blk, Geometry *g)
 {
-    const int nw = (m + 31) / 32, nwp = (nw + 2) & ~1, nwt = (nw + 4) & ~3;
-    const int lds = nwp * 8 + nwt * 4 + 16;
+    const int lds = plane_lds(m), nw = (m + 31) / 32, nwp = (nw + 2) & ~1;
     if (2 * lds > kLdsBytesPlane) return false;                         // two workgroups must share a CU: that is the point
-    int cpt = 0;
-#define X(C) if (!cpt && 8 * C >= n_chunks) cpt = C;
-    BGTH_PLANE_CPTS(X)
+    static const int low_knob = plane_knob("BGTH_PLANE_LOW", 1);
+    const int slots = plane_slots_per_cu(m);
+    // six waves per SIMD: three workgroups of 512 threads or two of 768 (chunks permitting: <= 20 per wave); else two of 512
+    int threads = 512, low = 0, cpt = 0;
+    if (low_knob && slots == 3) { threads = 512; low = 1; }
+    else if (low_knob && 12 * 20 >= n_chunks) { threads = 768; low = 1; }
+    const int waves = threads / 64;
+    if (threads == 768) {
+#define X(C) if (!cpt && waves * C >= n_chunks) cpt = C;
+        BGTH_PLANE_CPTS_768(X)
 #undef X
+    } else {
+#define X(C) if (!cpt && 8 * C >= n_chunks) cpt = C;
+        BGTH_PLANE_CPTS(X)
+#undef X
+    }
     if (!cpt) return false;
-    g->threads = 512; g->cpt = cpt; g->slices = 1; g->K = 1; g->wpp = 8; g->nbuf = 1; g->tog_off = nwp * 8;
-    g->lds_bytes = (lds + 15) & ~15;
+    g->threads = threads; g->cpt = cpt; g->slices = 1; g->K = 1; g->wpp = threads / 64; g->nbuf = 1; g->tog_off = nwp * 8;
+    g->low = low;
+    g->lds_bytes = lds;
     g->workgroups = ((n_blk + 7) / 8) * 16;                              // 8 sub-blocks x 2 planes per group of 16 ids
     g->dir_stage = -1;
     return true;
@@ -243,16 +275,25 @@ bool choose_plane_geometry(int m, int n_chunks, int n_blk, Geometry *g)
 
 hipError_t launch_plane_scan(const ScanArgs &a, const Geometry &g, hipStream_t s)
 {
-#define X(C)                                                                                                        \
-    if (g.cpt == C) {                                                                                               \
-        auto fn = plane_kernel<C>;                                                                                  \
+    const unsigned grid = a.skip1 ? (unsigned)((a.n_blk + 7) / 8 * 8) : (unsigned)g.workgroups;
+#define LAUNCH(FN)                                                                                                  \
+    {                                                                                                               \
+        auto fn = FN;                                                                                               \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes); \
         if (e != hipSuccess) return e;                                                                              \
-        hipLaunchKernelGGL(fn, dim3(a.skip1 ? (unsigned)((a.n_blk + 7) / 8 * 8) : (unsigned)g.workgroups), dim3(512), g.lds_bytes, s, a, a.rowdesc, a.rle, a.chunkinfo, a.segc); \
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(g.threads), g.lds_bytes, s, a, a.rowdesc, a.rle, a.chunkinfo, a.segc); \
         return hipGetLastError();                                                                                   \
     }
+#define X(C) if (g.cpt == C && g.threads == 512 && g.low == 1) LAUNCH((plane_kernel<C, 1, 512>))
     BGTH_PLANE_CPTS(X)
 #undef X
+#define X(C) if (g.cpt == C && g.threads == 768 && g.low == 1) LAUNCH((plane_kernel<C, 1, 768>))
+    BGTH_PLANE_CPTS_768(X)
+#undef X
+#define X(C) if (g.cpt == C && g.threads == 512 && g.low == 0) LAUNCH((plane_kernel<C, 0, 512>))
+    BGTH_PLANE_CPTS(X)
+#undef X
+#undef LAUNCH
     return hipErrorInvalidConfiguration;
 }
 
