@@ -428,7 +428,8 @@ template <bool SMALL>
 __global__ void filter_kernel(const FilterProgram prog, const int32_t *counts, int64_t n_rows, int ints_per_row,
                               uint8_t *flags, unsigned long long *n_pass)
 {
-    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long passed = 0;                               // (wave-uniform)
+    for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row - threadIdx.x < n_rows; row += (int64_t)gridDim.x * blockDim.x) {
     bool pass = false;
     if (row < n_rows) {
         const int32_t *c = counts + row * ints_per_row;
@@ -473,8 +474,9 @@ __global__ void filter_kernel(const FilterProgram prog, const int32_t *counts, i
         }
         flags[row] = pass ? 1 : 0;
     }
-    const unsigned long long b = __ballot(pass);
-    if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_pass, (unsigned long long)__popcll(b));
+    passed += (unsigned long long)__popcll(__ballot(pass));
+    }
+    if ((threadIdx.x & 63) == 0 && passed) atomicAdd(n_pass, passed);
 }
 
 hipError_t launch_filter(const FilterProgram &prog, const int32_t *counts, int64_t n_rows, int ints_per_row,
@@ -489,7 +491,9 @@ hipError_t launch_filter(const FilterProgram &prog, const int32_t *counts, int64
         else if (op - 16 >= 1 && op - 16 <= 4) { if (depth < 1) regular = false; }
         else { if (depth < 2) regular = false; --depth; }
     }
-    const dim3 grid((unsigned)((n_rows + 255) / 256)), block(256);
+    // a bounded grid walked in strides: a million rows as 4 k workgroups of one row per thread kept the dispatcher busy into
+    // the start of the next scan
+    const dim3 grid((unsigned)std::min<int64_t>((n_rows + 255) / 256, 1024)), block(256);
     if (regular && depth == 1 && deepest <= 4)
         hipLaunchKernelGGL(filter_kernel<true>, grid, block, 0, s, prog, counts, n_rows, ints_per_row, flags, n_pass);
     else
