@@ -141,7 +141,7 @@ def make_roofline(peak, T, sites, k_ms, rle_bytes_per_site, geo, workload, count
         kname = ("walk_kernel<%d, %d" if path and path.get("directory_path") else "scan_kernel<%d, %d") % (geo["threads"], geo["cols_per_thread"])
     r = {"bound": "valu_issue", "achieved": achieved, "peak": peak["ideal_mix_g_lookups_per_s"], "unit": "G rank-lookups/s",
          "frac": achieved / peak["ideal_mix_g_lookups_per_s"], "traffic": None,
-         "kernel": kname + (">" if kname.startswith("plane_kernel") else ", ...>"), "kernel_ms": k_ms, "lookups_per_launch": lookups,
+         "kernel": kname + (", ..., %d threads>" % geo["threads"] if kname.startswith("plane_kernel") else ", ...>"), "kernel_ms": k_ms, "lookups_per_launch": lookups,
          "peak_source": "code-independent ceiling: 1024 SIMDs x 64 lanes x clock / (5 x four-cycle-class + 3 x two-cycle-class cycles) for the "
                         "minimal 8-instruction lookup, class rates measured live as single-instruction streams (%.2f / %.2f cycles per "
                         "wave-instruction at 4 waves per SIMD) -- as if the classes added up and nothing else ever issued.  They do not add "
@@ -1088,7 +1088,7 @@ def main():
                                  "configuration), whole cohort, -G -f'AC>0'", 100000, 153 * 8192, 4, 0, "c4shard")):
                 try:
                     rec = secondary_record(torch, bgt_amd, np, peak, name, what, s_samples, s_sites, s_seed, s_every,
-                                           args.secondary_steps, 1, dev, local, tmp, 8192 + 2048 if s_samples > 50000 else 16384, cw,   # (past the second 'S' record)
+                                           args.secondary_steps if s_sites > 500000 else max(args.secondary_steps, 20), 1, dev, local, tmp,   # (short scans: three steps are at the mercy of one host hiccup) 8192 + 2048 if s_samples > 50000 else 16384, cw,   # (past the second 'S' record)
                                            inrun=not args.no_counters and s_samples > 50000)
                     rec["name"] = name
                     out["secondary"].append(rec)
