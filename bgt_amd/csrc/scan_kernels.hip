@@ -49,13 +49,23 @@ static long model_cost(int nw, int n_chunks, int n_blk, int nt, int cpt, int K, 
 {
     const int nwave = nt / 64, cap = nwave * cpt;
     const int slices = (n_chunks + cap - 1) / cap;
-    const long tB = (long)cpt * 64 * (nt / 256) * (nt == 1024 ? 100 : 115) / 100;   // measured: 2 waves per SIMD fill the VALU less well
-    const long lat = 8 + 5 * (nt / 256);                 // cycles per dependent instruction of a building wave
     const int wpp = wpp_for(nt, K);
+    // Team kernels (one workgroup per CU): 2 waves per SIMD fill the VALU less well than 4 (measured).  Pipelined narrow
+    // kernels share a CU between workgroups, and there the same columns on HALF the waves win: every wave pays ~3 columns' worth
+    // per row beside its lookups (statement set-up, counts), so 256 x 20 beats 512 x 10 at m = 5,008 (6.26 against 6.92 ms per
+    // 2 M sites), 512 x 20 beats 1024 x 10 at m = 10,000 (5.75 / 6.36 per 1 M), 256 x 8 beats 512 x 4 at m = 2,000 (4.23 /
+    // 4.86) -- up to ~24 columns: 512 x 40 at m = 20,000 loses to 1024 x 20 (13.8 against 11.0 ms; scripts/sweep.py, 2026-09-30).
+    long tB;
+    if (wpp == 1) tB = (long)(cpt + 3) * 64 * (nt / 256) * (cpt > 24 ? 130 : 100) / 100;
+    else tB = (long)cpt * 64 * (nt / 256) * (nt == 1024 ? 100 : 115) / 100;
+    const long lat = 8 + 5 * (nt / 256);                 // cycles per dependent instruction of a building wave
     long tA;
     if (wpp == 1) {
-        const int rounds = (2 * K + nwave - 1) / nwave;  // plane-rows per wave and batch
-        tA = (long)rounds * (120 + (long)(nw * 4) / 10) * lat / K;
+        // pipelined narrow mode: the builds of one workgroup run beside the walks of the CU's others, so a row's two
+        // plane-rows cost their instructions' issue slots (4 cycles each over 4 SIMDs), whatever the workgroup's size --
+        // with the (cpt + 3) above this reproduces the measured ratios at m = 2,000 / 5,008 / 10,000 (0.84 / 0.905 / 0.90)
+        (void)lat;
+        tA = 2 * (120 + (long)(nw * 4) / 10);
     } else {
         // team mode (wide cohorts), per row and wave: chunks of the string -> toggles (~260 instructions per
         // 256-byte chunk), directory trips of 256 words (~75), clearing the row, four barriers.  A wave gets one
@@ -109,6 +119,14 @@ bool choose_geometry(int m, int n_chunks, int G, int n_blk, int want_threads, in
         int K2 = want_K > 0 ? want_K : nt / 64;
         if (K2 > nt / 64) K2 = nt / 64;
         while (K2 > 1 && lds_need(nw, K2, G, nt, 2) > kLdsBytes) --K2;
+        // a CU must hold 16 waves of these workgroups (4 per SIMD): rows per batch few enough that 1024 / nt of them share its
+        // LDS -- but never fewer than 4 rows (m = 12,000, 512 x 24: K 8 = 97 KB, one workgroup per CU, 9.4 ms per 1 M sites;
+        // K 6 = 73 KB, two per CU, 7.1 ms)
+        if (want_K <= 0 && nt < 1024 && !team_only(nt, g->cpt)) {
+            int K3 = K2;
+            while (K3 > 4 && lds_need(nw, K3, G, nt, 2) > kLdsBytes * nt / 1024) --K3;
+            if (lds_need(nw, K3, G, nt, 2) <= kLdsBytes * nt / 1024) K2 = K3;
+        }
         if (!team_only(nt, g->cpt) && lds_need(nw, K2, G, nt, 2) <= kLdsBytes && wpp_for(nt, K2) == 1) { g->K = K2; g->nbuf = 2; g->wpp = 1; }
         else { g->K = best_K; g->nbuf = 1; g->wpp = wpp_for(nt, best_K); if (g->wpp == 1) g->wpp = 2; }
         if (g->nbuf == 1 && 2 * g->K * g->wpp > nt / 64) {            // a team per plane-row must exist
