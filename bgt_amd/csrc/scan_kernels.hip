@@ -55,17 +55,22 @@ static long model_cost(int nw, int n_chunks, int n_blk, int nt, int cpt, int K, 
     // per row beside its lookups (statement set-up, counts), so 256 x 20 beats 512 x 10 at m = 5,008 (6.26 against 6.92 ms per
     // 2 M sites), 512 x 20 beats 1024 x 10 at m = 10,000 (5.75 / 6.36 per 1 M), 256 x 8 beats 512 x 4 at m = 2,000 (4.23 /
     // 4.86) -- up to ~24 columns: 512 x 40 at m = 20,000 loses to 1024 x 20 (13.8 against 11.0 ms; scripts/sweep.py, 2026-09-30).
+    // (Only where ONE slice holds the selection: with several, the old prices keep the wide-cohort choices -- team kernels,
+    // directory path -- where they were measured: m = 34,000 as 512 x 24 x 3 slices runs at 1.97 T lookups/s, 3.0 T on the directory path.)
+    const bool one_slice = wpp == 1 && slices == 1;
     long tB;
-    if (wpp == 1) tB = (long)(cpt + 3) * 64 * (nt / 256) * (cpt > 24 ? 130 : 100) / 100;
+    if (one_slice) tB = (long)(cpt + 3) * 64 * (nt / 256) * (cpt > 24 ? 130 : 100) / 100;
     else tB = (long)cpt * 64 * (nt / 256) * (nt == 1024 ? 100 : 115) / 100;
     const long lat = 8 + 5 * (nt / 256);                 // cycles per dependent instruction of a building wave
     long tA;
-    if (wpp == 1) {
+    if (one_slice) {
         // pipelined narrow mode: the builds of one workgroup run beside the walks of the CU's others, so a row's two
         // plane-rows cost their instructions' issue slots (4 cycles each over 4 SIMDs), whatever the workgroup's size --
         // with the (cpt + 3) above this reproduces the measured ratios at m = 2,000 / 5,008 / 10,000 (0.84 / 0.905 / 0.90)
-        (void)lat;
         tA = 2 * (120 + (long)(nw * 4) / 10);
+    } else if (wpp == 1) {
+        const int rounds = (2 * K + nwave - 1) / nwave;  // plane-rows per wave and batch
+        tA = (long)rounds * (120 + (long)(nw * 4) / 10) * lat / K;
     } else {
         // team mode (wide cohorts), per row and wave: chunks of the string -> toggles (~260 instructions per
         // 256-byte chunk), directory trips of 256 words (~75), clearing the row, four barriers.  A wave gets one
