@@ -214,7 +214,7 @@ int view_run(int argc, char *argv[], FILE *out, FILE *err, const bgt_view_host_t
     else if (out_bcf) {
         long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
         bz = bgzw_open(out, clevel < 0 ? 1 : clevel);
-        bgzw_threads(bz, ncpu > 8 ? 8 : (int)ncpu);                 /* blocks are independent: same bytes, deflated in parallel */
+        bgzw_threads(bz, ncpu > 16 ? 16 : (int)ncpu);               /* blocks are independent: same bytes, deflated in parallel */
         bcf_hdr_write_stream(bz, bm->h_out);
     }
     else vcf_hdr_write_text(out, bm->h_out);
