@@ -105,8 +105,13 @@ static int do_server(int argc, char **argv)
         ++n_read;
     }
     if (!vcf_out && bm->n_aal > 0) {                                    /* :355-368 */
-        if (flag & BGT_F_CNT_HAP) { int n_hap; bgt_hapcnt_t *hc = bgtm_hapcnt(bm, &n_hap); char *t = bgtm_hapcnt_print_destroy(bm, n_hap, hc); fputs(t, stdout); free(t); }
-        if (flag & BGT_F_CNT_AL) { char *t = bgtm_alcnt_print(bm); fputs(t, stdout); free(t); }
+        if (flag & BGT_F_CNT_HAP) { int n_hap; bgt_hapcnt_t *hc = bgtm_hapcnt(bm, &n_hap); char *t = bgtm_hapcnt_print_destroy(bm, n_hap, hc); if (t) fputs(t, stdout); free(t); }
+        if (flag & BGT_F_CNT_AL) { char *t = bgtm_alcnt_print(bm); if (t) fputs(t, stdout); free(t); }   /* (NULL: no sample carries them all) */
+    }
+    if (!vcf_out && bm->n_aal > 0) {                                    /* the arrays themselves (bgt.c:859-876 fills them; bgt.h:112-113) */
+        int j;
+        if ((flag & BGT_F_CNT_AL) && bm->alcnt) { printf("alcnt[%d]:", bm->n_out); for (j = 0; j < bm->n_out; ++j) printf(" %d", bm->alcnt[j]); printf("\n"); }
+        if ((flag & BGT_F_CNT_HAP) && bm->hap) { printf("hap[%d]:", 2 * bm->n_out); for (j = 0; j < 2 * bm->n_out; ++j) printf(" %llx", (unsigned long long)bm->hap[j]); printf("\n"); }
     }
     if (n_read > max_read || bm->n_gt_read > max_gt) printf("*\n");
     printf("records=%d n_gt_read=%llu n_aal=%d\n", n_read, (unsigned long long)bm->n_gt_read, bm->n_aal);

@@ -86,3 +86,28 @@ def test_fold_errors_are_reported():
     rd.read()
     with pytest.raises(RuntimeError):
         rd.fold_last(1, 0)
+
+
+@pytest.mark.gpu
+def test_fold_arrays_equal_the_compiled_reference(tmp_path):
+    """bgtm_t::alcnt / ::hap as the COMPILED REFERENCE leaves them (bgt.c:859-876) -- tests/golden/folds.json, written by
+    tests/golden/make_folds_golden.py from oracle/_ref/libbgt_ref.so -- against the same call sequence (tests/integration/api_dump.c,
+    the order of bgt-server.go) over libbgt.so, where the two reductions run on the device (bgth_reader_fold_last per matched
+    site, bgth_reader_take_folds at the end): `-S`, `-H`, both, a reference-allele query, a subset, samples in any order, two
+    databases with groups, an allele set that matches nothing."""
+    import json
+    import os
+    import subprocess
+    import bgt_amd
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bgt_amd.build_library()
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "bgt_amd", "host")])
+    exe, lib = str(tmp_path / "api_mine"), os.path.join(root, "bgt_amd", "lib")
+    subprocess.check_call(["gcc", "-O1", "-Wall", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "integration", "api_dump.c"),
+                           "-o", exe, "-L", lib, "-lbgt", "-Wl,-rpath," + lib])
+    cases = json.load(open(os.path.join(root, "tests", "golden", "folds.json")))
+    assert len(cases) >= 9
+    for c in cases:
+        p = subprocess.run([exe] + c["args"], cwd=os.path.join(root, "tests", "golden", "bgt"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert p.returncode == 0, (c["args"], p.stderr.decode()[-300:])
+        assert p.stdout.decode() == c["stdout"], c["args"]
