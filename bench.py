@@ -1088,7 +1088,9 @@ def main():
                                  "configuration), whole cohort, -G -f'AC>0'", 100000, 153 * 8192, 4, 0, "c4shard")):
                 try:
                     rec = secondary_record(torch, bgt_amd, np, peak, name, what, s_samples, s_sites, s_seed, s_every,
-                                           args.secondary_steps if s_sites > 500000 else max(args.secondary_steps, 20), 1, dev, local, tmp,   # (short scans: three steps are at the mercy of one host hiccup) 8192 + 2048 if s_samples > 50000 else 16384, cw,   # (past the second 'S' record)
+                                           # (short scans: three steps are at the mercy of one host hiccup)
+                                           args.secondary_steps if s_sites > 500000 else max(args.secondary_steps, 20), 1, dev, local, tmp,
+                                           8192 + 2048 if s_samples > 50000 else 16384, cw,   # (past the second 'S' record)
                                            inrun=not args.no_counters and s_samples > 50000)
                     rec["name"] = name
                     out["secondary"].append(rec)
