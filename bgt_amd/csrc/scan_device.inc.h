@@ -98,7 +98,8 @@ __device__ __forceinline__ uint32_t rle_len(uint32_t byte)
 // wave ballot of the decoded bit.  Hand-scheduled: left to hipcc the unrolled row body keeps one
 // 64-bit SGPR condition per lookup alive to the end of the row and spills (measured: 151 VGPRs and
 // 333 v_writelane/v_readlane at 16 columns per thread; this form needs 2 VGPRs per column + 16).
-// Scratch registers are named (v104..v119) and declared as clobbers; every ds_read is waited for
+// Scratch registers are named (v64..v79: a kernel of few columns per thread then needs 80 VGPRs and six of its waves
+// share a SIMD; the columns of wider ones are allocated around them) and declared as clobbers; every ds_read is waited for
 // inside the statement; a lookup needs two of them: the low one is first the LDS address, then the shifted
 // word, then the candidate for bit = 1.  BASE operands are (LDS address of the plane-row) - 8, N0 operands are -n0.
 // ----------------------------------------------------------------------------------------------------
@@ -181,35 +182,35 @@ __device__ __forceinline__ uint32_t rle_len(uint32_t byte)
     "s_add_u32 " CA ", " CA ", vcc_lo\n\t"
 
 #define BGTH_STEP2_BOTH                                                                  \
-        BGTH_ASHR("v104", "%0") BGTH_ASHR("v106", "%1") BGTH_ASHR("v108", "%2") BGTH_ASHR("v110", "%3")  \
-        BGTH_MAD("v104", "%11") BGTH_MAD("v106", "%12") BGTH_MAD("v108", "%11") BGTH_MAD("v110", "%12")  \
-        "ds_read_b64 v[104:105], v104\n\t"                                               \
-        "ds_read_b64 v[106:107], v106\n\t"                                               \
-        "ds_read_b64 v[108:109], v108\n\t"                                               \
-        "ds_read_b64 v[110:111], v110\n\t"                                               \
+        BGTH_ASHR("v64", "%0") BGTH_ASHR("v66", "%1") BGTH_ASHR("v68", "%2") BGTH_ASHR("v70", "%3")  \
+        BGTH_MAD("v64", "%11") BGTH_MAD("v66", "%12") BGTH_MAD("v68", "%11") BGTH_MAD("v70", "%12")  \
+        "ds_read_b64 v[64:65], v64\n\t"                                               \
+        "ds_read_b64 v[66:67], v66\n\t"                                               \
+        "ds_read_b64 v[68:69], v68\n\t"                                               \
+        "ds_read_b64 v[70:71], v70\n\t"                                               \
         "s_waitcnt lgkmcnt(2)\n\t"                                                       \
-        BGTH_TAIL2("%0", "v104", "v105", "%4", "%13", "%1", "v106", "v107", "%5", "%14")  \
+        BGTH_TAIL2("%0", "v64", "v65", "%4", "%13", "%1", "v66", "v67", "%5", "%14")  \
         BGTH_COUNT("%4", "%5", "%8", "%9", "%10")                                        \
         "s_waitcnt lgkmcnt(0)\n\t"                                                       \
-        BGTH_TAIL2("%2", "v108", "v109", "%6", "%13", "%3", "v110", "v111", "%7", "%14")  \
+        BGTH_TAIL2("%2", "v68", "v69", "%6", "%13", "%3", "v70", "v71", "%7", "%14")  \
         BGTH_COUNT("%6", "%7", "%8", "%9", "%10")
 #define BGTH_STEP2_PLANE0                                                                \
-        BGTH_ADDR("v104", "%0", "%11") BGTH_ADDR("v108", "%2", "%11")                    \
-        "ds_read_b64 v[104:105], v104\n\t"                                               \
-        "ds_read_b64 v[108:109], v108\n\t"                                               \
+        BGTH_ADDR("v64", "%0", "%11") BGTH_ADDR("v68", "%2", "%11")                    \
+        "ds_read_b64 v[64:65], v64\n\t"                                               \
+        "ds_read_b64 v[68:69], v68\n\t"                                               \
         "s_mov_b64 %5, 0\n\t"                                                            \
         "s_mov_b64 %7, 0\n\t"                                                            \
         "s_waitcnt lgkmcnt(1)\n\t"                                                       \
-        BGTH_TAIL("%0", "v104", "v105", "v104", "%4", "%13")                             \
+        BGTH_TAIL("%0", "v64", "v65", "v64", "%4", "%13")                             \
         BGTH_COUNT1("%4", "%8")                                                          \
         "s_waitcnt lgkmcnt(0)\n\t"                                                       \
-        BGTH_TAIL("%2", "v108", "v109", "v108", "%6", "%13")                             \
+        BGTH_TAIL("%2", "v68", "v69", "v68", "%6", "%13")                             \
         BGTH_COUNT1("%6", "%8")
 #define BGTH_STEP2_OPERANDS                                                                                          \
         : "+v"(ra0), "+v"(ra1), "+v"(rb0), "+v"(rb1), "=&s"(ma0), "=&s"(ma1), "=&s"(mb0), "=&s"(mb1),               \
           "+s"(ca), "+s"(cb), "+s"(cc)                                                                               \
         : "s"(base0), "s"(base1), "s"(n00), "s"(n01)                                                                 \
-        : "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "vcc", "scc", "memory"
+        : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "vcc", "scc", "memory"
 
 // two columns x two planes: 4 LDS reads in flight.  ZP: with the all-zero-plane-1 shortcut, requested by passing
 // base1 = 0 (never a real operand value: a plane-1 row does not start at LDS address 8)
@@ -239,60 +240,60 @@ __device__ __forceinline__ void step2(uint32_t &ra0, uint32_t &ra1, uint32_t &rb
 }
 
 #define BGTH_STEP4_BOTH                                                                  \
-        BGTH_ASHR("v104", "%0") BGTH_ASHR("v106", "%1") BGTH_ASHR("v108", "%2") BGTH_ASHR("v110", "%3")  \
-        BGTH_ASHR("v112", "%4") BGTH_ASHR("v114", "%5") BGTH_ASHR("v116", "%6") BGTH_ASHR("v118", "%7")  \
-        BGTH_MAD("v104", "%19") BGTH_MAD("v106", "%20") BGTH_MAD("v108", "%19") BGTH_MAD("v110", "%20")  \
-        BGTH_MAD("v112", "%19") BGTH_MAD("v114", "%20") BGTH_MAD("v116", "%19") BGTH_MAD("v118", "%20")  \
-        "ds_read_b64 v[104:105], v104\n\t"                                               \
-        "ds_read_b64 v[106:107], v106\n\t"                                               \
-        "ds_read_b64 v[108:109], v108\n\t"                                               \
-        "ds_read_b64 v[110:111], v110\n\t"                                               \
-        "ds_read_b64 v[112:113], v112\n\t"                                               \
-        "ds_read_b64 v[114:115], v114\n\t"                                               \
-        "ds_read_b64 v[116:117], v116\n\t"                                               \
-        "ds_read_b64 v[118:119], v118\n\t"                                               \
+        BGTH_ASHR("v64", "%0") BGTH_ASHR("v66", "%1") BGTH_ASHR("v68", "%2") BGTH_ASHR("v70", "%3")  \
+        BGTH_ASHR("v72", "%4") BGTH_ASHR("v74", "%5") BGTH_ASHR("v76", "%6") BGTH_ASHR("v78", "%7")  \
+        BGTH_MAD("v64", "%19") BGTH_MAD("v66", "%20") BGTH_MAD("v68", "%19") BGTH_MAD("v70", "%20")  \
+        BGTH_MAD("v72", "%19") BGTH_MAD("v74", "%20") BGTH_MAD("v76", "%19") BGTH_MAD("v78", "%20")  \
+        "ds_read_b64 v[64:65], v64\n\t"                                               \
+        "ds_read_b64 v[66:67], v66\n\t"                                               \
+        "ds_read_b64 v[68:69], v68\n\t"                                               \
+        "ds_read_b64 v[70:71], v70\n\t"                                               \
+        "ds_read_b64 v[72:73], v72\n\t"                                               \
+        "ds_read_b64 v[74:75], v74\n\t"                                               \
+        "ds_read_b64 v[76:77], v76\n\t"                                               \
+        "ds_read_b64 v[78:79], v78\n\t"                                               \
         "s_waitcnt lgkmcnt(6)\n\t"                                                       \
-        BGTH_TAIL2("%0", "v104", "v105", "%8", "%21", "%1", "v106", "v107", "%9", "%22")  \
+        BGTH_TAIL2("%0", "v64", "v65", "%8", "%21", "%1", "v66", "v67", "%9", "%22")  \
         BGTH_COUNT("%8", "%9", "%16", "%17", "%18")                                      \
         "s_waitcnt lgkmcnt(4)\n\t"                                                       \
-        BGTH_TAIL2("%2", "v108", "v109", "%10", "%21", "%3", "v110", "v111", "%11", "%22") \
+        BGTH_TAIL2("%2", "v68", "v69", "%10", "%21", "%3", "v70", "v71", "%11", "%22") \
         BGTH_COUNT("%10", "%11", "%16", "%17", "%18")                                    \
         "s_waitcnt lgkmcnt(2)\n\t"                                                       \
-        BGTH_TAIL2("%4", "v112", "v113", "%12", "%21", "%5", "v114", "v115", "%13", "%22") \
+        BGTH_TAIL2("%4", "v72", "v73", "%12", "%21", "%5", "v74", "v75", "%13", "%22") \
         BGTH_COUNT("%12", "%13", "%16", "%17", "%18")                                    \
         "s_waitcnt lgkmcnt(0)\n\t"                                                       \
-        BGTH_TAIL2("%6", "v116", "v117", "%14", "%21", "%7", "v118", "v119", "%15", "%22") \
+        BGTH_TAIL2("%6", "v76", "v77", "%14", "%21", "%7", "v78", "v79", "%15", "%22") \
         BGTH_COUNT("%14", "%15", "%16", "%17", "%18")
 #define BGTH_STEP4_PLANE0                                                                \
-        BGTH_ADDR("v104", "%0", "%19") BGTH_ADDR("v108", "%2", "%19")                    \
-        BGTH_ADDR("v112", "%4", "%19") BGTH_ADDR("v116", "%6", "%19")                    \
-        "ds_read_b64 v[104:105], v104\n\t"                                               \
-        "ds_read_b64 v[108:109], v108\n\t"                                               \
-        "ds_read_b64 v[112:113], v112\n\t"                                               \
-        "ds_read_b64 v[116:117], v116\n\t"                                               \
+        BGTH_ADDR("v64", "%0", "%19") BGTH_ADDR("v68", "%2", "%19")                    \
+        BGTH_ADDR("v72", "%4", "%19") BGTH_ADDR("v76", "%6", "%19")                    \
+        "ds_read_b64 v[64:65], v64\n\t"                                               \
+        "ds_read_b64 v[68:69], v68\n\t"                                               \
+        "ds_read_b64 v[72:73], v72\n\t"                                               \
+        "ds_read_b64 v[76:77], v76\n\t"                                               \
         "s_mov_b64 %9, 0\n\t"                                                            \
         "s_mov_b64 %11, 0\n\t"                                                           \
         "s_mov_b64 %13, 0\n\t"                                                           \
         "s_mov_b64 %15, 0\n\t"                                                           \
         "s_waitcnt lgkmcnt(3)\n\t"                                                       \
-        BGTH_TAIL("%0", "v104", "v105", "v104", "%8", "%21")                             \
+        BGTH_TAIL("%0", "v64", "v65", "v64", "%8", "%21")                             \
         BGTH_COUNT1("%8", "%16")                                                         \
         "s_waitcnt lgkmcnt(2)\n\t"                                                       \
-        BGTH_TAIL("%2", "v108", "v109", "v108", "%10", "%21")                            \
+        BGTH_TAIL("%2", "v68", "v69", "v68", "%10", "%21")                            \
         BGTH_COUNT1("%10", "%16")                                                        \
         "s_waitcnt lgkmcnt(1)\n\t"                                                       \
-        BGTH_TAIL("%4", "v112", "v113", "v112", "%12", "%21")                            \
+        BGTH_TAIL("%4", "v72", "v73", "v72", "%12", "%21")                            \
         BGTH_COUNT1("%12", "%16")                                                        \
         "s_waitcnt lgkmcnt(0)\n\t"                                                       \
-        BGTH_TAIL("%6", "v116", "v117", "v116", "%14", "%21")                            \
+        BGTH_TAIL("%6", "v76", "v77", "v76", "%14", "%21")                            \
         BGTH_COUNT1("%14", "%16")
 #define BGTH_STEP4_OPERANDS                                                                                                  \
         : "+v"(r0[0]), "+v"(r1[0]), "+v"(r0[1]), "+v"(r1[1]), "+v"(r0[2]), "+v"(r1[2]), "+v"(r0[3]), "+v"(r1[3]),            \
           "=&s"(m0[0]), "=&s"(m1[0]), "=&s"(m0[1]), "=&s"(m1[1]), "=&s"(m0[2]), "=&s"(m1[2]), "=&s"(m0[3]), "=&s"(m1[3]),    \
           "+s"(ca), "+s"(cb), "+s"(cc)                                                                                       \
         : "s"(base0), "s"(base1), "s"(n00), "s"(n01)                                                                         \
-        : "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115",                    \
-          "v116", "v117", "v118", "v119", "vcc", "scc", "memory"
+        : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75",                    \
+          "v76", "v77", "v78", "v79", "vcc", "scc", "memory"
 
 // four columns x two planes: 8 LDS reads in flight
 template <bool ZP>
@@ -320,8 +321,8 @@ __device__ __forceinline__ void step4(uint32_t (&r0)[4], uint32_t (&r1)[4], uint
 }
 
 // One plane only, eight scratch registers just below the VGPR budget: the statement of the plane-split kernels at six waves
-// per SIMD (v72..v79, at most 80 VGPRs: three workgroups of 512 threads or two of 768 per CU).  The statements above name
-// v104..v119 and pin a kernel at 120.
+// per SIMD (v72..v79, at most 80 VGPRs: three workgroups of 512 threads or two of 768 per CU).  The two-plane statements
+// above name sixteen, v64..v79 (until late in round 4: v104..v119, which pinned every kernel at 120 VGPRs whatever it needed).
 #define BGTH_DEFINE_STEP4_PLANE(NAME, A, A1, AP, B, B1, BP, C, C1, CP, D, D1, DP)                                                      \
 __device__ __forceinline__ void NAME(uint32_t (&r0)[4], uint64_t (&m0)[4], uint32_t &ca, uint32_t base0, uint32_t n00)  \
 {                                                                                                                       \

@@ -57,7 +57,10 @@ static long model_cost(int nw, int n_chunks, int n_blk, int nt, int cpt, int K, 
     // 4.86) -- up to ~24 columns: 512 x 40 at m = 20,000 loses to 1024 x 20 (13.8 against 11.0 ms; scripts/sweep.py, 2026-09-30).
     // (Only where ONE slice holds the selection: with several, the old prices keep the wide-cohort choices -- team kernels,
     // directory path -- where they were measured: m = 34,000 as 512 x 24 x 3 slices runs at 1.97 T lookups/s, 3.0 T on the directory path.)
-    const bool one_slice = wpp == 1 && slices == 1;
+    // (... and only where EIGHT rows per batch fit the LDS twice over, m <= 20,480 -- where it was measured.  Selections of wider
+    // cohorts keep the old prices: every 4th sample of 40,000 haplotypes 5.0 ms as 1024 x 10 against 5.9 as 512 x 20, and a sparse
+    // selection of a wide cohort keeps the team geometry that sends it to the plane-split kernels.)
+    const bool one_slice = wpp == 1 && slices == 1 && 2 * (16 * 8 * ((nw + 2) & ~1)) <= kLdsBytes;
     long tB;
     if (one_slice) tB = (long)(cpt + 3) * 64 * (nt / 256) * (cpt > 24 ? 130 : 100) / 100;
     else tB = (long)cpt * 64 * (nt / 256) * (nt == 1024 ? 100 : 115) / 100;

@@ -233,8 +233,8 @@ __global__ __launch_bounds__(256) void count_planes_kernel(const uint64_t *__res
 #define BGTH_PLANE_CPTS(X) X(4) X(8) X(12) X(20) X(32)
 #define BGTH_PLANE_CPTS_768(X) X(4) X(8) X(12) X(16) X(20)
 
-// g->low: the register budget of the kernel (0: 120 VGPRs, 1: 80) = how many waves a SIMD holds (4 / 6).
-// BGTH_PLANE_LOW=0: the round-3 shape (two workgroups of 512 threads at 120 VGPRs) for A/B runs.
+// g->low: 1 = the one-plane statement and six waves per SIMD asked of the compiler (80 VGPRs); 0 = the round-3 shape (two
+// workgroups of 512 threads, the two-plane statement's plane-0 branch; BGTH_PLANE_LOW=0, for A/B runs).
 static int plane_knob(const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; }
 static int plane_lds(int m) { const int nw = (m + 31) / 32, nwp = (nw + 2) & ~1, nwt = (nw + 4) & ~3; return ((nwp * 8 + nwt * 4 + 16) + 15) & ~15; }
 // workgroups of the plane-split kernels a CU holds: three of 512 threads where their LDS allows (m <= 139,000), else two
