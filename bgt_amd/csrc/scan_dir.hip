@@ -142,8 +142,9 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
 
     const int m = a.m, nw = a.nw, nwp = a.dir_nwp, G = a.G;
     const uint32_t plane_bytes = (uint32_t)nwp * 8u;                     // multiple of 16
-    const bool staged = a.dir_stage & 1, warm = a.dir_stage & 2;
-    const int nplane = staged ? 3 : 2;
+    const bool four = a.dir_stage & 4;                                   // both planes of the next row land during this row's walk
+    const bool staged = !four && (a.dir_stage & 1), warm = !four && (a.dir_stage & 2);
+    const int nplane = four ? 4 : staged ? 3 : 2;
     int32_t *lcnt = reinterpret_cast<int32_t*>(smem + (size_t)nplane * plane_bytes);   // [2][cnt_stride]: rows alternate
     const int cnt_stride = MULTI ? G * 3 : NWAVE * 2;
     const uint32_t pad_rank = 32u * (uint32_t)nw;
@@ -192,6 +193,7 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
 
     for (int64_t row = blk_beg; row < blk_end; ++row) {
         const bool more = row + 1 < blk_end;
+        if (four && more) { dma_plane(c0 ^ 2, row + 1, 0); dma_plane(c1 ^ 2, row + 1, 1); }   // buffers {0, 1} and {2, 3} alternate
         if (staged && more) dma_plane(st, row + 1, 0);                   // lands during the walk
         // Plane 1 of the next row can only be fetched when this row's buffer is free, i.e. behind the barrier that ends
         // the walk; one dword per 128-byte line now (8 KB per wave-instruction) brings it into this XCD's L2 meanwhile.
@@ -295,7 +297,8 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
             }
         }
         BGTH_TICK(3);
-        if (more) {
+        if (four) { c0 ^= 2; c1 ^= 2; }                                  // (one barrier per row: the next row is already there)
+        else if (more) {
             if (staged) { const int nc0 = st; dma_plane(c1, row + 1, 1); st = c0; c0 = nc0; }
             else { dma_plane(c0, row + 1, 0); dma_plane(c1, row + 1, 1); }
             BGTH_TICK(4);
@@ -369,8 +372,12 @@ bool choose_walk_geometry(int m, int n_chunks, int G, int n_blk, int want_thread
     const int cap = g->threads / 64 * g->cpt;
     g->slices = (n_chunks + cap - 1) / cap;
     g->K = 1; g->wpp = g->threads / 64; g->nbuf = 1; g->tog_off = 0;
-    g->dir_stage = walk_lds_need(nw, G, g->threads, 3) <= kLdsBytesDir ? 1 : 0;
-    g->lds_bytes = (walk_lds_need(nw, G, g->threads, g->dir_stage ? 3 : 2) + 15) & ~15;
+    // plane buffers in LDS: four where they fit (m <= 160,000: both planes of the next row land during the walk, one barrier
+    // per row), else three (plane 0 of the next row lands during the walk, plane 1 behind it: two barriers), else two
+    static const int four_knob = [] { const char *v = getenv("BGTH_WALK_FOUR"); return v ? atoi(v) : 1; }();   // (0: A/B runs)
+    const int nplane = four_knob && walk_lds_need(nw, G, g->threads, 4) <= kLdsBytesDir ? 4 : walk_lds_need(nw, G, g->threads, 3) <= kLdsBytesDir ? 3 : 2;
+    g->dir_stage = nplane == 4 ? 4 : nplane == 3 ? 1 : 0;
+    g->lds_bytes = (walk_lds_need(nw, G, g->threads, nplane) + 15) & ~15;
     g->workgroups = ((n_blk + 7) / 8) * 8 * g->slices;
     return true;
 }

@@ -56,7 +56,7 @@ struct ScanArgs {
     uint32_t *dir_n0;
     int64_t   dir_row0;
     int32_t   dir_nwp;
-    int32_t   dir_stage;         // bit 0: three plane buffers in LDS (plane 0 of the next row lands while this row is walked; else
+    int32_t   dir_stage;         // bit 2: FOUR plane buffers (rows double-buffered, one barrier per row); bit 0: three plane buffers in LDS (plane 0 of the next row lands while this row is walked; else
                                  // two); bit 1: touch the next row's plane 1 during the walk so that its DMA finds it in the L2
     // Sparse plane 1 (scan_sparse.hip): the dense kernels run plane 0 alone (skip1) and write its ballots to h0; the tracker
     // kernel walks plane 1 as an ordered set and sets the bits of h1; count_planes joins them.
