@@ -1661,6 +1661,10 @@ static bool want_dir_path(const bgth_pbf_t *p, const Geometry &classic, bool tun
     if (variant_flag(kVariantDirAlways)) return true;
     if (use_zp(p)) return false;                         // (the walk-only kernel has no empty-plane shortcut: it looks plane 1 up)
     if (tuned) return false;                             // bgth_reader_tune names a classic geometry
+    // (... and most of a cohort whose pipelined geometry needs two column slices, each repeating the row build: m = 26,000 as
+    // 1024 x 16 x 2 runs at 2.83 T lookups/s, on the directory path at 3.16; m = 30,000: 3.03 / 3.14)
+    // (more than 24,576 columns: the slices are not those a SHORT scan is cut into to fill the chip)
+    if (classic.slices >= 2 && width > 24576 && 2 * (int64_t)width >= p->m) return true;
     return classic.nbuf == 1 && classic.wpp > 1 && (classic.slices >= 2 || 2 * (int64_t)width >= p->m);
 }
 
