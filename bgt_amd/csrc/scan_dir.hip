@@ -168,6 +168,29 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
         }
     }
     if (MULTI) for (int i = tid; i < 2 * cnt_stride; i += NT) lcnt[i] = 0;
+    // MULTI: the group of every row-step statement of this wave (see scan_kernel): counts accumulate on the scalar unit and
+    // leave for the LDS where the group changes; 255 = the statement straddles two groups
+    constexpr int STEP_ = S4 ? 4 : 2;
+    constexpr int NSTMT = (CPT + STEP_ - 1) / STEP_;
+    uint32_t stmt_group[MULTI ? NSTMT : 1];
+    if constexpr (MULTI) {
+        uint32_t last = 0;
+#pragma unroll
+        for (int q = 0; q < NSTMT; ++q) {
+            uint32_t g = 254u;
+#pragma unroll
+            for (int u = 0; u < STEP_; ++u) {
+                const int c = chunk0 + STEP_ * q + u;
+                if (STEP_ * q + u < CPT && c < a.n_chunks) {
+                    const uint32_t x = a.chunk_desc[c] & 255u;
+                    g = g == 254u ? x : (g == x ? g : 255u);
+                }
+            }
+            if (g == 254u) g = last;
+            stmt_group[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
+            if (g != 255u) last = g;
+        }
+    }
 
     // LDS-DMA of one plane-row: pieces of 1 KiB (64 lanes x 16 bytes) dealt round-robin over the waves
     const unsigned char *dirbase = reinterpret_cast<const unsigned char*>(a.dir);
@@ -217,10 +240,28 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
             constexpr int NKEEP = (CPT + 63) / 64;
             uint64_t keep0[NKEEP] = {}, keep1[NKEEP] = {};
             constexpr int STEP = S4 ? 4 : 2;                              // lookups in flight per statement: 8 or 4
+            uint32_t pa = 0, pb = 0, pc = 0;                          // MULTI: ca / cb / cc at the start of the current run
+            uint32_t run_g = MULTI ? (uint32_t)__builtin_amdgcn_readfirstlane((int)stmt_group[0]) : 0u;
+#define BGTH_FLUSH_GROUP(GRP)                                                                              \
+            do {                                                                                           \
+                const uint32_t a_ = ca - pa, b_ = cb - pb, n3_ = cc - pc, n1_ = a_ - n3_, n2_ = b_ - n3_, g_ = (GRP);                         \
+                if (emit && g_ < 254u && lane == 0) {                                                      \
+                    int32_t *dst = lcb + g_ * 3;                                                           \
+                    if (n1_) atomicAdd(dst + 0, (int32_t)n1_);                                             \
+                    if (n2_) atomicAdd(dst + 1, (int32_t)n2_);                                             \
+                    if (n3_) atomicAdd(dst + 2, (int32_t)n3_);                                             \
+                }                                                                                          \
+            } while (0)
 #pragma unroll
             for (int j = 0; j < CPT; j += STEP) {
                 uint64_t m0[4] = {0, 0, 0, 0}, m1[4] = {0, 0, 0, 0};
                 const int NC = (CPT - j) >= STEP ? STEP : 2;              // CPT is even: the tail is one pair
+                const uint32_t sg = MULTI ? (uint32_t)__builtin_amdgcn_readfirstlane((int)stmt_group[j / STEP]) : 0u;   // (uniform, and said so)
+                if (MULTI && sg != run_g) {
+                    BGTH_FLUSH_GROUP(run_g);
+                    pa = ca; pb = cb; pc = cc;                            // (the scalar sums only ever grow: a run is a difference)
+                    run_g = sg;
+                }
                 // The SIMD arbiter prefers its oldest wave: left alone, the four waves of a SIMD finish a row one after the
                 // other and the early ones idle at the barrier while the last walks nearly alone (at 7.6 instead of 4.0 cycles
                 // per instruction).  A wave's priority falls as it gets through its columns, so the laggards catch up.
@@ -243,7 +284,7 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
                 for (int u = 0; u < 4; ++u) {
                     if (u >= NC) break;
                     if (GT && lane == ((j + u) & 63)) { keep0[(j + u) >> 6] = m0[u]; keep1[(j + u) >> 6] = m1[u]; }
-                    if (MULTI) {
+                    if (MULTI && run_g == 255u) {
                         const int c = chunk0 + j + u;
                         if (emit && lane == 0 && c < a.n_chunks) {
                             int32_t *dst = lcb + (a.chunk_desc[c] & 255u) * 3;
@@ -253,7 +294,10 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
                         }
                     }
                 }
+                if (MULTI && run_g == 255u) { pa = ca; pb = cb; pc = cc; }
             }
+            if (MULTI) BGTH_FLUSH_GROUP(run_g);
+#undef BGTH_FLUSH_GROUP
             if (!MULTI && lane == 0)
                 reinterpret_cast<uint2*>(lcb)[wave] = make_uint2((ca - cc) | (cb - cc) << 16, cc);
             if (GT && emit) {
