@@ -709,6 +709,9 @@ template <int CPT> __device__ __forceinline__ void stepcc_row(uint32_t *r0, uint
     if constexpr ((CPT - NW_) % 4 >= 2) stepcc_n<2>(r0 + CPT - 2, r1 + CPT - 2, acc, np0, np1);
 }
 
+// SNAP = the image-open pass that snapshots the ranks at every sub-checkpoint row (ScanArgs::snap).  A template switch, not a
+// run-time test: as a run-time test its per-column skeleton (a predicate, a branch and two VALU instructions per column and ROW)
+// stayed in the walk loop of every scan -- 40 of the 360 VALU instructions of a C2 row.
 // Template switches:  MULTI = more than one sample group (per-chunk LDS atomics instead of per-wave
 // scalars);  GT = also emit the two bit planes of every row (slot order) for genotype output;
 // ZP = with the shortcut for rows whose plane 1 is all zero (chosen per image: worth a taken branch per statement
@@ -719,7 +722,7 @@ template <int CPT> __device__ __forceinline__ void stepcc_row(uint32_t *r0, uint
 
 // CC (narrow cohorts, one group, no bit planes, no ZP): the ballot-free, instruction-major row step of scan_step_cc.inc.h -- the
 // LDS address of a plane-row is folded into the ranks, n(code 3) is counted per lane, the per-plane counts come from the strings.
-template <int NT, int CPT, bool MULTI, bool GT, bool TEAM, bool ZP, bool CC = false>
+template <int NT, int CPT, bool MULTI, bool GT, bool TEAM, bool ZP, bool CC = false, bool SNAP = false>
 __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64_t *__restrict__ rowdesc,
                                                   const uint8_t *__restrict__ rle,
                                                   const uint32_t *__restrict__ chunkinfo,
@@ -1019,7 +1022,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
                 const uint32_t np0 = fold_of(s0) - 2u * fold_of(next_slot(s0)) - n00;
                 const uint32_t np1 = fold_of(s1) - 2u * fold_of(next_slot(s1)) - n01;
                 if (!(BGTH_SKIP(a, 0x2000))) set_wave_priority(((wave >> 2) + k) & 3);
-                if (a.snap && rb + k > blk_beg && ((rb + k) & (((int64_t)1 << a.snap_shift) - 1)) == 0) {
+                if (SNAP && a.snap && rb + k > blk_beg && ((rb + k) & (((int64_t)1 << a.snap_shift) - 1)) == 0) {
                     int32_t *dst = a.snap + ((rb + k) >> a.snap_shift) * (int64_t)(2 * m);
                     int ln = lane;
                     asm volatile("" : "+v"(ln));
@@ -1060,7 +1063,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
             // priority over the rows of a batch gives the four waves of a SIMD equal progress.
             if (!TEAM && !(BGTH_SKIP(a, 0x2000))) set_wave_priority(((wave >> 2) + k) & 3);   // (team mode: by columns, below; a priority that falls with the rows of the batch instead measured the same)
             if (ZP && (a.skip1 || n01 == 0u - (uint32_t)m)) base1 = 0u;   // plane 1 all zero (or not this kernel's): its lookups are skipped (see step2)
-            if (a.snap && rb + k > blk_beg && ((rb + k) & (((int64_t)1 << a.snap_shift) - 1)) == 0) {
+            if (SNAP && a.snap && rb + k > blk_beg && ((rb + k) & (((int64_t)1 << a.snap_shift) - 1)) == 0) {
                 // sub-checkpoint: the ranks before this row (image-open pass only)
                 int32_t *dst = a.snap + ((rb + k) >> a.snap_shift) * (int64_t)(2 * m);
                 int ln = lane;

@@ -6,10 +6,10 @@ namespace bgth {
 
 static const int kLdsBytesLocal = 160 * 1024;
 
-template <int NT, int CPT, bool MULTI, bool GT, bool TEAM, bool ZP, bool CC = false>
+template <int NT, int CPT, bool MULTI, bool GT, bool TEAM, bool ZP, bool CC = false, bool SNAP = false>
 static hipError_t launch_one(const ScanArgs &a, const Geometry &g, hipStream_t s)
 {
-    auto fn = scan_kernel<NT, CPT, MULTI, GT, TEAM, ZP, CC>;
+    auto fn = scan_kernel<NT, CPT, MULTI, GT, TEAM, ZP, CC, SNAP>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes);
     if (e != hipSuccess) return e;
@@ -29,6 +29,11 @@ static hipError_t launch_variant(const ScanArgs &a, const Geometry &g, hipStream
     // bit-exact and SLOWER in the kernel (11.4-12.3 ms against 10.9 ms on C2) although faster in isolation, so it does not ship.
     if constexpr (!ZP) if (v == 0 && a.cc_step && g.nbuf == 2) return launch_one<NT, CPT, false, false, false, false, true>(a, g, s);
 #endif
+    if (a.snap) {                                                  // the image-open pass (sub-checkpoints): counts only, one group
+        if (v == 0) return launch_one<NT, CPT, false, false, false, ZP, false, true>(a, g, s);
+        if (v == 1) return launch_one<NT, CPT, false, false, true, ZP, false, true>(a, g, s);
+        return hipErrorInvalidConfiguration;
+    }
     switch (v) {
     case 0: return launch_one<NT, CPT, false, false, false, ZP>(a, g, s);
     case 1: return launch_one<NT, CPT, false, false, true, ZP>(a, g, s);

@@ -85,10 +85,10 @@ hipError_t launch_rowindex(const uint64_t *rowdesc, const uint8_t *rle, int64_t 
 }
 
 // ----------------------------------------------------------------------------------------------------
-template <int CPT, bool MULTI, bool GT, bool ZP>
+template <int CPT, bool MULTI, bool GT, bool ZP, bool SNAP = false>
 static hipError_t launch_one(const ScanArgs &a, const Geometry &g, hipStream_t s)
 {
-    auto fn = scan_kernel<512, CPT, MULTI, GT, true, ZP>;
+    auto fn = scan_kernel<512, CPT, MULTI, GT, true, ZP, false, SNAP>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes);
     if (e != hipSuccess) return e;
@@ -100,6 +100,7 @@ template <int CPT, bool ZP>
 static hipError_t launch_variant(const ScanArgs &a, const Geometry &g, hipStream_t s)
 {
     if (g.wpp <= 1) return hipErrorInvalidConfiguration;          // team mode only
+    if (a.snap) return (a.G > 1 || a.h0) ? hipErrorInvalidConfiguration : launch_one<CPT, false, false, ZP, true>(a, g, s);   // the image-open pass
     switch ((a.G > 1 ? 2 : 0) | (a.h0 ? 1 : 0)) {
     case 0: return launch_one<CPT, false, false, ZP>(a, g, s);
     case 1: return launch_one<CPT, false, true, ZP>(a, g, s);
