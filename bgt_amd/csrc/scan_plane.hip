@@ -146,7 +146,9 @@ __global__ __launch_bounds__(NT, LOW == 1 ? 6 : 4) void plane_kernel(const ScanA
         if (walking) {
             const uint32_t base = lds0 - 8u;
             const uint32_t n0 = 0u - n0s[row & 1];
-            const bool emit = row >= a.row0;
+            // chunks of this wave whose ballots leave in this row, as ONE scalar integer: as a boolean per column the test was kept
+            // in 64-bit lane masks, spilled to VGPR lanes and read back with two v_readlane per column and row
+            const int n_emit = __builtin_amdgcn_readfirstlane(row >= a.row0 ? a.n_chunks - chunk0 : 0);
             uint32_t ca = 0, cb = 0, cc = 0;
             // The ballots leave straight from their SGPRs: one scalar store per column (s_store_dwordx2, written back by the
             // s_dcache_wb at the end of the kernel) instead of moving them into lanes first (two v_cndmask per column: a
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(NT, LOW == 1 ? 6 : 4) void plane_kernel(const ScanA
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     rk_[j + u] = q0[u];
-                    if (emit && chunk0 + j + u < a.n_chunks)             // wave-uniform
+                    if (j + u < n_emit)                                    // wave-uniform
                         asm volatile("s_store_dwordx2 %0, %1, %2" :: "s"(m0[u]), "s"(hrow), "n"((j + u) * 8) : "memory");
                     pm[u] = m0[u];
                 }
