@@ -7,6 +7,7 @@ set -u
 TAG=${1:-r01}; shift || true
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
+rm -rf $OUT                                  # (a second run into the same tag must not leave the files of the first beside its own)
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-secondary $*"
