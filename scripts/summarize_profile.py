@@ -18,7 +18,18 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
-for f in glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")):
+def newest(pattern):
+    """gpurun merges a call's files INTO gpurun_out/: a tag profiled twice holds both runs' files side by side (rocprofv3 names
+    them by process id).  Per directory only the newest counts."""
+    by_dir = {}
+    for f in glob.glob(pattern):
+        d = os.path.dirname(f)
+        if d not in by_dir or os.path.getmtime(f) > os.path.getmtime(by_dir[d]):
+            by_dir[d] = f
+    return sorted(by_dir.values())
+
+
+for f in newest(os.path.join(src, "trace", "*", "*kernel_stats.csv")):
     shutil.copy(f, os.path.join(dst, "kernel_stats.csv"))
 stats = list(csv.DictReader(open(os.path.join(dst, "kernel_stats.csv"))))
 # the bench-size launches: scripts/profile.sh runs 1 warm-up + 3 timed steps = 4 calls (other scan_kernel
@@ -33,7 +44,7 @@ prod = [r for r in stats if "dirbuild_kernel" in r["Name"]]
 pname = prod[0]["Name"] if prod else None
 if prod:
     out["producer"] = {"kernel": pname, "calls": int(prod[0]["Calls"]), "avg_ms": float(prod[0]["AverageNs"]) / 1e6, "counters": {}}
-for f in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv"))):
+for f in newest(os.path.join(src, "pmc_*", "*", "*counter_collection.csv")):
     agg, pagg = collections.defaultdict(list), collections.defaultdict(list)
     big = out["avg_ms"]
     for r in csv.DictReader(open(f)):
@@ -51,7 +62,7 @@ for f in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.c
         out["producer"]["counters"][c] = {"launches": len(v), "mean_per_launch": sum(v) / len(v)}
 calib = {}
 for w in (4, 16):
-    fs = glob.glob(os.path.join(src, "calib_w%d" % w, "*", "*counter_collection.csv"))
+    fs = newest(os.path.join(src, "calib_w%d" % w, "*", "*counter_collection.csv"))
     vals = [float(r["Counter_Value"]) for f in fs for r in csv.DictReader(open(f))
             if "stream_read" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE"]
     if vals:
