@@ -61,6 +61,155 @@ REF_BIN = os.path.join(ROOT, "oracle", "_ref", "bgt")
 MY_BIN = os.path.join(ROOT, "bgt_amd", "bin", "bgt")
 
 
+GUIDE_VALU_CYCLES = 2.0                    # MI355X_MICROARCH.md: one VALU wave-instruction per 2 cycles per SIMD (SIMD-32 halves)
+COMPACT_LIMIT = 4000                       # bytes of the final stdout line (the driver parses that line only)
+
+
+def _num(x, digits=4):
+    """A finite float rounded to `digits` significant digits, an int as it is, anything else None (strict JSON: no NaN / Infinity)."""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, int):
+        return x
+    try:
+        f = float(x)
+    except (TypeError, ValueError):
+        return None
+    if f != f or f in (float("inf"), float("-inf")):
+        return None
+    if f == 0.0:
+        return 0.0
+    from math import floor, log10
+    return round(f, max(0, digits - 1 - int(floor(log10(abs(f))))))
+
+
+def compact_roofline(r):
+    """Numbers only: what bounds the kernel, achieved against three ceilings (class sum measured live = `peak`; the product's own
+    statement alone on the chip; the micro-architecture guide's plain 2-cycle VALU issue), HBM traffic and its share of 8 TB/s."""
+    if not r:
+        return None
+    clock = r.get("peak_clock_ghz")
+    guide = 1024.0 * 64.0 * clock / (8.0 * GUIDE_VALU_CYCLES) if clock else None      # G lookups/s: 8 VALU per lookup
+    c = {"bound": r.get("bound"), "achieved": _num(r.get("achieved")), "peak": _num(r.get("peak")), "unit": r.get("unit"),
+         "frac": _num(r.get("frac")), "peak_own_statement": _num(r.get("peak_own_statement")),
+         "frac_of_own_statement": _num(r.get("frac_of_own_statement")),
+         "peak_guide_2cycle": _num(guide), "frac_of_guide_2cycle": _num(r["achieved"] / guide) if guide and r.get("achieved") else None,
+         "traffic": _num(r.get("traffic"), 6), "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x calibration + WRITE_SIZE)",
+         "traffic_in_run": bool(r.get("traffic_in_run", {}).get("hbm_bytes_per_launch")) if isinstance(r.get("traffic_in_run"), dict) else False,
+         "hbm_frac_measured": _num(r.get("hbm_frac_measured")), "hbm_peak_gbs": r.get("hbm_peak_gbs"),
+         "kernel": r.get("kernel"), "kernel_ms": _num(r.get("kernel_ms")), "lookups_per_launch": _num(r.get("lookups_per_launch"), 6),
+         "algorithmic_equiv_gbs": _num(r.get("algorithmic_equiv_gbs"))}
+    cn = r.get("counters") or {}
+    if cn.get("lds_busy") is not None:
+        c["lds_busy_profiled"] = _num(cn.get("lds_busy"), 3)
+        c["lds_conflict_frac_profiled"] = _num(cn.get("lds_conflict_frac"), 3)
+    return c
+
+
+def compact_record(out, detail_path=None):
+    """The ONE line the driver reads (last line of stdout): < COMPACT_LIMIT bytes, strict JSON (allow_nan=False), numbers and short
+    labels only.  Everything else of `out` goes to the detail file; the prose that used to sit in the record is DESIGN.md 4-5."""
+    if out.get("value") is None or "error" in out:
+        c = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "error", "failed_rank", "failed_local_rank") if k in out}
+        c["error"] = str(c.get("error", ""))[:600]
+        return json.dumps(c, allow_nan=False)
+    cfg = out.get("config", {})
+    geo = cfg.get("launch") or {}
+    c = {"metric": out["metric"], "value": _num(out["value"], 6), "unit": out["unit"], "n_gpus": out["n_gpus"], "steps": out["steps"],
+         "warmup": out["warmup"], "ms_per_step": _num(out["ms_per_step"], 5), "higher_is_better": True, "scaling": out.get("scaling") or "weak",
+         "vs_baseline": None, "dtype": out.get("dtype"), "data": out.get("data"),
+         "config": {"workload": cfg.get("workload"), "haplotypes": cfg.get("haplotypes"), "tracked_columns": cfg.get("tracked_columns"),
+                    "sites_per_gpu": cfg.get("sites_per_gpu"), "sites_total": cfg.get("sites_total"), "sharding": cfg.get("sharding"),
+                    "sites_passing_filter": cfg.get("sites_passing_filter"),
+                    "launch": {k: geo.get(k) for k in ("threads", "cols_per_thread", "slices", "rows_per_batch", "workgroups") if k in geo}},
+         "roofline": compact_roofline(out.get("roofline")), "parity_ok": out.get("parity_ok")}
+    par = out.get("parity")
+    if isinstance(par, dict):
+        c["parity"] = {"popcount_identity_ok": par.get("popcount_identity_ok"),
+                       "sites_checked_popcount_identity": par.get("sites_checked_popcount_identity"),
+                       "oracle_window_matches": (par.get("oracle_window") or {}).get("matches"),
+                       "oracle_window_rows": (par.get("oracle_window") or {}).get("rows")}
+    cb = out.get("cpu_baseline")
+    if cb:
+        c["cpu_baseline"] = {"value": _num(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                             "sample": (cb.get("sample") or "")[:160],
+                             "cli_stdout_identical_to_reference": cb.get("cli_stdout_identical_to_reference"),
+                             "gpu_matches_cpu_on_sample": cb.get("gpu_matches_cpu_on_sample")}
+        if isinstance(cb.get("all_cores"), dict) and cb["all_cores"].get("value"):
+            c["cpu_baseline"]["all_cores"] = {"value": _num(cb["all_cores"]["value"]), "processes": cb["all_cores"].get("processes")}
+        if "error" in cb:
+            c["cpu_baseline"] = {"error": str(cb["error"])[:200]}
+    for key in ("resident_end_to_end", "cli_end_to_end"):                       # the command line, like for like with cpu_baseline
+        e = out.get(key)
+        if isinstance(e, dict) and e.get("wall_s"):
+            c[key] = {"wall_s": _num(e["wall_s"]), "sites_per_s": _num(e.get("sites_per_s")), "output_lines": e.get("output_lines")}
+            if e.get("vs_cpu_baseline"):
+                c[key]["vs_cpu_baseline"] = _num(e["vs_cpu_baseline"])
+    if out.get("n_gpus", 1) > 1:
+        c["per_rank_kernel_ms"] = [_num(x) for x in out.get("per_rank_kernel_ms", [])]
+        c["gather_ms"] = _num(out.get("gather_ms"))
+        c["ranks"] = {k: out.get("ranks", {}).get(k) for k in ("world_size", "backend", "device_of_rank", "devices_visible")}
+    sec = []
+    for s in out.get("secondary", []):
+        if "error" in s and "sites_per_s" not in s and "commands" not in s:
+            sec.append({"name": s.get("name"), "error": str(s["error"])[:120]})
+        elif "commands" in s:                                                    # published commands through both binaries
+            for q in s["commands"]:
+                e = {"name": "%s: %s" % (s.get("name"), q.get("command")), "sites": s.get("sites"), "cold_s": _num(q.get("this_repo_s")),
+                     "resident_s": _num(q.get("resident_s")), "reference_s": _num(q.get("reference_s")),
+                     "published_s": q.get("published_s"), "stdout_identical": q.get("stdout_identical")}
+                sec.append({k: v for k, v in e.items() if v is not None})
+        elif "wall_s" in s:                                                      # a command line record (C5)
+            sec.append({"name": s.get("name"), "wall_s": _num(s["wall_s"]), "reference_s": _num(s.get("reference", {}).get("wall_s")),
+                        "stdout_identical": s.get("reference", {}).get("stdout_identical"),
+                        "sharded_stdout_identical": s.get("sharded", {}).get("stdout_identical")})
+        else:
+            rf = s.get("roofline") or {}
+            e = {"name": s.get("name"), "sites_per_s": _num(s.get("sites_per_s", s.get("value"))), "ms_per_step": _num(s.get("ms_per_step")),
+                 "kernel_ms": _num(s.get("kernel_ms", rf.get("kernel_ms"))), "frac": _num(rf.get("frac"), 3),
+                 "parity_ok": s.get("parity_ok"),
+                 "cpu_baseline_sites_per_s": _num((s.get("cpu_baseline") or {}).get("value"))}
+            if s.get("arena_kept"):
+                e["arena_kept_ms"] = _num(s["arena_kept"].get("kernel_ms"))
+            if s.get("n_gpus", 1) > 1:                                           # the block-sharded database riding along (N > 1)
+                sp = s.get("parity") or {}
+                e.update({"scaling": s.get("scaling"), "haplotypes": s.get("config", {}).get("haplotypes"),
+                          "sites_total": s.get("config", {}).get("sites_total"),
+                          "sites_checked_popcount_identity": sp.get("sites_checked_popcount_identity"),
+                          "per_rank_kernel_ms": [_num(x) for x in s.get("per_rank_kernel_ms", [])], "gather_ms": _num(s.get("gather_ms"))})
+            sec.append(e)
+    if sec:
+        c["secondary"] = sec
+    if out.get("parity_error"):
+        c["parity_error"] = str(out["parity_error"])[:300]
+    if detail_path:
+        c["detail"] = detail_path
+    line = json.dumps(c, allow_nan=False, separators=(",", ":"))
+    while len(line) > COMPACT_LIMIT and c.get("secondary"):                      # never over the limit: drop records from the end, say so
+        c["secondary"].pop()
+        c["secondary_truncated"] = True
+        line = json.dumps(c, allow_nan=False, separators=(",", ":"))
+    return line
+
+
+def emit(out, detail_arg=None):
+    """Full record -> the detail file (--detail PATH; default bench_detail.json at the repo root, and in gpurun_out/ where that
+    exists so that it travels back from the GPU box); compact line -> stdout, last."""
+    detail = None
+    try:
+        txt = json.dumps(out, indent=1, default=str)
+        targets = [detail_arg] if detail_arg else [os.path.join(d, "bench_detail.json") for d in (ROOT, os.path.join(ROOT, "gpurun_out"))
+                                                   if os.path.isdir(d)]
+        for t in targets:
+            with open(t, "w") as f:
+                f.write(txt)
+            detail = os.path.basename(t)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    print(compact_record(out, detail), flush=True)
+
+
 def lookup_peak(bgt_amd, device):
     """G rank-lookups/s the chip sustains running only the product's row step (live microbenchmark, ~40 ms)."""
     import ctypes as C
@@ -925,6 +1074,8 @@ def main():
     ap.add_argument("--cpt", type=int, default=0)
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--no-counters", action="store_true", help="skip the in-run rocprofv3 --pmc passes (HBM traffic of the scan kernel)")
+    ap.add_argument("--detail", default=None, help="where the full record goes (default: bench_detail.json beside bench.py); stdout carries "
+                                                   "one compact line")
     ap.add_argument("--counters-child", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.counters_child:
@@ -1113,7 +1264,7 @@ def main():
             except Exception as e:
                 out["secondary"].append({"name": "C5-cli", "error": repr(e)[:300]})
     if rank == 0:
-        print(json.dumps(out))
+        emit(out, args.detail)
     if world > 1:
         dist.destroy_process_group()
 
@@ -1128,5 +1279,5 @@ if __name__ == "__main__":
         print(json.dumps({"metric": "sites/sec `bgt view -G -f'AC>0'` whole-cohort scan", "value": None, "unit": "sites/s",
                           "n_gpus": int(os.environ.get("WORLD_SIZE", "1")), "error": repr(exc)[:600],
                           "failed_rank": int(os.environ.get("RANK", "0")), "failed_local_rank": int(os.environ.get("LOCAL_RANK", "0")),
-                          "traceback_tail": traceback.format_exc().splitlines()[-6:]}), flush=True)
+                          "traceback_tail": [t[:160] for t in traceback.format_exc().splitlines()[-6:]]}, allow_nan=False), flush=True)
         raise

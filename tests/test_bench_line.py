@@ -1,0 +1,101 @@
+"""bench.py's LAST stdout line is what the driver parses (round 4: a ~30 KB line with prose in it came back unparsed).  The
+formatter is fed a recorded full record (tests/golden/bench/record_r04_n1.json = round 4's own N = 1 run on the GPU box) and
+a multi-rank one; the line must be short, strict JSON, and carry the contract's keys."""
+import copy
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline", "cpu_baseline", "parity_ok")
+
+
+def strict(line):
+    def bad(c):
+        raise AssertionError("non-finite constant %s in the bench line" % c)
+    return json.loads(line, parse_constant=bad)
+
+
+@pytest.fixture()
+def record():
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "bench", "record_r04_n1.json")))
+
+
+def test_recorded_run_formats_to_a_short_strict_line(record):
+    line = bench.compact_record(record, "bench_detail.json")
+    assert "\n" not in line and len(line) < bench.COMPACT_LIMIT < 4096
+    out = strict(line)
+    for k in REQUIRED:
+        assert k in out, k
+    assert out["metric"] == record["metric"] and out["unit"] == "sites/s" and out["n_gpus"] == 1
+    assert abs(out["value"] - record["value"]) <= 1e-5 * record["value"]
+    assert "workload" in out["config"] and "model" not in out["config"] and out["config"]["haplotypes"] == 20000
+    r = out["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "frac_of_own_statement", "frac_of_guide_2cycle", "traffic", "kernel", "kernel_ms",
+              "hbm_frac_measured"):
+        assert k in r, k
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 2e-3
+    assert r["frac_of_guide_2cycle"] < r["frac"] < r["frac_of_own_statement"] < 1.0       # three ceilings, the strictest included
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "reference" and cb["cores"] == 1 and cb["value"] > 0 and cb["cli_stdout_identical_to_reference"] is True
+    names = [s["name"] for s in out["secondary"]]
+    assert names[:4] == ["HRC-GC", "HRC-GC-subset", "C3", "C4-shard"]
+    for s in out["secondary"][:4]:
+        assert set(("sites_per_s", "ms_per_step", "frac", "parity_ok")) <= set(s)
+    assert all(isinstance(v, (int, float, str, bool, type(None), list, dict)) for v in out.values())
+    assert max(len(v) for v in _strings(out)) <= 200                                  # labels, not paragraphs
+
+
+def _strings(o):
+    if isinstance(o, str):
+        yield o
+    elif isinstance(o, dict):
+        for v in o.values():
+            yield from _strings(v)
+    elif isinstance(o, list):
+        for v in o:
+            yield from _strings(v)
+
+
+def test_non_finite_numbers_never_reach_the_line(record):
+    bad = copy.deepcopy(record)
+    bad["roofline"]["frac"] = float("nan")
+    bad["roofline"]["traffic"] = float("inf")
+    bad["secondary"][0]["sites_per_s"] = float("-inf")
+    out = strict(bench.compact_record(bad))
+    assert out["roofline"]["frac"] is None and out["roofline"]["traffic"] is None and out["secondary"][0]["sites_per_s"] is None
+
+
+def test_many_secondary_records_are_cut_not_overflowed(record):
+    big = copy.deepcopy(record)
+    big["secondary"] = big["secondary"] * 12
+    line = bench.compact_record(big)
+    assert len(line) <= bench.COMPACT_LIMIT
+    out = strict(line)
+    assert out["secondary_truncated"] is True and out["value"] > 0
+
+
+def test_error_record_is_short_and_strict():
+    line = bench.compact_record({"metric": "m", "value": None, "unit": "sites/s", "n_gpus": 8, "error": "x" * 5000, "failed_rank": 3})
+    assert len(line) < 1000 and strict(line)["failed_rank"] == 3
+
+
+def test_multi_rank_record_keeps_what_the_scaling_run_needs(record):
+    mr = copy.deepcopy(record)
+    mr.update({"n_gpus": 8, "scaling": "weak", "per_rank_kernel_ms": [10.9] * 8, "gather_ms": 0.4,
+               "ranks": {"world_size": 8, "backend": "nccl", "device_of_rank": list(range(8)), "devices_visible": 8}})
+    c4 = copy.deepcopy(record)
+    c4.update({"name": "C4-sharded", "n_gpus": 8, "scaling": "strong", "per_rank_kernel_ms": [160.0] * 8, "gather_ms": 1.0})
+    for k in ("secondary", "cpu_baseline", "cli_end_to_end", "resident_end_to_end", "server"):
+        c4.pop(k, None)
+    mr["secondary"] = [c4]
+    out = strict(bench.compact_record(mr))
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak" and len(out["per_rank_kernel_ms"]) == 8
+    assert out["ranks"]["device_of_rank"] == list(range(8))
+    assert out["secondary"][0]["scaling"] == "strong" and len(out["secondary"][0]["per_rank_kernel_ms"]) == 8

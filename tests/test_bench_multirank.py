@@ -18,16 +18,22 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("workload,sites,extra", [("c4", 6 * 8192 - 1000, []), ("c2", 40000, ["--no-secondary"])])
-def test_two_ranks_on_one_device(workload, sites, extra):
+def test_two_ranks_on_one_device(workload, sites, extra, tmp_path):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--backend", "gloo", "--sites", str(sites)] + ["--workload", workload] + extra
+           "--backend", "gloo", "--sites", str(sites), "--detail", str(tmp_path / "detail.json")] + ["--workload", workload] + extra
     env = dict(os.environ, BENCH_ALL_RANKS_ON_DEVICE0="1", BGTH_DIR_ARENA_MB="6000")
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=1200, cwd=ROOT)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
-    line = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1]
-    out = json.loads(line)
+    line = p.stdout.decode().splitlines()[-1]                 # the driver reads the LAST line: compact, strict JSON
+    assert len(line) < 4096
+    short = json.loads(line, parse_constant=lambda c: pytest.fail("non-finite number in the bench line: " + c))
+    out = json.load(open(tmp_path / "detail.json"))           # the full record
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "roofline", "config", "parity_ok"):
+        assert k in short, k
+    assert short["n_gpus"] == 2 and short["parity_ok"] is True and abs(short["value"] - out["value"]) <= 1e-5 * out["value"]
+    assert short["parity"]["sites_checked_popcount_identity"] == short["config"]["sites_total"] and len(short["per_rank_kernel_ms"]) == 2
     assert out["n_gpus"] == 2 and out["value"] > 0
     assert out["scaling"] == ("strong" if workload == "c4" else "weak")
     if workload == "c4":
@@ -38,17 +44,23 @@ def test_two_ranks_on_one_device(workload, sites, extra):
     assert len(out["per_rank_kernel_ms"]) == 2 and "parity_error" not in out
 
 
-def test_default_run_of_two_ranks_carries_the_sharded_c4_record():
+def test_default_run_of_two_ranks_carries_the_sharded_c4_record(tmp_path):
     """The driver's command without --workload: the headline is the per-GPU C2 workload (weak scaling: a value the N = 1 value
     compares with), BASELINE configs[3] block-sharded over the ranks rides along as secondary record, both checked on the box."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--backend", "gloo", "--sites", "40000", "--secondary-sites", str(6 * 8192 - 1000), "--secondary-steps", "1"]
+           "--backend", "gloo", "--sites", "40000", "--secondary-sites", str(6 * 8192 - 1000), "--secondary-steps", "1",
+           "--detail", str(tmp_path / "detail.json")]
     env = dict(os.environ, BENCH_ALL_RANKS_ON_DEVICE0="1", BGTH_DIR_ARENA_MB="6000")
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=1200, cwd=ROOT)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
-    out = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    short = json.loads(p.stdout.decode().splitlines()[-1])
+    assert len(p.stdout.decode().splitlines()[-1]) < 4096 and short["scaling"] == "weak" and short["ranks"]["device_of_rank"] == [0, 0]
+    s0 = short["secondary"][0]
+    assert s0["name"] == "C4-sharded" and s0["scaling"] == "strong" and s0["haplotypes"] == 200000 and s0["parity_ok"] is True
+    assert s0["sites_checked_popcount_identity"] == s0["sites_total"] and s0["sites_per_s"] > 0
+    out = json.load(open(tmp_path / "detail.json"))
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["haplotypes"] == 20000 and out["parity_ok"] is True
     assert out["ranks"]["world_size"] == 2 and out["ranks"]["device_of_rank"] == [0, 0]
     sec = out["secondary"][0]
