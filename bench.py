@@ -453,6 +453,8 @@ def counters_child(spec):
     rle, lens = bgt_amd.synth_rows(m, 0, sites, seed)
     pbf = bgt_amd.HipPbf.from_rle(m, 13, rle, lens)
     rd = bgt_amd.HipReader(pbf)
+    if os.environ.get("BENCH_REBUILD_ROWS"):                     # directory path: every scan builds its rows, as the timed steps do
+        bgt_amd.force_kernels(bgt_amd.hip.FORCE_REBUILD_ROWS)
     for _ in range(4):
         rd.scan(0, sites)
 
@@ -794,13 +796,10 @@ def secondary_record(torch, bgt_amd, np, peak, name, what, n_samples, sites, see
     T = rd.width
     pipe = Pipeline(torch, bgt_amd, rd, 0, sites, dev, local, 1, 0, None)
     # ONE-SHOT figures first: every step builds its rows again (the directory path would otherwise walk the arena the
-    # previous step left; BGTH_VARIANT 128 forbids that) -- then the same steps with the arena kept, labelled so
+    # previous step left; FORCE_REBUILD_ROWS forbids that) -- then the same steps with the arena kept, labelled so
     kept = None
-    os.environ["BGTH_VARIANT"] = "128"
-    try:
+    with bgt_amd.forced_kernels(bgt_amd.hip.FORCE_REBUILD_ROWS):
         dt, k_ms, last = pipe.run(steps, warmup)
-    finally:
-        os.environ.pop("BGTH_VARIANT")
     geo, path = rd.geometry(), rd.path()
     if path["directory_path"]:
         dt2, k2, _ = pipe.run(steps, 1)
@@ -851,7 +850,7 @@ def secondary_record(torch, bgt_amd, np, peak, name, what, n_samples, sites, see
         # HBM bytes of the one-shot scan measured in this run: walk-only kernel + producer (the arena rebuilt by every scan);
         # after this process has given its image and arena back, so that the child's scan is one pass like the timed one
         kn = "walk_kernel<%d, %d" % (geo["threads"], geo["cols_per_thread"])
-        ic = inrun_counters(n_samples, sites, seed, tmp, kn, "dirbuild_kernel", {"BGTH_VARIANT": "128"})
+        ic = inrun_counters(n_samples, sites, seed, tmp, kn, "dirbuild_kernel", {"BENCH_REBUILD_ROWS": "1"})
         rec["roofline"]["traffic_in_run"] = ic
         if "hbm_bytes_per_launch" in ic:
             rec["roofline"]["traffic"] = ic["hbm_bytes_per_launch"]
@@ -926,16 +925,11 @@ def sharded_run(args, ctx, workload, steps, warmup, sites_arg):
     peak = ctx.peak
     pipe = Pipeline(torch, bgt_amd, rd, 0, sites, dev, local, world, rank, dist)
     # Every timed step does ALL the work of a pass: on the directory path (wide cohorts: C4) the rows are built again by every
-    # step instead of being walked from the arena the step before left behind (BGTH_VARIANT bit 128; no effect on the other
+    # step instead of being walked from the arena the step before left behind (FORCE_REBUILD_ROWS; no effect on the other
     # kernels).  The arena-kept rate is reported by the C4-shard secondary record, labelled.
-    one_shot_forced = "BGTH_VARIANT" not in os.environ
-    if one_shot_forced:
-        os.environ["BGTH_VARIANT"] = "128"
-    try:
+    one_shot_forced = True
+    with bgt_amd.forced_kernels(bgt_amd.hip.FORCE_REBUILD_ROWS):
         dt, k_ms, last = pipe.run(steps, warmup)
-    finally:
-        if one_shot_forced:
-            os.environ.pop("BGTH_VARIANT")
     n_pass = int(pipe.host_n_pass[last].item()) if rank == 0 else 0
     if rank == 0:
         host = pipe.host[last]

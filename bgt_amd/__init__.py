@@ -7,6 +7,6 @@ that ABI for tests, the benchmark and multi-GPU launch (torch.distributed over R
 decoder of its own and raises if the HIP library or a device is missing.
 """
 from .hip import (bench_lib, HipEncoder, HipFilter, HipPbf, HipReader, build_host_shell, build_library, host_lib, device_count, library_path, last_error, lib,  # noqa: F401
-                  shard_ranges, synth_rows)
+                  shard_ranges, synth_rows, force_kernels, forced_kernels)
 
-__all__ = ["bench_lib", "HipEncoder", "HipFilter", "HipPbf", "HipReader", "build_host_shell", "build_library", "host_lib", "device_count", "library_path", "last_error", "lib", "shard_ranges", "synth_rows"]
+__all__ = ["bench_lib", "HipEncoder", "HipFilter", "HipPbf", "HipReader", "build_host_shell", "build_library", "host_lib", "device_count", "library_path", "last_error", "lib", "shard_ranges", "synth_rows", "force_kernels", "forced_kernels"]

@@ -178,9 +178,6 @@ struct Selection {
     std::vector<int32_t> slot_col, slot_of_out, group_haps;
     std::vector<uint32_t> chunk_desc;
     int32_t *d_slot_col = nullptr, *d_slot_of_out = nullptr, *d_group_haps = nullptr;
-    int32_t *d_slot_of_col = nullptr;  // [m]: slot of a column, -1 = not selected (made on first use: the sparse plane-1 tracker)
-    size_t cap_soc = 0;
-    bool dup_cols = false;             // a column selected twice (one slot cannot stand for both: no tracker)
     uint32_t *d_chunk_desc = nullptr;
     size_t cap[4] = {0, 0, 0, 0};      // bytes behind the four device tables: a reader that is selected again (a pooled
                                        // reader serves query after query) allocates only when a table grows
@@ -190,8 +187,6 @@ struct Selection {
         if (d_slot_of_out) hipFree(d_slot_of_out);
         if (d_group_haps) hipFree(d_group_haps);
         if (d_chunk_desc) hipFree(d_chunk_desc);
-        if (d_slot_of_col) hipFree(d_slot_of_col);
-        d_slot_of_col = nullptr; cap_soc = 0;
         d_slot_col = d_slot_of_out = d_group_haps = nullptr;
         d_chunk_desc = nullptr;
         cap[0] = cap[1] = cap[2] = cap[3] = 0;
@@ -210,8 +205,6 @@ struct bgth_pbf_s {
     int64_t n = 0, n_blk = 0;         // n_blk: file blocks of 1 << shift rows
     int64_t n_sub = 0;                // sub-blocks of 1 << sub_shift rows: the unit the kernels work on
     int arena_share = 1;              // shards of one sharded image on this device (the directory arena is cap / arena_share)
-    bool n1_known = false;            // plane-1 statistics (ensure_plane1_stats): most ones in a row, ones in all rows
-    int64_t n1_max = 0, n1_sum = 0;
     // a partial image (bgth_pbf_open_rows) holds the file blocks that cover a row range: every internal index is
     // relative to row_off (a multiple of 1 << shift), the C ABI speaks file rows
     int64_t row_off = 0, n_total = 0;
@@ -241,22 +234,30 @@ struct bgth_pbf_s {
     std::vector<bgth_reader_t*> pool;
 };
 
-// Test / tuning knob BGTH_VARIANT: picks between kernel variants that all give the SAME results (like bgth_reader_tune):
-//   1 = team mode without the separate toggle array (the code path of cohorts too wide for it)
-//   2 / 4 = never / always the kernels with the all-zero-plane-1 shortcut
-//   32 / 64 = always / never the directory path (rows built once into an HBM arena, walk-only workgroups; default: wide
-//   cohorts whose columns span several workgroups);  128 = no reuse of an arena that already holds the rows of a scan
-enum { kVariantNoTog = 1, kVariantNeverZP = 2, kVariantAlwaysZP = 4, kVariantNoPrefetch = 16,    // 16: no window prefetch in the pull interface
-       kVariantDirAlways = 32, kVariantDirNever = 64, kVariantDirNoReuse = 128, kVariantDirNoWarm = 256,
-       kVariantSeqCheckpoints = 512,                       // 512: bgth_pbf_from_rle derives its checkpoints block after block
-       kVariantRcclSelf = 1024,                          // 1024: sharded scan_device gathers through RCCL even between shards of ONE device
-                                                           //       (send / receive to self): runs the RCCL path on a one-GPU box
-       kVariantPlaneNever = 2048, kVariantPlaneAlways = 4096,     // the plane-split kernels (sparse selections of wide cohorts)
-       kVariantNoWalkPrio = 16384,
-       kVariantNoCC = 65536,
-       kVariantSparseNever = 131072, kVariantSparseAlways = 262144 }; // plane 1 by the sparse tracker (scan_sparse.hip): never / whenever it is possible                                     // narrow kernels: never the ballot-free row step (scan_step_cc.inc.h)                               // walk-only / team kernels without progress-based wave priorities
-static bool variant_flag(int bit) { const char *d = getenv("BGTH_VARIANT"); return d && (atoi(d) & bit); }
-static bool ensure_plane1_stats(bgth_pbf_t *p, hipStream_t s);
+// Kernel families that all give the SAME results can be forced (bgth_force_kernels, include/bgt_hip.h: BGTH_FORCE_*) so that tests
+// run every family on shapes the CPU oracle decodes quickly; 0 = automatic.  The shipped library reads no environment variable
+// for this; the profiling build (make ABLATE=1) also honours BGTH_VARIANT=<bits> and three experiment bits of its own.
+enum { kVariantNoTog = BGTH_FORCE_NO_TOGGLE_ARRAY, kVariantNeverZP = BGTH_FORCE_NO_EMPTY_PLANE_SHORTCUT,
+       kVariantAlwaysZP = BGTH_FORCE_EMPTY_PLANE_SHORTCUT,
+       kVariantDirAlways = BGTH_FORCE_DIRECTORY_PATH, kVariantDirNever = BGTH_FORCE_NO_DIRECTORY_PATH,
+       kVariantDirNoReuse = BGTH_FORCE_REBUILD_ROWS,
+       kVariantSeqCheckpoints = BGTH_FORCE_SEQUENTIAL_CHECKPOINTS, kVariantRcclSelf = BGTH_FORCE_RCCL_TO_SELF,
+       kVariantPlaneNever = BGTH_FORCE_NO_PLANE_SPLIT, kVariantPlaneAlways = BGTH_FORCE_PLANE_SPLIT,
+       // profiling build only: no window prefetch in the pull interface | no L2 warming of the next row's plane 1 | no
+       // progress-based wave priorities in the walk
+       kVariantNoPrefetch = 16, kVariantDirNoWarm = 256, kVariantNoWalkPrio = 16384 };
+static std::atomic<unsigned> g_forced{0};
+extern "C" void bgth_force_kernels(unsigned flags) { g_forced.store(flags, std::memory_order_relaxed); }
+static bool variant_flag(int bit)
+{
+    unsigned f = g_forced.load(std::memory_order_relaxed);
+#ifdef BGTH_ABLATE
+    if (const char *d = getenv("BGTH_VARIANT")) f |= (unsigned)atoi(d);
+#else
+    if (bit == kVariantNoPrefetch || bit == kVariantDirNoWarm || bit == kVariantNoWalkPrio) return false;
+#endif
+    return (f & (unsigned)bit) != 0;
+}
 
 // Builds the row index once per image; later calls only return it.  The build is enqueued on `s`, the
 // stream of the scan that needs it, and waited for, so that other streams may use the index afterwards.
@@ -275,24 +276,6 @@ static bool ensure_rowindex(bgth_pbf_t *p, hipStream_t s)
     HIP_TRY(hipStreamSynchronize(s), { hipFree(ci); hipFree(sc); return false; });
     p->d_chunkinfo = ci; p->d_segc = sc; p->S8 = S8;
     p->rowindex_bytes = (int64_t)(n_ci + n_sc) * 4;
-    return true;
-}
-
-// Ones per plane-1 row (counted once per image, on the stream of the first scan that asks): what decides whether plane 1
-// is walked by the sparse tracker (scan_sparse.hip) -- work proportional to the ones -- or densely like plane 0.
-static bool ensure_plane1_stats(bgth_pbf_t *p, hipStream_t s)
-{
-    std::lock_guard<std::mutex> guard(p->rowindex_lock);
-    if (p->n1_known) return true;
-    unsigned long long *d_st = nullptr, h[2] = {0, 0};
-    int32_t *d_n1 = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_st, 16), return false);
-    HIP_TRY(hipMalloc((void**)&d_n1, (size_t)std::max<int64_t>(p->n, 1) * 4), { hipFree(d_st); return false; });
-    bool ok = hipMemsetAsync(d_st, 0, 16, s) == hipSuccess && launch_plane1_ones(p->d_rowdesc, p->d_rle, p->n, p->m, d_n1, d_st, s) == hipSuccess &&
-              hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h, d_st, 16, hipMemcpyDeviceToHost) == hipSuccess;
-    hipFree(d_st); hipFree(d_n1);
-    if (!ok) { set_err("[E::bgth] plane-1 statistics: %s", hipGetErrorString(hipGetLastError())); return false; }
-    p->n1_max = (int64_t)h[0]; p->n1_sum = (int64_t)h[1]; p->n1_known = true;
     return true;
 }
 
@@ -399,10 +382,6 @@ struct bgth_reader_s {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     DevBuf raw, fin, h0, h1, gt;      // scratch of every scan; results of bgth_reader_scan
     DevBuf ph0, ph1;                  // bit planes of the plane-split kernels when the caller wants counts only
-    DevBuf sp_e2s, sp_tail;           // sparse plane-1 tracker: epoch tables and tail references per sub-block of a launch
-    bool sparse1 = false;             // the last scan walked plane 1 with the tracker
-    hipStream_t stream2 = nullptr;    // the tracker's stream (beside the scan kernel's)
-    hipEvent_t ev_sp[2] = {nullptr, nullptr};
     int plane_path = 0;               // the last scan ran the plane-split kernels
     // directory path: the arena of {bits, ones before} rows and their zero counts; [dir_lo, dir_hi) = image rows it holds
     // from the last producer pass (a later scan inside that range only walks), dir_passes/dir_built = what the last scan did
@@ -413,6 +392,7 @@ struct bgth_reader_s {
     float dir_build_ms = 0;
     hipEvent_t ev_dir[2] = {nullptr, nullptr};
     hipEvent_t ev_gather = nullptr;   // sharded scan_device: this shard's counts have left for the root device
+    hipEvent_t ev_copied = nullptr;   // ... and the root stream's copy out of this shard's `fin` is done: the shard's next scan waits for it
     DevBuf carriers, hapsig;          // allele-set accumulators (bgth_reader_fold_last), zeroed when folds_live turns true
     bool folds_live = false;
     PullWindow win[2];                // pull interface: current window and the one being prefetched
@@ -488,19 +468,6 @@ static bool build_selection(Selection &s, int m, int n_sub, const int32_t *sub, 
     s.n_chunks = (int)s.chunk_desc.size();
     if (s.n_chunks == 0) { set_err("[E::bgth_reader_select] empty selection"); return false; }
     const size_t nslot = s.slot_col.size();
-    {
-        std::vector<int32_t> soc((size_t)m, -1);
-        s.dup_cols = false;
-        for (size_t i = 0; i < nslot; ++i)
-            if (s.slot_col[i] >= 0) { if (soc[s.slot_col[i]] >= 0) s.dup_cols = true; soc[s.slot_col[i]] = (int32_t)i; }
-        if (s.cap_soc < (size_t)m * 4) {
-            if (s.d_slot_of_col) hipFree(s.d_slot_of_col);
-            s.d_slot_of_col = nullptr; s.cap_soc = 0;
-            HIP_TRY(hipMalloc((void**)&s.d_slot_of_col, (size_t)m * 4), return false);
-            s.cap_soc = (size_t)m * 4;
-        }
-        HIP_TRY(hipMemcpy(s.d_slot_of_col, soc.data(), (size_t)m * 4, hipMemcpyHostToDevice), return false);
-    }
     auto grow = [&](void **ptr, size_t &have, size_t need) -> bool {
         if (need <= have) return true;
         if (*ptr) hipFree(*ptr);
@@ -548,16 +515,40 @@ static void fit_sub_shift(bgth_pbf_t *p, int64_t n)
         if (g.nbuf == 1 && g.wpp > 1 && choose_walk_geometry(p->m, chunks, 1, 4096, 0, 0, &w)) { slices = w.slices; plane = true; }
         else slots = 256 * (int64_t)std::max(1, std::min(2048 / g.threads, (160 * 1024) / std::max(1, g.lds_bytes)));
     }
+    // the finer checkpoints may not crowd the device: at most a sixteenth of the HBM that is free now (and never below 256 MB,
+    // which every default spacing of a real file stays under); a failed allocation falls back to the default (rank0_alloc)
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)4 << 30;
+    const double cap_bytes = std::max<double>((double)((size_t)256 << 20), (double)free_b / 16.0);
     double best = 1e30;
     int pick = top;
     for (int s = top; s >= std::min(top, 7); --s) {
         const int64_t subs = (n + ((int64_t)1 << s) - 1) >> s, wgs = subs * slices;
+        if (s < top && (double)subs * 8.0 * (double)p->m > cap_bytes) break;
         const double start = 1.0 + 10.0 / (double)((int64_t)1 << s);
         double t = start * (double)((wgs + slots - 1) / slots * slots) / (double)wgs;
         if (plane) { const int64_t ps = 256 * (int64_t)plane_slots_per_cu(p->m); t += start * (double)((2 * subs + ps - 1) / ps * ps) / (double)(2 * subs); }
         if (t < best * 0.98) { best = t; pick = s; }
     }
     p->sub_shift = pick;
+}
+
+// d_rank0 for the image's sub-checkpoints; when the spacing fit_sub_shift chose does not fit the HBM that is left, once more at
+// the default spacing (an image that opened before the spacing was fitted to the chip still opens)
+static bool rank0_alloc(bgth_pbf_t *p)
+{
+    const size_t per = (size_t)2 * p->m;
+    if (hipMalloc((void**)&p->d_rank0, (size_t)std::max<int64_t>(p->n_sub, 1) * per * 4) == hipSuccess) return true;
+    (void)hipGetLastError();
+    const int top = p->wide_plane ? p->shift : std::min(p->shift, 11);
+    if (p->sub_shift < top && !getenv("BGTH_SUB_SHIFT")) {
+        p->sub_shift = top;
+        set_rows(p, p->n);
+        if (hipMalloc((void**)&p->d_rank0, (size_t)std::max<int64_t>(p->n_sub, 1) * per * 4) == hipSuccess) return true;
+    }
+    p->d_rank0 = nullptr;
+    set_err("[E::bgth_pbf] out of HBM for the checkpoints (%lld x %zu bytes): %s", (long long)p->n_sub, per * 4, hipGetErrorString(hipGetLastError()));
+    return false;
 }
 
 static bgth_pbf_t *pbf_alloc(int device, int m, int g, int shift, int64_t n)
@@ -967,14 +958,14 @@ static bgth_pbf_t *open_mem_impl(const void *image, size_t len, int device)
         // sub-block index of its row; then one decode pass fills the sub-checkpoints in between
         const size_t np = perms.size(), per = (size_t)2 * m;
         if (np) {
-            const int d = p->shift - p->sub_shift;
             int32_t *d_perm = up.d_perm;
             int *d_bad = nullptr, bad = 0;
             up.d_perm = nullptr;
             if (!d_perm) HIP_TRY(hipMalloc((void**)&d_perm, np * 4), goto fail);
             HIP_TRY(hipMalloc((void**)&d_bad, 4), { hipFree(d_perm); goto fail; });
             HIP_TRY(hipMemset(d_bad, 0, 4), { hipFree(d_perm); hipFree(d_bad); goto fail; });
-            HIP_TRY(hipMalloc((void**)&p->d_rank0, std::max<int64_t>(p->n_sub, 1) * per * 4), { hipFree(d_perm); hipFree(d_bad); goto fail; });
+            if (!rank0_alloc(p)) { hipFree(d_perm); hipFree(d_bad); goto fail; }
+            const int d = p->shift - p->sub_shift;                // (after the allocation: it may fall back to the default spacing)
             if (perms.data()) HIP_TRY(hipMemcpy(d_perm, perms.data(), np * 4, hipMemcpyHostToDevice), { hipFree(d_perm); hipFree(d_bad); goto fail; });
             for (size_t b = 0; b < np / per; ++b)                 // validated: the records come from a file
                 HIP_TRY(launch_invert(d_perm + b * per, p->d_rank0 + ((size_t)b << d) * per, m, 2, nullptr, d_bad), { hipFree(d_perm); hipFree(d_bad); goto fail; });
@@ -1060,7 +1051,6 @@ static bool common_scan_args(ScanArgs &a, bgth_pbf_t *p, const Selection &sel, c
     a.n_slices = geo.slices;
     a.zp = use_zp(p) ? 1 : 0;
     a.walk_prio = variant_flag(kVariantNoWalkPrio) ? 0 : 1;
-    a.cc_step = sel.whole && sel.G == 1 && !variant_flag(kVariantNoCC) ? 1 : 0;
     if (geo.wpp > 1) {                                   // team (wide-cohort) kernels read the row index
         if (!ensure_rowindex(p, s)) return false;
         a.chunkinfo = p->d_chunkinfo;
@@ -1216,6 +1206,14 @@ extern "C" bgth_pbf_t *bgth_pbf_open_sharded(const char *path, int n_shards, con
             }
         }
         if (!ok || (p->shards.empty() && n_total > 0)) { bgth_pbf_close(p); return nullptr; }
+        // the parent describes its shards: their checkpoint spacing (each shard fitted its own to ITS row count; the pull
+        // windows of a sharded reader are cut in the parent's units, which must be whole units of every shard) is the coarsest
+        if (!p->shards.empty()) {
+            int coarsest = 0;
+            for (const bgth_pbf_t *sh : p->shards) coarsest = std::max(coarsest, sh->sub_shift);
+            p->sub_shift = coarsest;
+            set_rows(p, p->n);
+        }
         return p;
     });
 }
@@ -1402,7 +1400,7 @@ static bgth_pbf_t *from_rle_impl(int m, int g, int shift, int64_t n_rows, const 
         HIP_TRY(hipMalloc((void**)&p->d_rowdesc, std::max<size_t>(desc.size(), 1) * 8), goto fail);
         if (!desc.empty()) HIP_TRY(hipMemcpy(p->d_rowdesc, desc.data(), desc.size() * 8, hipMemcpyHostToDevice), goto fail);
         const size_t per = (size_t)2 * m;
-        HIP_TRY(hipMalloc((void**)&p->d_rank0, std::max<int64_t>(p->n_sub, 1) * per * 4), goto fail);
+        if (!rank0_alloc(p)) goto fail;
         std::vector<int32_t> ident(per);
         for (int k = 0; k < 2; ++k) for (int j = 0; j < m; ++j) ident[(size_t)k * m + j] = j;   // ref pbwt.c:103
         if (!build_selection(all, m, 0, nullptr, nullptr, 1)) goto fail;
@@ -1503,13 +1501,11 @@ static void reader_free(bgth_reader_t *r)
     r->win[0].release(); r->win[1].release();
     r->dir.release(); r->dir_n0.release();
     r->ph0.release(); r->ph1.release();
-    r->sp_e2s.release(); r->sp_tail.release();
     for (int i = 0; i < 4; ++i) if (r->ev[i]) hipEventDestroy(r->ev[i]);
     for (int i = 0; i < 2; ++i) if (r->ev_dir[i]) hipEventDestroy(r->ev_dir[i]);
     if (r->ev_gather) hipEventDestroy(r->ev_gather);
+    if (r->ev_copied) hipEventDestroy(r->ev_copied);
     if (r->stream) hipStreamDestroy(r->stream);
-    if (r->stream2) hipStreamDestroy(r->stream2);
-    for (hipEvent_t e : r->ev_sp) if (e) hipEventDestroy(e);
     delete r;
 }
 
@@ -1544,6 +1540,7 @@ extern "C" bgth_reader_t *bgth_reader_create(bgth_pbf_t *p)
         for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&r->ev[i]), { reader_free(r); return nullptr; });
         for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreate(&r->ev_dir[i]), { reader_free(r); return nullptr; });
         HIP_TRY(hipEventCreateWithFlags(&r->ev_gather, hipEventDisableTiming), { reader_free(r); return nullptr; });
+        HIP_TRY(hipEventCreateWithFlags(&r->ev_copied, hipEventDisableTiming), { reader_free(r); return nullptr; });
     }
     if (!guarded("bgth_reader_create", false, [&] { return build_selection(r->sel, p->m, 0, nullptr, nullptr, 1); })) { reader_free(r); return nullptr; }
     for (bgth_pbf_t *sh : p->shards) {
@@ -1729,36 +1726,6 @@ static int64_t enqueue_scan_wide_plane(bgth_reader_t *r, int64_t row0, int64_t r
     return rows;
 }
 
-// Decides whether plane 1 of this scan is walked by the sparse tracker and, if so, fills its arguments (a.blk0 / a.n_blk /
-// a.shift / a.rank0* are set): the image's plane 1 must be sparse (a row's ones cost the tracker about what 64 of them cost
-// a dense lookup pass), no column selected twice, its LDS and scratch must fit.  BGTH_VARIANT 131072 / 262144: never / whenever possible.
-static bool sparse_plane1_setup(bgth_reader_t *r, ScanArgs &a, hipStream_t s)
-{
-    bgth_pbf_t *p = r->pbf;
-    if (variant_flag(kVariantSparseNever) || r->sel.dup_cols || p->g_file == 1) return false;
-    // EXPERIMENTAL, opt-in (BGTH_VARIANT 262144): bit-exact (tests/test_dir_path.py::test_sparse_plane1_tracker) but not yet a
-    // gain -- C2: the tracker alone takes 6.9 ms per 1 M rows (a chain of ~8 k cycles per row and sub-block), the plane-0-only scan
-    // kernel 10.5 ms with its ballots written out, 18.8 ms together against 11.0 ms for the dense kernel (profiles/r04_sparse/).
-    const bool force = variant_flag(kVariantSparseAlways);
-    if (!force) return false;
-    if (!ensure_plane1_stats(p, s)) return false;
-    if (p->n1_max > 8192) return false;
-    const int icap = (int)std::max<int64_t>(64, (p->n1_max + 63) / 64 * 64);
-    int tcap = p->m > 65536 ? 131072 : 32768;
-    while (tcap < 8 * icap) tcap *= 2;
-    if (force && getenv("BGTH_SPARSE_TCAP"))                         // (tests: a small tail, so that epochs turn over)
-        tcap = std::max(std::max(4096, atoi(getenv("BGTH_SPARSE_TCAP")) / 4096 * 4096), (icap + 4095) / 4096 * 4096);
-    if (sparse_lds_bytes(p->m, tcap, icap) > 160 * 1024) return false;
-    const size_t mpad = (size_t)32 * ((((size_t)p->m + 31) / 32 + 127) & ~(size_t)127);
-    if (!r->sp_e2s.reserve((size_t)a.n_blk * 2 * mpad * 4) || !r->sp_tail.reserve((size_t)a.n_blk * (size_t)tcap * 4)) return false;
-    a.sp_e2s = (int32_t*)r->sp_e2s.p;
-    a.sp_tail = (int32_t*)r->sp_tail.p;
-    a.sp_slot_of_col = r->sel.d_slot_of_col;
-    a.sp_tcap = tcap;
-    a.sp_icap = icap;
-    return true;
-}
-
 static void collect_timing(bgth_reader_t *r);
 // enqueue decode+reduce of [row0,row1) on stream s; results in d_fin (+ optional planes)
 static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_t *d_fin, uint64_t *d_h0,
@@ -1780,8 +1747,10 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
     bool dirpath = want_dir_path(p, geo, r->tune_threads || r->tune_cpt || r->tune_K, r->sel.width);
     Geometry wgeo;
     if (dirpath) {
-        int wt = 0, wc = 0;                              // BGTH_WALK_GEOM=threads,cols: tuning knob of the walk-only kernel
-        if (const char *e = getenv("BGTH_WALK_GEOM")) sscanf(e, "%d,%d", &wt, &wc);
+        int wt = 0, wc = 0;
+#ifdef BGTH_ABLATE
+        if (const char *e = getenv("BGTH_WALK_GEOM")) sscanf(e, "%d,%d", &wt, &wc);   // threads,cols: tuning knob of the walk-only kernel
+#endif
         if (!choose_walk_geometry(p->m, r->sel.n_chunks, G, (int)(blk1 - blk0 + 1), wt, wc, &wgeo)) dirpath = false;
         // the team kernels also slice the columns of a SHORT scan to fill the chip; the directory path is for selections whose
         // columns do not fit one workgroup (every slice then repeats the build), not for those
@@ -1833,54 +1802,13 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
     if (!planepath && (G > 1 || r->geom.slices > 1))         // a single-group, single-slice launch stores its counts
         HIP_TRY(hipMemsetAsync(r->raw.p, 0, (size_t)rows * G * 3 * 4, s), return -1);
     if (timed) HIP_TRY(hipEventRecord(r->ev[1], s), return -1);
-    r->sparse1 = false;
     if (planepath) {
         a.h0 = p_h0; a.h1 = p_h1;
-        // Plane 1 by the sparse tracker (scan_sparse.hip) when its rows are nearly empty: the plane kernels then run plane 0
-        // alone, the tracker sets the bits of h1 (zeroed first), count_planes joins them as before.
-        if (sparse_plane1_setup(r, a, s)) {
-            HIP_TRY(hipMemsetAsync(p_h1, 0, (size_t)rows * r->sel.n_chunks * 8, s), return -1);
-            a.skip1 = 1;
-            r->sparse1 = true;
-        }
         HIP_TRY(launch_plane_scan(a, pgeo, s), return -1);
-        if (a.skip1) HIP_TRY(launch_sparse_plane1(a, s), return -1);
         HIP_TRY(launch_count_planes(p_h0, p_h1, r->sel.d_chunk_desc, (int32_t*)r->raw.p, rows, r->sel.n_chunks, G, s), return -1);
     }
     else if (!dirpath) {
-        // Narrow cohorts with a sparse plane 1: the scan kernel walks plane 0 alone and writes its ballots, the tracker sets the
-        // bits of plane 1 on a stream of its own beside it, count_planes joins the two.
-        uint64_t *n_h0 = d_h0, *n_h1 = d_h1;
-        bool sp = geo.nbuf == 2 && geo.slices == 1 && !(r->tune_threads || r->tune_cpt || r->tune_K) && !a.snap;
-        if (sp && !d_h0) {
-            const size_t pl = (size_t)rows * r->sel.n_chunks * 8;
-            if (!r->ph0.reserve(pl) || !r->ph1.reserve(pl)) sp = false;
-            else { n_h0 = (uint64_t*)r->ph0.p; n_h1 = (uint64_t*)r->ph1.p; }
-        }
-        // (half the rows per batch: the kernel builds no plane-1 rows, and the LDS it leaves lets the tracker's workgroups share its CUs)
-        Geometry sgeo;
-        // (the smallest batch that keeps the pipelined narrow mode: more than a quarter of the waves in rows)
-        const int sK = getenv("BGTH_SPARSE_K") ? atoi(getenv("BGTH_SPARSE_K")) : std::min(geo.K, geo.threads / 256 + 1);
-        sp = sp && choose_geometry(p->m, r->sel.n_chunks, 1, (int)(blk1 - blk0 + 1), geo.threads, geo.cpt, sK, &sgeo, false) &&
-             sgeo.nbuf == 2 && sgeo.slices == 1;
-        if (sp && sparse_plane1_setup(r, a, s)) {
-            a.K = sgeo.K; a.wpp = sgeo.wpp; a.nbuf = sgeo.nbuf; a.n_slices = sgeo.slices; a.G = 1;
-            r->geom = sgeo;
-            if (!r->stream2) HIP_TRY(hipStreamCreateWithFlags(&r->stream2, hipStreamNonBlocking), return -1);
-            if (!r->ev_sp[0]) { HIP_TRY(hipEventCreateWithFlags(&r->ev_sp[0], hipEventDisableTiming), return -1); HIP_TRY(hipEventCreateWithFlags(&r->ev_sp[1], hipEventDisableTiming), return -1); }
-            a.h0 = n_h0; a.h1 = n_h1; a.h_row0 = row0;
-            HIP_TRY(hipMemsetAsync(n_h1, 0, (size_t)rows * r->sel.n_chunks * 8, s), return -1);
-            HIP_TRY(hipEventRecord(r->ev_sp[0], s), return -1);
-            HIP_TRY(hipStreamWaitEvent(r->stream2, r->ev_sp[0], 0), return -1);
-            if (!getenv("BGTH_SPARSE_NOTRACK")) HIP_TRY(launch_sparse_plane1(a, r->stream2), return -1);   // (timing experiments only)
-            HIP_TRY(hipEventRecord(r->ev_sp[1], r->stream2), return -1);
-            a.skip1 = 1; a.zp = 1;
-            HIP_TRY(launch_scan(a, sgeo, s), return -1);
-            HIP_TRY(hipStreamWaitEvent(s, r->ev_sp[1], 0), return -1);
-            HIP_TRY(launch_count_planes(n_h0, n_h1, r->sel.d_chunk_desc, (int32_t*)r->raw.p, rows, r->sel.n_chunks, G, s), return -1);
-            r->sparse1 = true;
-        }
-        else HIP_TRY(launch_scan(a, geo, s), return -1);
+        HIP_TRY(launch_scan(a, geo, s), return -1);
     }
     else {
         // Passes over ranges of sub-blocks whose rows fit the arena: producer, then the walk-only kernel.  An arena that
@@ -2036,6 +1964,9 @@ static int64_t scan_device_sharded(bgth_reader_t *r, int64_t row0, int64_t row1,
             if (hipSetDevice(root_dev) != hipSuccess) { failed = true; break; }
             if (sr->stream != root_s && (hipEventRecord(sr->ev_gather, sr->stream) != hipSuccess || hipStreamWaitEvent(root_s, sr->ev_gather, 0) != hipSuccess)) { failed = true; break; }
             if (hipMemcpyAsync(dst, sr->fin.p, bytes, hipMemcpyDeviceToDevice, root_s) != hipSuccess) { failed = true; break; }
+            // ... and the shard's stream behind the copy: its NEXT scan (a caller that double-buffers d_counts enqueues it without a
+            // host synchronisation in between) overwrites `fin`, which a backed-up root stream may not have read yet
+            if (sr->stream != root_s && (hipEventRecord(sr->ev_copied, root_s) != hipSuccess || hipStreamWaitEvent(sr->stream, sr->ev_copied, 0) != hipSuccess)) { failed = true; break; }
         } else if (sr->pbf->device == root_dev) {                        // (test knob: the same bytes through RCCL, rank to itself)
             const int root = comm_rank(p, root_dev);
             if (hipSetDevice(root_dev) != hipSuccess || rccl().Send(sr->fin.p, bytes, 0, root, p->comm[root], sr->stream) != 0 ||
@@ -2156,7 +2087,7 @@ extern "C" int bgth_reader_last_path(const bgth_reader_t *rc, float out[4])
     bgth_reader_t *r = const_cast<bgth_reader_t*>(rc);
     if (!r->subs.empty()) return bgth_reader_last_path(r->subs[0], out);
     if (r->t_pending) { hipSetDevice(r->pbf->device); collect_timing(r); }
-    out[0] = (r->plane_path ? 2.f : r->geom.dir_stage >= 0 ? 1.f : 0.f) + (r->sparse1 ? 4.f : 0.f); out[1] = (float)r->dir_passes; out[2] = (float)r->dir_built; out[3] = r->dir_build_ms;
+    out[0] = (r->plane_path ? 2.f : r->geom.dir_stage >= 0 ? 1.f : 0.f); out[1] = (float)r->dir_passes; out[2] = (float)r->dir_built; out[3] = r->dir_build_ms;
     return 0;
 }
 

@@ -25,7 +25,6 @@
 #pragma once
 #include "scan_kernels.h"
 #include <stdlib.h>
-#include "scan_step_cc.inc.h"
 
 namespace bgth {
 
@@ -103,18 +102,6 @@ __device__ __forceinline__ uint32_t rle_len(uint32_t byte)
 // inside the statement; a lookup needs two of them: the low one is first the LDS address, then the shifted
 // word, then the candidate for bit = 1.  BASE operands are (LDS address of the plane-row) - 8, N0 operands are -n0.
 // ----------------------------------------------------------------------------------------------------
-#ifdef BGTH_CMPX_STEP
-// EXPERIMENT (make ccform N=.. CMPX=1): seven VALU per lookup -- q + oi goes to ALL lanes, then v_cmpx leaves only the lanes whose
-// bit is 1 active (it also writes the ballot), they take -n0 - oi, and the scalar unit re-opens the wave (every lane of these
-// kernels is active in the walk).
-#define BGTH_TAIL(Q, ELO, EHI, T, MASK, N0)            \
-    "v_lshlrev_b32 " ELO ", " Q ", " ELO "\n\t"        \
-    "v_bcnt_u32_b32 " EHI ", " ELO ", " EHI "\n\t"     \
-    "v_add_u32 " Q ", " Q ", " EHI "\n\t"              \
-    "v_cmpx_gt_i32_e64 " MASK ", 0, " ELO "\n\t"       \
-    "v_sub_u32 " Q ", " N0 ", " EHI "\n\t"             \
-    "s_mov_b64 exec, -1\n\t"
-#else
 #define BGTH_TAIL(Q, ELO, EHI, T, MASK, N0)            \
     "v_lshlrev_b32 " ELO ", " Q ", " ELO "\n\t"        \
     "v_bcnt_u32_b32 " EHI ", " ELO ", " EHI "\n\t"     \
@@ -122,7 +109,6 @@ __device__ __forceinline__ uint32_t rle_len(uint32_t byte)
     "v_sub_u32 " T ", " N0 ", " EHI "\n\t"             \
     "v_add_u32 " EHI ", " Q ", " EHI "\n\t"            \
     "v_cndmask_b32_e64 " Q ", " EHI ", " T ", " MASK "\n\t"
-#endif
 #define BGTH_ADDR(T, Q, BASE)                          \
     "v_ashrrev_i32 " T ", 5, " Q "\n\t"                \
     "v_mad_i32_i24 " T ", " T ", -8, " BASE "\n\t"
@@ -130,21 +116,6 @@ __device__ __forceinline__ uint32_t rle_len(uint32_t byte)
 // Two lookups with their dependent chains interleaved: a wave that shares its SIMD with only one other (the wide-cohort
 // kernels: 2 waves per SIMD) issues 8 % more lookups per cycle this way, four waves per SIMD are indifferent
 // (profiles/r02a_calibration: 4.56 vs 4.94 cycles per instruction at 2 waves, 3.99 vs 4.02 at 4).
-#ifdef BGTH_CMPX_STEP
-#define BGTH_TAIL2(QA, ELA, EHA, MA, N0A, QB, ELB, EHB, MB, N0B)  \
-    "v_lshlrev_b32 " ELA ", " QA ", " ELA "\n\t"                  \
-    "v_lshlrev_b32 " ELB ", " QB ", " ELB "\n\t"                  \
-    "v_bcnt_u32_b32 " EHA ", " ELA ", " EHA "\n\t"                \
-    "v_bcnt_u32_b32 " EHB ", " ELB ", " EHB "\n\t"                \
-    "v_add_u32 " QA ", " QA ", " EHA "\n\t"                       \
-    "v_add_u32 " QB ", " QB ", " EHB "\n\t"                       \
-    "v_cmpx_gt_i32_e64 " MA ", 0, " ELA "\n\t"                    \
-    "v_sub_u32 " QA ", " N0A ", " EHA "\n\t"                      \
-    "s_mov_b64 exec, -1\n\t"                                      \
-    "v_cmpx_gt_i32_e64 " MB ", 0, " ELB "\n\t"                    \
-    "v_sub_u32 " QB ", " N0B ", " EHB "\n\t"                      \
-    "s_mov_b64 exec, -1\n\t"
-#else
 #define BGTH_TAIL2(QA, ELA, EHA, MA, N0A, QB, ELB, EHB, MB, N0B)  \
     "v_lshlrev_b32 " ELA ", " QA ", " ELA "\n\t"                  \
     "v_lshlrev_b32 " ELB ", " QB ", " ELB "\n\t"                  \
@@ -158,7 +129,6 @@ __device__ __forceinline__ uint32_t rle_len(uint32_t byte)
     "v_add_u32 " EHB ", " QB ", " EHB "\n\t"                      \
     "v_cndmask_b32_e64 " QA ", " EHA ", " ELA ", " MA "\n\t"      \
     "v_cndmask_b32_e64 " QB ", " EHB ", " ELB ", " MB "\n\t"
-#endif
 #define BGTH_ASHR(T, Q)        "v_ashrrev_i32 " T ", 5, " Q "\n\t"
 #define BGTH_MAD(T, BASE)      "v_mad_i32_i24 " T ", " T ", -8, " BASE "\n\t"
 
@@ -665,48 +635,18 @@ __device__ __forceinline__ void chunk_toggles(const ScanArgs &a, uint32_t *words
 }
 
 // whole plane-row by one wave
-// fold: added to every entry's "ones before" (the CC kernels keep the LDS address of the row inside the ranks: see stepcc)
 __device__ __forceinline__ void build_plane_row(const ScanArgs &a, const uint8_t *__restrict__ rle, uint2 *bd,
                                                 uint32_t *n0_out, uint64_t desc, uint32_t pre0, uint32_t pre1, int lane,
-                                                uint32_t tail_mask, uint32_t fold = 0u)
+                                                uint32_t tail_mask)
 {
     const int nw = a.nw;
     for (int i = lane; i < nw; i += 64) bd[i] = make_uint2(0u, 0u);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     if (!(BGTH_SKIP(a, 2))) rle_toggles(a, rle, bd, desc, pre0, pre1, 0u, 0u, 2, lane);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    uint32_t carry_x = 0, carry_c = fold;
+    uint32_t carry_x = 0, carry_c = 0;
     if (!(BGTH_SKIP(a, 4))) directory_pass(bd, 0, nw, nw, tail_mask, carry_x, carry_c, lane);
-    if (lane == 0) *n0_out = (uint32_t)a.m - (carry_c - fold);
-}
-
-// ---- the ballot-free row step over CPT columns, in statements of NCH columns (scan_step_cc.inc.h) ----
-template <int NC> __device__ __forceinline__ void stepcc_n(uint32_t *r0, uint32_t *r1, uint32_t &acc, uint32_t np0, uint32_t np1)
-{
-    if constexpr (NC == 12) stepcc_12(r0, r1, acc, np0, np1);
-    else if constexpr (NC == 10) stepcc_10(r0, r1, acc, np0, np1);
-    else if constexpr (NC == 8) stepcc_8(r0, r1, acc, np0, np1);
-    else if constexpr (NC == 4) stepcc_4(r0, r1, acc, np0, np1);
-    else stepcc_2(r0, r1, acc, np0, np1);
-}
-// CPT columns in statements of 8 columns (16 lookups in flight: the best of profiles/r04_issue/ -- 20 in flight were slower
-// again), the rest in one of 4 and one of 2
-#ifndef BGTH_CC_FORM
-#define BGTH_CC_FORM 0
-#endif
-template <int CPT> __device__ __forceinline__ void stepcc_row(uint32_t *r0, uint32_t *r1, uint32_t &acc, uint32_t np0, uint32_t np1)
-{
-    // (experiments, profiles/r04_issue/: BGTH_CC_FORM 1 = the 8-column statement in two halves, 2 = 4-column statements, 5 = 10-column ones)
-    constexpr int W = BGTH_CC_FORM == 2 ? 4 : BGTH_CC_FORM == 5 ? 10 : 8;
-    constexpr int NW_ = CPT / W * W;
-#pragma unroll
-    for (int j = 0; j < NW_; j += W) {
-        if constexpr (BGTH_CC_FORM == 1) stepcc_8h(r0 + j, r1 + j, acc, np0, np1);
-        else stepcc_n<W>(r0 + j, r1 + j, acc, np0, np1);
-    }
-    if constexpr ((CPT - NW_) >= 8) stepcc_n<8>(r0 + NW_, r1 + NW_, acc, np0, np1);
-    if constexpr ((CPT - NW_) % 8 >= 4) stepcc_n<4>(r0 + CPT - (CPT - NW_) % 4 - 4, r1 + CPT - (CPT - NW_) % 4 - 4, acc, np0, np1);
-    if constexpr ((CPT - NW_) % 4 >= 2) stepcc_n<2>(r0 + CPT - 2, r1 + CPT - 2, acc, np0, np1);
+    if (lane == 0) *n0_out = (uint32_t)a.m - carry_c;
 }
 
 // SNAP = the image-open pass that snapshots the ranks at every sub-checkpoint row (ScanArgs::snap).  A template switch, not a
@@ -720,9 +660,7 @@ template <int CPT> __device__ __forceinline__ void stepcc_row(uint32_t *r0, uint
 #define BGTH_TICK(slot) do { if (BGTH_TIMES(a)) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
     tsum[slot] += now_ - tlast; tlast = now_; } } while (0)
 
-// CC (narrow cohorts, one group, no bit planes, no ZP): the ballot-free, instruction-major row step of scan_step_cc.inc.h -- the
-// LDS address of a plane-row is folded into the ranks, n(code 3) is counted per lane, the per-plane counts come from the strings.
-template <int NT, int CPT, bool MULTI, bool GT, bool TEAM, bool ZP, bool CC = false, bool SNAP = false>
+template <int NT, int CPT, bool MULTI, bool GT, bool TEAM, bool ZP, bool SNAP = false>
 __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64_t *__restrict__ rowdesc,
                                                   const uint8_t *__restrict__ rle,
                                                   const uint32_t *__restrict__ chunkinfo,
@@ -734,7 +672,6 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
     constexpr int NWAVE = NT / 64;
     static_assert(CPT % 2 == 0, "columns per thread are stepped in pairs");
     static_assert(CPT * 64 < 65536, "per-wave counts of a row are kept in 16 bits");
-    static_assert(!CC || (!MULTI && !GT && !TEAM && !ZP), "the ballot-free step serves the plain narrow kernel");
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -770,22 +707,15 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
 
     // ---- tracked slots of this thread: chunk c = chunk0 + j, slot = 64c + lane
     const int chunk0 = (slice * NWAVE + wave) * CPT;
-    // CC: rank + fold(row slot), fold = 4 x the LDS address of the plane-row the rank will be looked up in next; row slot i =
-    // buf * 2K + (2k + plane); the same plane's next row is two slots on, or -- behind the last row of a batch -- row 0 of the
-    // other buffer.  A row's entries carry fold(this) - fold(next) in their "ones before" (see build_plane_row), so the step
-    // that consumes a row leaves the ranks folded for the next one.
-    auto fold_of = [&](int i) -> uint32_t { return 4u * (lds0 + (uint32_t)i * (uint32_t)nwp * 8u); };
-    auto next_slot = [&](int i) -> int { const int buf = i / (2 * K), p = i - buf * 2 * K; return p + 2 < 2 * K ? i + 2 : (buf ^ 1) * 2 * K + (p & 1); };
     uint32_t r0[CPT], r1[CPT];
     {
         const int32_t *rk = a.rank0 + blk * a.rank0_blk_stride;
-        const uint32_t f0 = CC ? fold_of(0) : 0u, f1 = CC ? fold_of(1) : 0u;
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
             const int c = chunk0 + j;
             const int col = (c < a.n_chunks && !(BGTH_SKIP(a, 8))) ? a.slot_col[c * 64 + lane] : -1;
-            r0[j] = ~((col >= 0 ? (uint32_t)rk[col] : pad_rank) + f0);      // complemented ranks (see the row step)
-            r1[j] = ~((col >= 0 ? (uint32_t)rk[m + col] : pad_rank) + f1);
+            r0[j] = ~(col >= 0 ? (uint32_t)rk[col] : pad_rank);             // complemented ranks (see the row step)
+            r1[j] = ~(col >= 0 ? (uint32_t)rk[m + col] : pad_rank);
         }
     }
     if (MULTI) for (int i = tid; i < (TEAM ? 1 : 2) * K * G * 3; i += NT) lcnt[i] = 0;
@@ -814,7 +744,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
         }
     }
     for (int i = tid; i < (TEAM ? 1 : 2) * 2 * K; i += NT)
-        BD[(size_t)i * nwp + nw] = make_uint2(0u, CC ? fold_of(i) - fold_of(next_slot(i)) : 0u);   // a padding rank moves with the rows
+        BD[(size_t)i * nwp + nw] = make_uint2(0u, 0u);
     if (TEAM && TOG) {                                                   // cleared before any wave toggles into it
         for (int i = tid; i < 2 * K * nwt; i += NT) TOG[i] = 0u;
         lds_barrier();
@@ -898,9 +828,8 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int p = build_slot + i * NWAVE;
-                if (p < 2 * Kc && !(ZP && a.skip1 && (p & 1)))           // (skip1: plane 1 belongs to the sparse tracker, scan_sparse.hip)
-                    build_plane_row(a, rle, BDb + (size_t)p * nwp, n0b + p, cdsc[i], cpre[i][0], cpre[i][1], lane, tail_mask,
-                                    CC ? fold_of(buf * 2 * K + p) - fold_of(next_slot(buf * 2 * K + p)) : 0u);
+                if (p < 2 * Kc)
+                    build_plane_row(a, rle, BDb + (size_t)p * nwp, n0b + p, cdsc[i], cpre[i][0], cpre[i][1], lane, tail_mask);
             }
         } else {
             // team mode: wave tw of team `team` (= plane-row of the batch) takes the string's chunks tw, tw+wpp, ..
@@ -1012,44 +941,6 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
         const uint32_t *n0b = n0s + buf * 2 * K;
         int32_t *lcb = lcnt + buf * cnt_stride;
         const uint32_t bufbase = lds0 + (uint32_t)(buf * bd_stride) * 8u;
-        if constexpr (CC) {
-            if (!(BGTH_SKIP(a, 1)))
-            for (int k = 0; k < Kc; ++k) {
-                const int s0 = buf * 2 * K + 2 * k, s1 = s0 + 1;
-                const uint32_t n00 = (uint32_t)__builtin_amdgcn_readfirstlane(n0b[2 * k]);
-                const uint32_t n01 = (uint32_t)__builtin_amdgcn_readfirstlane(n0b[2 * k + 1]);
-                // N' = -n0 + fold(this row) - 2 fold(next row)  (scripts/gen_step_cc.py)
-                const uint32_t np0 = fold_of(s0) - 2u * fold_of(next_slot(s0)) - n00;
-                const uint32_t np1 = fold_of(s1) - 2u * fold_of(next_slot(s1)) - n01;
-                if (!(BGTH_SKIP(a, 0x2000))) set_wave_priority(((wave >> 2) + k) & 3);
-                if (SNAP && a.snap && rb + k > blk_beg && ((rb + k) & (((int64_t)1 << a.snap_shift) - 1)) == 0) {
-                    int32_t *dst = a.snap + ((rb + k) >> a.snap_shift) * (int64_t)(2 * m);
-                    int ln = lane;
-                    asm volatile("" : "+v"(ln));
-                    const uint32_t f0 = fold_of(s0), f1 = fold_of(s1);
-#pragma unroll
-                    for (int j = 0; j < CPT; ++j) {
-                        const int c = chunk0 + j;
-                        const int col = c < a.n_chunks ? a.slot_col[c * 64 + ln] : -1;
-                        if (col >= 0) { dst[col] = (int32_t)(~r0[j] - f0); dst[m + col] = (int32_t)(~r1[j] - f1); }
-                    }
-                }
-                uint32_t acc = 0;                                   // per lane: columns of this lane with code 3 in this row
-                stepcc_row<CPT>(r0, r1, acc, np0, np1);
-#if BGTH_CC_FORM == 7
-                const uint32_t cc = (uint32_t)__builtin_amdgcn_readfirstlane((int)acc);      // TIMING ONLY: wrong counts
-#else
-                const uint32_t cc = lane63(wave_incl_add(acc));
-#endif
-                // slot of (row, wave): {n(code 3) of this wave's columns, the row's ones of plane 0 (wave 0) / plane 1 (wave 1)}; only
-                // slice 0 brings the plane totals in
-                if (lane == 0)
-                    reinterpret_cast<uint2*>(lcb)[k * NWAVE + wave] =
-                        make_uint2(cc, slice == 0 && wave < 2 ? (uint32_t)m - (wave == 0 ? n00 : n01) : 0u);
-            }
-            BGTH_TICK(7);
-            return;
-        }
         if (!(BGTH_SKIP(a, 1)))
         for (int k = 0; k < Kc; ++k) {
             // operands of the row step: (LDS byte address of the plane-row) - 8 and -n0 (see BGTH_TAIL)
@@ -1062,7 +953,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
             // barrier while waves 12-15 finish it nearly alone (measured: walk 96 vs 189 ticks).  Rotating the user
             // priority over the rows of a batch gives the four waves of a SIMD equal progress.
             if (!TEAM && !(BGTH_SKIP(a, 0x2000))) set_wave_priority(((wave >> 2) + k) & 3);   // (team mode: by columns, below; a priority that falls with the rows of the batch instead measured the same)
-            if (ZP && (a.skip1 || n01 == 0u - (uint32_t)m)) base1 = 0u;   // plane 1 all zero (or not this kernel's): its lookups are skipped (see step2)
+            if (ZP && n01 == 0u - (uint32_t)m) base1 = 0u;   // plane 1 all zero: its lookups are skipped (see step2)
             if (SNAP && a.snap && rb + k > blk_beg && ((rb + k) & (((int64_t)1 << a.snap_shift) - 1)) == 0) {
                 // sub-checkpoint: the ranks before this row (image-open pass only)
                 int32_t *dst = a.snap + ((rb + k) >> a.snap_shift) * (int64_t)(2 * m);
@@ -1146,7 +1037,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
                     if (c < CPT && chunk0 + c < a.n_chunks) {
                         const size_t at = (size_t)(rb + k - a.row0) * a.n_chunks + chunk0 + c;
                         a.h0[at] = keep0[q];
-                        if (!(ZP && a.skip1)) a.h1[at] = keep1[q];
+                        a.h1[at] = keep1[q];
                     }
                 }
             }
@@ -1170,12 +1061,6 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
                 const int k = i / 3, comp = i - 3 * k;
                 if (rb + k >= a.row0) {
                     int32_t v = 0;
-                    if constexpr (CC) {                                  // n(code 1) = ones(plane 0) - n(code 3), n(code 2) likewise
-                        int32_t cc = 0;
-#pragma unroll
-                        for (int w = 0; w < NWAVE; ++w) cc += lcb[(k * NWAVE + w) * 2];
-                        v = comp == 2 ? cc : lcb[(k * NWAVE + comp) * 2 + 1] - cc;
-                    } else
 #pragma unroll
                     for (int w = 0; w < NWAVE; ++w) {
                         const uint32_t x = (uint32_t)lcb[(k * NWAVE + w) * 2 + (comp >> 1)];
@@ -1183,7 +1068,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
                     }
                     int32_t *dst = a.raw_counts + (size_t)(rb + k - a.row0) * 3 + comp;
                     if (a.n_slices == 1) *dst = v;                   // the only writer of this row: no zero-fill, no atomic
-                    else if (v) atomicAdd(dst, v);                   // (CC: a slice without the plane totals adds -n(code 3))
+                    else if (v) atomicAdd(dst, v);
                 }
             }
         }
@@ -1237,22 +1122,12 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
 #endif
     if (a.final_rank) {
         int32_t *fin = a.final_rank + (int64_t)bl * a.final_blk_stride;
-        uint32_t f0 = 0, f1 = 0;
-        if constexpr (CC) {                                              // the ranks are folded for the row slot behind the last row walked
-            const int64_t nrow = blk_end - blk_beg;
-            if (nrow <= 0) { f0 = fold_of(0); f1 = fold_of(1); }
-            else {
-                const int64_t last = nrow - 1;
-                const int sl = (int)((last / K) & 1) * 2 * K + 2 * (int)(last % K);
-                f0 = fold_of(next_slot(sl)); f1 = fold_of(next_slot(sl + 1));
-            }
-        }
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
             const int c = chunk0 + j;
             if (c < a.n_chunks) {
                 const int col = a.slot_col[c * 64 + lane];
-                if (col >= 0) { fin[col] = (int32_t)(~r0[j] - f0); fin[m + col] = (int32_t)(~r1[j] - f1); }
+                if (col >= 0) { fin[col] = (int32_t)~r0[j]; fin[m + col] = (int32_t)~r1[j]; }
             }
         }
     }

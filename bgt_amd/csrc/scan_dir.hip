@@ -418,7 +418,11 @@ bool choose_walk_geometry(int m, int n_chunks, int G, int n_blk, int want_thread
     g->K = 1; g->wpp = g->threads / 64; g->nbuf = 1; g->tog_off = 0;
     // plane buffers in LDS: four where they fit (m <= 160,000: both planes of the next row land during the walk, one barrier
     // per row), else three (plane 0 of the next row lands during the walk, plane 1 behind it: two barriers), else two
+#ifdef BGTH_ABLATE
     static const int four_knob = [] { const char *v = getenv("BGTH_WALK_FOUR"); return v ? atoi(v) : 1; }();   // (0: A/B runs)
+#else
+    constexpr int four_knob = 1;
+#endif
     const int nplane = four_knob && walk_lds_need(nw, G, g->threads, 4) <= kLdsBytesDir ? 4 : walk_lds_need(nw, G, g->threads, 3) <= kLdsBytesDir ? 3 : 2;
     g->dir_stage = nplane == 4 ? 4 : nplane == 3 ? 1 : 0;
     g->lds_bytes = (walk_lds_need(nw, G, g->threads, nplane) + 15) & ~15;

@@ -42,9 +42,7 @@ struct ScanArgs {
     const uint32_t *segc;
     int32_t  m, nw, shift, n_chunks, G, K, wpp, nbuf, S8;
     int32_t  zp;                 // use the kernels with the all-zero-plane-1 shortcut (the image has such rows)
-    int32_t  cc_step;            // the selection is the whole cohort in ONE group and no bit planes are wanted: the narrow kernels may
-                                 // count n(code 3) per lane and take the per-plane counts from the strings (BGTH_VARIANT 65536 forbids it)
-    int32_t  walk_prio;          // team kernels: progress-based wave priorities in the walk (BGTH_VARIANT 16384 switches them off)
+    int32_t  walk_prio;          // team kernels: progress-based wave priorities in the walk (the profiling build can switch them off)
     int32_t  tog_off;            // team mode: byte offset in LDS of the separate toggle array [2K][(nw+4)&~3], 0 = toggles in place
     int32_t  blk0, n_blk, n_slices;
     int64_t  row0, row1;         // rows whose results are emitted; decoding starts at blk0<<shift
@@ -58,14 +56,6 @@ struct ScanArgs {
     int32_t   dir_nwp;
     int32_t   dir_stage;         // bit 2: FOUR plane buffers (rows double-buffered, one barrier per row); bit 0: three plane buffers in LDS (plane 0 of the next row lands while this row is walked; else
                                  // two); bit 1: touch the next row's plane 1 during the walk so that its DMA finds it in the L2
-    // Sparse plane 1 (scan_sparse.hip): the dense kernels run plane 0 alone (skip1) and write its ballots to h0; the tracker
-    // kernel walks plane 1 as an ordered set and sets the bits of h1; count_planes joins them.
-    int32_t   skip1;
-    int32_t  *sp_e2s;            // [n_blk][2][32 * ceil128(words of m)]: epoch position -> output slot, two epochs
-    int32_t  *sp_tail;           // [n_blk][sp_tcap]: epoch position of every tail slot
-    const int32_t *sp_slot_of_col;   // [m]: output slot of a column, -1 = not selected
-    int32_t   sp_tcap;           // tail slots per sub-block (multiple of 4096)
-    int32_t   sp_icap;           // ones of a row the tracker holds: >= the most ones in a plane-1 row of the image, a multiple of 64
     // Profiling builds only (make ABLATE=1 -> libbgt_hip_ablate.so, used by scripts/profile.sh): the shipped library
     // compiles every one of these switches out (BGTH_SKIP / BGTH_TIMES below are constant 0) and never reads the
     // environment variables that set them -- an ablation switch makes the kernels return wrong numbers faster.
@@ -120,11 +110,6 @@ int plane_slots_per_cu(int m);   // workgroups of the plane-split kernels a CU h
 hipError_t launch_plane_scan(const ScanArgs &a, const Geometry &g, hipStream_t s);
 hipError_t launch_count_planes(const uint64_t *h0, const uint64_t *h1, const uint32_t *chunk_desc, int32_t *raw, int64_t n_rows,
                                int n_chunks, int G, hipStream_t s);
-// sparse plane 1 (scan_sparse.hip): the tracker over the sub-blocks of a.blk0 .. (needs sp_* and h1, zeroed), and the ones per row
-hipError_t launch_sparse_plane1(const ScanArgs &a, hipStream_t s);
-int sparse_lds_bytes(int m, int tcap, int icap);
-hipError_t launch_plane1_ones(const uint64_t *rowdesc, const uint8_t *rle, int64_t n_rows, int m, int32_t *n1, unsigned long long *stats,
-                              hipStream_t s);
 // walk-only plane kernels over the directory arena (scan_plane.hip; cohorts whose two bit-vectors do not fit the LDS together:
 // 327,000 < m <= 650,000): one workgroup per (sub-block, column slice, plane)
 bool choose_walk_plane_geometry(int m, int n_chunks, int n_blk, Geometry *g);

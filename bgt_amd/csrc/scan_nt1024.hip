@@ -6,10 +6,10 @@ namespace bgth {
 
 static const int kLdsBytesLocal = 160 * 1024;
 
-template <int NT, int CPT, bool MULTI, bool GT, bool TEAM, bool ZP, bool CC = false, bool SNAP = false>
+template <int NT, int CPT, bool MULTI, bool GT, bool TEAM, bool ZP, bool SNAP = false>
 static hipError_t launch_one(const ScanArgs &a, const Geometry &g, hipStream_t s)
 {
-    auto fn = scan_kernel<NT, CPT, MULTI, GT, TEAM, ZP, CC, SNAP>;
+    auto fn = scan_kernel<NT, CPT, MULTI, GT, TEAM, ZP, SNAP>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes);
     if (e != hipSuccess) return e;
@@ -21,17 +21,10 @@ static hipError_t launch_one(const ScanArgs &a, const Geometry &g, hipStream_t s
 template <int NT, int CPT, bool ZP>
 static hipError_t launch_variant(const ScanArgs &a, const Geometry &g, hipStream_t s)
 {
-    // (skip1: plane 0 alone, its ballots to h0 -- the counts come from count_planes, whatever the groups)
-    const int v = a.skip1 ? 2 : (a.G > 1 ? 4 : 0) | (a.h0 ? 2 : 0) | (g.wpp > 1 ? 1 : 0);
-#ifdef BGTH_CC_EXPERIMENT
-    // EXPERIMENT builds only (make ccform N=..; profiles/r04_issue/): one group, counts only, every column of the cohort tracked,
-    // pipelined narrow mode, no empty-plane shortcut -> the ballot-free instruction-major row step of scan_step_cc.inc.h.  It is
-    // bit-exact and SLOWER in the kernel (11.4-12.3 ms against 10.9 ms on C2) although faster in isolation, so it does not ship.
-    if constexpr (!ZP) if (v == 0 && a.cc_step && g.nbuf == 2) return launch_one<NT, CPT, false, false, false, false, true>(a, g, s);
-#endif
+    const int v = (a.G > 1 ? 4 : 0) | (a.h0 ? 2 : 0) | (g.wpp > 1 ? 1 : 0);
     if (a.snap) {                                                  // the image-open pass (sub-checkpoints): counts only, one group
-        if (v == 0) return launch_one<NT, CPT, false, false, false, ZP, false, true>(a, g, s);
-        if (v == 1) return launch_one<NT, CPT, false, false, true, ZP, false, true>(a, g, s);
+        if (v == 0) return launch_one<NT, CPT, false, false, false, ZP, true>(a, g, s);
+        if (v == 1) return launch_one<NT, CPT, false, false, true, ZP, true>(a, g, s);
         return hipErrorInvalidConfiguration;
     }
     switch (v) {

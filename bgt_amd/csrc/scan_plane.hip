@@ -41,10 +41,9 @@ __global__ __launch_bounds__(NT, LOW == 1 ? 6 : 4) void plane_kernel(const ScanA
     // has the longer strings, so a CU should hold one workgroup of each plane, whichever way the XCD fills its 32 CUs x 2
     // slots: neighbours in k (depth first) and ids 32 apart in k (breadth first) both get different planes.  (With plain
     // alternation the same launch took 19.6 or 24.9 ms depending on what ran before it.)
-    // (a.skip1: plane 1 is walked by the sparse tracker, scan_sparse.hip: every workgroup here is a plane-0 one)
     const int k = blockIdx.x >> 3;
-    const int plane = __builtin_amdgcn_readfirstlane(a.skip1 ? 0 : (k ^ (k >> 5)) & 1);
-    const int bl = __builtin_amdgcn_readfirstlane(a.skip1 ? (int)blockIdx.x : (k >> 1) * 8 + (int)(blockIdx.x & 7));
+    const int plane = __builtin_amdgcn_readfirstlane((k ^ (k >> 5)) & 1);
+    const int bl = __builtin_amdgcn_readfirstlane((k >> 1) * 8 + (int)(blockIdx.x & 7));
     if (bl >= a.n_blk) return;
 
     const int m = a.m, nw = a.nw, nwp = (nw + 2) & ~1, nwt = (nw + 4) & ~3;
@@ -204,7 +203,7 @@ __global__ __launch_bounds__(NT, LOW == 1 ? 6 : 4) void plane_kernel(const ScanA
     }
     asm volatile("s_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");     // the scalar stores of the ballots reach memory
 #ifdef BGTH_ABLATE
-    if (BGTH_TIMES(a) && lane == 0 && !a.skip1) for (int i = 0; i < 8; ++i) atomicAdd(a.debug_times + i, tsum[i]);   // (skip1: the tracker reports)
+    if (BGTH_TIMES(a) && lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(a.debug_times + i, tsum[i]);
 #endif
 }
 
@@ -277,7 +276,7 @@ bool choose_plane_geometry(int m, int n_chunks, int n_blk, Geometry *g)
 
 hipError_t launch_plane_scan(const ScanArgs &a, const Geometry &g, hipStream_t s)
 {
-    const unsigned grid = a.skip1 ? (unsigned)((a.n_blk + 7) / 8 * 8) : (unsigned)g.workgroups;
+    const unsigned grid = (unsigned)g.workgroups;
 #define LAUNCH(FN)                                                                                                  \
     {                                                                                                               \
         auto fn = FN;                                                                                               \

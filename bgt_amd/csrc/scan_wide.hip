@@ -88,7 +88,7 @@ hipError_t launch_rowindex(const uint64_t *rowdesc, const uint8_t *rle, int64_t 
 template <int CPT, bool MULTI, bool GT, bool ZP, bool SNAP = false>
 static hipError_t launch_one(const ScanArgs &a, const Geometry &g, hipStream_t s)
 {
-    auto fn = scan_kernel<512, CPT, MULTI, GT, true, ZP, false, SNAP>;
+    auto fn = scan_kernel<512, CPT, MULTI, GT, true, ZP, SNAP>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes);
     if (e != hipSuccess) return e;

@@ -126,6 +126,8 @@ def _load():
     L.bgth_pbf_rebase.argtypes = [C.c_void_p, C.c_void_p]
     L.bgth_reader_last_path.restype = C.c_int
     L.bgth_reader_last_path.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    L.bgth_force_kernels.restype = None
+    L.bgth_force_kernels.argtypes = [C.c_uint]
     L.bgth_reader_tune.restype = C.c_int
     L.bgth_reader_tune.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     return L
@@ -143,6 +145,36 @@ def lib():
 
 def last_error():
     return lib().bgth_last_error().decode()
+
+
+# bgth_force_kernels (include/bgt_hip.h: BGTH_FORCE_*): kernel families forced for tests / one-shot benchmark steps
+FORCE_NO_TOGGLE_ARRAY, FORCE_NO_EMPTY_PLANE_SHORTCUT, FORCE_EMPTY_PLANE_SHORTCUT = 1, 2, 4
+FORCE_DIRECTORY_PATH, FORCE_NO_DIRECTORY_PATH, FORCE_REBUILD_ROWS = 32, 64, 128
+FORCE_SEQUENTIAL_CHECKPOINTS, FORCE_RCCL_TO_SELF, FORCE_NO_PLANE_SPLIT, FORCE_PLANE_SPLIT = 512, 1024, 2048, 4096
+_forced = 0
+
+
+def force_kernels(flags=0):
+    """Process-wide: OR of FORCE_* (0 = automatic).  Returns the previous value."""
+    global _forced
+    prev, _forced = _forced, int(flags)
+    lib().bgth_force_kernels(_forced)
+    return prev
+
+
+class forced_kernels:
+    """with forced_kernels(FORCE_DIRECTORY_PATH): ...   -- restores the previous setting on exit."""
+
+    def __init__(self, flags):
+        self.flags = flags
+
+    def __enter__(self):
+        self.prev = force_kernels(self.flags)
+        return self
+
+    def __exit__(self, *exc):
+        force_kernels(self.prev)
+        return False
 
 
 def device_count():
@@ -392,7 +424,7 @@ class HipReader:
     def path(self):
         t = (C.c_float * 4)()
         lib().bgth_reader_last_path(self.h, t)
-        return {"directory_path": (int(t[0]) & 3) == 1, "plane_split": (int(t[0]) & 3) == 2, "sparse_plane1": bool(int(t[0]) & 4),
+        return {"directory_path": (int(t[0]) & 3) == 1, "plane_split": (int(t[0]) & 3) == 2,
                 "passes": int(t[1]), "producer_launches": int(t[2]), "producer_ms": t[3]}
 
     def geometry(self):

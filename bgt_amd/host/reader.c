@@ -1438,11 +1438,74 @@ static void *prep_worker(void *p)
 }
 
 /* merged sample list, groups, output header, device selections (ref bgt.c:597-676) */
+/* ---- the merged output: who is in it, and the header that announces it -------------------------------------------------
+ * Output sample t of a merge is sample out[j] of database i, databases in argv order, samples in .spl order
+ * (reference bgt.c:611-620).  One pass over the databases' selections fills the three per-sample tables; a merge that
+ * shows no genotype column at all (every sample masked by its minimal group size) becomes a -G run. */
+static void merged_sample_table(bgtm_t *bm)
+{
+    const size_t cap = (size_t)(bm->n_out ? bm->n_out : 1);
+    int db, t = 0, shown = 0;
+    bm->mgs = (int32_t*)realloc(bm->mgs, cap * sizeof(int32_t));
+    bm->group = (uint32_t*)realloc(bm->group, cap * sizeof(uint32_t));
+    bm->sample_idx = (uint64_t*)realloc(bm->sample_idx, cap * sizeof(uint64_t));
+    for (db = 0; db < bm->n_bgt; ++db) {
+        const bgt_t *one = bm->bgt[db];
+        const int32_t *file_mgs = one->f->mgs;
+        int j;
+        for (j = 0; j < one->n_out; ++j, ++t) {
+            const int smp = one->out[j];
+            bm->sample_idx[t] = (uint64_t)db << 32 | (uint32_t)smp;
+            bm->group[t] = bm->n_groups ? one->group[j] : 1;                /* no -s at all: everybody is group 1 */
+            bm->mgs[t] = file_mgs[smp] >= 0 ? file_mgs[smp] : bm->mgs_def;
+            shown += bm->mgs[t] <= 1;
+        }
+    }
+    if (bm->n_groups == 0) bm->n_groups = 1;
+    if (shown == 0) bm->flag |= BGT_F_NO_GT;
+}
+
+/* The header's meta lines as data: the goldens pin every byte (the reference prints them at bgt.c:628-658).  A count field
+ * comes in two flavours: the cohort's and, with suffix 1..n_groups, one per sample group. */
+typedef struct { const char *id, *what; } hdr_item_t;
+static const hdr_item_t k_hdr_counts[] = { {"AC", "Count of alternate alleles"}, {"AN", "Count of total alleles"} };
+static const hdr_item_t k_hdr_alts[] = {
+    {"M", "Multi-allele"}, {"DEL", "Deletion"}, {"DUP", "Duplication"}, {"INS", "Insertion"}, {"INV", "Inversion"},
+    {"DUP:TANDEM", "Tandem duplication"}, {"DEL:ME", "Deletion of mobile element"}, {"INS:ME", "Insertion of mobile element"} };
+#define N_ITEMS(a) ((int)(sizeof(a) / sizeof((a)[0])))
+
+static void header_text(const bgtm_t *bm, kstring_t *h)
+{
+    const bcf_hdr_t *first = bm->bgt[0]->f->h0;                             /* contigs: the first database speaks for all */
+    int g, k, db, t = 0;
+    ks_puts(h, "##fileformat=VCFv4.1\n");
+    for (k = 0; k < N_ITEMS(k_hdr_counts); ++k)
+        ks_printf(h, "##INFO=<ID=%s,Number=A,Type=String,Description=\"%s\">\n", k_hdr_counts[k].id, k_hdr_counts[k].what);
+    for (g = 1; g <= bm->n_groups; ++g)
+        for (k = 0; k < N_ITEMS(k_hdr_counts); ++k)
+            ks_printf(h, "##INFO=<ID=%s%d,Number=A,Type=String,Description=\"%s for sample group %d\">\n", k_hdr_counts[k].id, g,
+                      k_hdr_counts[k].what, g);
+    ks_puts(h, "##INFO=<ID=END,Number=1,Type=Integer,Description=\"Ending position\">\n"
+               "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n");
+    for (k = 0; k < N_ITEMS(k_hdr_alts); ++k)
+        ks_printf(h, "##ALT=<ID=%s,Description=\"%s\">\n", k_hdr_alts[k].id, k_hdr_alts[k].what);
+    for (k = 0; k < first->n[BCF_DT_CTG]; ++k)
+        ks_printf(h, "##contig=<ID=%s,length=%d>\n", first->id[BCF_DT_CTG][k].key, first->id[BCF_DT_CTG][k].val->info[0]);
+    ks_puts(h, "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO");
+    if (bm->flag & BGT_F_NO_GT) return;
+    ks_puts(h, "\tFORMAT");
+    for (db = 0; db < bm->n_bgt; ++db) {                                    /* one column per sample that may be shown */
+        const bgt_t *one = bm->bgt[db];
+        int j;
+        for (j = 0; j < one->n_out; ++j)
+            if (bm->mgs[t++] <= 1) { ks_putc(h, '\t'); ks_puts(h, one->f->f->rows[one->out[j]].name); }
+    }
+}
+
 int bgtm_prepare(bgtm_t *bm)
 {
     kstring_t h = {0, 0, 0};
-    const bcf_hdr_t *h0;
-    int i, j, m, need_counts, rc = 0;
+    int i, need_counts, rc = 0;
     if (bm->n_bgt == 0) return 0;
     /* does any output depend on a genotype?  not for `-G` without -C / -f / several groups (ref bgt.c:850) */
     need_counts = (bm->flag & BGT_F_SET_AC) || bm->site_flt || bm->n_fields > 0 || bm->n_groups > 1;
@@ -1466,53 +1529,8 @@ int bgtm_prepare(bgtm_t *bm)
         }
         free(job);
     }
-    bm->mgs = (int32_t*)realloc(bm->mgs, (size_t)(bm->n_out ? bm->n_out : 1) * 4);
-    bm->group = (uint32_t*)realloc(bm->group, (size_t)(bm->n_out ? bm->n_out : 1) * 4);
-    bm->sample_idx = (uint64_t*)realloc(bm->sample_idx, (size_t)(bm->n_out ? bm->n_out : 1) * 8);
-    for (i = m = 0; i < bm->n_bgt; ++i) {
-        const bgt_t *bgt = bm->bgt[i];
-        for (j = 0; j < bgt->n_out; ++j) {
-            bm->sample_idx[m] = (uint64_t)i << 32 | (uint32_t)bgt->out[j];
-            bm->group[m] = bm->n_groups ? bgt->group[j] : 1;
-            bm->mgs[m++] = bgt->f->mgs[bgt->out[j]] >= 0 ? bgt->f->mgs[bgt->out[j]] : bm->mgs_def;
-        }
-    }
-    if (bm->n_groups == 0) bm->n_groups = 1;
-    for (i = m = 0; i < bm->n_out; ++i) if (bm->mgs[i] <= 1) ++m;
-    if (m == 0) bm->flag |= BGT_F_NO_GT;
-
-    h0 = bm->bgt[0]->f->h0;
-    ks_puts(&h, "##fileformat=VCFv4.1\n");
-    ks_puts(&h, "##INFO=<ID=AC,Number=A,Type=String,Description=\"Count of alternate alleles\">\n");
-    ks_puts(&h, "##INFO=<ID=AN,Number=A,Type=String,Description=\"Count of total alleles\">\n");
-    for (i = 1; i <= bm->n_groups; ++i) {
-        ks_printf(&h, "##INFO=<ID=AC%d,Number=A,Type=String,Description=\"Count of alternate alleles for sample group %d\">\n", i, i);
-        ks_printf(&h, "##INFO=<ID=AN%d,Number=A,Type=String,Description=\"Count of total alleles for sample group %d\">\n", i, i);
-    }
-    ks_puts(&h, "##INFO=<ID=END,Number=1,Type=Integer,Description=\"Ending position\">\n");
-    ks_puts(&h, "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n");
-    ks_puts(&h, "##ALT=<ID=M,Description=\"Multi-allele\">\n");
-    ks_puts(&h, "##ALT=<ID=DEL,Description=\"Deletion\">\n");
-    ks_puts(&h, "##ALT=<ID=DUP,Description=\"Duplication\">\n");
-    ks_puts(&h, "##ALT=<ID=INS,Description=\"Insertion\">\n");
-    ks_puts(&h, "##ALT=<ID=INV,Description=\"Inversion\">\n");
-    ks_puts(&h, "##ALT=<ID=DUP:TANDEM,Description=\"Tandem duplication\">\n");
-    ks_puts(&h, "##ALT=<ID=DEL:ME,Description=\"Deletion of mobile element\">\n");
-    ks_puts(&h, "##ALT=<ID=INS:ME,Description=\"Insertion of mobile element\">\n");
-    for (i = 0; i < h0->n[BCF_DT_CTG]; ++i)
-        ks_printf(&h, "##contig=<ID=%s,length=%d>\n", h0->id[BCF_DT_CTG][i].key, h0->id[BCF_DT_CTG][i].val->info[0]);
-    ks_puts(&h, "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO");
-    if (!(bm->flag & BGT_F_NO_GT)) {
-        ks_puts(&h, "\tFORMAT");
-        for (i = m = 0; i < bm->n_bgt; ++i) {
-            const bgt_t *bgt = bm->bgt[i];
-            for (j = 0; j < bgt->n_out; ++j) {
-                if (bm->mgs[m++] > 1) continue;
-                ks_putc(&h, '\t');
-                ks_puts(&h, bgt->f->f->rows[bgt->out[j]].name);
-            }
-        }
-    }
+    merged_sample_table(bm);
+    header_text(bm, &h);
     if (bm->h_out) bcf_hdr_destroy(bm->h_out);
     bm->h_out = bcf_hdr_init();
     bm->h_out->l_text = (int32_t)h.l + 1; bm->h_out->m_text = (int32_t)h.m; bm->h_out->text = h.s;
@@ -1541,9 +1559,9 @@ int bgtm_prepare(bgtm_t *bm)
      * and bm->a[1] the merged text instead of the two byte planes.  The byte planes themselves are only needed
      * when a per-sample mask drops samples from the output (mgs > 1, ref bgt.c:300-311). */
     {
-        int want = 0;
-        for (i = m = 0; i < bm->n_out; ++i) if (bm->mgs[i] <= 1) ++m;
-        if (!(bm->flag & BGT_F_NO_GT)) want = m == bm->n_out ? BGTH_WANT_GT8 : BGTH_WANT_PLANES;
+        int want = 0, shown = 0;
+        for (i = 0; i < bm->n_out; ++i) shown += bm->mgs[i] <= 1;
+        if (!(bm->flag & BGT_F_NO_GT)) want = shown == bm->n_out ? BGTH_WANT_GT8 : BGTH_WANT_PLANES;
         if (bm->h_al && (bm->flag & (BGT_F_CNT_AL | BGT_F_CNT_HAP))) want = BGTH_WANT_BITS;   /* -S / -H: the rows stay on the device */
         for (i = 0; i < bm->n_bgt; ++i) {
             devrd_t *dv = (devrd_t*)bm->bgt[i]->pb;

@@ -422,40 +422,93 @@ static void *worker_main(void *arg)
  * may name files, so bgt_no_file stays 0 and no HTTP port is opened beside it.
  * ------------------------------------------------------------------------------------------------ */
 #define BGS_CACHE_MAX 256
-typedef struct { char *path; bgt_file_t *bf; struct timespec mtime; } cache_ent_t;
+/* One resident image per database path.  Queries hold references (cache_open / cache_close); an entry whose files changed on
+ * disk is re-pointed to a fresh bgt_open and the old image RETIRES: it stays with the queries that are reading it and is
+ * closed (its HBM given back) when the last of them returns. */
+typedef struct { bgt_file_t *bf; int refs; } image_t;
+typedef struct { char *path; image_t *img; struct timespec mtime[3]; } cache_ent_t;
 static cache_ent_t g_cache[BGS_CACHE_MAX];
 static int g_n_cache;
+static image_t **g_retired;
+static int g_n_retired, g_m_retired;
 static pthread_mutex_t g_cache_lock = PTHREAD_MUTEX_INITIALIZER;
+
+/* modification times of the three files of a database (prefix.pbf / .bcf / .spl); 0 on success */
+static int trio_mtimes(const char *pbf_path, struct timespec mt[3])
+{
+    static const char *const ext[3] = {"pbf", "bcf", "spl"};
+    char fn[PATH_MAX + 8];
+    const size_t n = strlen(pbf_path) - 3;
+    int k;
+    memcpy(fn, pbf_path, n);
+    for (k = 0; k < 3; ++k) {
+        struct stat st;
+        strcpy(fn + n, ext[k]);
+        memset(&mt[k], 0, sizeof(mt[k]));
+        if (stat(fn, &st) != 0) { if (k == 0) return -1; continue; }
+        mt[k] = st.st_mtim;
+    }
+    return 0;
+}
 
 static bgt_file_t *cache_open(const char *prefix, void *ctx)
 {
     char full[PATH_MAX], pbf[PATH_MAX + 8];
-    struct stat st;
-    bgt_file_t *bf = NULL;
+    struct timespec mt[3];
+    image_t *img = NULL;
     int i;
     (void)ctx;
     snprintf(pbf, sizeof(pbf), "%s.pbf", prefix);
-    if (realpath(pbf, full) == NULL || stat(full, &st) != 0) return NULL;   /* (the thread's own working directory: see unix_worker) */
+    if (realpath(pbf, full) == NULL || trio_mtimes(full, mt) != 0) return NULL;   /* (the thread's own working directory: see unix_worker) */
     pthread_mutex_lock(&g_cache_lock);
     for (i = 0; i < g_n_cache; ++i)
         if (strcmp(g_cache[i].path, full) == 0) {
-            /* a database that was rewritten since it was opened is opened again (the old image stays with its readers) */
-            if (g_cache[i].mtime.tv_sec == st.st_mtim.tv_sec && g_cache[i].mtime.tv_nsec == st.st_mtim.tv_nsec) bf = g_cache[i].bf;
+            if (memcmp(g_cache[i].mtime, mt, sizeof(mt)) == 0) img = g_cache[i].img;
             break;
         }
-    if (bf == NULL && (i < g_n_cache || g_n_cache < BGS_CACHE_MAX)) {
+    if (img == NULL && (i < g_n_cache || g_n_cache < BGS_CACHE_MAX)) {
+        bgt_file_t *bf;
         full[strlen(full) - 4] = 0;                                  /* back to the prefix */
         if ((bf = bgt_open(full)) != NULL) {
             if (bgt_file_preload(bf) < 0) fprintf(stderr, "[W::%s] '%s' is not resident yet; the first query will load it\n", __func__, full);
             strcat(full, ".pbf");
-            if (i == g_n_cache) { g_cache[i].path = strdup(full); ++g_n_cache; }
-            g_cache[i].bf = bf; g_cache[i].mtime = st.st_mtim;
+            img = (image_t*)calloc(1, sizeof(image_t));
+            img->bf = bf;
+            if (i == g_n_cache) { g_cache[i].path = strdup(full); g_cache[i].img = NULL; ++g_n_cache; }
+            if (g_cache[i].img) {                                    /* the database was rewritten: the old image retires */
+                image_t *old = g_cache[i].img;
+                if (old->refs == 0) { bgt_close(old->bf); free(old); }
+                else {
+                    if (g_n_retired == g_m_retired) {
+                        g_m_retired = g_m_retired ? 2 * g_m_retired : 8;
+                        g_retired = (image_t**)realloc(g_retired, (size_t)g_m_retired * sizeof(image_t*));
+                    }
+                    g_retired[g_n_retired++] = old;
+                }
+            }
+            g_cache[i].img = img; memcpy(g_cache[i].mtime, mt, sizeof(mt));
         }
     }
+    if (img) ++img->refs;
     pthread_mutex_unlock(&g_cache_lock);
-    return bf;
+    return img ? img->bf : NULL;
 }
-static void cache_close(bgt_file_t *bf, void *ctx) { (void)bf; (void)ctx; }   /* stays resident */
+
+static void cache_close(bgt_file_t *bf, void *ctx)
+{
+    int i;
+    (void)ctx;
+    pthread_mutex_lock(&g_cache_lock);
+    for (i = 0; i < g_n_cache; ++i)
+        if (g_cache[i].img && g_cache[i].img->bf == bf) { --g_cache[i].img->refs; break; }   /* (stays resident) */
+    if (i == g_n_cache)
+        for (i = 0; i < g_n_retired; ++i)
+            if (g_retired[i]->bf == bf) {
+                if (--g_retired[i]->refs == 0) { bgt_close(bf); free(g_retired[i]); g_retired[i] = g_retired[--g_n_retired]; }
+                break;
+            }
+    pthread_mutex_unlock(&g_cache_lock);
+}
 
 static int recv_all(int fd, void *buf, size_t len)
 {
@@ -468,6 +521,18 @@ static int recv_all(int fd, void *buf, size_t len)
     return 0;
 }
 
+static __thread int t_private_cwd;                                  /* this thread's chdir() moves nobody else */
+static pthread_mutex_t g_cwd_lock = PTHREAD_MUTEX_INITIALIZER;
+
+/* only the user who runs the server may hand it command lines (they name files the server then reads) */
+static int peer_is_me(int fd)
+{
+    struct ucred uc;
+    socklen_t len = sizeof(uc);
+    if (getsockopt(fd, SOL_SOCKET, SO_PEERCRED, &uc, &len) != 0) return 0;
+    return uc.uid == geteuid();
+}
+
 static void *unix_worker(void *arg)
 {
     const int fd = (int)(intptr_t)arg;
@@ -476,7 +541,7 @@ static void *unix_worker(void *arg)
     union { struct cmsghdr h; char buf[CMSG_SPACE(2 * sizeof(int))]; } cm;
     struct cmsghdr *c;
     uint32_t body = 0;
-    int fds[2] = {-1, -1}, argc = 0, i, rc = 1;
+    int fds[2] = {-1, -1}, argc = 0, i, rc = 1, cwd_locked = 0;
     char *req = NULL, *p, *end, **argv = NULL;
     unsigned char status[2] = {'S', 1};
     FILE *out = NULL, *err = NULL;
@@ -484,6 +549,7 @@ static void *unix_worker(void *arg)
     ssize_t n;
     static const bgt_view_host_t host = {cache_open, cache_close, NULL};
     setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+    if (!peer_is_me(fd)) { close(fd); return NULL; }
     memset(&mh, 0, sizeof(mh)); memset(&cm, 0, sizeof(cm));
     iov.iov_base = &body; iov.iov_len = 4;
     mh.msg_iov = &iov; mh.msg_iovlen = 1; mh.msg_control = cm.buf; mh.msg_controllen = sizeof(cm.buf);
@@ -502,7 +568,10 @@ static void *unix_worker(void *arg)
     setvbuf(err, NULL, _IONBF, 0);
     p = req + 6;
     /* this thread has a working directory of its own (unshare(CLONE_FS) when it started): relative paths in the
-     * arguments -- databases, -B / -d / -s / -a files -- mean what they mean to the client */
+     * arguments -- databases, -B / -d / -s / -a files -- mean what they mean to the client.  Where the kernel refuses a
+     * private one (a container without CAP_SYS_ADMIN: EPERM), chdir() moves the whole process: queries then run ONE AT A
+     * TIME under g_cwd_lock, each in its client's directory -- slower, never in another client's directory. */
+    if (!t_private_cwd) { pthread_mutex_lock(&g_cwd_lock); cwd_locked = 1; }
     if (chdir(p) != 0) { fprintf(err, "[E::main_view] the server cannot enter '%s'\n", p); goto done; }
     p += strlen(p) + 1;
     if (p >= end) goto done;
@@ -518,6 +587,7 @@ static void *unix_worker(void *arg)
     }
     status[1] = (unsigned char)rc;
 done:
+    if (cwd_locked) pthread_mutex_unlock(&g_cwd_lock);
     if (out) fclose(out); else if (fds[0] >= 0) close(fds[0]);        /* everything is written before the status leaves */
     if (err) fclose(err); else if (fds[1] >= 0) close(fds[1]);
     n = send(fd, status, 2, MSG_NOSIGNAL);
@@ -530,7 +600,10 @@ done:
 static void *unix_thread_main(void *arg)
 {
     /* a private working directory per thread: chdir() in one query must not move the others */
-    if (unshare(CLONE_FS) != 0) fprintf(stderr, "[W::%s] unshare(CLONE_FS) failed (%s): relative paths of clients resolve in the server's directory\n", __func__, strerror(errno));
+    static int warned;
+    t_private_cwd = unshare(CLONE_FS) == 0;
+    if (!t_private_cwd && !__sync_lock_test_and_set(&warned, 1))
+        fprintf(stderr, "[W::%s] unshare(CLONE_FS) failed (%s): queries run one at a time, each in its client's directory\n", __func__, strerror(errno));
     return unix_worker(arg);
 }
 
@@ -543,7 +616,14 @@ static int serve_unix(const char *path)
     srv = socket(AF_UNIX, SOCK_STREAM, 0);
     memset(&sa, 0, sizeof(sa)); sa.sun_family = AF_UNIX; strcpy(sa.sun_path, path);
     unlink(path);
-    if (srv < 0 || bind(srv, (struct sockaddr*)&sa, sizeof(sa)) < 0 || listen(srv, 128) < 0) {
+    {   /* the socket belongs to this user alone, whatever the umask (and every peer's uid is checked: peer_is_me) */
+        const mode_t um = umask(077);
+        const int rc_bind = srv < 0 ? -1 : bind(srv, (struct sockaddr*)&sa, sizeof(sa));
+        umask(um);
+        if (rc_bind == 0) chmod(path, 0600);
+        if (rc_bind < 0) { fprintf(stderr, "[E::%s] cannot listen on '%s': %s\n", __func__, path, strerror(errno)); return 1; }
+    }
+    if (listen(srv, 128) < 0) {
         fprintf(stderr, "[E::%s] cannot listen on '%s': %s\n", __func__, path, strerror(errno));
         return 1;
     }

@@ -213,14 +213,29 @@ int bgth_reader_last_geometry(const bgth_reader_t *r, int out[6]);
  * workgroup per bit plane, two per CU, counts from the bit planes), 1 if it took the directory path (wide cohorts whose columns span several
  * workgroups: every row's {bits, ones before} directory is built once into an HBM arena by a producer kernel and the
  * column slices only walk it, pulling rows into LDS by LDS-DMA), 0 for the kernels that rebuild the row per workgroup;
- * + 4 when plane 1 was walked by the sparse tracker (its rows nearly empty: work proportional to the ones; the kernels above
- * then ran plane 0 alone);
  * out[1] = passes over the arena, out[2] = producer launches (0: the arena still held the rows from the previous scan
  * of this reader), out[3] = milliseconds of the first producer launch.  BGTH_DIR_ARENA_MB bounds the arena
  * (default: 60 % of the HBM free at first use). */
 int bgth_reader_last_path(const bgth_reader_t *r, float out[4]);
 /* Override the automatic launch geometry (0 = automatic). For tuning and tests. */
 int bgth_reader_tune(bgth_reader_t *r, int threads, int cols_per_thread, int rows_per_batch);
+/* Test hook: force kernel families that the library otherwise chooses by the shape of the cohort and the selection.  Every
+ * family gives the same results; tests use this to run each of them on shapes the CPU oracle decodes in seconds, bench.py to
+ * make every timed step of the directory path rebuild its rows.  Process-wide, flags OR-ed, 0 = automatic (the default).
+ * The library reads no environment variable for this. */
+enum {
+    BGTH_FORCE_NO_TOGGLE_ARRAY          = 1,     /* team mode toggles in place (the path of cohorts too wide for the toggle array) */
+    BGTH_FORCE_NO_EMPTY_PLANE_SHORTCUT  = 2,     /* never / always the kernels that skip the lookups of an all-zero plane 1 */
+    BGTH_FORCE_EMPTY_PLANE_SHORTCUT     = 4,     /*   (reference pbwt.c:135-138) */
+    BGTH_FORCE_DIRECTORY_PATH           = 32,    /* always / never: rows built once into an HBM arena + walk-only workgroups */
+    BGTH_FORCE_NO_DIRECTORY_PATH        = 64,
+    BGTH_FORCE_REBUILD_ROWS             = 128,   /* a scan never walks the arena the previous scan of the reader left */
+    BGTH_FORCE_SEQUENTIAL_CHECKPOINTS   = 512,   /* bgth_pbf_from_rle derives its checkpoints block after block */
+    BGTH_FORCE_RCCL_TO_SELF             = 1024,  /* a sharded scan gathers through RCCL even between shards of ONE device */
+    BGTH_FORCE_NO_PLANE_SPLIT           = 2048,  /* never / always one workgroup per bit plane (sparse selections of wide cohorts) */
+    BGTH_FORCE_PLANE_SPLIT              = 4096
+};
+void bgth_force_kernels(unsigned flags);
 
 /* ---- site filter on the device (bgtm_pass_site_flt, reference bgt.c:700-719, for counts that stay in HBM) ----
  * The `-f` expression is parsed on the host (ke_parse) and exported as a reverse-Polish program (ke_export of

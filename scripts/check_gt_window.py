@@ -35,9 +35,9 @@ wrd = bgt_amd.HipReader(w)
 c2, g2 = wrd.scan(0, n, want_gt=True)
 print("window image on GPU == big image on GPU:", np.array_equal(c2, c), np.array_equal(g2, g))
 # big image with sequentially derived checkpoints
-os.environ["BGTH_VARIANT"] = "512"
+bgt_amd.force_kernels(int("512"))
 pbf2 = bgt_amd.HipPbf.from_rle(m, 13, rle, lens)
-os.environ.pop("BGTH_VARIANT")
+bgt_amd.force_kernels(0)
 rd2 = bgt_amd.HipReader(pbf2)
 c3, g3 = rd2.scan(a, a + n, want_gt=True)
 print("sequential checkpoints == parallel checkpoints:", np.array_equal(c3, c), np.array_equal(g3, g), "ranks equal", np.array_equal(pbf2.ranks_at(a), pbf.ranks_at(a)))

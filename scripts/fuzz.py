@@ -33,12 +33,12 @@ while time.time() < t_end:
     elif style == 3 and rows > 3:
         mat[rng.integers(0, rows)] = rng.integers(0, 4); mat[rng.integers(0, rows)] = 3
     data = orc.encode_pbf(mat, 2, shift)
-    os.environ.pop("BGTH_VARIANT", None)
+    bgt_amd.force_kernels(0)
     # kernel variants with identical results: 1 toggles in place, 2 / 4 never / always the empty-plane kernels, 32 the
     # directory path (producer + walk-only kernels) forced, 4096 the plane-split kernels forced, 128 no arena reuse
     flag = int(rng.choice([0, 0, 1, 2, 4, 4 | 1, 32, 32, 32 | 128, 4096, 4096, 4096 | 2, 32 | 2]))
     if flag:
-        os.environ["BGTH_VARIANT"] = str(flag)
+        bgt_amd.force_kernels(int(str(flag)))
     os.environ["BGTH_SUB_SHIFT"] = str(int(rng.integers(1, 12)))
     pbf = bgt_amd.HipPbf.from_bytes(data)
     for _ in range(3):

@@ -16,7 +16,7 @@ rle, lens = bgt_amd.synth_rows(m, 0, sites, 2)
 pbf = bgt_amd.HipPbf.from_rle(m, 13, rle, lens)
 rd = bgt_amd.HipReader(pbf)
 cols = np.arange(m, dtype=np.int32)
-os.environ["BGTH_VARIANT"] = "128"
+bgt_amd.force_kernels(int("128"))
 base = None
 for G, how in ((1, "none"), (2, "halves"), (2, "alternating samples"), (4, "quarters"), (8, "eighths")):
     if G == 1:

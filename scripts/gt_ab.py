@@ -13,7 +13,7 @@ m = 2 * samples
 rle, lens = bgt_amd.synth_rows(m, 0, sites, 2)
 pbf = bgt_amd.HipPbf.from_rle(m, 13, rle, lens)
 rd = bgt_amd.HipReader(pbf)
-os.environ["BGTH_VARIANT"] = "128"
+bgt_amd.force_kernels(int("128"))
 for want in (False, True, False, True):
     rd.scan(0, min(sites, 8192), want_gt=want)
     best = 1e9

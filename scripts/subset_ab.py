@@ -21,7 +21,7 @@ for sh in shapes.split(","):
     rd.select(np.stack([2 * s, 2 * s + 1], 1).reshape(-1))
     res = []
     for label, var in (("auto", 0), ("plane-split forced", 4096), ("plane-split never", 2048)):
-        os.environ["BGTH_VARIANT"] = str(128 + var)
+        bgt_amd.force_kernels(int(str(128 + var)))
         try:
             rd.scan(0, min(sites, 8192))
             best = 1e9
@@ -36,5 +36,5 @@ for sh in shapes.split(","):
         print("%-22s %-20s %8.3f ms  %4d thr x %2d col x %d slices K %d  %s" % (sh, label, best, g["threads"], g["cols_per_thread"], g["slices"], g["rows_per_batch"],
               "dir" if p["directory_path"] else "plane" if p["plane_split"] else "scan"), flush=True)
     print("   same counts:", all(np.array_equal(res[0], r) for r in res[1:]), flush=True)
-    os.environ.pop("BGTH_VARIANT", None)
+    bgt_amd.force_kernels(0)
     rd.close(); pbf.close()

@@ -16,7 +16,7 @@ m = 2 * n
 rle, lens = bgt_amd.synth_rows(m, 0, sites, 7)
 pbf = bgt_amd.HipPbf.from_rle(m, 13, rle, lens)
 rd = bgt_amd.HipReader(pbf)
-os.environ["BGTH_VARIANT"] = "128"
+bgt_amd.force_kernels(int("128"))
 rd.scan(0, sites)
 best = min((rd.scan(0, sites), rd.timing()["scan_ms"])[1] for _ in range(5))
 g = rd.geometry()

@@ -16,7 +16,7 @@ m = 2 * samples
 rle, lens = bgt_amd.synth_rows(m, 0, sites, 7)
 pbf = bgt_amd.HipPbf.from_rle(m, 13, rle, lens)
 rd = bgt_amd.HipReader(pbf)
-os.environ["BGTH_VARIANT"] = "128"                     # every scan builds its rows
+bgt_amd.force_kernels(int("128"))                     # every scan builds its rows
 rd.scan(0, min(sites, 16384))
 best, walk = 1e9, 1e9
 for _ in range(3):

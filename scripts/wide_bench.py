@@ -28,9 +28,9 @@ if sub:
 
 def run(label, variant, reps=3):
     if variant is None:
-        os.environ.pop("BGTH_VARIANT", None)
+        bgt_amd.force_kernels(0)
     else:
-        os.environ["BGTH_VARIANT"] = str(variant)
+        bgt_amd.force_kernels(int(str(variant)))
     out = None
     for i in range(reps):
         t = time.time()

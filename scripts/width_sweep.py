@@ -24,13 +24,13 @@ for n in widths:
     pbf = bgt_amd.HipPbf.from_rle(m, 13, rle, lens)
     del rle
     rd = bgt_amd.HipReader(pbf)
-    os.environ["BGTH_VARIANT"] = str(128 + int(os.environ.get("SWEEP_VARIANT", "0")))   # 128: every scan builds its rows (no arena carried over)
+    bgt_amd.force_kernels(int(str(128 + int(os.environ.get("SWEEP_VARIANT", "0")))))   # 128: every scan builds its rows (no arena carried over)
     rd.scan(0, min(sites, 16384))
     best = 1e9
     for _ in range(3):
         rd.scan(0, sites)
         best = min(best, rd.timing()["scan_ms"])
-    os.environ.pop("BGTH_VARIANT")
+    bgt_amd.force_kernels(0)
     g, p = rd.geometry(), rd.path()
     look = 2.0 * m * sites / (best * 1e-3) / 1e9
     kind = "directory path (producer + walk-only)" if p["directory_path"] else "plane-split" if p["plane_split"] else \

@@ -27,3 +27,12 @@ def require_ref(name="bgt"):
         pytest.fail("oracle/_ref/%s is missing: build it with `make -C oracle ref` where /root/reference exists "
                     "(it is git-ignored but travels to the GPU box with the snapshot)" % name)
     return path
+
+
+@pytest.fixture(autouse=True)
+def _kernel_choice_is_automatic_again():
+    """Tests force kernel families through bgth_force_kernels (process-wide): every test starts and ends with the automatic choice."""
+    yield
+    hip_mod = sys.modules.get("bgt_amd.hip")
+    if hip_mod is not None and getattr(hip_mod, "_forced", 0):
+        hip_mod.force_kernels(0)

@@ -59,6 +59,26 @@ def test_shipped_library_has_no_ablation_switches(libpath):
     assert b"BGTH_DEBUG_SKIP" not in host
 
 
+def test_shipped_library_carries_no_experiments_and_no_kernel_choice_by_environment(libpath):
+    """Round 4 shipped a losing experiment (plane 1 as an ordered set), a header of losing row steps and a dozen BGTH_VARIANT bits
+    read from the environment.  Now: kernel families are forced through bgth_force_kernels (an ABI call, used by tests), the
+    tuning knobs of the walk-only kernel exist in the profiling build only, the experiments are gone (git history and
+    profiles/r04_sparse, profiles/r04_issue keep them)."""
+    blob = open(libpath, "rb").read()
+    for name in (b"BGTH_VARIANT", b"BGTH_WALK_GEOM", b"BGTH_WALK_FOUR", b"BGTH_SPARSE", b"sparse_plane1", b"stepcc"):
+        assert name not in blob, name
+    syms = subprocess.check_output(["nm", "-D", "--defined-only", libpath]).decode()
+    assert " T bgth_force_kernels" in syms
+    src = os.path.join(ROOT, "bgt_amd", "csrc")
+    assert not os.path.exists(os.path.join(src, "scan_sparse.hip")) and not os.path.exists(os.path.join(src, "scan_step_cc.inc.h"))
+    for f in os.listdir(src):
+        if f.endswith((".hip", ".cpp", ".h")) and f not in ("issue_bench.hip", "microbench.hip"):
+            text = open(os.path.join(src, f)).read()
+            for m in re.finditer(r'getenv\("(BGTH_VARIANT|BGTH_WALK_[A-Z]+)"\)', text):      # only inside #ifdef BGTH_ABLATE
+                before = text[:m.start()]
+                assert before.rfind("#ifdef BGTH_ABLATE") > max(before.rfind("#endif"), before.rfind("#else")), (f, m.group(0))
+
+
 def test_measurement_tools_live_in_their_own_library(libpath):
     """The issue-rate calibration kernels behind bench.py's roofline are not product: libbgt_hip_bench.so exports exactly
     what include/bgt_hip_bench.h declares, and the product library carries none of it."""

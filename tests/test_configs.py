@@ -41,9 +41,9 @@ def test_c4_shard_ranges_equal_the_whole_scan(tmp_path, monkeypatch):
     whole = rd.scan(0, sites)
     # the per-GPU shape of C4 takes the directory path (rows built once, walk-only slices); the team kernels agree
     assert rd.path()["directory_path"] and rd.geometry()["slices"] >= 4, (rd.path(), rd.geometry())
-    monkeypatch.setenv("BGTH_VARIANT", "64")
+    bgt_amd.force_kernels(64)
     assert np.array_equal(rd.scan(0, sites), whole) and rd.geometry()["threads"] == 512 and not rd.path()["directory_path"]
-    monkeypatch.delenv("BGTH_VARIANT")
+    bgt_amd.force_kernels(0)
     # plane popcounts of every site (independent of any permutation state)
     ones = ones_per_string(rle, lens)
     c = whole[:, 0, :].astype(np.int64)

@@ -1,5 +1,5 @@
 """GPU parity of the directory path (bgt_amd/csrc/scan_dir.hip): rows built ONCE into an HBM arena by the producer
-kernel, column slices that only walk them (LDS-DMA).  Forced with BGTH_VARIANT=32 on shapes small enough for the
+kernel, column slices that only walk them (LDS-DMA).  Forced with bgth_force_kernels(BGTH_FORCE_DIRECTORY_PATH) on shapes small enough for the
 oracle; the automatic choice is checked on a wide cohort.  Bit-exact against the oracle (reference pbwt.c:69-170,
 bgt.c:735-757)."""
 import numpy as np
@@ -24,7 +24,7 @@ def hip():
 def test_forced_directory_path_small_shapes(hip, monkeypatch, seed, m, rows, shift):
     """Every shape class the classic kernels are tested on, through producer + walk-only kernel: partial tail words,
     one column, several checkpoint blocks, scans that start inside a block, subsets, groups, genotype planes."""
-    monkeypatch.setenv("BGTH_VARIANT", "32")
+    hip.force_kernels(32)
     rng = np.random.default_rng(seed)
     mat = scenarios.ld_matrix(rng, rows, m, n_founders=7, switch=0.1) if m > 8 else rng.integers(0, 4, (rows, m)).astype(np.uint8)
     if rows > 6:
@@ -78,7 +78,7 @@ def test_wide_cohort_takes_the_directory_path(hip, monkeypatch):
     assert np.array_equal(c2, oc)
     assert np.array_equal(rd.scan(9, 31), oc[9:31])
     # the classic team kernels give the same numbers
-    monkeypatch.setenv("BGTH_VARIANT", "64")
+    hip.force_kernels(64)
     c3 = rd.scan(0, rows)
     assert not rd.path()["directory_path"]
     assert np.array_equal(c3, oc)
@@ -88,7 +88,7 @@ def test_wide_cohort_takes_the_directory_path(hip, monkeypatch):
 
 def test_directory_path_in_several_passes(hip, monkeypatch):
     """An arena smaller than the range: sub-block ranges are built and walked pass by pass."""
-    monkeypatch.setenv("BGTH_VARIANT", "32")
+    hip.force_kernels(32)
     monkeypatch.setenv("BGTH_DIR_ARENA_MB", "1")                       # 13 sub-blocks of 8 rows x 10 KB
     rng = np.random.default_rng(5)
     m, rows, shift = 20000, 300, 3
@@ -107,10 +107,10 @@ def test_directory_path_in_several_passes(hip, monkeypatch):
 @pytest.mark.parametrize("seed,m,rows,shift,n_sel", [(21, 700, 90, 4, 40), (22, 41000, 40, 3, 900), (23, 9000, 300, 6, 2000),
                                                      (24, 64, 20, 2, 3), (25, 5000, 2100, 13, 1)])
 def test_plane_split_kernels(hip, monkeypatch, seed, m, rows, shift, n_sel):
-    """scan_plane.hip: one workgroup per bit plane (forced with BGTH_VARIANT=4096 on shapes the oracle decodes quickly):
+    """scan_plane.hip: one workgroup per bit plane (forced with BGTH_FORCE_PLANE_SPLIT on shapes the oracle decodes quickly):
     subsets of 1 to 2,000 samples, 1 and 3 groups, genotype planes, scans that start inside a block, several sub-blocks,
     rows of one run and noisy rows, several chunks per string and several directory trips (m = 41,000)."""
-    monkeypatch.setenv("BGTH_VARIANT", "4096")
+    hip.force_kernels(4096)
     rng = np.random.default_rng(seed)
     mat = scenarios.ld_matrix(rng, rows, m, n_founders=7, switch=0.1)
     mat[2] = 0; mat[3] = 1; mat[4] = 3
@@ -130,46 +130,8 @@ def test_plane_split_kernels(hip, monkeypatch, seed, m, rows, shift, n_sel):
         assert np.array_equal(c, oc) and np.array_equal(g, ogt), rd.geometry()
         a, b = rows // 3, rows - 1
         assert np.array_equal(rd.scan(a, b), oc[a:b])                  # counts only: planes in the reader's own buffers
-    monkeypatch.setenv("BGTH_VARIANT", "2048")
+    hip.force_kernels(2048)
     assert np.array_equal(rd.scan(0, rows), oc) and not rd.path()["plane_split"]
-    rd.close()
-    pbf.close()
-
-
-@pytest.mark.parametrize("seed,m,rows,shift,n_sel,pm,tcap", [(31, 700, 90, 4, 40, 0.02, "4096"), (32, 5000, 300, 6, 300, 0.004, None),
-                                                             (33, 41000, 40, 3, 900, 0.001, None), (34, 5000, 2100, 13, 1, 0.002, "4096"),
-                                                             (35, 6000, 260, 5, 2999, 0.01, "4096")])
-def test_sparse_plane1_tracker(hip, monkeypatch, seed, m, rows, shift, n_sel, pm, tcap):
-    """scan_sparse.hip (opt-in, BGTH_VARIANT 262144): plane 1 walked as an ordered set -- select / delete / append per one, epochs
-    compacted when the tail fills (a tail of 4,096 slots makes them turn over), rows of more than 64 ones (several waves), a row
-    that is all ones / all missing -- under the plane-split kernels (4096) and under the pipelined narrow kernel (plane 0 alone,
-    the tracker beside it on a second stream); 1 and 3 groups, genotype planes, scans that start inside a block."""
-    rng = np.random.default_rng(seed)
-    mat = scenarios.ld_matrix(rng, rows, m, n_founders=7, switch=0.1, p_missing=pm, p_multi=pm)
-    mat[2] = 0; mat[3] = 1; mat[5] = rng.integers(0, 2, m)
-    mat[7, rng.integers(0, m, 100)] = 3
-    data = orc.encode_pbf(mat, 2, shift)
-    pbf = hip.HipPbf.from_bytes(data)
-    rd = hip.HipReader(pbf)
-    smp = np.sort(rng.choice(m // 2, n_sel, replace=False))
-    cols = np.stack([2 * smp, 2 * smp + 1], 1).reshape(-1).astype(np.int32)
-    if tcap:
-        monkeypatch.setenv("BGTH_SPARSE_TCAP", tcap)
-    for variant in (4096 + 262144, 262144):
-        monkeypatch.setenv("BGTH_VARIANT", str(variant))
-        for n_groups in (1, 3):
-            group = (1 + (np.arange(n_sel) % n_groups)).astype(np.uint32) if n_groups > 1 else None
-            rd.select(cols, group=group, n_groups=n_groups)
-            oc, ogt = oracle_scan(data, 0, rows, cols=cols, group=group, n_groups=n_groups)
-            c, g = rd.scan(0, rows, want_gt=True)
-            used = rd.path()["sparse_plane1"]
-            assert np.array_equal(c, oc) and np.array_equal(g, ogt), (variant, rd.path(), rd.geometry())
-            a, b = rows // 3, rows - 1
-            assert np.array_equal(rd.scan(a, b), oc[a:b])
-            assert used or rd.path()["sparse_plane1"] or variant == 262144, rd.path()      # (the narrow form needs the pipelined geometry)
-        rd.select(None)
-        oc, _ = oracle_scan(data, 0, rows)
-        assert np.array_equal(rd.scan(0, rows), oc)
     rd.close()
     pbf.close()
 

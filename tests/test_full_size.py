@@ -66,13 +66,16 @@ def test_plane_popcounts_match_counts_everywhere(n_samples, sites, seed):
     assert np.array_equal(oc, counts[w0:w1])
 
 
-@pytest.mark.parametrize("name,n_samples,sites,seed,every", [("C3", 100000, 262144, 3, 20), ("C4 shard", 100000, 153 * 8192, 4, 7), ("C2", 10000, 1000000, 2, 3)])
+@pytest.mark.parametrize("name,n_samples,sites,seed,every", [("C3", 100000, 1000000, 3, 20), ("C4 shard", 100000, 153 * 8192, 4, 7), ("C2", 10000, 1000000, 2, 3)])
 def test_subsets_and_groups_at_width_against_the_oracle(name, n_samples, sites, seed, every, tmp_path):
-    """Subsets and sample groups AT WIDTH against the CPU oracle, not against themselves: a window of 2,560 rows that
-    starts 2,048 rows before a block boundary in the middle of the image (the strings are drawn again, built into a small image,
-    re-based onto the ranks the big image holds there -- bench.oracle_window -- and decoded by the oracle sequentially across the
-    boundary).  C3: every 20th of 100,000 samples (the plane-split kernels), one and three groups; one C4 shard (153 file blocks,
-    1,253,376 sites): a subset with three groups and the whole cohort in three groups (directory path); C2: the same at 10,000."""
+    """Subsets and sample groups AT WIDTH and AT LENGTH against the CPU oracle, not against themselves.  Three windows per shape:
+    across the FIRST block boundary, across a boundary in the MIDDLE of the image, and the last rows of the image with its
+    ragged last block (C3, C2: 1,000,000 = 122 x 8192 + 576 sites).  A window starts 2,048 rows (narrow cohorts: 8,192) before
+    its boundary; the strings are drawn again, built into a small image, re-based onto the ranks the big image holds there --
+    bench.oracle_window -- and decoded by the oracle sequentially across the boundary.  C3 = BASELINE configs[2] at its full
+    1,000,000 sites: every 20th of 100,000 samples (the plane-split kernels), one and three groups; one C4 shard (153 file
+    blocks, 1,253,376 sites): a subset with three groups and the whole cohort in three groups (directory path); C2: the same
+    at 10,000 samples."""
     import bgt_amd
     import bench
     m = 2 * n_samples
@@ -80,23 +83,37 @@ def test_subsets_and_groups_at_width_against_the_oracle(name, n_samples, sites, 
     pbf = bgt_amd.HipPbf.from_rle(m, 13, rle, lens)
     del rle
     rd = bgt_amd.HipReader(pbf)
-    mid = (sites // 2) // 8192 * 8192
     back, ahead = (2048, 512) if m > 20000 else (8192, 1024)
-    lo, hi = mid - back, mid + ahead
+    last_blk = (sites - 1) // 8192 * 8192                              # first row of the last (ragged or whole) block
+    windows = [("first boundary", 8192 - back if 8192 - back >= 4096 else 2 * 8192 - back, None),
+               ("middle", (sites // 2) // 8192 * 8192 - back, None),
+               ("end of the image", last_blk - back, sites)]
     sel = np.arange(0, n_samples, every)
     cols = np.stack([2 * sel, 2 * sel + 1], 1).reshape(-1).astype(np.int32)
-    for n_groups in (1, 3):
-        group = (1 + (np.arange(sel.size) % n_groups)).astype(np.uint32) if n_groups > 1 else None
-        rd.select(cols, group=group, n_groups=n_groups)
+    whole3 = (1 + (np.arange(n_samples) % 3)).astype(np.uint32)
+    for label, lo, hi in windows:
+        hi = lo + back + ahead if hi is None else hi
+        assert 4096 <= lo < hi <= sites
+        for n_groups in (1, 3):
+            group = (1 + (np.arange(sel.size) % n_groups)).astype(np.uint32) if n_groups > 1 else None
+            rd.select(cols, group=group, n_groups=n_groups)
+            got = rd.scan(lo, hi)
+            oc, _ = bench.oracle_window(bgt_amd, np, pbf, m, 13, seed, lo, lo, hi - lo, str(tmp_path), 0, cols, group, n_groups)
+            assert np.array_equal(got, oc), (name, label, n_groups, rd.path(), rd.geometry())
+        # the whole cohort in three groups
+        rd.select(np.arange(m, dtype=np.int32), group=whole3, n_groups=3)
         got = rd.scan(lo, hi)
-        oc, _ = bench.oracle_window(bgt_amd, np, pbf, m, 13, seed, lo, lo, hi - lo, str(tmp_path), 0, cols, group, n_groups)
-        assert np.array_equal(got, oc), (name, n_groups, rd.path(), rd.geometry())
-    # the whole cohort in three groups
-    group = (1 + (np.arange(n_samples) % 3)).astype(np.uint32)
-    rd.select(np.arange(m, dtype=np.int32), group=group, n_groups=3)
-    got = rd.scan(lo, hi)
-    oc, _ = bench.oracle_window(bgt_amd, np, pbf, m, 13, seed, lo, lo, hi - lo, str(tmp_path), 0, None, group, 3)
-    assert np.array_equal(got, oc), (name, "whole cohort, 3 groups", rd.path(), rd.geometry())
+        oc, _ = bench.oracle_window(bgt_amd, np, pbf, m, 13, seed, lo, lo, hi - lo, str(tmp_path), 0, None, whole3, 3)
+        assert np.array_equal(got, oc), (name, label, "whole cohort, 3 groups", rd.path(), rd.geometry())
+    if name == "C3":
+        # ... and the scan the benchmark times, over ALL 1,000,000 sites in one launch: its rows inside the three windows are the
+        # windows' (a scan that starts at row 0 and one that starts at a sub-checkpoint must agree on every row they share)
+        rd.select(cols)
+        full = rd.scan(0, sites)
+        assert rd.path()["plane_split"], rd.path()
+        for label, lo, hi in windows:
+            hi = lo + back + ahead if hi is None else hi
+            assert np.array_equal(full[lo:hi], rd.scan(lo, hi)), (name, label, "full-length scan against the window's")
     rd.close()
     pbf.close()
 

@@ -196,7 +196,7 @@ def test_wide_cohort_team_mode(hip, threads, cpt, K, in_place, monkeypatch):
     whose string stops short of m -- whole cohort, a sparse subset and two groups.  in_place: the variant for
     cohorts too wide for a separate toggle array in LDS (forced here through the debug knob)."""
     if in_place:
-        monkeypatch.setenv("BGTH_VARIANT", "1")
+        hip.force_kernels(1)
     rng = np.random.default_rng(77)
     m, rows, shift = 41000, 24, 3
     mat = scenarios.ld_matrix(rng, rows, m, n_founders=40, switch=0.2)
@@ -293,9 +293,9 @@ def test_sub_checkpoints(hip, tmp_path, monkeypatch, sub):
 def test_rows_with_an_empty_plane(hip, monkeypatch, force, threads, cpt, K):
     """Rows whose plane 1 (missing / <M>) is all zero take the shortcut of the ZP kernels (reference pbwt.c:135-138);
     a cohort that mixes such rows with ordinary ones, rows of one repeated code, and a plane-0-empty row, through both
-    kernel families (BGTH_VARIANT 2 = never, 4 = always use the ZP kernels), whole cohort, groups, genotypes."""
+    kernel families (bgth_force_kernels 2 = never, 4 = always use the ZP kernels), whole cohort, groups, genotypes."""
     if force:
-        monkeypatch.setenv("BGTH_VARIANT", force)
+        hip.force_kernels(int(force))
     rng = np.random.default_rng(123)
     m, rows, shift = 9000, 160, 5
     mat = scenarios.ld_matrix(rng, rows, m, n_founders=12, switch=0.03)
@@ -337,11 +337,11 @@ def split_rle(data):
                                                (55, 9, 16, 4), (56, 2600, 8192 + 4096 + 17, 12)])
 def test_checkpoints_rebuilt_on_device(hip, tmp_path, monkeypatch, seed, m, rows, shift, sequential):
     """bgth_pbf_from_rle derives every 'S' record on the GPU; saved file == the encoder's file, byte for byte.  Default:
-    every block at once from the identity order + composition of the blocks' rank maps; sequential (BGTH_VARIANT 512): one
+    every block at once from the identity order + composition of the blocks' rank maps; sequential (BGTH_FORCE_SEQUENTIAL_CHECKPOINTS): one
     launch per block.  Cases: many blocks, a ragged last block, exactly one block, team-mode width, sub-checkpoints
     inside the file blocks (shift 12 > the sub-block shift 11)."""
     if sequential:
-        monkeypatch.setenv("BGTH_VARIANT", "512")
+        hip.force_kernels(512)
     mat, data, rng = make_case(seed, m, rows, shift)
     m_, shift_, strings = split_rle(data)
     rle = np.frombuffer(b"".join(strings), np.uint8)

@@ -65,13 +65,13 @@ def test_sharded_image_equals_the_single_image(tmp_path, n_shards):
             assert np.array_equal(one.last_counts(), rd.last_counts())
     rd.seek(rows - 1); assert rd.read() is not None and rd.read() is None
     # counts that STAY on the device: the shards' pieces are gathered on shard 0's device (device copies between shards of
-    # one device; BGTH_VARIANT 1024 sends the same bytes through RCCL, rank to itself -- the code path of real multi-GPU
+    # one device; BGTH_FORCE_RCCL_TO_SELF sends the same bytes through RCCL, rank to itself -- the code path of real multi-GPU
     # nodes, exercised here on one device), and the device filter runs on the gathered array
     import torch
     want = one.scan(0, rows)
     for variant in (None, "1024"):
         if variant:
-            os.environ["BGTH_VARIANT"] = variant
+            bgt_amd.force_kernels(int(variant))
         try:
             for a, b in ((0, rows), (7, rows - 9), (16, 17)):
                 d = torch.full((b - a, 4, 3), -1, dtype=torch.int32, device="cuda")
@@ -89,7 +89,7 @@ def test_sharded_image_equals_the_single_image(tmp_path, n_shards):
             exp = (want[:, 1, 1] > 0) & (want[:, 2, 1] == 0)
             assert np.array_equal(flags.cpu().numpy() != 0, exp) and int(n_pass.item()) == int(exp.sum())
         finally:
-            os.environ.pop("BGTH_VARIANT", None)
+            bgt_amd.force_kernels(0)
     with pytest.raises(RuntimeError):                                 # bit planes are not gathered
         rd.scan_device(0, rows, d.data_ptr(), d.data_ptr(), d.data_ptr())
 
