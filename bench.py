@@ -575,31 +575,60 @@ def resident_end_to_end(prefix, sites, cpu_baseline_sites_per_s):
             srv.kill()
 
 
-def hrc_cli_record(tmp, n_samples=32488, sites=16384, seed=7):
-    """The four commands the reference publishes its numbers on (README.md:276-281, HRC r1: 32,488 samples) on a synthetic
-    cohort of that width, through both binaries: stdout compared, wall time of one process each (this repo's includes the HIP start)."""
+def hrc_cli_record(tmp, n_samples=32488, sites=142000, seed=7):
+    """The four commands the reference publishes its numbers on (README.md:276-281, HRC r1: 32,488 samples, ~142,000 sites of
+    chr11:10-20 Mb) on a synthetic cohort of that width AND length, through both binaries: stdout compared; wall time of one
+    cold process each (this repo's includes the HIP start and the image build), of the same command line answered by a resident
+    `bgt-server -u` (best of 3), and of the reference process -- beside the seconds the reference's README publishes."""
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bgt_amd", "host")])
     prefix = os.path.join(tmp, "hrc_%d_%d" % (n_samples, sites))
     if not os.path.exists(prefix + ".pbf"):
         subprocess.check_call([MY_BIN, "synth", prefix, str(n_samples), str(sites), str(seed)])
-    rec = {"name": "HRC-cli", "workload": "HRC r1 shape: %d samples (%d haplotypes) x %d sites (the first sites of the 142,000-site records "
-                                          "above), the reference's four published commands" % (n_samples, 2 * n_samples, sites), "commands": []}
-    for label, va in (("view -G (decode only)", ["-G"]), ("view -GC", ["-G", "-C"]),
-                      ("view -GC -s (2,499 of 32,488 samples)", ["-G", "-C", "-s", "idx%13==0"]),
-                      ("view -G -s A -s B (two groups)", ["-G", "-s", "idx<2500", "-s", "idx>=30000"])):
+    rec = {"name": "HRC-cli", "sites": sites,
+           "workload": "HRC r1 shape at the published length: %d samples (%d haplotypes) x %d sites, the reference's four published "
+                       "commands (README.md:276-281)" % (n_samples, 2 * n_samples, sites), "commands": []}
+    srv_bin = os.path.join(ROOT, "bgt_amd", "bin", "bgt-server")
+    sock = os.path.join(tmp, "hrc.sock")
+    srv = subprocess.Popen([srv_bin, "-u", sock, prefix], stderr=subprocess.DEVNULL)
+    try:
         t0 = time.perf_counter()
-        mine = subprocess.run([MY_BIN, "view"] + va + [prefix], stdout=subprocess.PIPE, check=True).stdout
-        t_mine = time.perf_counter() - t0
-        c = {"command": label, "this_repo_s": round(t_mine, 3), "stdout_bytes": len(mine)}
-        if os.path.exists(REF_BIN):
+        while not os.path.exists(sock):
+            if srv.poll() is not None or time.perf_counter() - t0 > 120:
+                raise RuntimeError("bgt-server -u did not come up")
+            time.sleep(0.02)
+        env_res = dict(os.environ, BGT_SERVER=sock)
+        for label, va, published in (("view -G", ["-G"], 11.0), ("view -GC", ["-G", "-C"], 30.0),
+                                     ("view -GC -s (2,499 of 32,488)", ["-G", "-C", "-s", "idx%13==0"], 4.0),
+                                     ("view -G -s A -s B", ["-G", "-s", "idx<2500", "-s", "idx>=30000"], 8.0)):
             t0 = time.perf_counter()
-            ref = subprocess.run([REF_BIN, "view"] + va + [prefix], stdout=subprocess.PIPE, check=True).stdout
-            c["reference_s"] = round(time.perf_counter() - t0, 3)
-            c["reference_sites_per_s"] = sites / c["reference_s"]
-            c["stdout_identical"] = hashlib.md5(ref).hexdigest() == hashlib.md5(mine).hexdigest()
-            if not c["stdout_identical"]:
-                rec["parity_error"] = "`bgt view %s` differs from the reference at the HRC width" % " ".join(va)
-        rec["commands"].append(c)
+            mine = subprocess.run([MY_BIN, "view"] + va + [prefix], stdout=subprocess.PIPE, check=True).stdout
+            t_cold = time.perf_counter() - t0
+            t_res, res_same = None, True
+            for _ in range(3):
+                t0 = time.perf_counter()
+                o = subprocess.run([MY_BIN, "view"] + va + [prefix], stdout=subprocess.PIPE, check=True, env=env_res).stdout
+                dt = time.perf_counter() - t0
+                t_res = dt if t_res is None or dt < t_res else t_res
+                res_same = res_same and hashlib.md5(o).hexdigest() == hashlib.md5(mine).hexdigest()
+            c = {"command": label, "this_repo_s": round(t_cold, 3), "resident_s": round(t_res, 4), "published_s": published,
+                 "stdout_bytes": len(mine), "resident_stdout_identical": res_same}
+            if not res_same:
+                rec["parity_error"] = "`bgt view %s` through the resident host differs from the local run" % " ".join(va)
+            if os.path.exists(REF_BIN):
+                t0 = time.perf_counter()
+                ref = subprocess.run([REF_BIN, "view"] + va + [prefix], stdout=subprocess.PIPE, check=True).stdout
+                c["reference_s"] = round(time.perf_counter() - t0, 3)
+                c["reference_sites_per_s"] = sites / c["reference_s"]
+                c["stdout_identical"] = hashlib.md5(ref).hexdigest() == hashlib.md5(mine).hexdigest() and res_same
+                if not c["stdout_identical"]:
+                    rec["parity_error"] = "`bgt view %s` differs from the reference at the HRC width" % " ".join(va)
+            rec["commands"].append(c)
+    finally:
+        srv.terminate()
+        try:
+            srv.wait(timeout=30)
+        except Exception:
+            srv.kill()
     return rec
 
 

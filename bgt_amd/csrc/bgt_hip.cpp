@@ -214,6 +214,11 @@ struct bgth_pbf_s {
     uint8_t  *d_rle = nullptr;
     uint64_t *d_rowdesc = nullptr;
     int32_t  *d_rank0 = nullptr;      // [n_sub][2][m] ranks by column at every (sub-)checkpoint
+    // [n_sub][m]: the plane-1 ranks of every (sub-)checkpoint in the order of its plane-0 ranks -- what a whole-cohort, one-group,
+    // counts-only scan starts from (slots in plane-0 rank order: profiles/r05_lds); built at the first such scan, dropped when the
+    // checkpoints change (rebase); order_failed: no HBM for it, the scans use the column order
+    int32_t  *d_order = nullptr;
+    bool      order_failed = false;
     int32_t  *d_final = nullptr;      // [2][m] ranks by column after the last row (images built by bgth_pbf_from_rle only)
     // row index (scan_kernels.h), built on the first wide-cohort (team-mode) launch
     uint32_t *d_chunkinfo = nullptr, *d_segc = nullptr;
@@ -243,6 +248,7 @@ enum { kVariantNoTog = BGTH_FORCE_NO_TOGGLE_ARRAY, kVariantNeverZP = BGTH_FORCE_
        kVariantDirNoReuse = BGTH_FORCE_REBUILD_ROWS,
        kVariantSeqCheckpoints = BGTH_FORCE_SEQUENTIAL_CHECKPOINTS, kVariantRcclSelf = BGTH_FORCE_RCCL_TO_SELF,
        kVariantPlaneNever = BGTH_FORCE_NO_PLANE_SPLIT, kVariantPlaneAlways = BGTH_FORCE_PLANE_SPLIT,
+       kVariantColumnOrder = BGTH_FORCE_COLUMN_ORDER,
        // profiling build only: no window prefetch in the pull interface | no L2 warming of the next row's plane 1 | no
        // progress-based wave priorities in the walk
        kVariantNoPrefetch = 16, kVariantDirNoWarm = 256, kVariantNoWalkPrio = 16384 };
@@ -594,6 +600,7 @@ extern "C" void bgth_pbf_close(bgth_pbf_t *p)
     if (p->d_rle) hipFree(p->d_rle);
     if (p->d_rowdesc) hipFree(p->d_rowdesc);
     if (p->d_rank0) hipFree(p->d_rank0);
+    if (p->d_order) hipFree(p->d_order);
     if (p->d_final) hipFree(p->d_final);
     if (p->d_chunkinfo) hipFree(p->d_chunkinfo);
     if (p->d_segc) hipFree(p->d_segc);
@@ -1281,6 +1288,7 @@ static bool derive_all_checkpoints(bgth_pbf_t *p, Selection &all, const std::vec
         HIP_TRY(hipDeviceSynchronize(), break);
         hipFree(p->d_rank0);
         p->d_rank0 = rebased; rebased = nullptr;
+        if (p->d_order) { hipFree(p->d_order); p->d_order = nullptr; }      // (derived from the checkpoints: built again on demand)
         ok = true;
     } while (0);
 done:
@@ -1344,6 +1352,7 @@ extern "C" int bgth_pbf_rebase(bgth_pbf_t *p, const int32_t *start_ranks)
         {   // readers of the image keep no ranks of their own; an arena a reader filled holds directory rows, which do not depend on the order
             hipFree(p->d_rank0);
             p->d_rank0 = out; out = nullptr;
+            if (p->d_order) { hipFree(p->d_order); p->d_order = nullptr; }
         }
         rc = 0;
     } while (0);
@@ -1484,7 +1493,8 @@ extern "C" int64_t bgth_pbf_rle_bytes(const bgth_pbf_t *p) { return p->rle_bytes
 extern "C" int64_t bgth_pbf_hbm_bytes(const bgth_pbf_t *p)
 {
     if (!p->shards.empty()) { int64_t t = 0; for (const bgth_pbf_t *sh : p->shards) t += bgth_pbf_hbm_bytes(sh); return t; }
-    return p->packed_bytes + 256 + p->n * 2 * 8 + p->n_sub * 2 * (int64_t)p->m * 4 + p->rowindex_bytes;
+    return p->packed_bytes + 256 + p->n * 2 * 8 + p->n_sub * 2 * (int64_t)p->m * 4 + p->rowindex_bytes +
+           (p->d_order ? p->n_sub * (int64_t)p->m * 4 : 0);
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -1781,6 +1791,22 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
     else if (!common_scan_args(a, p, r->sel, geo, s)) return -1;
     a.shift = p->sub_shift;                              // units = sub-blocks
     a.rank0_blk_stride = (int64_t)2 * p->m;
+    // Whole cohort, one group, counts only: the counts do not care which lane tracks which column, so slot s of a sub-block tracks
+    // the column whose plane-0 rank at its checkpoint is s.  The 64 lanes of a wave then start on 64 consecutive ranks, PBWT order
+    // keeps neighbours together for a while, and a wave's ds_read_b64 gather hits few distinct entries of the plane-0 row instead of
+    // 64 random ones: LDS bank-conflict cycles -40 % at the HRC shape (sub-blocks of 128 rows), -20 % on one C4 shard, -3 % on C2
+    // (2048 rows); kernel time -5.2 % / -2.3 % / -0.8 % (profiles/r05_lds).  BGTH_FORCE_COLUMN_ORDER keeps the slots in column order.
+    if (r->sel.whole && G == 1 && !d_h0 && !planepath && !variant_flag(kVariantColumnOrder)) {
+        std::lock_guard<std::mutex> guard(p->rowindex_lock);
+        if (!p->d_order && !p->order_failed) {
+            if (hipMalloc((void**)&p->d_order, (size_t)std::max<int64_t>(p->n_sub, 1) * p->m * 4) != hipSuccess) { (void)hipGetLastError(); p->d_order = nullptr; p->order_failed = true; }
+            else HIP_TRY(launch_plane1_by_plane0(p->d_rank0, p->d_order, p->m, p->n_sub, s), return -1);
+            // (built on the stream of this scan; another reader's stream may use it only after this launch: both are ordered by
+            //  the lock's holder synchronising below)
+            if (p->d_order) HIP_TRY(hipStreamSynchronize(s), return -1);
+        }
+        if (p->d_order) { a.order0 = p->d_order; a.order_blk_stride = (int64_t)p->m; }
+    }
     a.raw_counts = (int32_t*)r->raw.p;
     a.h0 = d_h0;
     a.h1 = d_h1;

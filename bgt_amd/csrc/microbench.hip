@@ -15,7 +15,7 @@ namespace bgth {
 // one workgroup per CU (the launch asks for more than half the LDS), NT / 256 waves per SIMD
 enum { MIX_FMA = 0, MIX_ADD = 1, MIX_STEP = 2, MIX_BCNT = 3, MIX_CMPSEL = 4, MIX_MAD24 = 5, MIX_STEP_LDS_FLAT = 6,
        MIX_STEP_LDS_RANDOM = 7, MIX_LSHL = 8, MIX_LDS_ONLY_FLAT = 9, MIX_LDS_ONLY_RANDOM = 10,
-       MIX_IL2 = 11, MIX_IL4 = 12, MIX_IL8 = 13, MIX_N = 14 };
+       MIX_IL2 = 11, MIX_IL4 = 12, MIX_IL8 = 13, MIX_STEP_LDS_CLUSTERED = 14, MIX_N = 15 };
 
 // eight independent instances of one instruction, registers v40..v47 (+ v48..v55 as second operands)
 #define R8(OP) OP(40) OP(41) OP(42) OP(43) OP(44) OP(45) OP(46) OP(47)
@@ -34,10 +34,12 @@ __global__ void issue_rate_kernel(int iters, unsigned long long *cycles, uint32_
     constexpr int NE = 4096;                                  // 32 KB of {bits, before} entries: a row of m = 131072 columns
     constexpr bool IL = MIX == MIX_IL2 || MIX == MIX_IL4 || MIX == MIX_IL8;
     constexpr bool RANDOM = MIX == MIX_STEP_LDS_RANDOM || MIX == MIX_LDS_ONLY_RANDOM || IL;
-    if (MIX == MIX_STEP_LDS_FLAT || MIX == MIX_STEP_LDS_RANDOM || MIX == MIX_LDS_ONLY_FLAT || MIX == MIX_LDS_ONLY_RANDOM || IL) {
+    constexpr bool CLUSTERED = MIX == MIX_STEP_LDS_CLUSTERED;   // long runs + 64 consecutive ranks per wave and lookup: what rank-ordered slots would see
+    if (MIX == MIX_STEP_LDS_FLAT || MIX == MIX_STEP_LDS_RANDOM || MIX == MIX_LDS_ONLY_FLAT || MIX == MIX_LDS_ONLY_RANDOM || IL || CLUSTERED) {
         // a VALID directory, so that the row step is a true LF-mapping and the ranks stay inside the row for any number
         // of steps: RANDOM = pseudo-random bits with their prefix popcounts; FLAT = the all-zero row (ranks never move)
-        for (int i = threadIdx.x; i < NE; i += blockDim.x) tab[i] = make_uint2(RANDOM ? 0x9e3779b9u * (uint32_t)(i + 1) * (uint32_t)(i + 7) : 0u, 0u);
+        // (CLUSTERED: four runs of 1024 words -- neighbours in rank stay neighbours under the LF-mapping unless a run boundary falls between them)
+        for (int i = threadIdx.x; i < NE; i += blockDim.x) tab[i] = make_uint2(RANDOM ? 0x9e3779b9u * (uint32_t)(i + 1) * (uint32_t)(i + 7) : CLUSTERED ? 0u - (uint32_t)((i >> 10) & 1) : 0u, 0u);
         __syncthreads();
         if (threadIdx.x == 0) {
             uint32_t run = 0;
@@ -52,6 +54,7 @@ __global__ void issue_rate_kernel(int iters, unsigned long long *cycles, uint32_
         // FLAT: lane l reads entry l (+ 64 i): conflict-free; RANDOM: a different pseudo-random entry per lane and step
         uint32_t r = RANDOM
                          ? (((uint32_t)(threadIdx.x * 8 + i) * 2654435761u) ^ seed) % (NE * 32u)
+                         : CLUSTERED ? ((((uint32_t)((threadIdx.x >> 6) * 8 + i) * 2654435761u) ^ seed) % (NE * 32u - 64u)) + (uint32_t)lane
                          : (uint32_t)((lane + 64 * i) * 32 + (lane & 31));
         q[i] = ~r;
     }
@@ -83,7 +86,7 @@ __global__ void issue_rate_kernel(int iters, unsigned long long *cycles, uint32_
     } else {
         // the row step on 4 columns x 2 planes = 8 lookups per statement (step4 of scan_device.inc.h, the statement the
         // scan kernel's walk is made of, SALU count accumulation included), four statements per loop iteration
-        constexpr bool LDS = MIX == MIX_STEP_LDS_FLAT || MIX == MIX_STEP_LDS_RANDOM;
+        constexpr bool LDS = MIX == MIX_STEP_LDS_FLAT || MIX == MIX_STEP_LDS_RANDOM || MIX == MIX_STEP_LDS_CLUSTERED;
         constexpr bool ONLY = MIX == MIX_LDS_ONLY_FLAT || MIX == MIX_LDS_ONLY_RANDOM;
         uint32_t r0[4] = {q[0], q[2], q[4], q[6]}, r1[4] = {q[1], q[3], q[5], q[7]};
         uint64_t m0[4], m1[4];
@@ -272,6 +275,7 @@ static const MixInfo kMix[MIX_N] = {
     {"v_lshlrev_b32", 64, 0}, {"ds_read_b64 + its 2 address VALU, conflict-free", 4 * 16, 4 * 8}, {"ds_read_b64 + its 2 address VALU, random entries", 4 * 16, 4 * 8},
     {"row step, tails of 2 lookups interleaved, random entries", 4 * 8 * 8, 4 * 8}, {"row step, tails of 4 lookups interleaved, random entries", 4 * 8 * 8, 4 * 8},
     {"row step, tails of 8 lookups interleaved, random entries", 4 * 8 * 8, 4 * 8},
+    {"row step + ds_read_b64, 64 consecutive ranks per wave and lookup (long runs)", 4 * 8 * 8, 4 * 8},
 };
 
 template <int MIX>
@@ -303,7 +307,7 @@ hipError_t run_issue_rate(int mix, int waves_per_simd, int iters, double out[4])
         hipEventRecord(e0, nullptr);
         switch (mix) {
 #define X(M) case M: e = launch_mix<M>(threads, iters, cyc, sink, nullptr); break;
-        X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13)
+        X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14)
 #undef X
         }
         hipEventRecord(e1, nullptr);

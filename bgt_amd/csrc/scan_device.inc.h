@@ -649,6 +649,25 @@ __device__ __forceinline__ void build_plane_row(const ScanArgs &a, const uint8_t
     if (lane == 0) *n0_out = (uint32_t)a.m - carry_c;
 }
 
+// Start ranks of tracked slot `slot` in sub-block `blk` (rk = the sub-block's checkpoint, [2][m] ranks by column).  With a.order0 (an
+// experiment of the profiling build: whole cohort, one group, counts only -- the counts do not care which lane tracks which
+// column) slot s tracks the column whose plane-0 rank at the checkpoint is s, so that the 64 lanes of a wave start on 64
+// consecutive ranks and -- PBWT order keeps neighbours together -- read few distinct entries of a plane-0 row instead of 64
+// random ones (LDS bank conflicts).
+__device__ __forceinline__ void slot_start_ranks(const ScanArgs &a, int64_t blk, const int32_t *rk, int slot, bool in, uint32_t pad,
+                                                 uint32_t &q0, uint32_t &q1)
+{
+    if (a.order0) {
+        const bool on = in && slot < a.m;
+        q0 = ~(on ? (uint32_t)slot : pad);
+        q1 = ~(on ? (uint32_t)a.order0[blk * a.order_blk_stride + slot] : pad);
+        return;
+    }
+    const int col = in ? a.slot_col[slot] : -1;
+    q0 = ~(col >= 0 ? (uint32_t)rk[col] : pad);                          // complemented ranks (see the row step)
+    q1 = ~(col >= 0 ? (uint32_t)rk[a.m + col] : pad);
+}
+
 // SNAP = the image-open pass that snapshots the ranks at every sub-checkpoint row (ScanArgs::snap).  A template switch, not a
 // run-time test: as a run-time test its per-column skeleton (a predicate, a branch and two VALU instructions per column and ROW)
 // stayed in the walk loop of every scan -- 40 of the 360 VALU instructions of a C2 row.
@@ -713,9 +732,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
             const int c = chunk0 + j;
-            const int col = (c < a.n_chunks && !(BGTH_SKIP(a, 8))) ? a.slot_col[c * 64 + lane] : -1;
-            r0[j] = ~(col >= 0 ? (uint32_t)rk[col] : pad_rank);             // complemented ranks (see the row step)
-            r1[j] = ~(col >= 0 ? (uint32_t)rk[m + col] : pad_rank);
+            slot_start_ranks(a, blk, rk, c * 64 + lane, c < a.n_chunks && !(BGTH_SKIP(a, 8)), pad_rank, r0[j], r1[j]);
         }
     }
     if (MULTI) for (int i = tid; i < (TEAM ? 1 : 2) * K * G * 3; i += NT) lcnt[i] = 0;

@@ -162,9 +162,7 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
             const int c = chunk0 + j;
-            const int col = c < a.n_chunks ? a.slot_col[c * 64 + lane] : -1;
-            r0[j] = ~(col >= 0 ? (uint32_t)rk[col] : pad_rank);         // complemented ranks (see the row step)
-            r1[j] = ~(col >= 0 ? (uint32_t)rk[m + col] : pad_rank);
+            slot_start_ranks(a, blk, rk, c * 64 + lane, c < a.n_chunks, pad_rank, r0[j], r1[j]);
         }
     }
     if (MULTI) for (int i = tid; i < 2 * cnt_stride; i += NT) lcnt[i] = 0;

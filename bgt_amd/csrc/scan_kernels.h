@@ -30,6 +30,8 @@ struct ScanArgs {
     const int32_t  *rank0;       // initial ranks by column: [blk][2][m] (blk_stride = 2*m) or one [2][m]
     int64_t         rank0_blk_stride;
     const int32_t  *slot_col;    // [n_chunks*64] column of each tracked slot, -1 = padding
+    const int32_t  *order0;      // experiment (profiling build, profiles/r05_lds): != NULL = slot s of a sub-block tracks the column of
+    int64_t         order_blk_stride;   //   plane-0 rank s at its checkpoint; order0[blk * stride + s] = that column's plane-1 rank
     const uint32_t *chunk_desc;  // [n_chunks]
     int32_t        *raw_counts;  // [(row1-row0)][G][3] += {n(code1), n(code2), n(code3)}
     uint64_t       *h0, *h1;     // optional [(row1-row0)][n_chunks] bit planes in slot order
@@ -102,6 +104,7 @@ hipError_t launch_finalize(const int32_t *raw, int32_t *out, const int32_t *grou
                            int G, hipStream_t s);
 // inv[perm[j]] = j for n_perm permutations of m entries each.  bad != NULL (untrusted input): entries outside
 // 0..m-1 are not stored and every record is checked to be a permutation; *bad (device int) becomes non-zero otherwise
+hipError_t launch_plane1_by_plane0(const int32_t *rank, int32_t *out, int m, int64_t n_rec, hipStream_t s);
 hipError_t launch_invert(const int32_t *perm, int32_t *inv, int m, int64_t n_perm, hipStream_t s, int *bad = nullptr);
 // plane-split kernels (scan_plane.hip; sparse selections of wide cohorts): one workgroup per (sub-block, plane), two per CU;
 // the planes meet in count_planes (raw[row][g][3] = the three popcounts per group from the bit planes h0 / h1)

@@ -210,6 +210,24 @@ __global__ void invert_kernel(const int32_t *perm, int32_t *inv, int m, int64_t 
     inv[base + p] = (int32_t)(i - base);
 }
 
+// Experiment of the profiling build (profiles/r05_lds): out[rec][rank0[rec][col]] = rank1[rec][col] -- the plane-1 ranks of every
+// (sub-)checkpoint in the order of its plane-0 ranks, so that slots laid out in plane-0 rank order start without a gather.
+__global__ void plane1_by_plane0_kernel(const int32_t *rank, int32_t *out, int m, int64_t total)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int64_t rec = i / m;
+    const int32_t col = (int32_t)(i - rec * m);
+    out[rec * m + rank[rec * 2 * m + col]] = rank[rec * 2 * m + m + col];
+}
+hipError_t launch_plane1_by_plane0(const int32_t *rank, int32_t *out, int m, int64_t n_rec, hipStream_t s)
+{
+    const int64_t total = n_rec * m;
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(plane1_by_plane0_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, rank, out, m, total);
+    return hipGetLastError();
+}
+
 __global__ void verify_inverse_kernel(const int32_t *perm, const int32_t *inv, int m, int64_t total, int *bad)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

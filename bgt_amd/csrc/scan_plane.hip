@@ -78,34 +78,44 @@ __global__ __launch_bounds__(NT, LOW == 1 ? 6 : 4) void plane_kernel(const ScanA
     uint64_t *hout = plane ? a.h1 : a.h0;
     const int tw = wave;
 
+    // (Round 5, measured and dropped -- profiles/r05_c3/README.md: the toggles' chunks dealt to the waves that have no column to walk,
+    // two chunks each: C3 13.9 -> 17.9 ms, a wave's SECOND chunk is not prefetched and its loads sit in the row's critical path;
+    // the walk's all-padding statements skipped by a wave-uniform branch: 13.9 -> 13.9 ms, they only ever filled empty issue slots.)
     // What the toggles of a row need from memory -- its descriptor, this wave's first chunk of the string with that chunk's
     // row-index record, the carries of this wave's directory trips and the row's number of ones -- is fetched a row AHEAD,
     // behind the walk (the descriptor two rows ahead, so that nothing waits for an address either).  Everything goes through
     // vector loads, uniform addresses included: scalar loads would count in lgkmcnt, and the walk's every statement opens with
-    // s_waitcnt lgkmcnt(0).  (Before: descriptor -> string -> decode as a chain inside the toggles phase, 1.8 k of a row's
-    // 8.6 k cycles.)
-    auto vidx = [](uint64_t i) { uint32_t lo = (uint32_t)i, hi = (uint32_t)(i >> 32); asm volatile("" : "+v"(lo), "+v"(hi)); return (uint64_t)hi << 32 | lo; };
-    auto load_desc = [&](int64_t row) -> uint64_t { return row < blk_end ? rowdesc[vidx((uint64_t)(2 * row + plane))] : 0ull; };
+    // s_waitcnt lgkmcnt(0).  Addresses: a wave-uniform 64-bit base computed on the scalar unit + a 32-bit lane offset (the
+    // loads' saddr form) -- as 64-bit per-lane arithmetic the prefetch cost every wave ~34 VALU instructions per row, 12 % of
+    // the kernel's.  Rows are counted from the sub-block's first (32 bits).
+    const int nrows = __builtin_amdgcn_readfirstlane((int)(blk_end - blk_beg));
+    const uint32_t str0 = (uint32_t)(2 * blk_beg) + (uint32_t)plane;     // string index of relative row 0 (< 2^31 strings)
+    auto vzero = []() { uint32_t z = 0; asm volatile("" : "+v"(z)); return z; };
+    auto load_desc = [&](int i) -> uint64_t {                          // relative row i
+        if (i >= nrows) return 0ull;
+        const uint32_t bo = (str0 + 2u * (uint32_t)i) * 8u + vzero();
+        return *reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(rowdesc) + bo);
+    };
     struct Ahead { uint32_t w, ci, cyl; };
-    auto load_ahead = [&](int64_t row, uint64_t d) -> Ahead {       // d = the row's descriptor (already here)
+    auto load_ahead = [&](int i, uint64_t d) -> Ahead {                // d = the row's descriptor (already here, wave-uniform)
         Ahead p = {0u, 0u, 0u};
-        if (row >= blk_end) return p;
-        const int64_t sidx = 2 * row + plane;
+        if (i >= nrows) return p;
+        const uint64_t sidx = (uint64_t)str0 + 2u * (uint32_t)i;
         const uint32_t slen = (uint32_t)(d >> kDescLenShift);
         const uint64_t off = d & kDescOffMask;
-        const uint32_t *sc = segc + (size_t)sidx * (size_t)(a.S8 + 1);
+        const char *sc = reinterpret_cast<const char*>(segc + sidx * (uint64_t)(a.S8 + 1));   // (uniform)
         const int t = tw + lane * WPP;                                  // (ntrip <= 40: lane 63 has no trip and carries the row's ones)
-        if (t < ntrip || lane == 63) p.cyl = sc[lane == 63 ? a.S8 : t];
-        const uint32_t k0 = (uint32_t)tw * 256u + 4u * (uint32_t)lane;
-        if (k0 < slen) p.w = reinterpret_cast<const uint32_t*>(rle + off)[tw * 64 + lane];
-        if ((uint32_t)tw * 256u < slen) p.ci = chunkinfo[vidx(((off + (uint64_t)tw * 256u) >> 8) + (uint64_t)sidx)];
+        if (t < ntrip || lane == 63) p.cyl = *reinterpret_cast<const uint32_t*>(sc + 4u * (uint32_t)(lane == 63 ? a.S8 : t));
+        const uint32_t c0 = (uint32_t)tw * 256u;                         // this wave's first chunk of the string
+        if (c0 + 4u * (uint32_t)lane < slen) p.w = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(rle + off + c0) + 4u * (uint32_t)lane);
+        if (c0 < slen) p.ci = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(chunkinfo + (((off + c0) >> 8) + sidx)) + vzero());
         return p;
     };
 
-    // toggles of row `row` into TOG (the array is clean: the directory pass clears what it reads)
+    // toggles of relative row i into TOG (the array is clean: the directory pass clears what it reads)
     uint32_t keep_cyl = 0, keep_tot = 0;
-    auto toggles = [&](int64_t row, uint64_t d, const Ahead &p) {
-        const int64_t sidx = 2 * row + plane;
+    auto toggles = [&](int i, uint64_t d, const Ahead &p) {
+        const uint64_t sidx = (uint64_t)str0 + 2u * (uint32_t)i;
         const uint32_t slen = (uint32_t)(d >> kDescLenShift);
         const uint64_t off = d & kDescOffMask;
         keep_cyl = lane == 63 ? 0u : p.cyl;
@@ -116,45 +126,46 @@ __global__ __launch_bounds__(NT, LOW == 1 ? 6 : 4) void plane_kernel(const ScanA
             if (c == tw) { w = p.w; ci = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.ci); }
             else {
                 w = k0 < slen ? reinterpret_cast<const uint32_t*>(rle + off)[c * 64 + lane] : 0u;
-                ci = chunkinfo[((off + (uint64_t)c * 256u) >> 8) + (uint64_t)sidx];
+                ci = chunkinfo[((off + (uint64_t)c * 256u) >> 8) + sidx];
             }
             if (ci & kChunkDead) break;
             const ChunkDecode cd = decode_chunk(w, k0, slen, lane);
             chunk_toggles(a, TOG, 1, cd, ci & kChunkPosMask, ci >> 31, lane);
         }
     };
-    // cur: row + 1 of the loop below (fetched an iteration ago); d_next: descriptor of row + 2
+    // cur: relative row i + 1 of the loop below (fetched an iteration ago); d_next: descriptor of row i + 2
     uint64_t d_cur, d_next;
     Ahead cur;
     {
-        const uint64_t d0 = load_desc(blk_beg);
-        d_next = load_desc(blk_beg + 1);
+        const uint64_t d0 = load_desc(0);
+        d_next = load_desc(1);
         d_cur = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(d0 >> 32)) << 32 | (uint32_t)__builtin_amdgcn_readfirstlane((int)d0);
-        cur = load_ahead(blk_beg, d_cur);
+        cur = load_ahead(0, d_cur);
     }
+    const int emit_from = __builtin_amdgcn_readfirstlane(a.row0 > blk_beg ? (int)(a.row0 - blk_beg) : 0);   // first relative row whose ballots leave
 
     // (profiling build only: cycles per phase -- 0 walk, 1 toggles, 2 barrier, 3 directory, 4 barrier)
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = BGTH_TIMES(a) ? __builtin_amdgcn_s_memtime() : 0ull;
     // Loop (iteration -1 only prepares row blk_beg):   walk(row) + toggles(row+1) | directory(row+1) |     two barriers per row
-    for (int64_t row = blk_beg - 1; row < blk_end; ++row) {
-        const bool walking = row >= blk_beg, more = row + 1 < blk_end;
+    for (int i = -1; i < nrows; ++i) {
+        const bool walking = i >= 0, more = i + 1 < nrows;
         // row + 2: its descriptor came an iteration ago; its data and the descriptor of row + 3 travel behind this walk
         const uint64_t d_ahead = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(d_next >> 32)) << 32 | (uint32_t)__builtin_amdgcn_readfirstlane((int)d_next);
-        const Ahead ahead = load_ahead(row + 2, d_ahead);
-        d_next = load_desc(row + 3);
-        if (walking) {
-            const uint32_t base = lds0 - 8u;
-            const uint32_t n0 = 0u - n0s[row & 1];
+        const Ahead ahead = load_ahead(i + 2, d_ahead);
+        d_next = load_desc(i + 3);
+        if (walking && !(BGTH_SKIP(a, 0x10000))) {                       // (profiling build: 0x10000 no walk, 0x20000 no toggles,
+            const uint32_t base = lds0 - 8u;                             //  0x40000 no directory trips, 0x80000 no barriers -- timing only)
+            const uint32_t n0 = 0u - n0s[i & 1];
             // chunks of this wave whose ballots leave in this row, as ONE scalar integer: as a boolean per column the test was kept
             // in 64-bit lane masks, spilled to VGPR lanes and read back with two v_readlane per column and row
-            const int n_emit = __builtin_amdgcn_readfirstlane(row >= a.row0 ? a.n_chunks - chunk0 : 0);
+            const int n_emit = __builtin_amdgcn_readfirstlane(i >= emit_from ? a.n_chunks - chunk0 : 0);
             uint32_t ca = 0, cb = 0, cc = 0;
             // The ballots leave straight from their SGPRs: one scalar store per column (s_store_dwordx2, written back by the
             // s_dcache_wb at the end of the kernel) instead of moving them into lanes first (two v_cndmask per column: a
             // quarter of this walk's VALU instructions).
             // A scalar store reads its data registers when it EXECUTES, not when it issues: the ballots of a group stay in
             // their SGPRs (pm) until the next statement's opening s_waitcnt lgkmcnt(0) has retired the stores.
-            uint64_t *hrow = hout + (size_t)(row - a.h_row0) * a.n_chunks + chunk0;
+            uint64_t *hrow = hout + (size_t)(blk_beg + i - a.h_row0) * a.n_chunks + chunk0;
             uint64_t pm[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < CPT; j += 4) {
@@ -187,17 +198,17 @@ __global__ __launch_bounds__(NT, LOW == 1 ? 6 : 4) void plane_kernel(const ScanA
         // The build of the next row is a latency chain of few instructions (decode, LDS atomics, prefix scans, two barriers):
         // it goes ahead of the walk of the CU's other workgroup, which fills the issue slots it leaves.
         if (a.walk_prio) __builtin_amdgcn_s_setprio(3);
-        if (more) toggles(row + 1, d_cur, cur);
+        if (more && !(BGTH_SKIP(a, 0x20000))) toggles(i + 1, d_cur, cur);
         d_cur = d_ahead; cur = ahead;
         BGTH_TICK(1);
-        lds_barrier();                                                   // every wave is past its walk; the toggles are complete
+        if (!(BGTH_SKIP(a, 0x80000))) lds_barrier();                    // every wave is past its walk; the toggles are complete
         BGTH_TICK(2);
-        if (more) {
+        if (more && !(BGTH_SKIP(a, 0x40000))) {
             directory_trips_tog<2>(TOG, BD, tw, WPP, ntrip, nw, tail_mask, keep_cyl, lane);
-            if (tid == 0) n0s[(row + 1) & 1] = (uint32_t)m - keep_tot;
+            if (tid == 0) n0s[(i + 1) & 1] = (uint32_t)m - keep_tot;
         }
         BGTH_TICK(3);
-        lds_barrier();
+        if (!(BGTH_SKIP(a, 0x80000))) lds_barrier();
         if (a.walk_prio) __builtin_amdgcn_s_setprio(0);
         BGTH_TICK(4);
     }
@@ -236,7 +247,11 @@ __global__ __launch_bounds__(256) void count_planes_kernel(const uint64_t *__res
 
 // g->low: 1 = the one-plane statement and six waves per SIMD asked of the compiler (80 VGPRs); 0 = the round-3 shape (two
 // workgroups of 512 threads, the two-plane statement's plane-0 branch; BGTH_PLANE_LOW=0, for A/B runs).
+#ifdef BGTH_ABLATE
 static int plane_knob(const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; }
+#else
+static int plane_knob(const char *, int dflt) { return dflt; }       // (the shipped library reads no tuning knob from the environment)
+#endif
 static int plane_lds(int m) { const int nw = (m + 31) / 32, nwp = (nw + 2) & ~1, nwt = (nw + 4) & ~3; return ((nwp * 8 + nwt * 4 + 16) + 15) & ~15; }
 // workgroups of the plane-split kernels a CU holds: three of 512 threads where their LDS allows (m <= 139,000), else two
 int plane_slots_per_cu(int m)
@@ -254,6 +269,8 @@ bool choose_plane_geometry(int m, int n_chunks, int n_blk, Geometry *g)
     // six waves per SIMD: three workgroups of 512 threads or two of 768 (chunks permitting: <= 20 per wave); else two of 512
     int threads = 512, low = 0, cpt = 0;
     if (low_knob && slots == 3) { threads = 512; low = 1; }
+    // (round 5, measured and dropped: two workgroups of 896 threads at 72 VGPRs = seven waves per SIMD, 12 columns per wave, no wave
+    // with two directory units: C3 19.6 ms against 13.9 -- profiles/r05_c3)
     else if (low_knob && 12 * 20 >= n_chunks) { threads = 768; low = 1; }
     const int waves = threads / 64;
     if (threads == 768) {

@@ -357,6 +357,57 @@ def test_checkpoints_rebuilt_on_device(hip, tmp_path, monkeypatch, seed, m, rows
     assert np.array_equal(rd.scan(0, rows), oc)
 
 
+@pytest.mark.parametrize("seed,m,rows,shift,sub,force", [(41, 5008, 300, 5, None, 0), (42, 20000, 70, 4, "2", 0), (43, 41000, 40, 3, None, 0),
+                                                         (44, 6400, 130, 6, "3", 32), (45, 1, 12, 2, None, 0), (46, 63, 40, 13, None, 32),
+                                                         (47, 9000, 160, 5, "4", 4)])
+def test_slots_in_rank_order_count_what_slots_in_column_order_count(hip, monkeypatch, seed, m, rows, shift, sub, force):
+    """Whole cohort, one group, counts only: the slots of a sub-block are its columns in the order of their plane-0 ranks at its
+    checkpoint (round 5: fewer LDS bank conflicts in the walk's gather -- profiles/r05_lds); BGTH_FORCE_COLUMN_ORDER keeps the
+    column order.  Both against the oracle: narrow, pipelined, team and forced directory-path kernels, the empty-plane-1
+    shortcut, sub-checkpoints inside the blocks, scans that start and end inside sub-blocks, a reader that leaves the whole
+    cohort for a subset and comes back, and an image whose checkpoints change under the table (bgth_pbf_rebase)."""
+    if sub:
+        monkeypatch.setenv("BGTH_SUB_SHIFT", sub)
+    mat, data, rng = make_case(seed, m, rows, shift, n_founders=9, switch=0.05)
+    if force == 4:
+        mat[::3] &= 1                                                # rows whose plane 1 is empty
+        data = orc.encode_pbf(mat, 2, shift)
+    oc, _ = oracle_scan(data, 0, rows)
+    pbf = hip.HipPbf.from_bytes(data)
+    rd = hip.HipReader(pbf)
+    for order in (0, hip.hip.FORCE_COLUMN_ORDER, 0):
+        hip.force_kernels(force | order)
+        assert np.array_equal(rd.scan(0, rows), oc), (order, rd.geometry(), rd.path())
+        for a, b in ((1, rows), (rows // 3, rows - 2), (rows - 1, rows)):
+            assert np.array_equal(rd.scan(a, b), oc[a:b]), (order, a, b)
+    if m >= 64:
+        cols = np.arange(0, m, 3, dtype=np.int32)
+        rd.select(cols)
+        sc, _ = oracle_scan(data, 0, rows, cols=cols)
+        assert np.array_equal(rd.scan(0, rows), sc)
+        rd.select(None)
+        assert np.array_equal(rd.scan(0, rows), oc)
+    # genotype planes are wanted: the slot order is the selection's again (the planes are in slot order)
+    c, g = rd.scan(0, rows, want_gt=True)
+    assert np.array_equal(c, oc) and np.array_equal(g, oracle_scan(data, 0, rows)[1])
+    rd.close(); pbf.close()
+    # checkpoints that change under the table: an image from bare strings, scanned, re-based, scanned again
+    _, _, strings = split_rle(data)
+    rle = np.frombuffer(b"".join(strings), np.uint8)
+    lens = np.array([len(x) for x in strings], np.uint32)
+    img = hip.HipPbf.from_rle(m, shift, rle, lens)
+    r2 = hip.HipReader(img)
+    hip.force_kernels(force)
+    assert np.array_equal(r2.scan(0, rows), oc)
+    start = np.stack([rng.permutation(m).astype(np.int32), rng.permutation(m).astype(np.int32)])
+    img.rebase(start)
+    after = r2.scan(0, rows)
+    hip.force_kernels(force | hip.hip.FORCE_COLUMN_ORDER)
+    assert np.array_equal(r2.scan(0, rows), after)
+    assert m == 1 or not np.array_equal(after, oc) or rows < 4      # (a random start order pairs the planes' bits differently)
+    r2.close(); img.close()
+
+
 def test_shards_of_one_database_opened_side_by_side(hip, tmp_path):
     """SURVEY 8e with ONE database: every shard is built from the identity order on its own (bgth_pbf_from_rle), the
     final ranks are chained (shard r starts from final(r-1) o ... o final(0), bgth_pbf_rebase) and the shards' scans

@@ -94,6 +94,54 @@ def test_sharded_image_equals_the_single_image(tmp_path, n_shards):
         rd.scan_device(0, rows, d.data_ptr(), d.data_ptr(), d.data_ptr())
 
 
+@pytest.mark.gpu
+def test_eight_shards_at_the_width_of_configs_3_share_one_device(tmp_path, monkeypatch):
+    """The dry run a first 8-GPU node deserves: a database at the WIDTH of BASELINE configs[3] (100,000
+    samples) dealt over EIGHT shards that all live on device 0, every shard on the directory path with its arena capped at
+    its share (an eighth) of the device's arena budget -- set small here, so that every shard walks its rows in several
+    passes -- double-buffered device scans on a caller's stream (the pattern of bench.py; the second scan of a shard may not
+    overwrite counts the first gather has not copied yet: ADVICE r4), gathered counts equal to the single image's on every row,
+    and the HBM the eight readers keep within the budget."""
+    import torch
+    import bgt_amd
+    m, shift = 200000, 13
+    rows = 8 * 3 * 8192 - 1000                                       # 24 file blocks, the last one ragged: 3 per shard
+    rle, lens = bgt_amd.synth_rows(m, 0, rows, 4)                    # seed 4 = C4 (SURVEY 8d)
+    one_img = bgt_amd.HipPbf.from_rle(m, shift, rle, lens)
+    del rle
+    path = str(tmp_path / "c4w.pbf")
+    one_img.save(path)
+    one = bgt_amd.HipReader(one_img)
+    want = one.scan(0, rows)
+    assert one.path()["directory_path"]
+    one.close(); one_img.close()
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    budget_mb = 6000
+    monkeypatch.setenv("BGTH_DIR_ARENA_MB", str(budget_mb))          # per shard: 750 MB = 7,680 rows of 100 KB: three sub-blocks a pass
+    free0 = torch.cuda.mem_get_info()[0]
+    pbf = bgt_amd.HipPbf.open_sharded(path, [0] * 8)
+    assert pbf.n == rows and pbf.n_shards == 8
+    rd = bgt_amd.HipReader(pbf)
+    st = torch.cuda.Stream()
+    bufs = [torch.full((rows, 1, 3), -1, dtype=torch.int32, device="cuda") for _ in range(2)]
+    with bgt_amd.forced_kernels(bgt_amd.hip.FORCE_REBUILD_ROWS):
+        for k in range(4):                                           # back to back, nothing waits on the host in between
+            assert rd.scan_device(0, rows, bufs[k & 1].data_ptr(), stream=st.cuda_stream) == rows
+    st.synchronize()
+    for b in bufs:
+        assert np.array_equal(b.cpu().numpy(), want)
+    p = rd.path()
+    assert p["directory_path"] and p["passes"] >= 2, p               # (of shard 0: its arena holds a part of its rows at a time)
+    used = free0 - torch.cuda.mem_get_info()[0]
+    image = pbf.hbm_bytes
+    assert used <= image + (budget_mb << 20) + (1 << 30), (used, image)   # images + the eight arenas (<= the budget) + readers' buffers
+    a, b = 2 * 8192 + 5, 21 * 8192 - 3                               # a range that starts and ends inside shards
+    d = torch.zeros((b - a, 1, 3), dtype=torch.int32, device="cuda")
+    rd.scan_device(a, b, d.data_ptr())
+    assert np.array_equal(d.cpu().numpy(), want[a:b])
+    rd.close(); pbf.close()
+
+
 def md5_of(cmd, env=None):
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
     return p.returncode, hashlib.md5(p.stdout).hexdigest(), len(p.stdout), p.stderr.decode()[-300:]
