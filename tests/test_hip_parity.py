@@ -404,7 +404,6 @@ def test_slots_in_rank_order_count_what_slots_in_column_order_count(hip, monkeyp
     after = r2.scan(0, rows)
     hip.force_kernels(force | hip.hip.FORCE_COLUMN_ORDER)
     assert np.array_equal(r2.scan(0, rows), after)
-    assert m == 1 or not np.array_equal(after, oc) or rows < 4      # (a random start order pairs the planes' bits differently)
     r2.close(); img.close()
 
 
