@@ -1902,9 +1902,11 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
         hipFree(d_times);
         const Geometry &tg = dirpath ? wgeo : planepath ? pgeo : geo;   // (directory path: stage DMA | walk | wait | counts | plane-1 DMA | wait;
                                                                         //  plane-split: walk | toggles | barrier | directory | barrier)
-        const double waves = (double)tg.workgroups * ((a.debug_skip & 0x100) ? 1 : tg.threads / 64), nb = (double)rows / tg.K;
-        fprintf(stderr, "[bgth debug] memtime ticks per wave and batch: prefetch %.0f | clear %.0f | wait %.0f | toggles %.0f | wait %.0f | directory %.0f | wait %.0f | walk %.0f\n",
-                h[0] / waves / nb, h[1] / waves / nb, h[2] / waves / nb, h[3] / waves / nb, h[4] / waves / nb, h[5] / waves / nb, h[6] / waves / nb, h[7] / waves / nb);
+        // a row (batch of K rows) is visited by `slices` workgroups (plane-split kernels: by two, one per plane)
+        const double waves = (double)(planepath ? 2 : tg.slices) * ((a.debug_skip & 0x100) ? 1 : tg.threads / 64), nb = (double)rows / tg.K;
+        fprintf(stderr, "[bgth debug] memtime ticks per wave and row batch, phases 0..7: %.0f | %.0f | %.0f | %.0f | %.0f | %.0f | %.0f | %.0f   (sum %.0f)\n",
+                h[0] / waves / nb, h[1] / waves / nb, h[2] / waves / nb, h[3] / waves / nb, h[4] / waves / nb, h[5] / waves / nb, h[6] / waves / nb, h[7] / waves / nb,
+                (double)(h[0] + h[1] + h[2] + h[3] + h[4] + h[5] + h[6] + h[7]) / waves / nb);
     }
     HIP_TRY(launch_finalize((const int32_t*)r->raw.p, d_fin, r->sel.d_group_haps, rows, G, s), return -1);
     if (timed) HIP_TRY(hipEventRecord(r->ev[3], s), return -1);

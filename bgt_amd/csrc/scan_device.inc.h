@@ -527,6 +527,8 @@ __device__ __forceinline__ void directory_trips_tog(uint32_t *tog, uint2 *bd, in
         }
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
+            if (!on[j]) continue;                                        // (wave-uniform: a row's odd last trip has no partner -- before,
+                                                                         //  its empty partner was computed and scanned all the same)
             const uint32_t cy = (uint32_t)__builtin_amdgcn_readlane((int)cyl, u + j);
             const int i0 = (tt[j] << 8) + 4 * lane;
             const uint32_t tq[4] = {q[j].x, q[j].y, q[j].z, q[j].w};

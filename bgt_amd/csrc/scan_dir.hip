@@ -195,6 +195,7 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
     const int npiece = (int)((plane_bytes + 1023u) >> 10);
     auto dma_plane = [&](int buf, int64_t row, int plane) {
         const unsigned char *src = dirbase + (size_t)(2 * (row - a.dir_row0) + plane) * plane_bytes;
+        if (BGTH_SKIP(a, 0x100000)) return;                              // (profiling build, timing only: 0x10000 no walk, 0x80000 no barriers, 0x100000 no DMA)
         for (int pc = wave; pc < npiece; pc += NWAVE) {
             const uint32_t off = (uint32_t)pc * 1024u + (uint32_t)lane * 16u;
             if (off < plane_bytes)
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
         }
         BGTH_TICK(0);
         // ---- walk the row: ranks stay in registers
-        {
+        if (!(BGTH_SKIP(a, 0x10000))) {
             const uint32_t base0 = lds0 + (uint32_t)c0 * plane_bytes - 8u;
             const uint32_t base1 = lds0 + (uint32_t)c1 * plane_bytes - 8u;
             const int64_t pr = 2 * (row - a.dir_row0);
@@ -313,8 +314,15 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
         BGTH_TICK(1);
         asm volatile("" :: "v"(touched));                                // (the touch is waited for here, not before the walk)
         wait_vm0();                                                      // this wave's pieces of the staged plane have landed
-        lds_barrier();                                                   // every wave is past its walk: both planes are free
+        if (!(BGTH_SKIP(a, 0x80000))) lds_barrier();                    // every wave is past its walk: both planes are free
         BGTH_TICK(2);
+        // three buffers: the next row's plane 1 (and with two buffers its plane 0) can only start now -- ahead of the counts, so
+        // that they run while it travels (round 5; before: counts, then the DMA, its latency behind both)
+        if (!four && more) {
+            if (staged) { const int nc0 = st; dma_plane(c1, row + 1, 1); st = c0; c0 = nc0; }
+            else { dma_plane(c0, row + 1, 0); dma_plane(c1, row + 1, 1); }
+        }
+        BGTH_TICK(4);
         // ---- counts of this row and slice -> HBM
         {
             int32_t *lcb = lcnt + (int)(row & 1) * cnt_stride;
@@ -341,11 +349,8 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
         BGTH_TICK(3);
         if (four) { c0 ^= 2; c1 ^= 2; }                                  // (one barrier per row: the next row is already there)
         else if (more) {
-            if (staged) { const int nc0 = st; dma_plane(c1, row + 1, 1); st = c0; c0 = nc0; }
-            else { dma_plane(c0, row + 1, 0); dma_plane(c1, row + 1, 1); }
-            BGTH_TICK(4);
             wait_vm0();
-            lds_barrier();
+            if (!(BGTH_SKIP(a, 0x80000))) lds_barrier();
             BGTH_TICK(5);
         }
     }
