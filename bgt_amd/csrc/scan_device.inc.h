@@ -651,23 +651,64 @@ __device__ __forceinline__ void build_plane_row(const ScanArgs &a, const uint8_t
     if (lane == 0) *n0_out = (uint32_t)a.m - carry_c;
 }
 
-// Start ranks of tracked slot `slot` in sub-block `blk` (rk = the sub-block's checkpoint, [2][m] ranks by column).  With a.order0 (an
-// experiment of the profiling build: whole cohort, one group, counts only -- the counts do not care which lane tracks which
-// column) slot s tracks the column whose plane-0 rank at the checkpoint is s, so that the 64 lanes of a wave start on 64
-// consecutive ranks and -- PBWT order keeps neighbours together -- read few distinct entries of a plane-0 row instead of 64
-// random ones (LDS bank conflicts).
-__device__ __forceinline__ void slot_start_ranks(const ScanArgs &a, int64_t blk, const int32_t *rk, int slot, bool in, uint32_t pad,
-                                                 uint32_t &q0, uint32_t &q1)
+// Start ranks of a thread's CPT tracked slots (chunk c = chunk0 + j, slot = 64 c + lane) in sub-block `blk`; rk = the sub-block's
+// checkpoint, [2][m] ranks by column.  Complemented ranks (see the row step); `pad` for slots behind the selection.
+//   a.order0 (whole cohort, one group, counts only -- the counts do not care which lane tracks which column): slot s tracks the
+//   column whose plane-0 rank at the checkpoint is s, so that the 64 lanes of a wave start on 64 consecutive ranks and -- PBWT
+//   order keeps neighbours together -- read few distinct entries of a plane-0 row instead of 64 random ones (profiles/r05_lds).
+// Every load is unconditional (clamped index, the result selected afterwards) and the dependent gathers form a second loop: as
+// `if (col >= 0) rank = rk[col]` per column the compiler emitted load - s_waitcnt vmcnt(0) - branch - load - wait ..., THREE
+// memory round trips per column one after the other: ~100 of them at the start of every workgroup of the HRC shape, whose
+// sub-blocks are only 128 rows long (round 5).
+template <int CPT>
+__device__ __forceinline__ void load_start_ranks(const ScanArgs &a, int64_t blk, const int32_t *__restrict__ rk, int chunk0, int lane,
+                                                 bool skip_all, uint32_t pad, uint32_t (&r0)[CPT], uint32_t (&r1)[CPT])
 {
+    const int m = a.m;
+    constexpr int B = 16;                                               // columns per batch of loads in flight (registers)
     if (a.order0) {
-        const bool on = in && slot < a.m;
-        q0 = ~(on ? (uint32_t)slot : pad);
-        q1 = ~(on ? (uint32_t)a.order0[blk * a.order_blk_stride + slot] : pad);
+        const int32_t *__restrict__ ord = a.order0 + blk * a.order_blk_stride;
+#pragma unroll
+        for (int j0 = 0; j0 < CPT; j0 += B) {
+            uint32_t t[B];
+#pragma unroll
+            for (int j = j0; j < j0 + B && j < CPT; ++j) {
+                const int slot = (chunk0 + j) * 64 + lane;
+                t[j - j0] = (uint32_t)ord[slot < m ? slot : 0];
+            }
+#pragma unroll
+            for (int j = j0; j < j0 + B && j < CPT; ++j) {
+                const int slot = (chunk0 + j) * 64 + lane;
+                const bool on = !skip_all && chunk0 + j < a.n_chunks && slot < m;
+                r0[j] = ~(on ? (uint32_t)slot : pad);
+                r1[j] = ~(on ? t[j - j0] : pad);
+            }
+        }
         return;
     }
-    const int col = in ? a.slot_col[slot] : -1;
-    q0 = ~(col >= 0 ? (uint32_t)rk[col] : pad);                          // complemented ranks (see the row step)
-    q1 = ~(col >= 0 ? (uint32_t)rk[a.m + col] : pad);
+    const int last = a.n_chunks * 64 - 1;
+#pragma unroll
+    for (int j0 = 0; j0 < CPT; j0 += B) {
+        int col[B];
+        uint32_t t0[B], t1[B];
+#pragma unroll
+        for (int j = j0; j < j0 + B && j < CPT; ++j) {
+            const int slot = (chunk0 + j) * 64 + lane;
+            col[j - j0] = a.slot_col[slot <= last ? slot : 0];
+        }
+#pragma unroll
+        for (int j = j0; j < j0 + B && j < CPT; ++j) {
+            const int cc = col[j - j0] >= 0 ? col[j - j0] : 0;
+            t0[j - j0] = (uint32_t)rk[cc];
+            t1[j - j0] = (uint32_t)rk[m + cc];
+        }
+#pragma unroll
+        for (int j = j0; j < j0 + B && j < CPT; ++j) {
+            const bool on = !skip_all && chunk0 + j < a.n_chunks && col[j - j0] >= 0;
+            r0[j] = ~(on ? t0[j - j0] : pad);
+            r1[j] = ~(on ? t1[j - j0] : pad);
+        }
+    }
 }
 
 // SNAP = the image-open pass that snapshots the ranks at every sub-checkpoint row (ScanArgs::snap).  A template switch, not a
@@ -731,11 +772,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
     uint32_t r0[CPT], r1[CPT];
     {
         const int32_t *rk = a.rank0 + blk * a.rank0_blk_stride;
-#pragma unroll
-        for (int j = 0; j < CPT; ++j) {
-            const int c = chunk0 + j;
-            slot_start_ranks(a, blk, rk, c * 64 + lane, c < a.n_chunks && !(BGTH_SKIP(a, 8)), pad_rank, r0[j], r1[j]);
-        }
+        load_start_ranks<CPT>(a, blk, rk, chunk0, lane, BGTH_SKIP(a, 8) != 0, pad_rank, r0, r1);
     }
     if (MULTI) for (int i = tid; i < (TEAM ? 1 : 2) * K * G * 3; i += NT) lcnt[i] = 0;
     // MULTI: the group of every row-step statement of this wave (four chunks, the tail two): slots are laid out group by group,

@@ -159,11 +159,7 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
     uint32_t r0[CPT], r1[CPT];
     {
         const int32_t *rk = a.rank0 + blk * a.rank0_blk_stride;
-#pragma unroll
-        for (int j = 0; j < CPT; ++j) {
-            const int c = chunk0 + j;
-            slot_start_ranks(a, blk, rk, c * 64 + lane, c < a.n_chunks, pad_rank, r0[j], r1[j]);
-        }
+        load_start_ranks<CPT>(a, blk, rk, chunk0, lane, false, pad_rank, r0, r1);
     }
     if (MULTI) for (int i = tid; i < 2 * cnt_stride; i += NT) lcnt[i] = 0;
     // MULTI: the group of every row-step statement of this wave (see scan_kernel): counts accumulate on the scalar unit and

@@ -63,13 +63,20 @@ __global__ __launch_bounds__(NT, LOW == 1 ? 6 : 4) void plane_kernel(const ScanA
     const int chunk0 = wave * CPT;
     uint32_t rk_[CPT];
     {
-        const int32_t *rk = a.rank0 + blk * a.rank0_blk_stride + (int64_t)plane * m;
+        // (unconditional loads from clamped indices, the gathers in a second loop: see load_start_ranks)
+        const int32_t *__restrict__ rk = a.rank0 + blk * a.rank0_blk_stride + (int64_t)plane * m;
+        const int last = a.n_chunks * 64 - 1;
+        int col_[CPT];
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
-            const int c = chunk0 + j;
-            const int col = c < a.n_chunks ? a.slot_col[c * 64 + lane] : -1;
-            rk_[j] = ~(col >= 0 ? (uint32_t)rk[col] : pad_rank);
+            const int slot = (chunk0 + j) * 64 + lane;
+            col_[j] = a.slot_col[slot <= last ? slot : 0];
         }
+        uint32_t t_[CPT];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) t_[j] = (uint32_t)rk[col_[j] >= 0 ? col_[j] : 0];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) rk_[j] = ~(chunk0 + j < a.n_chunks && col_[j] >= 0 ? t_[j] : pad_rank);
     }
     for (int i = tid; i < nwt; i += NT) TOG[i] = 0u;
     if (tid == 0) BD[nw] = make_uint2(0u, 0u);
@@ -360,13 +367,20 @@ __global__ __launch_bounds__(NT) void walk_plane_kernel(const ScanArgs a, const 
     const int chunk0 = (slice * NWAVE + wave) * CPT;
     uint32_t rk_[CPT];
     {
-        const int32_t *rk = a.rank0 + blk * a.rank0_blk_stride + (int64_t)plane * m;
+        // (unconditional loads from clamped indices, the gathers in a second loop: see load_start_ranks)
+        const int32_t *__restrict__ rk = a.rank0 + blk * a.rank0_blk_stride + (int64_t)plane * m;
+        const int last = a.n_chunks * 64 - 1;
+        int col_[CPT];
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
-            const int c = chunk0 + j;
-            const int col = c < a.n_chunks ? a.slot_col[c * 64 + lane] : -1;
-            rk_[j] = ~(col >= 0 ? (uint32_t)rk[col] : pad_rank);
+            const int slot = (chunk0 + j) * 64 + lane;
+            col_[j] = a.slot_col[slot <= last ? slot : 0];
         }
+        uint32_t t_[CPT];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) t_[j] = (uint32_t)rk[col_[j] >= 0 ? col_[j] : 0];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) rk_[j] = ~(chunk0 + j < a.n_chunks && col_[j] >= 0 ? t_[j] : pad_rank);
     }
     const unsigned char *dirbase = reinterpret_cast<const unsigned char*>(a.dir);
     const int npiece = (int)((plane_bytes + 1023u) >> 10);
