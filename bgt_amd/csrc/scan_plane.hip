@@ -88,7 +88,9 @@ __global__ __launch_bounds__(NT, LOW == 1 ? 6 : 4) void plane_kernel(const ScanA
     // (Round 5, measured and dropped -- profiles/r05_c3/README.md: the toggles' chunks dealt to the waves that have no column to walk,
     // two chunks each: C3 13.9 -> 17.9 ms, a wave's SECOND chunk is not prefetched and its loads sit in the row's critical path; the
     // same with three chunks prefetched in the registers a walker keeps ranks in: 14.6 ms, and +9 % on a shape WITHOUT an idle wave --
-    // the branches around the loads cost the compiler its vmcnt bookkeeping, the toggles then wait for the loads just issued;
+    // the branches around the loads cost the compiler its vmcnt bookkeeping, the toggles then wait for the loads just issued; with
+    // a row loop of its own per role (walker / toggle wave, same barriers) that is cured and C3 runs 13.3 -> 13.15 ms: the toggles
+    // beside the walk instead of behind it buy 1 %, not the 1.7 ms the ablation prices them at -- not worth three loop bodies;
     // the walk's all-padding statements skipped by a wave-uniform branch: 13.9 -> 13.9 ms, they only ever filled empty issue slots.)
     // What the toggles of a row need from memory -- its descriptor, this wave's first chunk of the string with that chunk's
     // row-index record, the carries of this wave's directory trips and the row's number of ones -- is fetched a row AHEAD,
