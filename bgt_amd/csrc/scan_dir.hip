@@ -186,40 +186,52 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
         }
     }
 
-    // LDS-DMA of one plane-row: pieces of 1 KiB (64 lanes x 16 bytes) dealt round-robin over the waves
+    // LDS-DMA of one plane-row: pieces of 1 KiB (64 lanes x 16 bytes) dealt round-robin over the waves.  A wave's lane offset, its
+    // number of pieces and the lanes of its last piece are constants of the kernel; the source is a running pointer (the next row's
+    // plane 0, advanced by two plane-rows per row) -- as `dirbase + (2 (row - dir_row0) + plane) * plane_bytes` per call, with a
+    // 64-bit multiply, a loop and a compare per piece, the two or three calls of a row were ~60 scalar instructions per wave: 16
+    // waves x 60 on the CU's one scalar unit = the ~1.1 k cycles every row spent ISSUING its DMA (profiles/r05_walk).
     const unsigned char *dirbase = reinterpret_cast<const unsigned char*>(a.dir);
     const int npiece = (int)((plane_bytes + 1023u) >> 10);
-    auto dma_plane = [&](int buf, int64_t row, int plane) {
-        const unsigned char *src = dirbase + (size_t)(2 * (row - a.dir_row0) + plane) * plane_bytes;
-        if (BGTH_SKIP(a, 0x100000)) return;                              // (profiling build, timing only: 0x10000 no walk, 0x80000 no barriers, 0x100000 no DMA)
-        for (int pc = wave; pc < npiece; pc += NWAVE) {
-            const uint32_t off = (uint32_t)pc * 1024u + (uint32_t)lane * 16u;
-            if (off < plane_bytes)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off),
-                                                 (__attribute__((address_space(3))) void*)(smem + (size_t)buf * plane_bytes + (size_t)pc * 1024u),
-                                                 16, 0, 0);
+    const uint32_t voff = (uint32_t)wave * 1024u + (uint32_t)lane * 16u;
+    const int npc = __builtin_amdgcn_readfirstlane(wave < npiece ? (npiece - wave + NWAVE - 1) / NWAVE : 0);
+    // (every lane of the workgroup is active where the DMA is issued: the last piece's lanes are an exec mask kept in SGPRs)
+    const uint64_t last_lanes = __ballot(npc > 0 && voff + (uint32_t)(npc - 1) * (uint32_t)(NWAVE * 1024) < plane_bytes);
+    const uint32_t lds_wave = lds0 + (uint32_t)wave * 1024u;
+    auto dma_plane = [&](int buf, const unsigned char *src) {
+        if (BGTH_SKIP(a, 0x100000) || npc == 0) return;                  // (profiling build, timing only: 0x10000 no walk, 0x80000 no barriers, 0x100000 no DMA)
+        uint32_t m0v = lds_wave + (uint32_t)buf * plane_bytes;
+#pragma unroll 1
+        for (int k = 0; k + 1 < npc; ++k) {
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(src), "s"(m0v) : "memory");
+            src += NWAVE * 1024;
+            m0v += NWAVE * 1024;
         }
+        asm volatile("s_mov_b64 exec, %3\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b64 exec, -1"
+                     :: "v"(voff), "s"(src), "s"(m0v), "s"(last_lanes) : "memory");
     };
+    auto row_src = [&](int64_t row) { return dirbase + (size_t)(2 * (row - a.dir_row0)) * plane_bytes; };   // plane 0 of `row`
 
     // (profiling build only: cycles per phase -- 0 stage DMA issue, 1 walk, 2 wait + barrier, 3 counts, 4 plane-1 DMA issue,
     //  5 its wait + barrier)
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = BGTH_TIMES(a) ? __builtin_amdgcn_s_memtime() : 0ull;
     int c0 = 0, c1 = 1, st = 2;                                          // plane buffers: current row's planes, staging
-    if (blk_beg < blk_end) { dma_plane(c0, blk_beg, 0); dma_plane(c1, blk_beg, 1); }
+    if (blk_beg < blk_end) { dma_plane(c0, row_src(blk_beg)); dma_plane(c1, row_src(blk_beg) + plane_bytes); }
     wait_vm0();
     lds_barrier();
+    const unsigned char *nsrc = row_src(blk_beg + 1);                    // plane 0 of the row after the one being walked
 
     for (int64_t row = blk_beg; row < blk_end; ++row) {
         const bool more = row + 1 < blk_end;
-        if (four && more) { dma_plane(c0 ^ 2, row + 1, 0); dma_plane(c1 ^ 2, row + 1, 1); }   // buffers {0, 1} and {2, 3} alternate
-        if (staged && more) dma_plane(st, row + 1, 0);                   // lands during the walk
+        if (four && more) { dma_plane(c0 ^ 2, nsrc); dma_plane(c1 ^ 2, nsrc + plane_bytes); }   // buffers {0, 1} and {2, 3} alternate
+        if (staged && more) dma_plane(st, nsrc);                         // lands during the walk
         // Plane 1 of the next row can only be fetched when this row's buffer is free, i.e. behind the barrier that ends
         // the walk; one dword per 128-byte line now (8 KB per wave-instruction) brings it into this XCD's L2 meanwhile.
         uint32_t touched = 0;
         if (warm && more) {
             const uint32_t off = ((uint32_t)wave * 64u + (uint32_t)lane) * 128u;
             if (off < plane_bytes)
-                touched = *reinterpret_cast<const uint32_t*>(dirbase + (size_t)(2 * (row + 1 - a.dir_row0) + 1) * plane_bytes + off);
+                touched = *reinterpret_cast<const uint32_t*>(nsrc + plane_bytes + off);
         }
         BGTH_TICK(0);
         // ---- walk the row: ranks stay in registers
@@ -315,9 +327,10 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
         // three buffers: the next row's plane 1 (and with two buffers its plane 0) can only start now -- ahead of the counts, so
         // that they run while it travels (round 5; before: counts, then the DMA, its latency behind both)
         if (!four && more) {
-            if (staged) { const int nc0 = st; dma_plane(c1, row + 1, 1); st = c0; c0 = nc0; }
-            else { dma_plane(c0, row + 1, 0); dma_plane(c1, row + 1, 1); }
+            if (staged) { const int nc0 = st; dma_plane(c1, nsrc + plane_bytes); st = c0; c0 = nc0; }
+            else { dma_plane(c0, nsrc); dma_plane(c1, nsrc + plane_bytes); }
         }
+        nsrc += 2 * (size_t)plane_bytes;
         BGTH_TICK(4);
         // ---- counts of this row and slice -> HBM
         {

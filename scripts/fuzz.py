@@ -36,7 +36,7 @@ while time.time() < t_end:
     bgt_amd.force_kernels(0)
     # kernel variants with identical results: 1 toggles in place, 2 / 4 never / always the empty-plane kernels, 32 the
     # directory path (producer + walk-only kernels) forced, 4096 the plane-split kernels forced, 128 no arena reuse
-    flag = int(rng.choice([0, 0, 1, 2, 4, 4 | 1, 32, 32, 32 | 128, 4096, 4096, 4096 | 2, 32 | 2]))
+    flag = int(rng.choice([0, 0, 0, 8, 1, 2, 4, 4 | 1, 32, 32, 32 | 8, 32 | 128, 4096, 4096, 4096 | 2, 32 | 2]))
     if flag:
         bgt_amd.force_kernels(int(str(flag)))
     os.environ["BGTH_SUB_SHIFT"] = str(int(rng.integers(1, 12)))
