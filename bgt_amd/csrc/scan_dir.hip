@@ -221,8 +221,14 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
     lds_barrier();
     const unsigned char *nsrc = row_src(blk_beg + 1);                    // plane 0 of the row after the one being walked
 
-    for (int64_t row = blk_beg; row < blk_end; ++row) {
-        const bool more = row + 1 < blk_end;
+    // (rows counted from the sub-block's first, 32 bits, and the rows' zero counts behind a running pointer: the loop's own
+    //  bookkeeping stays on the scalar unit without 64-bit compares in VGPRs)
+    const int nrows = __builtin_amdgcn_readfirstlane((int)(blk_end - blk_beg));
+    const int emit_from = __builtin_amdgcn_readfirstlane(a.row0 > blk_beg ? (int)(a.row0 - blk_beg) : 0);
+    const uint32_t *n0p = n0tab + 2 * (blk_beg - a.dir_row0);
+    for (int ri = 0; ri < nrows; ++ri, n0p += 2) {
+        const int64_t row = blk_beg + ri;
+        const bool more = ri + 1 < nrows;
         if (four && more) { dma_plane(c0 ^ 2, nsrc); dma_plane(c1 ^ 2, nsrc + plane_bytes); }   // buffers {0, 1} and {2, 3} alternate
         if (staged && more) dma_plane(st, nsrc);                         // lands during the walk
         // Plane 1 of the next row can only be fetched when this row's buffer is free, i.e. behind the barrier that ends
@@ -238,11 +244,10 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
         if (!(BGTH_SKIP(a, 0x10000))) {
             const uint32_t base0 = lds0 + (uint32_t)c0 * plane_bytes - 8u;
             const uint32_t base1 = lds0 + (uint32_t)c1 * plane_bytes - 8u;
-            const int64_t pr = 2 * (row - a.dir_row0);
-            const uint32_t n00 = 0u - n0tab[pr];
-            const uint32_t n01 = 0u - n0tab[pr + 1];
-            int32_t *lcb = lcnt + (int)(row & 1) * cnt_stride;
-            const bool emit = row >= a.row0;
+            const uint32_t n00 = 0u - n0p[0];
+            const uint32_t n01 = 0u - n0p[1];
+            int32_t *lcb = lcnt + (ri & 1) * cnt_stride;
+            const bool emit = ri >= emit_from;
             uint32_t ca = 0, cb = 0, cc = 0;
             constexpr int NKEEP = (CPT + 63) / 64;
             uint64_t keep0[NKEEP] = {}, keep1[NKEEP] = {};
@@ -334,8 +339,8 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
         BGTH_TICK(4);
         // ---- counts of this row and slice -> HBM
         {
-            int32_t *lcb = lcnt + (int)(row & 1) * cnt_stride;
-            if (row >= a.row0) {
+            int32_t *lcb = lcnt + (ri & 1) * cnt_stride;
+            if (ri >= emit_from) {
                 if (MULTI) {
                     for (int i = tid; i < G * 3; i += NT) {
                         const int32_t v = lcb[i];
