@@ -122,7 +122,9 @@ hipError_t launch_dirbuild(const ScanArgs &a, int64_t row_lo, int64_t row_hi, hi
 // ----------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-template <int NT, int CPT, bool MULTI, bool GT, bool S4>
+// NB: plane buffers known at compile time (4 or 3; the counts-only one-group kernels, where a row's bookkeeping is a visible share
+// of its time -- as run-time flags the compiler kept them as lane masks and re-tested them through VGPRs every row), 0 = a.dir_stage decides
+template <int NT, int CPT, bool MULTI, bool GT, bool S4, int NB = 0>
 __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32_t *__restrict__ n0tab)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -142,8 +144,8 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
 
     const int m = a.m, nw = a.nw, nwp = a.dir_nwp, G = a.G;
     const uint32_t plane_bytes = (uint32_t)nwp * 8u;                     // multiple of 16
-    const bool four = a.dir_stage & 4;                                   // both planes of the next row land during this row's walk
-    const bool staged = !four && (a.dir_stage & 1), warm = !four && (a.dir_stage & 2);
+    const bool four = NB == 4 || (NB == 0 && (a.dir_stage & 4));         // both planes of the next row land during this row's walk
+    const bool staged = NB == 3 || (NB == 0 && !four && (a.dir_stage & 1)), warm = !four && (a.dir_stage & 2);
     const int nplane = four ? 4 : staged ? 3 : 2;
     int32_t *lcnt = reinterpret_cast<int32_t*>(smem + (size_t)nplane * plane_bytes);   // [2][cnt_stride]: rows alternate
     const int cnt_stride = MULTI ? G * 3 : NWAVE * 2;
@@ -447,10 +449,10 @@ bool choose_walk_geometry(int m, int n_chunks, int G, int n_blk, int want_thread
     return true;
 }
 
-template <int NT, int CPT, bool MULTI, bool GT>
+template <int NT, int CPT, bool MULTI, bool GT, int NB = 0>
 static hipError_t launch_walk_one(const ScanArgs &a, const Geometry &g, hipStream_t s)
 {
-    auto fn = walk_kernel<NT, CPT, MULTI, GT, (NT <= 512)>;           // 1024 threads: 128 VGPRs, lookups in pairs (8 scratch registers)
+    auto fn = walk_kernel<NT, CPT, MULTI, GT, (NT <= 512), NB>;       // 1024 threads: 128 VGPRs, lookups in pairs (8 scratch registers)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(fn, dim3(g.workgroups), dim3(NT), g.lds_bytes, s, a, a.dir_n0);
@@ -463,7 +465,9 @@ hipError_t launch_walk(const ScanArgs &a, const Geometry &g, hipStream_t s)
 #define X(NT_, CPT_)                                                                \
     if (g.threads == NT_ && g.cpt == CPT_) {                                        \
         switch (v) {                                                                \
-        case 0: return launch_walk_one<NT_, CPT_, false, false>(a, g, s);           \
+        case 0: return (a.dir_stage & 4) ? launch_walk_one<NT_, CPT_, false, false, 4>(a, g, s)                      \
+                     : (a.dir_stage & 1) ? launch_walk_one<NT_, CPT_, false, false, 3>(a, g, s)                      \
+                                         : launch_walk_one<NT_, CPT_, false, false>(a, g, s);                        \
         case 1: return launch_walk_one<NT_, CPT_, false, true>(a, g, s);            \
         case 2: return launch_walk_one<NT_, CPT_, true, false>(a, g, s);            \
         default: return launch_walk_one<NT_, CPT_, true, true>(a, g, s);            \
