@@ -290,33 +290,31 @@ __device__ __forceinline__ void step4(uint32_t (&r0)[4], uint32_t (&r1)[4], uint
     }
 }
 
+// (No counts: its only user, the plane-split kernel, takes them from the bit planes -- until round 5 every column still paid an
+// s_bcnt1 + s_add into a sum nobody read.)
 // One plane only, eight scratch registers just below the VGPR budget: the statement of the plane-split kernels at six waves
 // per SIMD (v72..v79, at most 80 VGPRs: three workgroups of 512 threads or two of 768 per CU).  The two-plane statements
 // above name sixteen, v64..v79 (until late in round 4: v104..v119, which pinned every kernel at 120 VGPRs whatever it needed).
 #define BGTH_DEFINE_STEP4_PLANE(NAME, A, A1, AP, B, B1, BP, C, C1, CP, D, D1, DP)                                                      \
-__device__ __forceinline__ void NAME(uint32_t (&r0)[4], uint64_t (&m0)[4], uint32_t &ca, uint32_t base0, uint32_t n00)  \
+__device__ __forceinline__ void NAME(uint32_t (&r0)[4], uint64_t (&m0)[4], uint32_t base0, uint32_t n00)               \
 {                                                                                                                       \
     asm volatile(                                                                                                       \
         "s_waitcnt lgkmcnt(0)\n\t"                                                                                      \
-        BGTH_ADDR(A, "%0", "%9") BGTH_ADDR(B, "%1", "%9")                                                               \
-        BGTH_ADDR(C, "%2", "%9") BGTH_ADDR(D, "%3", "%9")                                                               \
+        BGTH_ADDR(A, "%0", "%8") BGTH_ADDR(B, "%1", "%8")                                                               \
+        BGTH_ADDR(C, "%2", "%8") BGTH_ADDR(D, "%3", "%8")                                                               \
         "ds_read_b64 " AP ", " A "\n\t"                                                                                 \
         "ds_read_b64 " BP ", " B "\n\t"                                                                                 \
         "ds_read_b64 " CP ", " C "\n\t"                                                                                 \
         "ds_read_b64 " DP ", " D "\n\t"                                                                                 \
         "s_waitcnt lgkmcnt(3)\n\t"                                                                                      \
-        BGTH_TAIL("%0", A, A1, A, "%4", "%10")                                                                          \
-        BGTH_COUNT1("%4", "%8")                                                                                         \
+        BGTH_TAIL("%0", A, A1, A, "%4", "%9")                                                                          \
         "s_waitcnt lgkmcnt(2)\n\t"                                                                                      \
-        BGTH_TAIL("%1", B, B1, B, "%5", "%10")                                                                          \
-        BGTH_COUNT1("%5", "%8")                                                                                         \
+        BGTH_TAIL("%1", B, B1, B, "%5", "%9")                                                                          \
         "s_waitcnt lgkmcnt(1)\n\t"                                                                                      \
-        BGTH_TAIL("%2", C, C1, C, "%6", "%10")                                                                          \
-        BGTH_COUNT1("%6", "%8")                                                                                         \
+        BGTH_TAIL("%2", C, C1, C, "%6", "%9")                                                                          \
         "s_waitcnt lgkmcnt(0)\n\t"                                                                                      \
-        BGTH_TAIL("%3", D, D1, D, "%7", "%10")                                                                          \
-        BGTH_COUNT1("%7", "%8")                                                                                         \
-        : "+v"(r0[0]), "+v"(r0[1]), "+v"(r0[2]), "+v"(r0[3]), "=&s"(m0[0]), "=&s"(m0[1]), "=&s"(m0[2]), "=&s"(m0[3]), "+s"(ca) \
+        BGTH_TAIL("%3", D, D1, D, "%7", "%9")                                                                          \
+        : "+v"(r0[0]), "+v"(r0[1]), "+v"(r0[2]), "+v"(r0[3]), "=&s"(m0[0]), "=&s"(m0[1]), "=&s"(m0[2]), "=&s"(m0[3])            \
         : "s"(base0), "s"(n00)                                                                                          \
         : A, A1, B, B1, C, C1, D, D1, "vcc", "scc", "memory");                                                          \
 }

@@ -155,6 +155,7 @@ __global__ __launch_bounds__(NT, LOW == 1 ? 6 : 4) void plane_kernel(const ScanA
     }
     const int emit_from = __builtin_amdgcn_readfirstlane(a.row0 > blk_beg ? (int)(a.row0 - blk_beg) : 0);   // first relative row whose ballots leave
 
+    uint64_t *hnext = hout + ((int64_t)blk_beg - a.h_row0) * a.n_chunks + chunk0;   // this wave's ballots of the row to be walked next
     // (profiling build only: cycles per phase -- 0 walk, 1 toggles, 2 barrier, 3 directory, 4 barrier)
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = BGTH_TIMES(a) ? __builtin_amdgcn_s_memtime() : 0ull;
     // Loop (iteration -1 only prepares row blk_beg):   walk(row) + toggles(row+1) | directory(row+1) |     two barriers per row
@@ -170,13 +171,14 @@ __global__ __launch_bounds__(NT, LOW == 1 ? 6 : 4) void plane_kernel(const ScanA
             // chunks of this wave whose ballots leave in this row, as ONE scalar integer: as a boolean per column the test was kept
             // in 64-bit lane masks, spilled to VGPR lanes and read back with two v_readlane per column and row
             const int n_emit = __builtin_amdgcn_readfirstlane(i >= emit_from ? a.n_chunks - chunk0 : 0);
-            uint32_t ca = 0, cb = 0, cc = 0;
+            [[maybe_unused]] uint32_t ca = 0, cb = 0, cc = 0;
             // The ballots leave straight from their SGPRs: one scalar store per column (s_store_dwordx2, written back by the
             // s_dcache_wb at the end of the kernel) instead of moving them into lanes first (two v_cndmask per column: a
             // quarter of this walk's VALU instructions).
             // A scalar store reads its data registers when it EXECUTES, not when it issues: the ballots of a group stay in
             // their SGPRs (pm) until the next statement's opening s_waitcnt lgkmcnt(0) has retired the stores.
-            uint64_t *hrow = hout + (size_t)(blk_beg + i - a.h_row0) * a.n_chunks + chunk0;
+            uint64_t *hrow = hnext;                                      // (a running pointer: no 64-bit multiply per row on the scalar unit)
+            hnext += a.n_chunks;
             uint64_t pm[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < CPT; j += 4) {
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(NT, LOW == 1 ? 6 : 4) void plane_kernel(const ScanA
                 uint32_t q0[4] = {rk_[j], rk_[j + 1], rk_[j + 2], rk_[j + 3]};
                 uint32_t q1[4] = {0u, 0u, 0u, 0u};                       // (plane-0 branch of the statement: untouched)
                 uint64_t m0[4] = {0, 0, 0, 0}, m1[4] = {0, 0, 0, 0};
-                if constexpr (LOW == 1) step4_plane_low(q0, m0, ca, base, n0);
+                if constexpr (LOW == 1) step4_plane_low(q0, m0, base, n0);
                 else step4<true>(q0, q1, m0, m1, ca, cb, cc, base, 0u, n0, 0u);
                 asm volatile("" :: "s"(pm[0]), "s"(pm[1]), "s"(pm[2]), "s"(pm[3]));
 #pragma unroll
