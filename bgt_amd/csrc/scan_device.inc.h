@@ -1049,7 +1049,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
                 }
                 // team mode (one row per barrier): a wave's priority falls as it gets through its columns, so that the waves of
                 // a SIMD finish the row together instead of one after the other (scan_dir.hip: -8 % for the walk-only kernel)
-                if (TEAM && a.walk_prio) {
+                if (TEAM && BGTH_WALK_PRIO(a)) {
                     if (j == 0) __builtin_amdgcn_s_setprio(3);
                     else if (j == (CPT / 4 / 4) * 4) __builtin_amdgcn_s_setprio(2);
                     else if (j == (CPT / 2 / 4) * 4) __builtin_amdgcn_s_setprio(1);

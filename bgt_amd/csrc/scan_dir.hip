@@ -279,7 +279,7 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
                 // The SIMD arbiter prefers its oldest wave: left alone, the four waves of a SIMD finish a row one after the
                 // other and the early ones idle at the barrier while the last walks nearly alone (at 7.6 instead of 4.0 cycles
                 // per instruction).  A wave's priority falls as it gets through its columns, so the laggards catch up.
-                if (!(a.dir_stage & 8)) {
+                if (BGTH_DIR_PRIO(a)) {
                     if (j == 0) __builtin_amdgcn_s_setprio(3);
                     else if (j == (CPT / 4 / STEP) * STEP) __builtin_amdgcn_s_setprio(2);
                     else if (j == (CPT / 2 / STEP) * STEP) __builtin_amdgcn_s_setprio(1);

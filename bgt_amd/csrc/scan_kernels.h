@@ -70,9 +70,13 @@ struct ScanArgs {
 #ifdef BGTH_ABLATE
 #define BGTH_SKIP(a, bit) ((a).debug_skip & (bit))
 #define BGTH_TIMES(a)     ((a).debug_times != nullptr)
+#define BGTH_WALK_PRIO(a) ((a).walk_prio != 0)
+#define BGTH_DIR_PRIO(a)  (!((a).dir_stage & 8))
 #else
 #define BGTH_SKIP(a, bit) 0
 #define BGTH_TIMES(a)     false
+#define BGTH_WALK_PRIO(a) true          // (only the profiling build can switch the progress-based wave priorities off: a run-time
+#define BGTH_DIR_PRIO(a)  true          //  flag was re-tested through a VGPR several times per row)
 #endif
 
 // columns per thread instantiated for each workgroup size (keep in sync with kGeoms in scan_kernels.hip)

@@ -107,6 +107,8 @@ __global__ __launch_bounds__(NT, LOW == 1 ? 6 : 4) void plane_kernel(const ScanA
         const uint32_t bo = (str0 + 2u * (uint32_t)i) * 8u + vzero();
         return *reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(rowdesc) + bo);
     };
+    const char *sc0 = reinterpret_cast<const char*>(segc + (uint64_t)str0 * (uint64_t)(a.S8 + 1));
+    const uint32_t sc_step = 2u * (uint32_t)(a.S8 + 1) * 4u;
     struct Ahead { uint32_t w, ci, cyl; };
     auto load_ahead = [&](int i, uint64_t d) -> Ahead {                // d = the row's descriptor (already here, wave-uniform)
         Ahead p = {0u, 0u, 0u};
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(NT, LOW == 1 ? 6 : 4) void plane_kernel(const ScanA
         const uint64_t sidx = (uint64_t)str0 + 2u * (uint32_t)i;
         const uint32_t slen = (uint32_t)(d >> kDescLenShift);
         const uint64_t off = d & kDescOffMask;
-        const char *sc = reinterpret_cast<const char*>(segc + sidx * (uint64_t)(a.S8 + 1));   // (uniform)
+        const char *sc = sc0 + (size_t)(uint32_t)i * sc_step;           // (uniform; the row's carries: 2 strings x (S8 + 1) words per row)
         const int t = tw + lane * WPP;                                  // (ntrip <= 40: lane 63 has no trip and carries the row's ones)
         if (t < ntrip || lane == 63) p.cyl = *reinterpret_cast<const uint32_t*>(sc + 4u * (uint32_t)(lane == 63 ? a.S8 : t));
         const uint32_t c0 = (uint32_t)tw * 256u;                         // this wave's first chunk of the string
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(NT, LOW == 1 ? 6 : 4) void plane_kernel(const ScanA
                 // a wave's priority falls as it gets through its columns (2 -> 1 -> 0 at 40 % and 80 %), so that the waves of a
                 // SIMD reach the barrier together instead of one after the other -- below the build's 3 throughout
                 // (thresholds 4/12, 8/16, 4/8 of 20 columns measured: 16.75 / 16.59 / 16.92 ms against 17.36 without)
-                if (a.walk_prio) {
+                if (BGTH_WALK_PRIO(a)) {
                     constexpr int T1 = (2 * CPT / 5 / 4) * 4, T2 = (4 * CPT / 5 / 4) * 4;
                     if (j == 0) __builtin_amdgcn_s_setprio(2);
                     else if (T1 > 0 && j == T1) __builtin_amdgcn_s_setprio(1);
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(NT, LOW == 1 ? 6 : 4) void plane_kernel(const ScanA
         BGTH_TICK(0);
         // The build of the next row is a latency chain of few instructions (decode, LDS atomics, prefix scans, two barriers):
         // it goes ahead of the walk of the CU's other workgroup, which fills the issue slots it leaves.
-        if (a.walk_prio) __builtin_amdgcn_s_setprio(3);
+        if (BGTH_WALK_PRIO(a)) __builtin_amdgcn_s_setprio(3);
         if (more && !(BGTH_SKIP(a, 0x20000))) toggles(i + 1, d_cur, cur);
         d_cur = d_ahead; cur = ahead;
         BGTH_TICK(1);
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(NT, LOW == 1 ? 6 : 4) void plane_kernel(const ScanA
         }
         BGTH_TICK(3);
         if (!(BGTH_SKIP(a, 0x80000))) lds_barrier();
-        if (a.walk_prio) __builtin_amdgcn_s_setprio(0);
+        if (BGTH_WALK_PRIO(a)) __builtin_amdgcn_s_setprio(0);
         BGTH_TICK(4);
     }
     asm volatile("s_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");     // the scalar stores of the ballots reach memory
