@@ -1797,6 +1797,7 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
     // 64 random ones: LDS bank-conflict cycles -40 % at the HRC shape (sub-blocks of 128 rows), -20 % on one C4 shard, -3 % on C2
     // (2048 rows); kernel time -5.2 % / -2.3 % / -0.8 % (profiles/r05_lds).  BGTH_FORCE_COLUMN_ORDER keeps the slots in column order.
     if (r->sel.whole && G == 1 && !d_h0 && !planepath && !variant_flag(kVariantColumnOrder)) {
+        a.whole_counts = 1;                              // ... and only n(code 3) is counted: the planes' ones are the rows' own (BGTH_COUNT3)
         std::lock_guard<std::mutex> guard(p->rowindex_lock);
         if (!p->d_order && !p->order_failed) {
             if (hipMalloc((void**)&p->d_order, (size_t)std::max<int64_t>(p->n_sub, 1) * p->m * 4) != hipSuccess) { (void)hipGetLastError(); p->d_order = nullptr; p->order_failed = true; }

@@ -142,6 +142,13 @@ __device__ __forceinline__ uint32_t rle_len(uint32_t byte)
     "s_and_b64 vcc, " M0 ", " M1 "\n\t"                \
     "s_bcnt1_i32_b64 vcc_lo, vcc\n\t"                  \
     "s_add_u32 " CC ", " CC ", vcc_lo\n\t"
+// Whole cohort, one group, counts only (WC): the ones of a plane over ALL columns are the row's own (m - n0, known from its
+// string), so only the columns with a one in BOTH planes are counted: n(code 1) = ones0 - n(code 3), n(code 2) = ones1 - n(code 3).
+// Three scalar instructions per column instead of seven (round 5: C2 -1.6 %, one C4 shard -1.5 %).
+#define BGTH_COUNT3(M0, M1, CA, CB, CC)                \
+    "s_and_b64 vcc, " M0 ", " M1 "\n\t"                \
+    "s_bcnt1_i32_b64 vcc_lo, vcc\n\t"                  \
+    "s_add_u32 " CC ", " CC ", vcc_lo\n\t"
 
 // When plane 1 of the row is all zero (no missing call, no <M>: most sites of a fully called panel) its ranks do not
 // move (reference pbwt.c:135-138) and its lookups are skipped.  The choice is a SCALAR branch inside the
@@ -151,7 +158,7 @@ __device__ __forceinline__ uint32_t rle_len(uint32_t byte)
     "s_bcnt1_i32_b64 vcc_lo, " M0 "\n\t"               \
     "s_add_u32 " CA ", " CA ", vcc_lo\n\t"
 
-#define BGTH_STEP2_BOTH                                                                  \
+#define BGTH_STEP2_BODY(CNT)                                                             \
         BGTH_ASHR("v64", "%0") BGTH_ASHR("v66", "%1") BGTH_ASHR("v68", "%2") BGTH_ASHR("v70", "%3")  \
         BGTH_MAD("v64", "%11") BGTH_MAD("v66", "%12") BGTH_MAD("v68", "%11") BGTH_MAD("v70", "%12")  \
         "ds_read_b64 v[64:65], v64\n\t"                                               \
@@ -160,10 +167,11 @@ __device__ __forceinline__ uint32_t rle_len(uint32_t byte)
         "ds_read_b64 v[70:71], v70\n\t"                                               \
         "s_waitcnt lgkmcnt(2)\n\t"                                                       \
         BGTH_TAIL2("%0", "v64", "v65", "%4", "%13", "%1", "v66", "v67", "%5", "%14")  \
-        BGTH_COUNT("%4", "%5", "%8", "%9", "%10")                                        \
+        CNT("%4", "%5", "%8", "%9", "%10")                                               \
         "s_waitcnt lgkmcnt(0)\n\t"                                                       \
         BGTH_TAIL2("%2", "v68", "v69", "%6", "%13", "%3", "v70", "v71", "%7", "%14")  \
-        BGTH_COUNT("%6", "%7", "%8", "%9", "%10")
+        CNT("%6", "%7", "%8", "%9", "%10")
+#define BGTH_STEP2_BOTH BGTH_STEP2_BODY(BGTH_COUNT)
 #define BGTH_STEP2_PLANE0                                                                \
         BGTH_ADDR("v64", "%0", "%11") BGTH_ADDR("v68", "%2", "%11")                    \
         "ds_read_b64 v[64:65], v64\n\t"                                               \
@@ -184,7 +192,7 @@ __device__ __forceinline__ uint32_t rle_len(uint32_t byte)
 
 // two columns x two planes: 4 LDS reads in flight.  ZP: with the all-zero-plane-1 shortcut, requested by passing
 // base1 = 0 (never a real operand value: a plane-1 row does not start at LDS address 8)
-template <bool ZP>
+template <bool ZP, bool WC = false>
 __device__ __forceinline__ void step2(uint32_t &ra0, uint32_t &ra1, uint32_t &rb0, uint32_t &rb1,
                                       uint64_t &ma0, uint64_t &ma1, uint64_t &mb0, uint64_t &mb1,
                                       uint32_t &ca, uint32_t &cb, uint32_t &cc,
@@ -201,6 +209,11 @@ __device__ __forceinline__ void step2(uint32_t &ra0, uint32_t &ra1, uint32_t &rb
             BGTH_STEP2_PLANE0
             ".Lbgth_e_%=:\n\t"
             BGTH_STEP2_OPERANDS);
+    } else if constexpr (WC) {
+        asm volatile(
+            "s_waitcnt lgkmcnt(0)\n\t"
+            BGTH_STEP2_BODY(BGTH_COUNT3)
+            BGTH_STEP2_OPERANDS);
     } else {
         asm volatile(
             "s_waitcnt lgkmcnt(0)\n\t"
@@ -209,7 +222,7 @@ __device__ __forceinline__ void step2(uint32_t &ra0, uint32_t &ra1, uint32_t &rb
     }
 }
 
-#define BGTH_STEP4_BOTH                                                                  \
+#define BGTH_STEP4_BODY(CNT)                                                             \
         BGTH_ASHR("v64", "%0") BGTH_ASHR("v66", "%1") BGTH_ASHR("v68", "%2") BGTH_ASHR("v70", "%3")  \
         BGTH_ASHR("v72", "%4") BGTH_ASHR("v74", "%5") BGTH_ASHR("v76", "%6") BGTH_ASHR("v78", "%7")  \
         BGTH_MAD("v64", "%19") BGTH_MAD("v66", "%20") BGTH_MAD("v68", "%19") BGTH_MAD("v70", "%20")  \
@@ -224,16 +237,17 @@ __device__ __forceinline__ void step2(uint32_t &ra0, uint32_t &ra1, uint32_t &rb
         "ds_read_b64 v[78:79], v78\n\t"                                               \
         "s_waitcnt lgkmcnt(6)\n\t"                                                       \
         BGTH_TAIL2("%0", "v64", "v65", "%8", "%21", "%1", "v66", "v67", "%9", "%22")  \
-        BGTH_COUNT("%8", "%9", "%16", "%17", "%18")                                      \
+        CNT("%8", "%9", "%16", "%17", "%18")                                             \
         "s_waitcnt lgkmcnt(4)\n\t"                                                       \
         BGTH_TAIL2("%2", "v68", "v69", "%10", "%21", "%3", "v70", "v71", "%11", "%22") \
-        BGTH_COUNT("%10", "%11", "%16", "%17", "%18")                                    \
+        CNT("%10", "%11", "%16", "%17", "%18")                                           \
         "s_waitcnt lgkmcnt(2)\n\t"                                                       \
         BGTH_TAIL2("%4", "v72", "v73", "%12", "%21", "%5", "v74", "v75", "%13", "%22") \
-        BGTH_COUNT("%12", "%13", "%16", "%17", "%18")                                    \
+        CNT("%12", "%13", "%16", "%17", "%18")                                           \
         "s_waitcnt lgkmcnt(0)\n\t"                                                       \
         BGTH_TAIL2("%6", "v76", "v77", "%14", "%21", "%7", "v78", "v79", "%15", "%22") \
-        BGTH_COUNT("%14", "%15", "%16", "%17", "%18")
+        CNT("%14", "%15", "%16", "%17", "%18")
+#define BGTH_STEP4_BOTH BGTH_STEP4_BODY(BGTH_COUNT)
 #define BGTH_STEP4_PLANE0                                                                \
         BGTH_ADDR("v64", "%0", "%19") BGTH_ADDR("v68", "%2", "%19")                    \
         BGTH_ADDR("v72", "%4", "%19") BGTH_ADDR("v76", "%6", "%19")                    \
@@ -266,7 +280,7 @@ __device__ __forceinline__ void step2(uint32_t &ra0, uint32_t &ra1, uint32_t &rb
           "v76", "v77", "v78", "v79", "vcc", "scc", "memory"
 
 // four columns x two planes: 8 LDS reads in flight
-template <bool ZP>
+template <bool ZP, bool WC = false>
 __device__ __forceinline__ void step4(uint32_t (&r0)[4], uint32_t (&r1)[4], uint64_t (&m0)[4], uint64_t (&m1)[4],
                                       uint32_t &ca, uint32_t &cb, uint32_t &cc,
                                       uint32_t base0, uint32_t base1, uint32_t n00, uint32_t n01)
@@ -281,6 +295,11 @@ __device__ __forceinline__ void step4(uint32_t (&r0)[4], uint32_t (&r1)[4], uint
             ".Lbgth_z_%=:\n\t"
             BGTH_STEP4_PLANE0
             ".Lbgth_e_%=:\n\t"
+            BGTH_STEP4_OPERANDS);
+    } else if constexpr (WC) {
+        asm volatile(
+            "s_waitcnt lgkmcnt(0)\n\t"
+            BGTH_STEP4_BODY(BGTH_COUNT3)
             BGTH_STEP4_OPERANDS);
     } else {
         asm volatile(
@@ -720,7 +739,9 @@ __device__ __forceinline__ void load_start_ranks(const ScanArgs &a, int64_t blk,
 #define BGTH_TICK(slot) do { if (BGTH_TIMES(a)) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
     tsum[slot] += now_ - tlast; tlast = now_; } } while (0)
 
-template <int NT, int CPT, bool MULTI, bool GT, bool TEAM, bool ZP, bool SNAP = false>
+// WC: whole cohort, one group, counts only (ScanArgs::whole_counts; narrow pipelined kernels without the empty-plane shortcut): the
+// per-plane ones come from the rows' strings, only n(code 3) is counted (BGTH_COUNT3).
+template <int NT, int CPT, bool MULTI, bool GT, bool TEAM, bool ZP, bool SNAP = false, bool WC = false>
 __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64_t *__restrict__ rowdesc,
                                                   const uint8_t *__restrict__ rle,
                                                   const uint32_t *__restrict__ chunkinfo,
@@ -732,6 +753,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
     constexpr int NWAVE = NT / 64;
     static_assert(CPT % 2 == 0, "columns per thread are stepped in pairs");
     static_assert(CPT * 64 < 65536, "per-wave counts of a row are kept in 16 bits");
+    static_assert(!WC || (!MULTI && !GT && !TEAM && !ZP), "whole-cohort counting serves the plain narrow kernel");
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1058,11 +1080,11 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
                 if (NC == 4) {
                     uint32_t q0[4] = {r0[j], r0[j + 1], r0[j + 2], r0[j + 3]};
                     uint32_t q1[4] = {r1[j], r1[j + 1], r1[j + 2], r1[j + 3]};
-                    step4<ZP>(q0, q1, m0, m1, ca, cb, cc, base0, base1, n00, n01);
+                    step4<ZP, WC>(q0, q1, m0, m1, ca, cb, cc, base0, base1, n00, n01);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) { r0[j + u] = q0[u]; r1[j + u] = q1[u]; }
                 } else {
-                    step2<ZP>(r0[j], r1[j], r0[j + 1], r1[j + 1], m0[0], m1[0], m0[1], m1[1], ca, cb, cc, base0, base1, n00, n01);
+                    step2<ZP, WC>(r0[j], r1[j], r0[j + 1], r1[j + 1], m0[0], m1[0], m0[1], m1[1], ca, cb, cc, base0, base1, n00, n01);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -1082,8 +1104,15 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
             }
             if (MULTI) BGTH_FLUSH_GROUP(run_g);
 #undef BGTH_FLUSH_GROUP
-            if (!MULTI && lane == 0)
-                reinterpret_cast<uint2*>(lcb)[k * NWAVE + wave] = make_uint2((ca - cc) | (cb - cc) << 16, cc);
+            if (!MULTI && lane == 0) {
+                // WC: slot = {n(code 3) of this wave's columns, the row's ones of plane 0 (wave 0) / plane 1 (wave 1)}: the plane
+                // totals enter once, through slice 0 (n00 / n01 are -zeros: ones = m + n0x)
+                if constexpr (WC)
+                    reinterpret_cast<uint2*>(lcb)[k * NWAVE + wave] =
+                        make_uint2(cc, slice == 0 && wave < 2 ? (uint32_t)m + (wave == 0 ? n00 : n01) : 0u);
+                else
+                    reinterpret_cast<uint2*>(lcb)[k * NWAVE + wave] = make_uint2((ca - cc) | (cb - cc) << 16, cc);
+            }
             if (GT && emit) {
 #pragma unroll
                 for (int q = 0; q < NKEEP; ++q) {
@@ -1115,6 +1144,12 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
                 const int k = i / 3, comp = i - 3 * k;
                 if (rb + k >= a.row0) {
                     int32_t v = 0;
+                    if constexpr (WC) {                                  // n(code 1) = ones(plane 0) - n(code 3), n(code 2) likewise
+                        int32_t c3 = 0;
+#pragma unroll
+                        for (int w = 0; w < NWAVE; ++w) c3 += lcb[(k * NWAVE + w) * 2];
+                        v = comp == 2 ? c3 : lcb[(k * NWAVE + comp) * 2 + 1] - c3;
+                    } else
 #pragma unroll
                     for (int w = 0; w < NWAVE; ++w) {
                         const uint32_t x = (uint32_t)lcb[(k * NWAVE + w) * 2 + (comp >> 1)];

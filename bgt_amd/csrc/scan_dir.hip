@@ -124,7 +124,8 @@ __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" :
 
 // NB: plane buffers known at compile time (4 or 3; the counts-only one-group kernels, where a row's bookkeeping is a visible share
 // of its time -- as run-time flags the compiler kept them as lane masks and re-tested them through VGPRs every row), 0 = a.dir_stage decides
-template <int NT, int CPT, bool MULTI, bool GT, bool S4, int NB = 0>
+// WC: whole cohort, one group, counts only -- n(code 3) alone is counted, the planes' ones come from the rows' zero counts (BGTH_COUNT3)
+template <int NT, int CPT, bool MULTI, bool GT, bool S4, int NB = 0, bool WC = false>
 __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32_t *__restrict__ n0tab)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -288,11 +289,11 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
                 if (NC == 4) {
                     uint32_t q0[4] = {r0[j], r0[j + 1], r0[j + 2], r0[j + 3]};
                     uint32_t q1[4] = {r1[j], r1[j + 1], r1[j + 2], r1[j + 3]};
-                    step4<false>(q0, q1, m0, m1, ca, cb, cc, base0, base1, n00, n01);
+                    step4<false, WC>(q0, q1, m0, m1, ca, cb, cc, base0, base1, n00, n01);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) { r0[j + u] = q0[u]; r1[j + u] = q1[u]; }
                 } else {
-                    step2<false>(r0[j], r1[j], r0[j + 1], r1[j + 1], m0[0], m1[0], m0[1], m1[1], ca, cb, cc, base0, base1, n00, n01);
+                    step2<false, WC>(r0[j], r1[j], r0[j + 1], r1[j + 1], m0[0], m1[0], m0[1], m1[1], ca, cb, cc, base0, base1, n00, n01);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -312,8 +313,12 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
             }
             if (MULTI) BGTH_FLUSH_GROUP(run_g);
 #undef BGTH_FLUSH_GROUP
-            if (!MULTI && lane == 0)
-                reinterpret_cast<uint2*>(lcb)[wave] = make_uint2((ca - cc) | (cb - cc) << 16, cc);
+            if (!MULTI && lane == 0) {
+                if constexpr (WC)                                        // {n(code 3) of this wave, the row's ones of plane 0 / 1 (waves 0 / 1 of slice 0)}
+                    reinterpret_cast<uint2*>(lcb)[wave] = make_uint2(cc, slice == 0 && wave < 2 ? (uint32_t)m + (wave == 0 ? n00 : n01) : 0u);
+                else
+                    reinterpret_cast<uint2*>(lcb)[wave] = make_uint2((ca - cc) | (cb - cc) << 16, cc);
+            }
             if (GT && emit) {
 #pragma unroll
                 for (int q = 0; q < NKEEP; ++q) {
@@ -351,6 +356,12 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
                 } else if (tid < 3) {
                     const int comp = tid;
                     int32_t v = 0;
+                    if constexpr (WC) {
+                        int32_t c3 = 0;
+#pragma unroll
+                        for (int w = 0; w < NWAVE; ++w) c3 += lcb[w * 2];
+                        v = comp == 2 ? c3 : lcb[comp * 2 + 1] - c3;
+                    } else
 #pragma unroll
                     for (int w = 0; w < NWAVE; ++w) {
                         const uint32_t x = (uint32_t)lcb[w * 2 + (comp >> 1)];
@@ -449,10 +460,10 @@ bool choose_walk_geometry(int m, int n_chunks, int G, int n_blk, int want_thread
     return true;
 }
 
-template <int NT, int CPT, bool MULTI, bool GT, int NB = 0>
+template <int NT, int CPT, bool MULTI, bool GT, int NB = 0, bool WC = false>
 static hipError_t launch_walk_one(const ScanArgs &a, const Geometry &g, hipStream_t s)
 {
-    auto fn = walk_kernel<NT, CPT, MULTI, GT, (NT <= 512), NB>;       // 1024 threads: 128 VGPRs, lookups in pairs (8 scratch registers)
+    auto fn = walk_kernel<NT, CPT, MULTI, GT, (NT <= 512), NB, WC>;       // 1024 threads: 128 VGPRs, lookups in pairs (8 scratch registers)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(fn, dim3(g.workgroups), dim3(NT), g.lds_bytes, s, a, a.dir_n0);
@@ -465,7 +476,10 @@ hipError_t launch_walk(const ScanArgs &a, const Geometry &g, hipStream_t s)
 #define X(NT_, CPT_)                                                                \
     if (g.threads == NT_ && g.cpt == CPT_) {                                        \
         switch (v) {                                                                \
-        case 0: return (a.dir_stage & 4) ? launch_walk_one<NT_, CPT_, false, false, 4>(a, g, s)                      \
+        case 0: if (a.whole_counts && (a.dir_stage & 5))                                                             \
+                    return (a.dir_stage & 4) ? launch_walk_one<NT_, CPT_, false, false, 4, true>(a, g, s)             \
+                                             : launch_walk_one<NT_, CPT_, false, false, 3, true>(a, g, s);            \
+                return (a.dir_stage & 4) ? launch_walk_one<NT_, CPT_, false, false, 4>(a, g, s)                      \
                      : (a.dir_stage & 1) ? launch_walk_one<NT_, CPT_, false, false, 3>(a, g, s)                      \
                                          : launch_walk_one<NT_, CPT_, false, false>(a, g, s);                        \
         case 1: return launch_walk_one<NT_, CPT_, false, true>(a, g, s);            \

@@ -44,6 +44,7 @@ struct ScanArgs {
     const uint32_t *segc;
     int32_t  m, nw, shift, n_chunks, G, K, wpp, nbuf, S8;
     int32_t  zp;                 // use the kernels with the all-zero-plane-1 shortcut (the image has such rows)
+    int32_t  whole_counts;       // whole cohort, one group, no bit planes: kernels may count n(code 3) only and take the planes' ones from the strings
     int32_t  walk_prio;          // team kernels: progress-based wave priorities in the walk (the profiling build can switch them off)
     int32_t  tog_off;            // team mode: byte offset in LDS of the separate toggle array [2K][(nw+4)&~3], 0 = toggles in place
     int32_t  blk0, n_blk, n_slices;

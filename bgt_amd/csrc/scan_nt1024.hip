@@ -6,10 +6,10 @@ namespace bgth {
 
 static const int kLdsBytesLocal = 160 * 1024;
 
-template <int NT, int CPT, bool MULTI, bool GT, bool TEAM, bool ZP, bool SNAP = false>
+template <int NT, int CPT, bool MULTI, bool GT, bool TEAM, bool ZP, bool SNAP = false, bool WC = false>
 static hipError_t launch_one(const ScanArgs &a, const Geometry &g, hipStream_t s)
 {
-    auto fn = scan_kernel<NT, CPT, MULTI, GT, TEAM, ZP, SNAP>;
+    auto fn = scan_kernel<NT, CPT, MULTI, GT, TEAM, ZP, SNAP, WC>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes);
     if (e != hipSuccess) return e;
@@ -27,6 +27,8 @@ static hipError_t launch_variant(const ScanArgs &a, const Geometry &g, hipStream
         if (v == 1) return launch_one<NT, CPT, false, false, true, ZP, true>(a, g, s);
         return hipErrorInvalidConfiguration;
     }
+    // whole cohort, one group, counts only, pipelined narrow mode, no empty-plane shortcut: n(code 3) alone is counted (WC)
+    if constexpr (!ZP) if (v == 0 && a.whole_counts) return launch_one<NT, CPT, false, false, false, false, false, true>(a, g, s);
     switch (v) {
     case 0: return launch_one<NT, CPT, false, false, false, ZP>(a, g, s);
     case 1: return launch_one<NT, CPT, false, false, true, ZP>(a, g, s);

@@ -362,8 +362,9 @@ def test_checkpoints_rebuilt_on_device(hip, tmp_path, monkeypatch, seed, m, rows
                                                          (47, 9000, 160, 5, "4", 4)])
 def test_slots_in_rank_order_count_what_slots_in_column_order_count(hip, monkeypatch, seed, m, rows, shift, sub, force):
     """Whole cohort, one group, counts only: the slots of a sub-block are its columns in the order of their plane-0 ranks at its
-    checkpoint (round 5: fewer LDS bank conflicts in the walk's gather -- profiles/r05_lds); BGTH_FORCE_COLUMN_ORDER keeps the
-    column order.  Both against the oracle: narrow, pipelined, team and forced directory-path kernels, the empty-plane-1
+    checkpoint (round 5: fewer LDS bank conflicts in the walk's gather -- profiles/r05_lds), and only n(code 3) is counted per
+    column, the planes' ones being the rows' own (3 instead of 7 scalar instructions per column); BGTH_FORCE_COLUMN_ORDER keeps
+    the general path.  Both against the oracle: narrow, pipelined, team and forced directory-path kernels, the empty-plane-1
     shortcut, sub-checkpoints inside the blocks, scans that start and end inside sub-blocks, a reader that leaves the whole
     cohort for a subset and comes back, and an image whose checkpoints change under the table (bgth_pbf_rebase)."""
     if sub:
