@@ -461,7 +461,7 @@ def counters_child(spec):
 def reference_cli_baseline(n_samples, ns, seed, view_args, tmp, what, all_cores=False):
     """The compiled reference's `bgt view` on a database of the first `ns` sites of the cohort; also this repo's CLI on
     the same command (stdout compared)."""
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bgt_amd", "host")])
+    __import__("bgt_amd").build_host_shell()
     prefix = os.path.join(tmp, "db_%d_%d" % (n_samples, ns))
     if not os.path.exists(prefix + ".pbf"):
         subprocess.check_call([MY_BIN, "synth", prefix, str(n_samples), str(ns), str(seed)])
@@ -506,7 +506,7 @@ def cli_end_to_end(n_samples, sites, seed, tmp):
     runtime, .pbf map + parse + upload + sub-checkpoints, site table, one device scan, filter, VCF text of every passing
     site -- the wall time a user sees (output to /dev/null; the stdout of a shorter database is compared with the
     reference binary in cpu_baseline)."""
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bgt_amd", "host")])
+    __import__("bgt_amd").build_host_shell()
     prefix = os.path.join(tmp, "full_%d_%d" % (n_samples, sites))
     t0 = time.perf_counter()
     subprocess.check_call([MY_BIN, "synth", prefix, str(n_samples), str(sites), str(seed)])
@@ -580,7 +580,7 @@ def hrc_cli_record(tmp, n_samples=32488, sites=142000, seed=7):
     chr11:10-20 Mb) on a synthetic cohort of that width AND length, through both binaries: stdout compared; wall time of one
     cold process each (this repo's includes the HIP start and the image build), of the same command line answered by a resident
     `bgt-server -u` (best of 3), and of the reference process -- beside the seconds the reference's README publishes."""
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bgt_amd", "host")])
+    __import__("bgt_amd").build_host_shell()
     prefix = os.path.join(tmp, "hrc_%d_%d" % (n_samples, sites))
     if not os.path.exists(prefix + ".pbf"):
         subprocess.check_call([MY_BIN, "synth", prefix, str(n_samples), str(sites), str(seed)])
@@ -636,7 +636,7 @@ def c5_record(tmp, n_samples=50000, sites=65536):
     """configs[4] (C5) in its product form on one device: two databases (seeds 5 and 6: the same positions, independent
     alleles), two sample groups across both, `-f 'AC1>0&&AC2==0'` -- this repo's CLI (one device image per database, and
     with BGT_GPUS every database dealt over four shards) and the compiled reference on the same files, stdout compared."""
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bgt_amd", "host")])
+    __import__("bgt_amd").build_host_shell()
     dbs = []
     for tag, seed in (("c5a", 5), ("c5b", 6)):
         prefix = os.path.join(tmp, "%s_%d_%d" % (tag, n_samples, sites))

@@ -17,12 +17,50 @@ def library_path():
     return _LIB_PATH
 
 
-def build_library(force=False):
-    """Compile the gfx950 library in-tree (hipcc cross-compiles without a GPU)."""
+def _digest(paths):
+    """sha1 over the names and bytes of the given source files."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(paths):
+        h.update(os.path.relpath(f, _HERE).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def _built(stamp, digest, outputs):
+    """A build is current when its outputs exist and the stamp written after it names these very sources.  By CONTENT, not by
+    modification time: a snapshot of the tree on another machine (the GPU box) carries this machine's mtimes -- with the clocks
+    a few minutes apart every `make` there found its prerequisites "newer" and recompiled (GPU tests: 80 s in the first test that
+    built, ~10 s in every later one that called make)."""
+    try:
+        return all(os.path.exists(o) for o in outputs) and open(stamp).read().strip() == digest
+    except OSError:
+        return False
+
+
+def _csrc_sources():
+    import glob
     src = os.path.join(_HERE, "csrc")
+    inc = os.path.join(os.path.dirname(_HERE), "include")
+    return (glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.cpp")) + glob.glob(os.path.join(src, "*.h")) +
+            [os.path.join(src, "Makefile")] + glob.glob(os.path.join(inc, "*.h")))
+
+
+def build_library(force=False):
+    """Compile the gfx950 library in-tree (hipcc cross-compiles without a GPU).  Nothing happens when the libraries on disk were
+    built from exactly these sources (lib/.csrc.stamp)."""
+    src = os.path.join(_HERE, "csrc")
+    stamp = os.path.join(_HERE, "lib", ".csrc.stamp")
+    digest = _digest(_csrc_sources())
     if force and os.path.exists(_LIB_PATH):
         os.remove(_LIB_PATH)
+    default_lib = os.path.join(_HERE, "lib", "libbgt_hip.so")
+    if not force and _built(stamp, digest, [default_lib, os.path.join(_HERE, "lib", "libbgt_hip_bench.so")]):
+        return _LIB_PATH
     subprocess.check_call(["make", "-s", "-C", src])
+    with open(stamp, "w") as f:
+        f.write(digest + "\n")
     return _LIB_PATH
 
 
@@ -52,9 +90,22 @@ def bench_lib():
 
 
 def build_host_shell():
-    """Compile the C host shell (bgt_amd/host -> lib/libbgt.so, bin/bgt); needs lib/libbgt_hip.so."""
-    subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "host")])
-    return os.path.join(_HERE, "lib", "libbgt.so")
+    """Compile the C host shell (bgt_amd/host -> lib/libbgt.so, bin/bgt, bin/bgt-server); needs lib/libbgt_hip.so.  Nothing happens
+    when what is on disk was built from exactly these sources and this device library (lib/.host.stamp)."""
+    import glob
+    host = os.path.join(_HERE, "host")
+    inc = os.path.join(os.path.dirname(_HERE), "include")
+    stamp = os.path.join(_HERE, "lib", ".host.stamp")
+    srcs = (glob.glob(os.path.join(host, "*.c")) + glob.glob(os.path.join(host, "*.h")) + [os.path.join(host, "Makefile")] +
+            glob.glob(os.path.join(inc, "*.h")))
+    digest = _digest(srcs) + ":" + _digest(_csrc_sources())          # (libbgt.so links the device library)
+    outs = [os.path.join(_HERE, "lib", "libbgt.so"), os.path.join(_HERE, "bin", "bgt"), os.path.join(_HERE, "bin", "bgt-server")]
+    if _built(stamp, digest, outs):
+        return outs[0]
+    subprocess.check_call(["make", "-s", "-C", host])
+    with open(stamp, "w") as f:
+        f.write(digest + "\n")
+    return outs[0]
 
 
 def _hip_runtime_first():

@@ -101,7 +101,7 @@ def test_fold_arrays_equal_the_compiled_reference(tmp_path):
     import bgt_amd
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     bgt_amd.build_library()
-    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "bgt_amd", "host")])
+    __import__("bgt_amd").build_host_shell()
     exe, lib = str(tmp_path / "api_mine"), os.path.join(root, "bgt_amd", "lib")
     subprocess.check_call(["gcc", "-O1", "-Wall", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "integration", "api_dump.c"),
                            "-o", exe, "-L", lib, "-lbgt", "-Wl,-rpath," + lib])

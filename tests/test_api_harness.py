@@ -19,7 +19,7 @@ BGT = os.path.join(ROOT, "bgt_amd", "bin", "bgt")
 def harness(tmp_path_factory):
     import bgt_amd
     bgt_amd.build_library()
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bgt_amd", "host")])
+    __import__("bgt_amd").build_host_shell()
     require_ref("libbgt_ref.so")
     d = tmp_path_factory.mktemp("api")
     mine, ref = str(d / "api_mine"), str(d / "api_ref")

@@ -25,7 +25,7 @@ def reference_binary_present():
 def c1(tmp_path_factory):
     import bgt_amd
     bgt_amd.build_library()
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bgt_amd", "host")])
+    __import__("bgt_amd").build_host_shell()
     d = tmp_path_factory.mktemp("c1")
     prefix = str(d / "c1")
     subprocess.check_call([BGT, "synth", prefix, "2504", "50000", "1"])
@@ -74,7 +74,7 @@ def test_two_database_group_join_like_config5(tmp_path):
     sample groups, `-f'AC1>0&&AC2==0'`; plus the variants with genotypes and with three groups."""
     import bgt_amd
     bgt_amd.build_library()
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bgt_amd", "host")])
+    __import__("bgt_amd").build_host_shell()
     a, b = str(tmp_path / "dba"), str(tmp_path / "dbb")
     subprocess.check_call([BGT, "synth", a, "5000", "30000", "5"])
     subprocess.check_call([BGT, "synth", b, "4000", "30000", "6"])
@@ -122,7 +122,7 @@ def test_wide_cohort_subset_like_config3(tmp_path):
     a few samples.  The reference decodes 200,000-wide rows on the CPU: ~0.5 ms per site."""
     import bgt_amd
     bgt_amd.build_library()
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bgt_amd", "host")])
+    __import__("bgt_amd").build_host_shell()
     db = str(tmp_path / "c3")
     subprocess.check_call([BGT, "synth", db, "100000", "12000", "3"], timeout=600)
     for args in (["-G", "-C", "-s", "idx%20==0", "-n", "9000"],
@@ -144,7 +144,7 @@ def test_one_shot_walk_of_a_wide_cohort(tmp_path, monkeypatch):
     without the hint, and as with an arena too small for one pass."""
     import bgt_amd
     bgt_amd.build_library()
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bgt_amd", "host")])
+    __import__("bgt_amd").build_host_shell()
     db = str(tmp_path / "w")
     subprocess.check_call([BGT, "synth", db, "100000", "12000", "4"], timeout=600)
     args = ["-G", "-f", "AC>0"]

@@ -21,7 +21,7 @@ MANIFEST = json.load(open(os.path.join(GOLD, "manifest.json")))
 def built():
     import bgt_amd
     bgt_amd.build_library()
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bgt_amd", "host")])
+    __import__("bgt_amd").build_host_shell()
     assert os.path.exists(BGT) and os.path.exists(LIB)
 
 

@@ -17,7 +17,7 @@ BGT = os.path.join(ROOT, "bgt_amd", "bin", "bgt")
 def built():
     import bgt_amd
     bgt_amd.build_library()
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bgt_amd", "host")])
+    __import__("bgt_amd").build_host_shell()
 
 
 def run(cmd):

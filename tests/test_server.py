@@ -73,7 +73,7 @@ DEVICE = [
 def servers(tmp_path_factory):
     import bgt_amd
     bgt_amd.build_library()
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bgt_amd", "host")])
+    __import__("bgt_amd").build_host_shell()
     require_ref("libbgt_ref.so")
     ref = str(tmp_path_factory.mktemp("srv") / "bgt-server-ref")
     refdir = os.path.join(ROOT, "oracle", "_ref")

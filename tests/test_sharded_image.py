@@ -154,7 +154,7 @@ def test_bgt_view_over_shards_like_configs_3_and_4(tmp_path):
     import bgt_amd
     ref = require_ref("bgt")
     bgt_amd.build_library()
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bgt_amd", "host")])
+    __import__("bgt_amd").build_host_shell()
     a, b = str(tmp_path / "dba"), str(tmp_path / "dbb")
     subprocess.check_call([BGT, "synth", a, "3000", "40000", "5"])       # 5 file blocks
     subprocess.check_call([BGT, "synth", b, "2000", "40000", "6"])
