@@ -800,7 +800,10 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
     // leaving for the LDS only where the group changes (255: the statement straddles two groups -- its chunks are counted one
     // by one).  Before: three LDS atomics per chunk and row, 2.6 x the time of the ungrouped scan.
     constexpr int NSTMT = (CPT + 3) / 4;
-    uint32_t stmt_group[MULTI ? NSTMT : 1];
+    // (four group numbers to a word, kept in SGPRs: as a VGPR per statement the table cost the 50-column walk-only kernel 25 registers
+    //  it did not have -- it spilled, and a two-group scan of a C4-width cohort took 2.7 x the ungrouped time)
+    uint32_t stmt_groups[MULTI ? (NSTMT + 3) / 4 : 1] = {};
+    auto stmt_group = [&](int q) -> uint32_t { return (stmt_groups[q >> 2] >> (8 * (q & 3))) & 255u; };
     if constexpr (MULTI) {
         uint32_t last = 0;
 #pragma unroll
@@ -815,7 +818,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
                 }
             }
             if (g == 254u) g = last;                                             // (padding chunks count nothing: any group)
-            stmt_group[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
+            stmt_groups[q >> 2] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(stmt_groups[q >> 2] | g << (8 * (q & 3))));
             if (g != 255u) last = g;
         }
     }
@@ -1047,7 +1050,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
             constexpr int NKEEP = (CPT + 63) / 64;                     // lane l keeps the masks of chunks l, l + 64
             uint64_t keep0[NKEEP] = {}, keep1[NKEEP] = {};
             uint32_t pa = 0, pb = 0, pc = 0;                          // MULTI: ca / cb / cc at the start of the current run
-            uint32_t run_g = MULTI ? (uint32_t)__builtin_amdgcn_readfirstlane((int)stmt_group[0]) : 0u;   // MULTI: the group ca / cb / cc are accumulating for
+            uint32_t run_g = MULTI ? (uint32_t)__builtin_amdgcn_readfirstlane((int)stmt_group(0)) : 0u;   // MULTI: the group ca / cb / cc are accumulating for
             // ... and their way into the row's per-group counts (lane 0 adds; the sums themselves are wave-uniform scalars)
 #define BGTH_FLUSH_GROUP(GRP)                                                                              \
             do {                                                                                           \
@@ -1063,7 +1066,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
             for (int j = 0; j < CPT; j += 4) {
                 uint64_t m0[4] = {0, 0, 0, 0}, m1[4] = {0, 0, 0, 0};
                 const int NC = (CPT - j) >= 4 ? 4 : 2;                // CPT is even: the tail is one pair
-                const uint32_t sg = MULTI ? (uint32_t)__builtin_amdgcn_readfirstlane((int)stmt_group[j >> 2]) : 0u;   // (uniform, and said so)
+                const uint32_t sg = MULTI ? (uint32_t)__builtin_amdgcn_readfirstlane((int)stmt_group(j >> 2)) : 0u;   // (uniform, and said so)
                 if (MULTI && sg != run_g) {
                     BGTH_FLUSH_GROUP(run_g);
                     pa = ca; pb = cb; pc = cc;                            // (the scalar sums only ever grow: a run is a difference)

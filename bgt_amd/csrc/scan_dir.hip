@@ -169,7 +169,10 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
     // leave for the LDS where the group changes; 255 = the statement straddles two groups
     constexpr int STEP_ = S4 ? 4 : 2;
     constexpr int NSTMT = (CPT + STEP_ - 1) / STEP_;
-    uint32_t stmt_group[MULTI ? NSTMT : 1];
+    // (four group numbers to a word, kept in SGPRs: as a VGPR per statement the table cost the 50-column walk-only kernel 25 registers
+    //  it did not have -- it spilled, and a two-group scan of a C4-width cohort took 2.7 x the ungrouped time)
+    uint32_t stmt_groups[MULTI ? (NSTMT + 3) / 4 : 1] = {};
+    auto stmt_group = [&](int q) -> uint32_t { return (stmt_groups[q >> 2] >> (8 * (q & 3))) & 255u; };
     if constexpr (MULTI) {
         uint32_t last = 0;
 #pragma unroll
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
                 }
             }
             if (g == 254u) g = last;
-            stmt_group[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
+            stmt_groups[q >> 2] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(stmt_groups[q >> 2] | g << (8 * (q & 3))));
             if (g != 255u) last = g;
         }
     }
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
             uint64_t keep0[NKEEP] = {}, keep1[NKEEP] = {};
             constexpr int STEP = S4 ? 4 : 2;                              // lookups in flight per statement: 8 or 4
             uint32_t pa = 0, pb = 0, pc = 0;                          // MULTI: ca / cb / cc at the start of the current run
-            uint32_t run_g = MULTI ? (uint32_t)__builtin_amdgcn_readfirstlane((int)stmt_group[0]) : 0u;
+            uint32_t run_g = MULTI ? (uint32_t)__builtin_amdgcn_readfirstlane((int)stmt_group(0)) : 0u;
 #define BGTH_FLUSH_GROUP(GRP)                                                                              \
             do {                                                                                           \
                 const uint32_t a_ = ca - pa, b_ = cb - pb, n3_ = cc - pc, n1_ = a_ - n3_, n2_ = b_ - n3_, g_ = (GRP);                         \
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
             for (int j = 0; j < CPT; j += STEP) {
                 uint64_t m0[4] = {0, 0, 0, 0}, m1[4] = {0, 0, 0, 0};
                 const int NC = (CPT - j) >= STEP ? STEP : 2;              // CPT is even: the tail is one pair
-                const uint32_t sg = MULTI ? (uint32_t)__builtin_amdgcn_readfirstlane((int)stmt_group[j / STEP]) : 0u;   // (uniform, and said so)
+                const uint32_t sg = MULTI ? (uint32_t)__builtin_amdgcn_readfirstlane((int)stmt_group(j / STEP)) : 0u;   // (uniform, and said so)
                 if (MULTI && sg != run_g) {
                     BGTH_FLUSH_GROUP(run_g);
                     pa = ca; pb = cb; pc = cc;                            // (the scalar sums only ever grow: a run is a difference)
