@@ -216,6 +216,38 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
         asm volatile("s_mov_b64 exec, %3\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b64 exec, -1"
                      :: "v"(voff), "s"(src), "s"(m0v), "s"(last_lanes) : "memory");
     };
+    // One piece (the wave's k-th) of a plane-row, for the DMA that is dealt out over the walk's statements: a wave whose DMA
+    // instructions wait for the vector-memory path at the top of the row (49 KB-sized instructions per plane and CU, 16 cycles each)
+    // cannot issue its walk behind them -- in-order issue -- and the SIMDs idle; one piece between two statements is taken at once.
+    auto dma_piece = [&](int buf, const unsigned char *src, int k) {
+        if (BGTH_SKIP(a, 0x100000)) return;
+        const uint32_t m0v = lds_wave + (uint32_t)buf * plane_bytes + (uint32_t)k * (uint32_t)(NWAVE * 1024);
+        const uint64_t lanes = k + 1 == npc ? last_lanes : ~0ull;
+        asm volatile("s_mov_b64 exec, %3\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b64 exec, -1"
+                     :: "v"(voff), "s"(src + (size_t)k * (NWAVE * 1024)), "s"(m0v), "s"(lanes) : "memory");
+    };
+    // Where a wave issues them: its k-th piece ahead of statement k (plane 1's, with four buffers, from statement MAXP on) -- or,
+    // with three buffers of ~50 KB (TURNS: 3-4 pieces per wave), the waves take turns: bit q of `issue_mask` = this wave issues
+    // its next piece ahead of statement q, the turns spread over the first 5/8 of the statements so that the last piece has the
+    // rest of the walk to land.  Sixteen waves at the same statement queue for the one address path all the same (~360 cycles per
+    // piece and wave).  One C4 shard / HRC shape x 142,000 / x 524,288 sites, ms: at the top of the row 156.5 / 5.31 / 19.15,
+    // k-th piece at statement k 156.3 / 5.21 / 18.72, turns 152.2 / 5.33 / 19.08 (the test and the out-of-line branch per statement
+    // cost the 16-statement kernel what the turns give it).
+    constexpr bool TURNS = NB == 3;
+    constexpr int NSTMT_W = (CPT + (S4 ? 4 : 2) - 1) / (S4 ? 4 : 2);
+    constexpr int MAXP = (54 + NWAVE - 1) / NWAVE;                      // pieces per wave and plane: three <= 54 KB planes fit the LDS (checked at launch)
+    static_assert(NSTMT_W >= 2 * MAXP && NSTMT_W <= 32, "a statement per piece");
+    uint32_t issue_mask = 0;
+    {
+        const int total = npc;                                           // (three buffers: plane 0 of the next row only)
+        const int W = total > NSTMT_W * 5 / 8 ? total : NSTMT_W * 5 / 8;
+        for (int i = 0; TURNS && i < total; ++i) {
+            int q = (wave * W / NWAVE + i * W / total) % W;
+            while (issue_mask >> q & 1u) q = (q + 1) % W;
+            issue_mask |= 1u << q;
+        }
+        issue_mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)issue_mask);
+    }
     auto row_src = [&](int64_t row) { return dirbase + (size_t)(2 * (row - a.dir_row0)) * plane_bytes; };   // plane 0 of `row`
 
     // (profiling build only: cycles per phase -- 0 stage DMA issue, 1 walk, 2 wait + barrier, 3 counts, 4 plane-1 DMA issue,
@@ -232,11 +264,19 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
     const int nrows = __builtin_amdgcn_readfirstlane((int)(blk_end - blk_beg));
     const int emit_from = __builtin_amdgcn_readfirstlane(a.row0 > blk_beg ? (int)(a.row0 - blk_beg) : 0);
     const uint32_t *n0p = n0tab + 2 * (blk_beg - a.dir_row0);
+    uint32_t z0 = nrows > 0 ? n0p[0] : 0u, z1 = nrows > 0 ? n0p[1] : 0u;   // the rows' zero counts, fetched a row ahead
     for (int ri = 0; ri < nrows; ++ri, n0p += 2) {
         const int64_t row = blk_beg + ri;
         const bool more = ri + 1 < nrows;
-        if (four && more) { dma_plane(c0 ^ 2, nsrc); dma_plane(c1 ^ 2, nsrc + plane_bytes); }   // buffers {0, 1} and {2, 3} alternate
-        if (staged && more) dma_plane(st, nsrc);                         // lands during the walk
+        const uint32_t n00 = 0u - z0, n01 = 0u - z1;
+        if (more) { z0 = n0p[2]; z1 = n0p[3]; }
+        // the next row's plane 0 (four buffers: and its plane 1; {0, 1} and {2, 3} alternate) lands during the walk: issued
+        // piece by piece between the walk's statements (MAXP pieces per wave and plane at most: the LDS holds <= 52 KB planes)
+        const bool inwalk = (four || staged) && more && !BGTH_SKIP(a, 0x10000);     // (npc <= MAXP: three planes fit the LDS, checked at launch)
+        if ((four || staged) && more && !inwalk) { dma_plane(four ? c0 ^ 2 : st, nsrc); if (four) dma_plane(c1 ^ 2, nsrc + plane_bytes); }
+        const int nb0 = four ? c0 ^ 2 : st, nb1 = c1 ^ 2;
+        const uint32_t turns = inwalk ? issue_mask : 0u;
+        int kk = 0;                                                      // pieces issued so far: plane 0's, then plane 1's
         // Plane 1 of the next row can only be fetched when this row's buffer is free, i.e. behind the barrier that ends
         // the walk; one dword per 128-byte line now (8 KB per wave-instruction) brings it into this XCD's L2 meanwhile.
         uint32_t touched = 0;
@@ -250,8 +290,6 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
         if (!(BGTH_SKIP(a, 0x10000))) {
             const uint32_t base0 = lds0 + (uint32_t)c0 * plane_bytes - 8u;
             const uint32_t base1 = lds0 + (uint32_t)c1 * plane_bytes - 8u;
-            const uint32_t n00 = 0u - n0p[0];
-            const uint32_t n01 = 0u - n0p[1];
             int32_t *lcb = lcnt + (ri & 1) * cnt_stride;
             const bool emit = ri >= emit_from;
             uint32_t ca = 0, cb = 0, cc = 0;
@@ -279,6 +317,16 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
                     BGTH_FLUSH_GROUP(run_g);
                     pa = ca; pb = cb; pc = cc;                            // (the scalar sums only ever grow: a run is a difference)
                     run_g = sg;
+                }
+                {
+                    const int q = j / STEP;
+                    if constexpr (TURNS) {                                // this wave's turn: its next piece of the next row
+                        if (__builtin_expect(turns >> q & 1u, 0)) {       // (out of line: a taken branch per statement costs a row ~4 %)
+                            dma_piece(nb0, nsrc, kk);
+                            ++kk;
+                        }
+                    } else if (q < MAXP) { if (inwalk && q < npc) dma_piece(nb0, nsrc, q); }
+                    else if (q < 2 * MAXP) { if (inwalk && four && q - MAXP < npc) dma_piece(nb1, nsrc + plane_bytes, q - MAXP); }
                 }
                 // The SIMD arbiter prefers its oldest wave: left alone, the four waves of a SIMD finish a row one after the
                 // other and the early ones idle at the barrier while the last walks nearly alone (at 7.6 instead of 4.0 cycles
@@ -467,6 +515,8 @@ template <int NT, int CPT, bool MULTI, bool GT, int NB = 0, bool WC = false>
 static hipError_t launch_walk_one(const ScanArgs &a, const Geometry &g, hipStream_t s)
 {
     auto fn = walk_kernel<NT, CPT, MULTI, GT, (NT <= 512), NB, WC>;       // 1024 threads: 128 VGPRs, lookups in pairs (8 scratch registers)
+    // (the next row's planes are fetched a piece per statement: at most ceil(54 / waves) pieces of 1 KiB per wave and plane)
+    if ((a.dir_stage & 5) && (a.dir_nwp * 8 + 1023) / 1024 > (54 + NT / 64 - 1) / (NT / 64) * (NT / 64)) return hipErrorInvalidConfiguration;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(fn, dim3(g.workgroups), dim3(NT), g.lds_bytes, s, a, a.dir_n0);
