@@ -338,6 +338,23 @@ __device__ __forceinline__ void NAME(uint32_t (&r0)[4], uint64_t (&m0)[4], uint3
         : A, A1, B, B1, C, C1, D, D1, "vcc", "scc", "memory");                                                          \
 }
 BGTH_DEFINE_STEP4_PLANE(step4_plane_low, "v72", "v73", "v[72:73]", "v74", "v75", "v[74:75]", "v76", "v77", "v[76:77]", "v78", "v79", "v[78:79]")
+// (the same on v64..v71, and its tail of two lookups: the walk-only kernel that takes a row's planes one after the other, scan_dir.hip)
+BGTH_DEFINE_STEP4_PLANE(step4_plane_mid, "v64", "v65", "v[64:65]", "v66", "v67", "v[66:67]", "v68", "v69", "v[68:69]", "v70", "v71", "v[70:71]")
+__device__ __forceinline__ void step2_plane_mid(uint32_t &ra, uint32_t &rb, uint64_t &ma, uint64_t &mb, uint32_t base0, uint32_t n00)
+{
+    asm volatile(
+        "s_waitcnt lgkmcnt(0)\n\t"
+        BGTH_ADDR("v64", "%0", "%4") BGTH_ADDR("v66", "%1", "%4")
+        "ds_read_b64 v[64:65], v64\n\t"
+        "ds_read_b64 v[66:67], v66\n\t"
+        "s_waitcnt lgkmcnt(1)\n\t"
+        BGTH_TAIL("%0", "v64", "v65", "v64", "%2", "%5")
+        "s_waitcnt lgkmcnt(0)\n\t"
+        BGTH_TAIL("%1", "v66", "v67", "v66", "%3", "%5")
+        : "+v"(ra), "+v"(rb), "=&s"(ma), "=&s"(mb)
+        : "s"(base0), "s"(n00)
+        : "v64", "v65", "v66", "v67", "vcc", "scc", "memory");
+}
 
 // ----------------------------------------------------------------------------------------------------
 // Phase A for one plane-row, executed by ONE wave: RLE string -> bit-vector + rank directory in LDS.

@@ -235,7 +235,9 @@ enum {
     BGTH_FORCE_SEQUENTIAL_CHECKPOINTS   = 512,   /* bgth_pbf_from_rle derives its checkpoints block after block */
     BGTH_FORCE_RCCL_TO_SELF             = 1024,  /* a sharded scan gathers through RCCL even between shards of ONE device */
     BGTH_FORCE_NO_PLANE_SPLIT           = 2048,  /* never / always one workgroup per bit plane (sparse selections of wide cohorts) */
-    BGTH_FORCE_PLANE_SPLIT              = 4096
+    BGTH_FORCE_PLANE_SPLIT              = 4096,
+    BGTH_FORCE_THREE_PLANE_BUFFERS      = 8192   /* directory path: the walk-only kernels of cohorts too wide for four plane-row buffers in
+                                                  * LDS (m > 160,000: a row's planes walked one after the other) on narrower ones */
 };
 void bgth_force_kernels(unsigned flags);
 
