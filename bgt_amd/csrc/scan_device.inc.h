@@ -63,6 +63,16 @@ __device__ __forceinline__ void lds_barrier()
 }
 
 // s_setprio takes an immediate
+// ... and a priority known only at run time is a branch: as a two-level tree, one or two taken branches (hipcc's switch: up to four
+// branch instructions per call; s_setreg on STATUS.USER_PRIO is ignored -- scripts/setreg_prio_probe.hip)
+__device__ __forceinline__ void set_wave_priority_uniform(uint32_t p)
+{
+    asm volatile("s_bitcmp1_b32 %0, 1\n\ts_cbranch_scc1 2f\n\ts_bitcmp1_b32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_setprio 0\n\ts_branch 9f\n"
+                 "1:\n\ts_setprio 1\n\ts_branch 9f\n"
+                 "2:\n\ts_bitcmp1_b32 %0, 0\n\ts_cbranch_scc1 3f\n\ts_setprio 2\n\ts_branch 9f\n"
+                 "3:\n\ts_setprio 3\n"
+                 "9:" :: "s"(p) : "scc");
+}
 __device__ __forceinline__ void set_wave_priority(int p)
 {
     switch (p) {
@@ -338,23 +348,6 @@ __device__ __forceinline__ void NAME(uint32_t (&r0)[4], uint64_t (&m0)[4], uint3
         : A, A1, B, B1, C, C1, D, D1, "vcc", "scc", "memory");                                                          \
 }
 BGTH_DEFINE_STEP4_PLANE(step4_plane_low, "v72", "v73", "v[72:73]", "v74", "v75", "v[74:75]", "v76", "v77", "v[76:77]", "v78", "v79", "v[78:79]")
-// (the same on v64..v71, and its tail of two lookups: the walk-only kernel that takes a row's planes one after the other, scan_dir.hip)
-BGTH_DEFINE_STEP4_PLANE(step4_plane_mid, "v64", "v65", "v[64:65]", "v66", "v67", "v[66:67]", "v68", "v69", "v[68:69]", "v70", "v71", "v[70:71]")
-__device__ __forceinline__ void step2_plane_mid(uint32_t &ra, uint32_t &rb, uint64_t &ma, uint64_t &mb, uint32_t base0, uint32_t n00)
-{
-    asm volatile(
-        "s_waitcnt lgkmcnt(0)\n\t"
-        BGTH_ADDR("v64", "%0", "%4") BGTH_ADDR("v66", "%1", "%4")
-        "ds_read_b64 v[64:65], v64\n\t"
-        "ds_read_b64 v[66:67], v66\n\t"
-        "s_waitcnt lgkmcnt(1)\n\t"
-        BGTH_TAIL("%0", "v64", "v65", "v64", "%2", "%5")
-        "s_waitcnt lgkmcnt(0)\n\t"
-        BGTH_TAIL("%1", "v66", "v67", "v66", "%3", "%5")
-        : "+v"(ra), "+v"(rb), "=&s"(ma), "=&s"(mb)
-        : "s"(base0), "s"(n00)
-        : "v64", "v65", "v66", "v67", "vcc", "scc", "memory");
-}
 
 // ----------------------------------------------------------------------------------------------------
 // Phase A for one plane-row, executed by ONE wave: RLE string -> bit-vector + rank directory in LDS.
@@ -1037,18 +1030,23 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
         const uint32_t *n0b = n0s + buf * 2 * K;
         int32_t *lcb = lcnt + buf * cnt_stride;
         const uint32_t bufbase = lds0 + (uint32_t)(buf * bd_stride) * 8u;
+        // The rows' zero counts: lane l holds the batch's l-th (one LDS read per batch) and a row takes its two by v_readlane --
+        // read from the LDS row by row they were a round trip (ds_read, s_waitcnt, two v_readfirstlane) at the top of every row,
+        // ~5 % of a 20-column row.
+        const bool n0_in_lanes = 2 * K <= 64;
+        const uint32_t n0_lane = n0_in_lanes ? n0b[lane < 2 * K ? lane : 0] : 0u;
         if (!(BGTH_SKIP(a, 1)))
         for (int k = 0; k < Kc; ++k) {
             // operands of the row step: (LDS byte address of the plane-row) - 8 and -n0 (see BGTH_TAIL)
             const uint32_t base0 = bufbase + (uint32_t)(2 * k) * (uint32_t)nwp * 8u - 8u;
             uint32_t base1 = base0 + (uint32_t)nwp * 8u;
-            const uint32_t n00 = 0u - (uint32_t)__builtin_amdgcn_readfirstlane(n0b[2 * k]);
-            const uint32_t n01 = 0u - (uint32_t)__builtin_amdgcn_readfirstlane(n0b[2 * k + 1]);
+            const uint32_t n00 = 0u - (uint32_t)(n0_in_lanes ? __builtin_amdgcn_readlane((int)n0_lane, 2 * k) : __builtin_amdgcn_readfirstlane(n0b[2 * k]));
+            const uint32_t n01 = 0u - (uint32_t)(n0_in_lanes ? __builtin_amdgcn_readlane((int)n0_lane, 2 * k + 1) : __builtin_amdgcn_readfirstlane(n0b[2 * k + 1]));
             const bool emit = (rb + k) >= a.row0;
             // The SIMD arbiter prefers its oldest wave: left alone, waves 0-3 race through a batch and idle at the
             // barrier while waves 12-15 finish it nearly alone (measured: walk 96 vs 189 ticks).  Rotating the user
             // priority over the rows of a batch gives the four waves of a SIMD equal progress.
-            if (!TEAM && !(BGTH_SKIP(a, 0x2000))) set_wave_priority(((wave >> 2) + k) & 3);   // (team mode: by columns, below; a priority that falls with the rows of the batch instead measured the same)
+            if (!TEAM && !(BGTH_SKIP(a, 0x2000))) set_wave_priority_uniform((uint32_t)((wave >> 2) + k));   // (team mode: by columns, below; a priority that falls with the rows of the batch instead measured the same)
             if (ZP && n01 == 0u - (uint32_t)m) base1 = 0u;   // plane 1 all zero: its lookups are skipped (see step2)
             if (SNAP && a.snap && rb + k > blk_beg && ((rb + k) & (((int64_t)1 << a.snap_shift) - 1)) == 0) {
                 // sub-checkpoint: the ranks before this row (image-open pass only)

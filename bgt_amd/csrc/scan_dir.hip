@@ -234,7 +234,6 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
     // k-th piece at statement k 156.3 / 5.21 / 18.72, turns 152.2 / 5.33 / 19.08 (the test and the out-of-line branch per statement
     // cost the 16-statement kernel what the turns give it).
     constexpr bool TURNS = NB == 3;
-    constexpr bool SPLIT = NB == 3 && WC && !S4 && !MULTI && !GT && NWAVE == 16;
     constexpr int NSTMT_W = (CPT + (S4 ? 4 : 2) - 1) / (S4 ? 4 : 2);
     constexpr int MAXP = (54 + NWAVE - 1) / NWAVE;                      // pieces per wave and plane: three <= 54 KB planes fit the LDS (checked at launch)
     static_assert(NSTMT_W >= 2 * MAXP && NSTMT_W <= 32, "a statement per piece");
@@ -267,113 +266,10 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
     const uint32_t *n0p = n0tab + 2 * (blk_beg - a.dir_row0);
     uint32_t z0 = nrows > 0 ? n0p[0] : 0u, z1 = nrows > 0 ? n0p[1] : 0u;   // the rows' zero counts, fetched a row ahead
 
-    // PLANES IN TURN (three ~50 KB buffers, whole cohort, counts only): a row's plane 0 is walked for all columns, then its plane 1.
-    // With both planes walked together the next row's plane 1 could only be fetched behind the barrier that ends the walk, its
-    // ~1.5 k cycles exposed in every row of ~14.6 k (profiles/r05_walk); now the barrier between the planes frees plane 0's buffer
-    // for it, and each fetch has a whole row to land: X = plane 0 (row i), Y = plane 1 (i), Z <- plane 0 (i+1) during phase A,
-    // X <- plane 1 (i+1) during phase B.  n(code 3) needs plane 0's bit beside plane 1's: it is read off the column's NEW plane-0
-    // rank (the stable partition puts the ones behind the row's n0 zeros: bit = rank >= n0, in complement q < -n0), and only in
-    // statements whose plane-1 ballots are not all empty.
-    if constexpr (SPLIT) {
-        constexpr int NSP = (CPT + 3) / 4;
-        uint32_t phase_turns = 0;
-        {
-            const int total = npc, W = total > NSP * 5 / 8 ? total : NSP * 5 / 8;
-            for (int i = 0; i < total; ++i) {
-                int q = (wave * W / NWAVE + i * W / total) % W;
-                while (phase_turns >> q & 1u) q = (q + 1) % W;
-                phase_turns |= 1u << q;
-            }
-            phase_turns = (uint32_t)__builtin_amdgcn_readfirstlane((int)phase_turns);
-        }
-        // (all but this wave's `keep` youngest fetches have landed; loads return in order)
-        auto wait_vm_keep = [&](int keep) {
-            switch (keep) {
-            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-            }
-        };
-        for (int ri = 0; ri < nrows; ++ri, n0p += 2) {
-            const int64_t row = blk_beg + ri;
-            const bool more = ri + 1 < nrows;
-            const uint32_t n00 = 0u - z0, n01 = 0u - z1;
-            if (more) { z0 = n0p[2]; z1 = n0p[3]; }
-            const uint32_t turns = more ? phase_turns : 0u;
-            // ---- phase A: plane 0
-            {
-                const uint32_t base0 = lds0 + (uint32_t)c0 * plane_bytes - 8u;
-                int kk = 0;
-#pragma unroll
-                for (int j = 0; j < CPT; j += 4) {
-                    const int q = j / 4;
-                    if (__builtin_expect(turns >> q & 1u, 0)) { dma_piece(st, nsrc, kk); ++kk; }
-                    if (j == 0) __builtin_amdgcn_s_setprio(3);
-                    else if (j == (CPT / 4 / 4) * 4) __builtin_amdgcn_s_setprio(2);
-                    else if (j == (CPT / 2 / 4) * 4) __builtin_amdgcn_s_setprio(1);
-                    else if (j == (3 * CPT / 4 / 4) * 4) __builtin_amdgcn_s_setprio(0);
-                    uint64_t mm[4];
-                    if (CPT - j >= 4) {
-                        uint32_t q0[4] = {r0[j], r0[j + 1], r0[j + 2], r0[j + 3]};
-                        step4_plane_mid(q0, mm, base0, n00);
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) r0[j + u] = q0[u];
-                    } else {
-                        step2_plane_mid(r0[j], r0[j + 1], mm[0], mm[1], base0, n00);
-                    }
-                }
-                wait_vm_keep(kk);                                        // this wave's pieces of plane 1 (fetched during the last row) have landed
-                lds_barrier();                                           // ... everybody's; every wave is past plane 0: its buffer is free
-            }
-            // ---- phase B: plane 1, n(code 3)
-            {
-                const uint32_t base1 = lds0 + (uint32_t)c1 * plane_bytes - 8u;
-                uint32_t cc = 0;
-                int kk = 0;
-#pragma unroll
-                for (int j = 0; j < CPT; j += 4) {
-                    const int q = j / 4;
-                    if (__builtin_expect(turns >> q & 1u, 0)) { dma_piece(c0, nsrc + plane_bytes, kk); ++kk; }
-                    if (j == 0) __builtin_amdgcn_s_setprio(3);
-                    else if (j == (CPT / 4 / 4) * 4) __builtin_amdgcn_s_setprio(2);
-                    else if (j == (CPT / 2 / 4) * 4) __builtin_amdgcn_s_setprio(1);
-                    else if (j == (3 * CPT / 4 / 4) * 4) __builtin_amdgcn_s_setprio(0);
-                    uint64_t mm[4] = {0, 0, 0, 0};
-                    if (CPT - j >= 4) {
-                        uint32_t q1[4] = {r1[j], r1[j + 1], r1[j + 2], r1[j + 3]};
-                        step4_plane_mid(q1, mm, base1, n01);
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) r1[j + u] = q1[u];
-                    } else {
-                        step2_plane_mid(r1[j], r1[j + 1], mm[0], mm[1], base1, n01);
-                    }
-                    if (__builtin_expect((mm[0] | mm[1] | mm[2] | mm[3]) != 0, 0)) {
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                            if (j + u < CPT) cc += (uint32_t)__popcll(mm[u] & __ballot((int32_t)r0[j + u] < (int32_t)n00));
-                    }
-                }
-                int32_t *lcb = lcnt + (ri & 1) * cnt_stride;
-                if (lane == 0)
-                    reinterpret_cast<uint2*>(lcb)[wave] = make_uint2(cc, slice == 0 && wave < 2 ? (uint32_t)m + (wave == 0 ? n00 : n01) : 0u);
-                wait_vm_keep(kk);                                        // the next row's plane 0 (fetched during phase A) has landed
-                lds_barrier();                                           // ... and every wave is past plane 1
-                nsrc += 2 * (size_t)plane_bytes;
-                if (ri >= emit_from && tid < 3) {
-                    int32_t c3 = 0;
-#pragma unroll
-                    for (int w = 0; w < NWAVE; ++w) c3 += lcb[w * 2];
-                    const int32_t v = tid == 2 ? c3 : lcb[tid * 2 + 1] - c3;
-                    int32_t *dst = a.raw_counts + (size_t)(row - a.row0) * 3 + tid;
-                    if (a.n_slices == 1) *dst = v;
-                    else if (v) atomicAdd(dst, v);
-                }
-            }
-            { const int nc0 = st; st = c1; c1 = c0; c0 = nc0; }
-        }
-    } else
+    // (Measured and not kept, round 5: a row's planes walked IN TURN at three buffers -- plane 0 for all columns, a barrier that frees
+    //  its buffer for the next row's plane 1, then plane 1, n(code 3) read off the column's new plane-0 rank (bit = rank >= n0) in
+    //  the statements whose plane-1 ballots are not all empty.  Every fetch then has a whole row to land; one C4 shard 150.1 ->
+    //  150.6 ms: the barrier between the planes costs what the exposed fetch did.  profiles/r05_walk has the per-wave times.)
     for (int ri = 0; ri < nrows; ++ri, n0p += 2) {
         const int64_t row = blk_beg + ri;
         const bool more = ri + 1 < nrows;
