@@ -1763,7 +1763,7 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
         if (const char *e = getenv("BGTH_WALK_GEOM")) sscanf(e, "%d,%d", &wt, &wc);   // threads,cols: tuning knob of the walk-only kernel
 #endif
         if (!choose_walk_geometry(p->m, r->sel.n_chunks, G, (int)(blk1 - blk0 + 1), wt, wc, &wgeo)) dirpath = false;
-        else if (variant_flag(kVariantThreeBuffers) && wgeo.dir_stage == 4) wgeo.dir_stage = 1;   // (test hook: the LDS of four holds three)
+        else if (variant_flag(kVariantThreeBuffers) && (wgeo.dir_stage & 4)) wgeo.dir_stage = 1;   // (test hook: the LDS of four holds three)
         // the team kernels also slice the columns of a SHORT scan to fill the chip; the directory path is for selections whose
         // columns do not fit one workgroup (every slice then repeats the build), not for those
         else if (wgeo.slices < 2 && 2 * (int64_t)r->sel.width < p->m && !variant_flag(kVariantDirAlways)) dirpath = false;

@@ -1035,6 +1035,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
         // ~5 % of a 20-column row.
         const bool n0_in_lanes = 2 * K <= 64;
         const uint32_t n0_lane = n0_in_lanes ? n0b[lane < 2 * K ? lane : 0] : 0u;
+        if (!TEAM && NT >= 512) __builtin_amdgcn_s_setprio(3);
         if (!(BGTH_SKIP(a, 1)))
         for (int k = 0; k < Kc; ++k) {
             // operands of the row step: (LDS byte address of the plane-row) - 8 and -n0 (see BGTH_TAIL)
@@ -1046,7 +1047,16 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
             // The SIMD arbiter prefers its oldest wave: left alone, waves 0-3 race through a batch and idle at the
             // barrier while waves 12-15 finish it nearly alone (measured: walk 96 vs 189 ticks).  Rotating the user
             // priority over the rows of a batch gives the four waves of a SIMD equal progress.
-            if (!TEAM && !(BGTH_SKIP(a, 0x2000))) set_wave_priority_uniform((uint32_t)((wave >> 2) + k));   // (team mode: by columns, below; a priority that falls with the rows of the batch instead measured the same)
+            if (!TEAM && !(BGTH_SKIP(a, 0x2000))) {
+                // 512 and 1024 threads (one to three workgroups per CU): a wave's priority falls over the LAST rows of the batch, as in
+                // the walk-only kernel (scan_dir.hip): 3 until three rows before the end, then 2, 1, 0.  C2, ms per 1 M sites: no
+                // priorities 11.74, rotated over the rows (until round 5) 10.37, falling evenly over the batch 10.54 (+0.3 for the
+                // run-time choice in that build), over its last three rows 10.05; 3,500 / 5,000 / 7,000 / 8,500 samples -4.1 / -3.3 /
+                // -2.3 / -4.9 %.  Five workgroups of 256 threads per CU, each at its own point of its batch, keep the rotation:
+                // 2,504 samples 2.65 against 2.74.
+                if constexpr (NT >= 512) { if (k + 3 >= Kc) set_wave_priority_uniform((uint32_t)(Kc - 1 - k)); }
+                else set_wave_priority_uniform((uint32_t)((wave >> 2) + k));
+            }   // (team mode: by columns, below; a priority that falls with the rows of the batch instead measured the same)
             if (ZP && n01 == 0u - (uint32_t)m) base1 = 0u;   // plane 1 all zero: its lookups are skipped (see step2)
             if (SNAP && a.snap && rb + k > blk_beg && ((rb + k) & (((int64_t)1 << a.snap_shift) - 1)) == 0) {
                 // sub-checkpoint: the ranks before this row (image-open pass only)
@@ -1089,11 +1099,12 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
                 }
                 // team mode (one row per barrier): a wave's priority falls as it gets through its columns, so that the waves of
                 // a SIMD finish the row together instead of one after the other (scan_dir.hip: -8 % for the walk-only kernel)
-                if (TEAM && BGTH_WALK_PRIO(a)) {
+                if (TEAM && BGTH_WALK_PRIO(a)) {                         // (the steps close to the end of the row: scan_dir.hip)
+                    constexpr int NS = (CPT + 3) / 4;
                     if (j == 0) __builtin_amdgcn_s_setprio(3);
-                    else if (j == (CPT / 4 / 4) * 4) __builtin_amdgcn_s_setprio(2);
-                    else if (j == (CPT / 2 / 4) * 4) __builtin_amdgcn_s_setprio(1);
-                    else if (j == (3 * CPT / 4 / 4) * 4) __builtin_amdgcn_s_setprio(0);
+                    else if (j / 4 == NS * 5 / 8) __builtin_amdgcn_s_setprio(2);
+                    else if (j / 4 == NS * 13 / 16) __builtin_amdgcn_s_setprio(1);
+                    else if (j / 4 == NS * 15 / 16) __builtin_amdgcn_s_setprio(0);
                 }
                 if (NC == 4) {
                     uint32_t q0[4] = {r0[j], r0[j + 1], r0[j + 2], r0[j + 3]};

@@ -145,9 +145,13 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
 
     const int m = a.m, nw = a.nw, nwp = a.dir_nwp, G = a.G;
     const uint32_t plane_bytes = (uint32_t)nwp * 8u;                     // multiple of 16
-    const bool four = NB == 4 || (NB == 0 && (a.dir_stage & 4));         // both planes of the next row land during this row's walk
+    // NB = 8, 16: ROWS PER BARRIER -- narrow plane-rows (<= 19 KB: m <= 78,000; <= 9 KB: m <= 38,000) leave the LDS room for two
+    // sets of 2 or 4 rows, and the workgroup meets once per 2 or 4 rows instead of once per row (the wait at the barrier -- the SIMD
+    // arbiter's oldest waves are through a row ~15 % ahead of its youngest -- was 13 % of a row at the HRC shape)
+    constexpr int RPB = NB >= 8 ? NB / 4 : 1;
+    const bool four = NB >= 4 || (NB == 0 && (a.dir_stage & 4));         // both planes of the next row land during this row's walk
     const bool staged = NB == 3 || (NB == 0 && !four && (a.dir_stage & 1)), warm = !four && (a.dir_stage & 2);
-    const int nplane = four ? 4 : staged ? 3 : 2;
+    const int nplane = NB >= 8 ? NB : four ? 4 : staged ? 3 : 2;
     int32_t *lcnt = reinterpret_cast<int32_t*>(smem + (size_t)nplane * plane_bytes);   // [2][cnt_stride]: rows alternate
     const int cnt_stride = MULTI ? G * 3 : NWAVE * 2;
     const uint32_t pad_rank = 32u * (uint32_t)nw;
@@ -254,10 +258,11 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
     //  5 its wait + barrier)
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = BGTH_TIMES(a) ? __builtin_amdgcn_s_memtime() : 0ull;
     int c0 = 0, c1 = 1, st = 2;                                          // plane buffers: current row's planes, staging
-    if (blk_beg < blk_end) { dma_plane(c0, row_src(blk_beg)); dma_plane(c1, row_src(blk_beg) + plane_bytes); }
+    for (int r = 0; r < RPB; ++r)                                        // (buffer 2 r + p: plane p of the batch's r-th row)
+        if (blk_beg + r < blk_end) { dma_plane(2 * r, row_src(blk_beg + r)); dma_plane(2 * r + 1, row_src(blk_beg + r) + plane_bytes); }
     wait_vm0();
     lds_barrier();
-    const unsigned char *nsrc = row_src(blk_beg + 1);                    // plane 0 of the row after the one being walked
+    const unsigned char *nsrc = row_src(blk_beg + RPB);                  // plane 0 of the row (batch) after the one being walked
 
     // (rows counted from the sub-block's first, 32 bits, and the rows' zero counts behind a running pointer: the loop's own
     //  bookkeeping stays on the scalar unit without 64-bit compares in VGPRs)
@@ -270,6 +275,81 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
     //  its buffer for the next row's plane 1, then plane 1, n(code 3) read off the column's new plane-0 rank (bit = rank >= n0) in
     //  the statements whose plane-1 ballots are not all empty.  Every fetch then has a whole row to land; one C4 shard 150.1 ->
     //  150.6 ms: the barrier between the planes costs what the exposed fetch did.  profiles/r05_walk has the per-wave times.)
+    if constexpr (RPB > 1) {
+        static_assert(!MULTI && !GT, "counts of one group");
+        constexpr int STEP = S4 ? 4 : 2;
+        int set = 0;                                                     // buffers [set * 2 RPB, (set + 1) * 2 RPB): this batch's rows
+        for (int ri = 0; ri < nrows; ri += RPB, n0p += 2 * RPB) {
+            const int nb = nrows - ri < RPB ? nrows - ri : RPB, nnext = nrows - ri - nb < RPB ? nrows - ri - nb : RPB;
+            uint32_t zz[2 * RPB];
+#pragma unroll
+            for (int r = 0; r < RPB; ++r) { zz[2 * r] = r < nb ? n0p[2 * r] : 0u; zz[2 * r + 1] = r < nb ? n0p[2 * r + 1] : 0u; }
+#pragma unroll
+            for (int r = 0; r < RPB; ++r) {
+                if (r >= nb) break;
+                const uint32_t base0 = lds0 + (uint32_t)(set * 2 * RPB + 2 * r) * plane_bytes - 8u, base1 = base0 + plane_bytes;
+                const uint32_t n00 = 0u - zz[2 * r], n01 = 0u - zz[2 * r + 1];
+                const bool inwalk = r < nnext;                           // the next batch's r-th row lands during this row's walk
+                const int nb0 = (set ^ 1) * 2 * RPB + 2 * r;
+                const unsigned char *src = nsrc + (size_t)(2 * r) * plane_bytes;
+                uint32_t ca = 0, cb = 0, cc = 0;
+#pragma unroll
+                for (int j = 0; j < CPT; j += STEP) {
+                    uint64_t m0[4] = {0, 0, 0, 0}, m1[4] = {0, 0, 0, 0};
+                    const int q = j / STEP;
+                    if (q < MAXP) { if (inwalk && q < npc) dma_piece(nb0, src, q); }
+                    else if (q < 2 * MAXP) { if (inwalk && q - MAXP < npc) dma_piece(nb0 + 1, src + plane_bytes, q - MAXP); }
+                    {   // a wave's priority falls as it gets through the BATCH, the steps close to its end (see the one-row loop below)
+                        constexpr int NS = (CPT + STEP - 1) / STEP, TOT = RPB * NS;
+                        const int g = r * NS + q;
+                        if (g == 0) __builtin_amdgcn_s_setprio(3);
+                        else if (g == TOT * 5 / 8) __builtin_amdgcn_s_setprio(2);
+                        else if (g == TOT * 13 / 16) __builtin_amdgcn_s_setprio(1);
+                        else if (g == TOT * 15 / 16) __builtin_amdgcn_s_setprio(0);
+                    }
+                    if ((CPT - j) >= STEP && STEP == 4) {
+                        uint32_t q0[4] = {r0[j], r0[j + 1], r0[j + 2], r0[j + 3]};
+                        uint32_t q1[4] = {r1[j], r1[j + 1], r1[j + 2], r1[j + 3]};
+                        step4<false, WC>(q0, q1, m0, m1, ca, cb, cc, base0, base1, n00, n01);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { r0[j + u] = q0[u]; r1[j + u] = q1[u]; }
+                    } else {
+                        step2<false, WC>(r0[j], r1[j], r0[j + 1], r1[j + 1], m0[0], m1[0], m0[1], m1[1], ca, cb, cc, base0, base1, n00, n01);
+                    }
+                }
+                if (lane == 0) {
+                    uint2 *slot = reinterpret_cast<uint2*>(lcnt + (set * RPB + r) * cnt_stride) + wave;
+                    if constexpr (WC) *slot = make_uint2(cc, slice == 0 && wave < 2 ? (uint32_t)m + (wave == 0 ? n00 : n01) : 0u);
+                    else *slot = make_uint2((ca - cc) | (cb - cc) << 16, cc);
+                }
+            }
+            wait_vm0();                                                  // this wave's pieces of the next batch have landed
+            lds_barrier();                                               // ... everybody's; every wave is through this batch
+            nsrc += (size_t)(2 * RPB) * plane_bytes;
+            if (tid < 3 * nb) {
+                const int r = tid / 3, comp = tid - 3 * r;
+                if (ri + r >= emit_from) {
+                    const int32_t *lcb = lcnt + (set * RPB + r) * cnt_stride;
+                    int32_t v = 0;
+                    if constexpr (WC) {
+                        int32_t c3 = 0;
+#pragma unroll
+                        for (int w = 0; w < NWAVE; ++w) c3 += lcb[w * 2];
+                        v = comp == 2 ? c3 : lcb[comp * 2 + 1] - c3;
+                    } else
+#pragma unroll
+                    for (int w = 0; w < NWAVE; ++w) {
+                        const uint32_t x = (uint32_t)lcb[w * 2 + (comp >> 1)];
+                        v += (int32_t)(comp == 0 ? x & 0xffffu : comp == 1 ? x >> 16 : x);
+                    }
+                    int32_t *dst = a.raw_counts + (size_t)(blk_beg + ri + r - a.row0) * 3 + comp;
+                    if (a.n_slices == 1) *dst = v;
+                    else if (v) atomicAdd(dst, v);
+                }
+            }
+            set ^= 1;
+        }
+    } else
     for (int ri = 0; ri < nrows; ++ri, n0p += 2) {
         const int64_t row = blk_beg + ri;
         const bool more = ri + 1 < nrows;
@@ -335,12 +415,18 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
                 }
                 // The SIMD arbiter prefers its oldest wave: left alone, the four waves of a SIMD finish a row one after the
                 // other and the early ones idle at the barrier while the last walks nearly alone (at 7.6 instead of 4.0 cycles
-                // per instruction).  A wave's priority falls as it gets through its columns, so the laggards catch up.
+                // per instruction).  A wave's priority falls as it gets through its columns, so the laggards catch up -- in steps
+                // close to the END of the walk: among waves of one priority the oldest still goes first, and only the lead it gains
+                // in the last stretch is waited for at the barrier (per-wave times in profiles/r05_walk: the oldest four were through
+                // a row 15 % ahead of the youngest).  Steps at 1/4, 1/2, 3/4 of the statements (until round 5) / 1/2, 3/4, 7/8 /
+                // 5/8, 13/16, 15/16 / 3/4, 7/8, 31/32: one C4 shard 150.4 / 147.6 / 145.6 / 148.6 ms, HRC shape x 524,288 sites
+                // 18.50 / 18.50 / 18.22 / 18.94.
                 if (BGTH_DIR_PRIO(a)) {
+                    constexpr int NS = (CPT + STEP - 1) / STEP;
                     if (j == 0) __builtin_amdgcn_s_setprio(3);
-                    else if (j == (CPT / 4 / STEP) * STEP) __builtin_amdgcn_s_setprio(2);
-                    else if (j == (CPT / 2 / STEP) * STEP) __builtin_amdgcn_s_setprio(1);
-                    else if (j == (3 * CPT / 4 / STEP) * STEP) __builtin_amdgcn_s_setprio(0);
+                    else if (j / STEP == NS * 5 / 8) __builtin_amdgcn_s_setprio(2);
+                    else if (j / STEP == NS * 13 / 16) __builtin_amdgcn_s_setprio(1);
+                    else if (j / STEP == NS * 15 / 16) __builtin_amdgcn_s_setprio(0);
                 }
                 if (NC == 4) {
                     uint32_t q0[4] = {r0[j], r0[j + 1], r0[j + 2], r0[j + 3]};
@@ -463,7 +549,7 @@ static int walk_lds_need(int nw, int G, int threads, int nplane)
 {
     const int nwp = (nw + 2) & ~1;
     const int cnt = G > 1 ? G * 3 * 4 : (threads / 64) * 8;
-    return nplane * nwp * 8 + 2 * cnt + 64;
+    return nplane * nwp * 8 + 2 * cnt * (nplane >= 8 ? nplane / 4 : 1) + 64;
 }
 
 bool choose_walk_geometry(int m, int n_chunks, int G, int n_blk, int want_threads, int want_cpt, Geometry *g)
@@ -509,8 +595,11 @@ bool choose_walk_geometry(int m, int n_chunks, int G, int n_blk, int want_thread
 #else
     constexpr int four_knob = 1;
 #endif
-    const int nplane = four_knob && walk_lds_need(nw, G, g->threads, 4) <= kLdsBytesDir ? 4 : walk_lds_need(nw, G, g->threads, 3) <= kLdsBytesDir ? 3 : 2;
-    g->dir_stage = nplane == 4 ? 4 : nplane == 3 ? 1 : 0;
+    // ... and sixteen or eight (one group): two sets of 4 or 2 rows, one barrier per set
+    const int nplane = four_knob && G == 1 && walk_lds_need(nw, G, g->threads, 16) <= kLdsBytesDir ? 16
+                     : four_knob && G == 1 && walk_lds_need(nw, G, g->threads, 8) <= kLdsBytesDir ? 8
+                     : four_knob && walk_lds_need(nw, G, g->threads, 4) <= kLdsBytesDir ? 4 : walk_lds_need(nw, G, g->threads, 3) <= kLdsBytesDir ? 3 : 2;
+    g->dir_stage = nplane == 16 ? 4 | 32 : nplane == 8 ? 4 | 16 : nplane == 4 ? 4 : nplane == 3 ? 1 : 0;   // (bits 4 / 5: 2 / 4 rows per barrier)
     g->lds_bytes = (walk_lds_need(nw, G, g->threads, nplane) + 15) & ~15;
     g->workgroups = ((n_blk + 7) / 8) * 8 * g->slices;
     return true;
@@ -535,7 +624,9 @@ hipError_t launch_walk(const ScanArgs &a, const Geometry &g, hipStream_t s)
     if (g.threads == NT_ && g.cpt == CPT_) {                                        \
         switch (v) {                                                                \
         case 0: if (a.whole_counts && (a.dir_stage & 5))                                                             \
-                    return (a.dir_stage & 4) ? launch_walk_one<NT_, CPT_, false, false, 4, true>(a, g, s)             \
+                    return (a.dir_stage & 32) ? launch_walk_one<NT_, CPT_, false, false, 16, true>(a, g, s)           \
+                         : (a.dir_stage & 16) ? launch_walk_one<NT_, CPT_, false, false, 8, true>(a, g, s)            \
+                         : (a.dir_stage & 4) ? launch_walk_one<NT_, CPT_, false, false, 4, true>(a, g, s)             \
                                              : launch_walk_one<NT_, CPT_, false, false, 3, true>(a, g, s);            \
                 return (a.dir_stage & 4) ? launch_walk_one<NT_, CPT_, false, false, 4>(a, g, s)                      \
                      : (a.dir_stage & 1) ? launch_walk_one<NT_, CPT_, false, false, 3>(a, g, s)                      \

@@ -15,7 +15,7 @@ import bgt_amd  # noqa: E402
 SHAPES = {  # name: (samples, sites, seed, every, reps)
     "c2": (10000, 1000000, 2, 0, 8), "c3": (100000, 1000000, 3, 20, 5), "hrc": (32488, 142000, 7, 0, 10),
     "hrcsub": (32488, 142000, 7, 13, 10), "c4": (100000, 153 * 8192, 4, 0, 2), "small": (2504, 1000000, 1, 0, 8),
-    "c3half": (50000, 1000000, 3, 10, 5), "hrc13k": (13000, 1000000, 9, 0, 5), "hrclong": (32488, 524288, 7, 0, 4),
+    "team40k": (20000, 262144, 11, 0, 4), "mid10k": (5000, 1000000, 12, 0, 5), "c3half": (50000, 1000000, 3, 10, 5), "hrc13k": (13000, 1000000, 9, 0, 5), "hrclong": (32488, 524288, 7, 0, 4),
 }
 for name in (sys.argv[1:] or ["c2", "c3", "hrc", "hrcsub"]):
     samples, sites, seed, every, reps = SHAPES[name]

@@ -361,13 +361,15 @@ def test_checkpoints_rebuilt_on_device(hip, tmp_path, monkeypatch, seed, m, rows
                                                          (44, 6400, 130, 6, "3", 32), (45, 1, 12, 2, None, 0), (46, 63, 40, 13, None, 32),
                                                          (47, 9000, 160, 5, "4", 4), (48, 7000, 150, 5, "3", 32 | 8192),
                                                          (49, 130, 60, 3, None, 32 | 8192), (50, 30000, 50, 4, None, 32 | 8192),
-                                                         (51, 200000, 20, 3, None, 0)])
+                                                         (51, 200000, 20, 3, None, 0), (52, 41000, 45, 3, None, 32),
+                                                         (53, 70000, 37, 4, "2", 32)])
 def test_slots_in_rank_order_count_what_slots_in_column_order_count(hip, monkeypatch, seed, m, rows, shift, sub, force):
     """Whole cohort, one group, counts only: the slots of a sub-block are its columns in the order of their plane-0 ranks at its
     checkpoint (round 5: fewer LDS bank conflicts in the walk's gather -- profiles/r05_lds), and only n(code 3) is counted per
     column, the planes' ones being the rows' own (3 instead of 7 scalar instructions per column); BGTH_FORCE_COLUMN_ORDER keeps
     the general path.  Both against the oracle: narrow, pipelined, team and forced directory-path kernels (with four plane-row
-    buffers, and with three -- BGTH_FORCE_THREE_PLANE_BUFFERS, as at m = 200,000: a row's planes walked in turn), the empty-plane-1
+    buffers, with sixteen and eight -- four and two rows per barrier, m <= 38,000 / 78,000 --, and with three -- BGTH_FORCE_THREE_PLANE_BUFFERS,
+    as at m = 200,000), the empty-plane-1
     shortcut, sub-checkpoints inside the blocks, scans that start and end inside sub-blocks, a reader that leaves the whole
     cohort for a subset and comes back, and an image whose checkpoints change under the table (bgth_pbf_rebase)."""
     if sub:
