@@ -1049,12 +1049,12 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
             // priority over the rows of a batch gives the four waves of a SIMD equal progress.
             if (!TEAM && !(BGTH_SKIP(a, 0x2000))) {
                 // 512 and 1024 threads (one to three workgroups per CU): a wave's priority falls over the LAST rows of the batch, as in
-                // the walk-only kernel (scan_dir.hip): 3 until three rows before the end, then 2, 1, 0.  C2, ms per 1 M sites: no
+                // the walk-only kernel (scan_dir.hip): 3 until four rows before the end, then 2, 2, 1, 0.  C2, ms per 1 M sites: no
                 // priorities 11.74, rotated over the rows (until round 5) 10.37, falling evenly over the batch 10.54 (+0.3 for the
-                // run-time choice in that build), over its last three rows 10.05; 3,500 / 5,000 / 7,000 / 8,500 samples -4.1 / -3.3 /
-                // -2.3 / -4.9 %.  Five workgroups of 256 threads per CU, each at its own point of its batch, keep the rotation:
+                // run-time choice in that build), 2, 1, 0 over its last three rows 10.05, 2, 2, 1, 0 over its last four 9.95,
+                // 2, 2, 1, 1, 0 10.01; 3,500 / 5,000 / 7,000 / 8,500 samples -4.1 / -4.2 / -2.3 / -4.9 %.  Five workgroups of 256 threads per CU, each at its own point of its batch, keep the rotation:
                 // 2,504 samples 2.65 against 2.74.
-                if constexpr (NT >= 512) { if (k + 3 >= Kc) set_wave_priority_uniform((uint32_t)(Kc - 1 - k)); }
+                if constexpr (NT >= 512) { if (k + 4 >= Kc) set_wave_priority_uniform((uint32_t)(Kc - 1 - k > 2 ? 2 : Kc - 1 - k)); }
                 else set_wave_priority_uniform((uint32_t)((wave >> 2) + k));
             }   // (team mode: by columns, below; a priority that falls with the rows of the batch instead measured the same)
             if (ZP && n01 == 0u - (uint32_t)m) base1 = 0u;   // plane 1 all zero: its lookups are skipped (see step2)
