@@ -35,8 +35,9 @@ stats = list(csv.DictReader(open(os.path.join(dst, "kernel_stats.csv"))))
 # the bench-size launches: scripts/profile.sh runs 1 warm-up + 3 timed steps = 4 calls (other scan_kernel
 # instances are the one-block passes that derive the synthetic cohort's checkpoints during set-up)
 scan = [r for r in stats if "scan_kernel" in r["Name"] or "walk_kernel" in r["Name"] or "plane_kernel<" in r["Name"]]
-four = [r for r in scan if int(r["Calls"]) == 4]
-main = max(four or scan, key=lambda r: float(r["AverageNs"]))
+# (the trace pass runs TRACE_STEPS + 5 calls, 25 by default; older runs 4: the instantiation called that often, else the most-called)
+want = [r for r in scan if int(r["Calls"]) in (4, int(os.environ.get("TRACE_STEPS", "20")) + 5)]
+main = max(want or scan, key=lambda r: (int(r["Calls"]), float(r["AverageNs"])))
 kname = main["Name"]
 out = {"kernel": kname, "calls": int(main["Calls"]), "avg_ms": float(main["AverageNs"]) / 1e6, "counters": {}}
 # the directory path's producer (rows built once into the HBM arena), when the profiled scans ran it
