@@ -509,6 +509,7 @@ static void set_rows(bgth_pbf_t *p, int64_t n)
 // -- ~10 rows' worth of start-up per workgroup against the idle tail of the last round -- is taken, the default unless a finer
 // one is >= 2 % better: 1 M rows keep 2048 (scripts/subshift_ab.py: 10.9 ms at 2048, 11.2 ms at 256), the HRC-shaped 142,000 x
 // 64,976 takes 128 (8.7 -> 6.5 ms), 50,000 x 5,008 takes 128 (2.3 -> 0.24 ms).  Costs rows * m / 2^(sub_shift-3) bytes.
+static bool want_dir_path(const bgth_pbf_t *p, const Geometry &classic, bool tuned, int width);
 static void fit_sub_shift(bgth_pbf_t *p, int64_t n)
 {
     if (getenv("BGTH_SUB_SHIFT") || p->wide_plane || n <= 0) return;
@@ -519,7 +520,7 @@ static void fit_sub_shift(bgth_pbf_t *p, int64_t n)
     Geometry g, w;                                       //   one workgroup per sub-block and plane, two per CU
     if (choose_geometry(p->m, chunks, 1, 4096, 0, 0, 0, &g)) {
         slices = g.slices;
-        if (g.nbuf == 1 && g.wpp > 1 && choose_walk_geometry(p->m, chunks, 1, 4096, 0, 0, &w)) { slices = w.slices; plane = true; }
+        if (want_dir_path(p, g, false, p->m) && choose_walk_geometry(p->m, chunks, 1, 4096, 0, 0, &w)) { slices = w.slices; plane = true; }
         else slots = 256 * (int64_t)std::max(1, std::min(2048 / g.threads, (160 * 1024) / std::max(1, g.lds_bytes)));
     }
     // the finer checkpoints may not crowd the device: at most a sixteenth of the HBM that is free now (and never below 256 MB,
@@ -527,6 +528,20 @@ static void fit_sub_shift(bgth_pbf_t *p, int64_t n)
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)4 << 30;
     const double cap_bytes = std::max<double>((double)((size_t)256 << 20), (double)free_b / 16.0);
+    if (plane) {
+        // Directory path (walk-only workgroups, one per CU): a workgroup's start-up is a few rows' worth (the start ranks come in
+        // batches of loads), and many short workgroups balance the CUs better than the rounds alone say -- one C4 shard 147.3 / 145.6 /
+        // 142.2 / 140.6 / 140.2 ms at 2048 / 1024 / 512 / 256 / 128 rows, 13,000 samples x 1 M 15.29 ... 14.69, C3's plane-split
+        // kernels on the same image +-1 %.  The finest spacing of >= 128 rows that stays under ~80 rounds of workgroups and the cap.
+        int pick = top;
+        for (int s = top - 1; s >= std::min(top, 7); --s) {
+            const int64_t subs = (n + ((int64_t)1 << s) - 1) >> s, wgs = subs * slices;
+            if ((double)subs * 8.0 * (double)p->m > cap_bytes || (wgs + slots - 1) / slots > 80) break;
+            pick = s;
+        }
+        p->sub_shift = pick;
+        return;
+    }
     double best = 1e30;
     int pick = top;
     for (int s = top; s >= std::min(top, 7); --s) {
@@ -534,7 +549,6 @@ static void fit_sub_shift(bgth_pbf_t *p, int64_t n)
         if (s < top && (double)subs * 8.0 * (double)p->m > cap_bytes) break;
         const double start = 1.0 + 10.0 / (double)((int64_t)1 << s);
         double t = start * (double)((wgs + slots - 1) / slots * slots) / (double)wgs;
-        if (plane) { const int64_t ps = 256 * (int64_t)plane_slots_per_cu(p->m); t += start * (double)((2 * subs + ps - 1) / ps * ps) / (double)(2 * subs); }
         if (t < best * 0.98) { best = t; pick = s; }
     }
     p->sub_shift = pick;
@@ -1663,7 +1677,7 @@ static size_t dir_arena_cap(int device)
 // span several workgroups (every slice of the team kernels rebuilds the row); BGTH_VARIANT 32 / 64 force / forbid it.
 // (round 4: also for ONE column slice when most of the cohort is selected -- m = 34,000: 11.7 ms against the team kernels' 13.2 ms per
 // 524,288 sites; the producer's arena is small there and the walk-only workgroup has no build phases to idle through)
-static bool want_dir_path(const bgth_pbf_t *p, const Geometry &classic, bool tuned, int width = 0)
+static bool want_dir_path(const bgth_pbf_t *p, const Geometry &classic, bool tuned, int width)
 {
     if (variant_flag(kVariantDirNever)) return false;
     if (variant_flag(kVariantDirAlways)) return true;
