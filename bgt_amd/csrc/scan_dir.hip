@@ -76,6 +76,7 @@ __global__ __launch_bounds__(NT) void dirbuild_kernel(const ScanArgs a, const ui
         const uint64_t off = cd0 & kDescOffMask;
         const uint32_t cyl = lane == 63 ? 0u : here.cyl;
         const uint32_t tot1 = (uint32_t)__builtin_amdgcn_readlane((int)here.cyl, 63);
+        if (!BGTH_SKIP(a, 0x200000))                                      // (profiling build: the producer without its toggles, timing only)
         for (int c = tw; (uint32_t)c * 256u < slen; c += WPP) {
             const uint32_t k0 = (uint32_t)c * 256u + 4u * (uint32_t)lane;
             uint32_t w, ci;
