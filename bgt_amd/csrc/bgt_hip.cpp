@@ -520,7 +520,11 @@ static void fit_sub_shift(bgth_pbf_t *p, int64_t n)
     Geometry g, w;                                       //   one workgroup per sub-block and plane, two per CU
     if (choose_geometry(p->m, chunks, 1, 4096, 0, 0, 0, &g)) {
         slices = g.slices;
-        if (want_dir_path(p, g, false, p->m) && choose_walk_geometry(p->m, chunks, 1, 4096, 0, 0, &w)) { slices = w.slices; plane = true; }
+        const int64_t n_was = p->n;
+        p->n = n;                                        // (use_zp compares the rows whose plane 1 is empty with the image's rows)
+        const bool dir = want_dir_path(p, g, false, p->m);
+        p->n = n_was;
+        if (dir && choose_walk_geometry(p->m, chunks, 1, 4096, 0, 0, &w)) { slices = w.slices; plane = true; }
         else slots = 256 * (int64_t)std::max(1, std::min(2048 / g.threads, (160 * 1024) / std::max(1, g.lds_bytes)));
     }
     // the finer checkpoints may not crowd the device: at most a sixteenth of the HBM that is free now (and never below 256 MB,
@@ -1415,6 +1419,7 @@ static bgth_pbf_t *from_rle_impl(int m, int g, int shift, int64_t n_rows, const 
     p->rle_bytes = (int64_t)src;
     p->packed_bytes = (int64_t)off;
     rle = packed.data();
+    if (p->n_empty1) { fit_sub_shift(p, n_rows); set_rows(p, n_rows); }   // (the kernel family, and with it the spacing, depends on the empty plane-1 rows)
     Selection all;
     {
         const size_t pad = 256;

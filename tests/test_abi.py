@@ -106,3 +106,14 @@ def test_product_sources_never_touch_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", ".c")):
                 text = open(os.path.join(base, f)).read()
                 assert "liborc" not in text and "import orc" not in text and "oracle/" not in text, f
+
+
+def test_python_force_flags_are_the_headers():
+    """bgt_amd/hip.py restates the BGTH_FORCE_* values of include/bgt_hip.h (bgth_force_kernels): the same names, the same bits."""
+    import bgt_amd.hip as hip
+    text = open(os.path.join(ROOT, "include", "bgt_hip.h")).read()
+    enum = dict((k, int(v)) for k, v in re.findall(r"BGTH_(FORCE_[A-Z_]+)\s*=\s*(\d+)", text))
+    assert len(enum) >= 12 and len(set(enum.values())) == len(enum)
+    for name, value in enum.items():
+        assert getattr(hip, name) == value, name
+    assert all(v & (v - 1) == 0 for v in enum.values())               # single bits: they are OR-ed
