@@ -1692,6 +1692,9 @@ static bool want_dir_path(const bgth_pbf_t *p, const Geometry &classic, bool tun
     // 1024 x 16 x 2 runs at 2.83 T lookups/s, on the directory path at 3.16; m = 30,000: 3.03 / 3.14)
     // (more than 24,576 columns: the slices are not those a SHORT scan is cut into to fill the chip)
     if (classic.slices >= 2 && width > 24576 && 2 * (int64_t)width >= p->m) return true;
+    // (round 5: one slice of 1024 threads -- four waves per SIMD -- with >= 4 rows per batch keeps the scan kernels: m = 32,768 as
+    // 1024 x 32, K 4 runs at 4.20 T lookups/s, on the directory path at 3.70)
+    if (classic.threads == 1024 && classic.slices == 1 && classic.K >= 4) return false;
     return classic.nbuf == 1 && classic.wpp > 1 && (classic.slices >= 2 || 2 * (int64_t)width >= p->m);
 }
 

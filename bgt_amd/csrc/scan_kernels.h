@@ -83,7 +83,7 @@ struct ScanArgs {
 // columns per thread instantiated for each workgroup size (keep in sync with kGeoms in scan_kernels.hip)
 #define BGTH_CPT_256(X)  X(2) X(4) X(8) X(12) X(16) X(20)
 #define BGTH_CPT_512(X)  X(4) X(8) X(10) X(12) X(16) X(20) X(24) X(32) X(40) X(48)
-#define BGTH_CPT_1024(X) X(4) X(8) X(10) X(12) X(16) X(20) X(24)
+#define BGTH_CPT_1024(X) X(4) X(8) X(10) X(12) X(16) X(20) X(24) X(28) X(32) X(36) X(40)
 // team kernels only (wide cohorts: as many columns per workgroup as the 256 VGPRs of a 512-thread
 // workgroup hold, so that few column slices repeat the per-row bit-vector build)
 #define BGTH_CPT_512_WIDE(X) X(64) X(80) X(98)

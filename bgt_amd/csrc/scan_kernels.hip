@@ -14,7 +14,7 @@ static const int kLdsBytes = 160 * 1024;
 #define BGTH_GEOMS(X) \
     X(256, 2) X(256, 4) X(256, 8) X(256, 12) X(256, 16) X(256, 20) \
     X(512, 4) X(512, 8) X(512, 10) X(512, 12) X(512, 16) X(512, 20) X(512, 24) X(512, 32) X(512, 40) X(512, 48) \
-    X(1024, 4) X(1024, 8) X(1024, 10) X(1024, 12) X(1024, 16) X(1024, 20) X(1024, 24) \
+    X(1024, 4) X(1024, 8) X(1024, 10) X(1024, 12) X(1024, 16) X(1024, 20) X(1024, 24) X(1024, 28) X(1024, 32) X(1024, 36) X(1024, 40) \
     X(512, 64) X(512, 80) X(512, 98)          /* team mode only (scan_wide.hip) */
 
 static bool team_only(int nt, int cpt) { return nt == 512 && cpt > 48; }
@@ -101,6 +101,9 @@ bool choose_geometry(int m, int n_chunks, int G, int n_blk, int want_threads, in
         const int nt = kGeoms[i].nt, cpt = kGeoms[i].cpt;
         if (want_threads && nt != want_threads) continue;
         if (want_cpt && cpt != want_cpt) continue;
+        // 1024 x 28 ... 40 (round 5): for selections ONE such workgroup holds, 24,577-40,960 columns (m = 28,000: 4.16 T lookups/s
+        // against 3.31 on the directory path, 36,000: 4.03 / 3.54); wider selections keep the choices they were measured with
+        if (nt == 1024 && cpt > 24 && !want_cpt && n_chunks > (nt / 64) * cpt) continue;
         // rows per batch: as many as fit the LDS, at most one per wave (a wave builds <= 2 plane-rows)
         int K = want_K > 0 ? want_K : nt / 64;
         if (K > nt / 64) K = nt / 64;

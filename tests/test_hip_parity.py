@@ -165,7 +165,8 @@ def test_sample_groups(hip, seed, m, rows, shift, G):
                                            (512, 16, 5), (512, 20, 8), (1024, 4, 16), (1024, 8, 2), (1024, 10, 9),
                                            (1024, 12, 3), (1024, 16, 7), (1024, 20, 5), (1024, 24, 1), (512, 24, 1),
                                            (512, 32, 2), (512, 40, 4), (512, 48, 1), (256, 2, 2), (1024, 8, 4),
-                                           (512, 64, 1), (512, 80, 1), (512, 98, 1)])
+                                           (512, 64, 1), (512, 80, 1), (512, 98, 1), (1024, 28, 6), (1024, 32, 5),
+                                           (1024, 36, 4), (1024, 40, 2)])
 def test_every_launch_geometry(hip, threads, cpt, K):
     """Force each kernel instantiation (and multi-slice launches) on one cohort."""
     mat, data, rng = make_case(41, 5008, 130, 5, n_founders=7, switch=0.04)
@@ -362,7 +363,8 @@ def test_checkpoints_rebuilt_on_device(hip, tmp_path, monkeypatch, seed, m, rows
                                                          (47, 9000, 160, 5, "4", 4), (48, 7000, 150, 5, "3", 32 | 8192),
                                                          (49, 130, 60, 3, None, 32 | 8192), (50, 30000, 50, 4, None, 32 | 8192),
                                                          (51, 200000, 20, 3, None, 0), (52, 41000, 45, 3, None, 32),
-                                                         (53, 70000, 37, 4, "2", 32)])
+                                                         (53, 70000, 37, 4, "2", 32), (54, 27000, 50, 4, None, 0),
+                                                         (55, 32768, 40, 3, None, 0), (56, 39000, 34, 3, None, 0)])
 def test_slots_in_rank_order_count_what_slots_in_column_order_count(hip, monkeypatch, seed, m, rows, shift, sub, force):
     """Whole cohort, one group, counts only: the slots of a sub-block are its columns in the order of their plane-0 ranks at its
     checkpoint (round 5: fewer LDS bank conflicts in the walk's gather -- profiles/r05_lds), and only n(code 3) is counted per
