@@ -34,7 +34,7 @@ for n in widths:
     g, p = rd.geometry(), rd.path()
     look = 2.0 * m * sites / (best * 1e-3) / 1e9
     kind = "directory path (producer + walk-only)" if p["directory_path"] else "plane-split" if p["plane_split"] else \
-        ("pipelined narrow" if g["rows_per_batch"] >= g["threads"] // 128 and g["slices"] == 1 and m <= 50000 else "team")
+        ("pipelined" if 4 * g["rows_per_batch"] > g["threads"] // 64 and g["slices"] == 1 and m <= 50000 else "team")   # (a wave builds its plane-rows alone / teams of waves per plane-row)
     rows.append({"samples": n, "haplotypes": m, "sites": sites, "ms": best, "sites_per_s": sites / best * 1e3, "g_lookups_per_s": look,
                  "frac_of_ideal_mix": look / peak["ideal_mix_g_lookups_per_s"], "frac_of_own_statement": look / peak["g_lookups_per_s"],
                  "launch": "%d thr x %d col x %d slices, K %d" % (g["threads"], g["cols_per_thread"], g["slices"], g["rows_per_batch"]), "kernels": kind})
