@@ -1,5 +1,5 @@
 // Host side of the gfx950 kernels: launch geometry (cost model) and the small companion kernels.
-// The scan kernel itself lives in scan_device.inc.h and is instantiated in scan_nt{256,512,1024}.hip.
+// The scan kernel itself lives in scan_device.inc.h and is instantiated by scan_nt.hip, once per launch geometry.
 #include "scan_kernels.h"
 #include <stdlib.h>
 
@@ -156,17 +156,30 @@ bool choose_geometry(int m, int n_chunks, int G, int n_blk, int want_threads, in
     return true;
 }
 
-hipError_t launch_scan_nt256(const ScanArgs &a, const Geometry &g, hipStream_t s);
-hipError_t launch_scan_nt512(const ScanArgs &a, const Geometry &g, hipStream_t s);
-hipError_t launch_scan_nt1024(const ScanArgs &a, const Geometry &g, hipStream_t s);
+// one translation unit (scan_nt.hip) per geometry
+#define X(C_) hipError_t launch_scan_nt256_c##C_(const ScanArgs &a, const Geometry &g, hipStream_t s);
+BGTH_CPT_256(X)
+#undef X
+#define X(C_) hipError_t launch_scan_nt512_c##C_(const ScanArgs &a, const Geometry &g, hipStream_t s);
+BGTH_CPT_512(X)
+#undef X
+#define X(C_) hipError_t launch_scan_nt1024_c##C_(const ScanArgs &a, const Geometry &g, hipStream_t s);
+BGTH_CPT_1024(X)
+#undef X
 hipError_t launch_scan_wide(const ScanArgs &a, const Geometry &g, hipStream_t s);
 
 hipError_t launch_scan(const ScanArgs &a, const Geometry &g, hipStream_t s)
 {
-    if (g.threads == 256) return launch_scan_nt256(a, g, s);
     if (team_only(g.threads, g.cpt)) return launch_scan_wide(a, g, s);
-    if (g.threads == 512) return launch_scan_nt512(a, g, s);
-    if (g.threads == 1024) return launch_scan_nt1024(a, g, s);
+#define X(C_) if (g.threads == 256 && g.cpt == C_) return launch_scan_nt256_c##C_(a, g, s);
+    BGTH_CPT_256(X)
+#undef X
+#define X(C_) if (g.threads == 512 && g.cpt == C_) return launch_scan_nt512_c##C_(a, g, s);
+    BGTH_CPT_512(X)
+#undef X
+#define X(C_) if (g.threads == 1024 && g.cpt == C_) return launch_scan_nt1024_c##C_(a, g, s);
+    BGTH_CPT_1024(X)
+#undef X
     return hipErrorInvalidConfiguration;
 }
 

@@ -1,5 +1,7 @@
-// Instantiations of the scan kernel for workgroups of 256 threads (one translation unit per workgroup
-// size so that `make -j` compiles them in parallel).
+// Instantiations of the scan kernel for ONE launch geometry: compiled once per (threads, columns per thread) of BGTH_CPT_256 / _512 /
+// _1024 with -DBGTH_NT=<threads> -DBGTH_CPT=<columns> (Makefile) -- `make -j` compiles them side by side, and a process loads the
+// code object of the geometry it launches (HIP loads a translation unit's kernels at the first launch of one of them: as one
+// unit per workgroup size the 1024-thread kernels were 7.4 MB, ~11 ms per MB to load).
 #include "scan_device.inc.h"
 
 namespace bgth {
@@ -41,12 +43,14 @@ static hipError_t launch_variant(const ScanArgs &a, const Geometry &g, hipStream
     }
 }
 
-hipError_t launch_scan_nt256(const ScanArgs &a, const Geometry &g, hipStream_t s)
+#ifndef BGTH_NT
+#error "compile with -DBGTH_NT=<threads> -DBGTH_CPT=<columns per thread>"
+#endif
+#define BGTH_CAT4(a, b, c, d) a##b##c##d
+#define BGTH_LAUNCH_NAME(nt, cpt) BGTH_CAT4(launch_scan_nt, nt, _c, cpt)
+hipError_t BGTH_LAUNCH_NAME(BGTH_NT, BGTH_CPT)(const ScanArgs &a, const Geometry &g, hipStream_t s)
 {
-#define X(CPT_) if (g.cpt == CPT_) return a.zp ? launch_variant<256, CPT_, true>(a, g, s) : launch_variant<256, CPT_, false>(a, g, s);
-    BGTH_CPT_256(X)
-#undef X
-    return hipErrorInvalidConfiguration;
+    return a.zp ? launch_variant<BGTH_NT, BGTH_CPT, true>(a, g, s) : launch_variant<BGTH_NT, BGTH_CPT, false>(a, g, s);
 }
 
 }  // namespace bgth
