@@ -19,6 +19,7 @@
 namespace bgth {
 
 static const int kLdsBytesDir = 160 * 1024;
+static const int kSoloWords = 3200;                  // plane-rows of up to 102,400 positions are built by one wave each (dirbuild_solo_kernel)
 
 // ----------------------------------------------------------------------------------------------------
 // producer
@@ -99,16 +100,97 @@ __global__ __launch_bounds__(NT) void dirbuild_kernel(const ScanArgs a, const ui
     }
 }
 
+// ... and for narrow plane-rows (a string of one or two 256-byte chunks, a handful of directory trips) every WAVE builds plane-rows of
+// its own: no barrier, four plane-rows in flight per workgroup instead of one whose toggles three of the four waves wait for.
+// HRC shape x 142,000 sites: producer 1.30 -> 1.22 ms (3.5 -> 3.8 TB/s of stores), the scan 5.10 -> 4.97; x 524,288: 18.25 -> 18.12.
+template <int NT>
+__global__ __launch_bounds__(NT) void dirbuild_solo_kernel(const ScanArgs a, const uint64_t *__restrict__ rowdesc,
+                                                           const uint8_t *__restrict__ rle, const uint32_t *__restrict__ chunkinfo,
+                                                           const uint32_t *__restrict__ segc, int64_t str_lo, int64_t str_hi, int per_wg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int WPP = NT / 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int tw = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = a.m, nw = a.nw, nwp = a.dir_nwp;
+    const int nwt = (nw + 4) & ~3;
+    uint32_t *trow = reinterpret_cast<uint32_t*>(smem) + (size_t)tw * nwt;   // this wave's toggle words
+    for (int i = lane; i < nwt; i += 64) trow[i] = 0u;
+    const uint32_t tail_mask = (m & 31) ? ((1u << (m & 31)) - 1u) : 0xffffffffu;
+    const int ntrip = (nw + 255) >> 8;                                   // (<= 63: checked at launch)
+    const int64_t s0 = str_lo + (int64_t)blockIdx.x * per_wg;
+    int64_t s1 = s0 + per_wg;
+    if (s1 > str_hi) s1 = str_hi;
+    struct Ahead { uint32_t w, ci, cyl; };
+    auto load_ahead = [&](int64_t sidx, uint64_t d) -> Ahead {
+        Ahead p = {0u, 0u, 0u};
+        if (sidx >= s1) return p;
+        const uint32_t slen = (uint32_t)(d >> kDescLenShift);
+        const uint64_t off = d & kDescOffMask;
+        const uint32_t *sc = segc + (size_t)sidx * (size_t)(a.S8 + 1);
+        if (lane < ntrip || lane == 63) p.cyl = sc[lane == 63 ? a.S8 : lane];
+        if (4u * (uint32_t)lane < slen) p.w = reinterpret_cast<const uint32_t*>(rle + off)[lane];
+        if (slen) p.ci = chunkinfo[(off >> 8) + (uint64_t)sidx];
+        return p;
+    };
+    int64_t sidx = s0 + tw;
+    uint64_t desc = sidx < s1 ? rowdesc[sidx] : 0ull;
+    uint64_t desc1 = sidx + WPP < s1 ? rowdesc[sidx + WPP] : 0ull;
+    Ahead cur = load_ahead(sidx, desc);
+    for (; sidx < s1; sidx += WPP) {
+        const uint64_t cd0 = desc;
+        const Ahead here = cur;
+        desc = desc1;
+        cur = load_ahead(sidx + WPP, desc);
+        desc1 = sidx + 2 * WPP < s1 ? rowdesc[sidx + 2 * WPP] : 0ull;
+        const uint32_t slen = (uint32_t)(cd0 >> kDescLenShift);
+        const uint64_t off = cd0 & kDescOffMask;
+        const uint32_t cyl = lane == 63 ? 0u : here.cyl;
+        const uint32_t tot1 = (uint32_t)__builtin_amdgcn_readlane((int)here.cyl, 63);
+        for (int c = 0; (uint32_t)c * 256u < slen; ++c) {
+            const uint32_t k0 = (uint32_t)c * 256u + 4u * (uint32_t)lane;
+            uint32_t w, ci;
+            if (c == 0) { w = here.w; ci = here.ci; }
+            else {
+                w = k0 < slen ? reinterpret_cast<const uint32_t*>(rle + off)[c * 64 + lane] : 0u;
+                ci = chunkinfo[((off + (uint64_t)c * 256u) >> 8) + (uint64_t)sidx];
+            }
+            if (ci & kChunkDead) break;
+            const ChunkDecode cd = decode_chunk(w, k0, slen, lane);
+            chunk_toggles(a, trow, 1, cd, ci & kChunkPosMask, ci >> 31, lane);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the wave's own toggles (LDS atomics) have landed
+        uint2 *dst = a.dir + (size_t)(sidx - 2 * a.dir_row0) * (size_t)nwp;
+        directory_trips_tog<2>(trow, dst, 0, 1, ntrip, nw, tail_mask, cyl, lane);
+        if (lane == 0) {
+            for (int i = nw; i < nwp; ++i) dst[i] = make_uint2(0u, 0u);
+            a.dir_n0[sidx - 2 * a.dir_row0] = (uint32_t)m - tot1;
+        }
+    }
+}
+
 hipError_t launch_dirbuild(const ScanArgs &a, int64_t row_lo, int64_t row_hi, hipStream_t s)
 {
     if (row_hi <= row_lo) return hipSuccess;
     const int nwt = (a.nw + 4) & ~3;
     const int lds = 2 * nwt * 4;
     if (lds > kLdsBytesDir) return hipErrorInvalidConfiguration;
+    const int64_t n_str = 2 * (row_hi - row_lo);
+    if (a.nw <= kSoloWords) {                                            // narrow plane-rows: a wave per plane-row
+        auto fs = dirbuild_solo_kernel<256>;
+        const int lds_solo = 4 * nwt * 4;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fs), hipFuncAttributeMaxDynamicSharedMemorySize, lds_solo);
+        if (e != hipSuccess) return e;
+        int per_wg = 32;
+        while (per_wg > 4 && (n_str + per_wg - 1) / per_wg < 3072) per_wg >>= 1;
+        const int64_t grid = (n_str + per_wg - 1) / per_wg;
+        hipLaunchKernelGGL(fs, dim3((unsigned)grid), dim3(256), lds_solo, s, a, a.rowdesc, a.rle, a.chunkinfo, a.segc,
+                           2 * row_lo, 2 * row_hi, per_wg);
+        return hipGetLastError();
+    }
     auto fn = dirbuild_kernel<256>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    const int64_t n_str = 2 * (row_hi - row_lo);
     // plane-rows per workgroup: enough to amortise the start of a workgroup, few enough to spread short ranges over the chip
     int per_wg = 16;
     while (per_wg > 2 && (n_str + per_wg - 1) / per_wg < 3072) per_wg >>= 1;
