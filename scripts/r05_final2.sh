@@ -8,5 +8,5 @@ bash scripts/profile.sh r05_hrc --workload hrc --sites 142000 > /dev/null 2>&1
 bash scripts/profile.sh r05_hrcsub --workload hrc --sites 142000 --every 13 > /dev/null 2>&1
 bash scripts/profile.sh r05_c4shard --workload c4 --sites 1253376 > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT
-python scripts/width_sweep.py 1000,2504,5000,10000,12000,13000,17000,25000,32488,35000,50000,70000,100000 > gpurun_out/width_sweep.log 2>&1; tail -16 gpurun_out/width_sweep.log
+python scripts/width_sweep.py 1000,2504,5000,10000,12000,13000,15000,17000,20000,25000,32488,35000,50000,70000,100000 > gpurun_out/width_sweep.log 2>&1; tail -16 gpurun_out/width_sweep.log
 python scripts/groups_ab.py 2>/dev/null | tail -6
