@@ -41,7 +41,7 @@ main = max(want or scan, key=lambda r: (int(r["Calls"]), float(r["AverageNs"])))
 kname = main["Name"]
 out = {"kernel": kname, "calls": int(main["Calls"]), "avg_ms": float(main["AverageNs"]) / 1e6, "counters": {}}
 # the directory path's producer (rows built once into the HBM arena), when the profiled scans ran it
-prod = [r for r in stats if "dirbuild_kernel" in r["Name"]]
+prod = [r for r in stats if "dirbuild_" in r["Name"] and int(r["Calls"]) == int(main["Calls"])] or [r for r in stats if "dirbuild_" in r["Name"]]
 pname = prod[0]["Name"] if prod else None
 if prod:
     out["producer"] = {"kernel": pname, "calls": int(prod[0]["Calls"]), "avg_ms": float(prod[0]["AverageNs"]) / 1e6, "counters": {}}
