@@ -182,6 +182,9 @@ hipError_t launch_dirbuild(const ScanArgs &a, int64_t row_lo, int64_t row_hi, hi
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fs), hipFuncAttributeMaxDynamicSharedMemorySize, lds_solo);
         if (e != hipSuccess) return e;
         int per_wg = 32;
+#ifdef BGTH_ABLATE
+        if (const char *e = getenv("BGTH_SOLO_PER_WG")) per_wg = atoi(e);   // (profiling build: tuning knob)
+#endif
         while (per_wg > 4 && (n_str + per_wg - 1) / per_wg < 3072) per_wg >>= 1;
         const int64_t grid = (n_str + per_wg - 1) / per_wg;
         hipLaunchKernelGGL(fs, dim3((unsigned)grid), dim3(256), lds_solo, s, a, a.rowdesc, a.rle, a.chunkinfo, a.segc,
