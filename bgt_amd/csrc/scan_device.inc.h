@@ -1080,7 +1080,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
 #define BGTH_FLUSH_GROUP(GRP)                                                                              \
             do {                                                                                           \
                 const uint32_t a_ = ca - pa, b_ = cb - pb, n3_ = cc - pc, n1_ = a_ - n3_, n2_ = b_ - n3_, g_ = (GRP);                         \
-                if (emit && g_ < 254u && lane == 0) {                                                      \
+                if (emit && g_ < 254u && lane == 0 && !BGTH_SKIP(a, 0x400000)) {   /* (profiling build: no flush, timing only) */ \
                     int32_t *dst = lcb + ((size_t)k * G + g_) * 3;                                         \
                     if (n1_) atomicAdd(dst + 0, (int32_t)n1_);                                             \
                     if (n2_) atomicAdd(dst + 1, (int32_t)n2_);                                             \
@@ -1092,7 +1092,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
                 uint64_t m0[4] = {0, 0, 0, 0}, m1[4] = {0, 0, 0, 0};
                 const int NC = (CPT - j) >= 4 ? 4 : 2;                // CPT is even: the tail is one pair
                 const uint32_t sg = MULTI ? (uint32_t)__builtin_amdgcn_readfirstlane((int)stmt_group(j >> 2)) : 0u;   // (uniform, and said so)
-                if (MULTI && sg != run_g) {
+                if (MULTI && __builtin_expect(sg != run_g, 0)) {             // (out of line: the common path falls through)
                     BGTH_FLUSH_GROUP(run_g);
                     pa = ca; pb = cb; pc = cc;                            // (the scalar sums only ever grow: a run is a difference)
                     run_g = sg;
@@ -1119,7 +1119,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
                 for (int u = 0; u < 4; ++u) {
                     if (u >= NC) break;
                     if (GT && lane == ((j + u) & 63)) { keep0[(j + u) >> 6] = m0[u]; keep1[(j + u) >> 6] = m1[u]; }
-                    if (MULTI && run_g == 255u) {                            // a statement across two groups: chunk by chunk
+                    if (MULTI && __builtin_expect(run_g == 255u, 0)) {                            // a statement across two groups: chunk by chunk
                         const int c = chunk0 + j + u;                        // wave-uniform
                         if (emit && lane == 0 && c < a.n_chunks) {
                             int32_t *dst = lcb + ((size_t)k * G + (a.chunk_desc[c] & 255u)) * 3;
@@ -1129,7 +1129,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
                         }
                     }
                 }
-                if (MULTI && run_g == 255u) { pa = ca; pb = cb; pc = cc; }  // (its sums were taken from the masks)
+                if (MULTI && __builtin_expect(run_g == 255u, 0)) { pa = ca; pb = cb; pc = cc; }  // (its sums were taken from the masks)
             }
             if (MULTI) BGTH_FLUSH_GROUP(run_g);
 #undef BGTH_FLUSH_GROUP

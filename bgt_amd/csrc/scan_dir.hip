@@ -484,7 +484,7 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
                 uint64_t m0[4] = {0, 0, 0, 0}, m1[4] = {0, 0, 0, 0};
                 const int NC = (CPT - j) >= STEP ? STEP : 2;              // CPT is even: the tail is one pair
                 const uint32_t sg = MULTI ? (uint32_t)__builtin_amdgcn_readfirstlane((int)stmt_group(j / STEP)) : 0u;   // (uniform, and said so)
-                if (MULTI && sg != run_g) {
+                if (MULTI && __builtin_expect(sg != run_g, 0)) {             // (out of line: the common path falls through)
                     BGTH_FLUSH_GROUP(run_g);
                     pa = ca; pb = cb; pc = cc;                            // (the scalar sums only ever grow: a run is a difference)
                     run_g = sg;
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
                 for (int u = 0; u < 4; ++u) {
                     if (u >= NC) break;
                     if (GT && lane == ((j + u) & 63)) { keep0[(j + u) >> 6] = m0[u]; keep1[(j + u) >> 6] = m1[u]; }
-                    if (MULTI && run_g == 255u) {
+                    if (MULTI && __builtin_expect(run_g == 255u, 0)) {
                         const int c = chunk0 + j + u;
                         if (emit && lane == 0 && c < a.n_chunks) {
                             int32_t *dst = lcb + (a.chunk_desc[c] & 255u) * 3;
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
                         }
                     }
                 }
-                if (MULTI && run_g == 255u) { pa = ca; pb = cb; pc = cc; }
+                if (MULTI && __builtin_expect(run_g == 255u, 0)) { pa = ca; pb = cb; pc = cc; }
             }
             if (MULTI) BGTH_FLUSH_GROUP(run_g);
 #undef BGTH_FLUSH_GROUP
