@@ -1033,16 +1033,16 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
         // The rows' zero counts: lane l holds the batch's l-th (one LDS read per batch) and a row takes its two by v_readlane --
         // read from the LDS row by row they were a round trip (ds_read, s_waitcnt, two v_readfirstlane) at the top of every row,
         // ~5 % of a 20-column row.
-        const bool n0_in_lanes = 2 * K <= 64;
-        const uint32_t n0_lane = n0_in_lanes ? n0b[lane < 2 * K ? lane : 0] : 0u;
+        // (K <= waves per workgroup <= 16: the 2 K values always fit the 64 lanes)
+        const uint32_t n0_lane = n0b[lane < 2 * K ? lane : 0];
         if (!TEAM && NT >= 512) __builtin_amdgcn_s_setprio(3);
         if (!(BGTH_SKIP(a, 1)))
         for (int k = 0; k < Kc; ++k) {
             // operands of the row step: (LDS byte address of the plane-row) - 8 and -n0 (see BGTH_TAIL)
             const uint32_t base0 = bufbase + (uint32_t)(2 * k) * (uint32_t)nwp * 8u - 8u;
             uint32_t base1 = base0 + (uint32_t)nwp * 8u;
-            const uint32_t n00 = 0u - (uint32_t)(n0_in_lanes ? __builtin_amdgcn_readlane((int)n0_lane, 2 * k) : __builtin_amdgcn_readfirstlane(n0b[2 * k]));
-            const uint32_t n01 = 0u - (uint32_t)(n0_in_lanes ? __builtin_amdgcn_readlane((int)n0_lane, 2 * k + 1) : __builtin_amdgcn_readfirstlane(n0b[2 * k + 1]));
+            const uint32_t n00 = 0u - (uint32_t)__builtin_amdgcn_readlane((int)n0_lane, 2 * k);
+            const uint32_t n01 = 0u - (uint32_t)__builtin_amdgcn_readlane((int)n0_lane, 2 * k + 1);
             const bool emit = (rb + k) >= a.row0;
             // The SIMD arbiter prefers its oldest wave: left alone, waves 0-3 race through a batch and idle at the
             // barrier while waves 12-15 finish it nearly alone (measured: walk 96 vs 189 ticks).  Rotating the user
