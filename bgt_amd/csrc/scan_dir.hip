@@ -383,8 +383,10 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
                 for (int j = 0; j < CPT; j += STEP) {
                     uint64_t m0[4] = {0, 0, 0, 0}, m1[4] = {0, 0, 0, 0};
                     const int q = j / STEP;
-                    if (q < MAXP) { if (inwalk && q < npc) dma_piece(nb0, src, q); }
-                    else if (q < 2 * MAXP) { if (inwalk && q - MAXP < npc) dma_piece(nb0 + 1, src + plane_bytes, q - MAXP); }
+                    // (a wave's first piece of a plane in line, further ones -- narrow plane-rows have one per wave -- out of line: the
+                    //  common path falls through instead of branching around six absent pieces per row)
+                    if (q < MAXP) { if (__builtin_expect(inwalk && q < npc, q == 0)) dma_piece(nb0, src, q); }
+                    else if (q < 2 * MAXP) { if (__builtin_expect(inwalk && q - MAXP < npc, q == MAXP)) dma_piece(nb0 + 1, src + plane_bytes, q - MAXP); }
                     {   // a wave's priority falls as it gets through the BATCH, the steps close to its end (see the one-row loop below)
                         constexpr int NS = (CPT + STEP - 1) / STEP, TOT = RPB * NS;
                         const int g = r * NS + q;
@@ -496,8 +498,8 @@ __global__ __launch_bounds__(NT) void walk_kernel(const ScanArgs a, const uint32
                             dma_piece(nb0, nsrc, kk);
                             ++kk;
                         }
-                    } else if (q < MAXP) { if (inwalk && q < npc) dma_piece(nb0, nsrc, q); }
-                    else if (q < 2 * MAXP) { if (inwalk && four && q - MAXP < npc) dma_piece(nb1, nsrc + plane_bytes, q - MAXP); }
+                    } else if (q < MAXP) { if (__builtin_expect(inwalk && q < npc, q == 0)) dma_piece(nb0, nsrc, q); }
+                    else if (q < 2 * MAXP) { if (__builtin_expect(inwalk && four && q - MAXP < npc, q == MAXP)) dma_piece(nb1, nsrc + plane_bytes, q - MAXP); }
                 }
                 // The SIMD arbiter prefers its oldest wave: left alone, the four waves of a SIMD finish a row one after the
                 // other and the early ones idle at the barrier while the last walks nearly alone (at 7.6 instead of 4.0 cycles
