@@ -84,18 +84,21 @@ def _num(x, digits=4):
 
 
 def compact_roofline(r):
-    """Numbers only: what bounds the kernel, achieved against three ceilings (class sum measured live = `peak`; the product's own
-    statement alone on the chip; the micro-architecture guide's plain 2-cycle VALU issue), HBM traffic and its share of 8 TB/s."""
+    """Numbers only.  `peak` / `frac` = the micro-architecture guide's plain VALU issue (one wave-instruction per 2 cycles and SIMD,
+    8 instructions per lookup): a hardware number anyone can recompute from kernel_ms, lookups_per_launch and clock_ghz.  Secondary,
+    named: the class sum measured live and the product's own statement alone on the chip.  HBM: measured traffic per launch beside
+    the compulsory floor (strings + descriptors + checkpoints of the tracked columns + counts)."""
     if not r:
         return None
-    clock = r.get("peak_clock_ghz")
-    guide = 1024.0 * 64.0 * clock / (8.0 * GUIDE_VALU_CYCLES) if clock else None      # G lookups/s: 8 VALU per lookup
     c = {"bound": r.get("bound"), "achieved": _num(r.get("achieved")), "peak": _num(r.get("peak")), "unit": r.get("unit"),
-         "frac": _num(r.get("frac")), "peak_own_statement": _num(r.get("peak_own_statement")),
-         "frac_of_own_statement": _num(r.get("frac_of_own_statement")),
-         "peak_guide_2cycle": _num(guide), "frac_of_guide_2cycle": _num(r["achieved"] / guide) if guide and r.get("achieved") else None,
+         "frac": _num(r.get("frac")), "peak_is": "1024 SIMDs x 64 lanes x clock_ghz / (8 VALU x 2 cycles) (MI355X_MICROARCH.md)",
+         "clock_ghz": _num(r.get("peak_clock_ghz")),
+         "peak_class_sum": _num(r.get("peak_class_sum")), "frac_of_class_sum": _num(r.get("frac_of_class_sum")),
+         "peak_own_statement": _num(r.get("peak_own_statement")), "frac_of_own_statement": _num(r.get("frac_of_own_statement")),
          "traffic": _num(r.get("traffic"), 6), "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x calibration + WRITE_SIZE)",
          "traffic_in_run": bool(r.get("traffic_in_run", {}).get("hbm_bytes_per_launch")) if isinstance(r.get("traffic_in_run"), dict) else False,
+         "hbm_floor_bytes": _num(r.get("hbm_floor_bytes"), 6),
+         "traffic_over_floor": _num(r["traffic"] / r["hbm_floor_bytes"], 3) if r.get("traffic") and r.get("hbm_floor_bytes") else None,
          "hbm_frac_measured": _num(r.get("hbm_frac_measured")), "hbm_peak_gbs": r.get("hbm_peak_gbs"),
          "kernel": r.get("kernel"), "kernel_ms": _num(r.get("kernel_ms")), "lookups_per_launch": _num(r.get("lookups_per_launch"), 6),
          "algorithmic_equiv_gbs": _num(r.get("algorithmic_equiv_gbs"))}
@@ -129,6 +132,9 @@ def compact_record(out, detail_path=None):
                        "sites_checked_popcount_identity": par.get("sites_checked_popcount_identity"),
                        "oracle_window_matches": (par.get("oracle_window") or {}).get("matches"),
                        "oracle_window_rows": (par.get("oracle_window") or {}).get("rows")}
+        frz = par.get("from_row_zero")
+        if isinstance(frz, dict):
+            c["parity"]["from_row_zero"] = {k: frz.get(k) for k in ("sites", "of_sites", "oracle_counts_match", "reference_stdout_identical")}
     cb = out.get("cpu_baseline")
     if cb:
         c["cpu_baseline"] = {"value": _num(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
@@ -210,6 +216,11 @@ def emit(out, detail_arg=None):
     print(compact_record(out, detail), flush=True)
 
 
+def guide_peak(peak):
+    """G lookups/s at the guide's plain VALU issue: 1024 SIMDs x 64 lanes x clock / (8 instructions x 2 cycles)"""
+    return 1024.0 * 64.0 * peak["clock_ghz"] / (8.0 * GUIDE_VALU_CYCLES)
+
+
 def lookup_peak(bgt_amd, device):
     """G rank-lookups/s the chip sustains running only the product's row step (live microbenchmark, ~40 ms)."""
     import ctypes as C
@@ -280,7 +291,17 @@ def replayed_counters(workload, sites, kernel_name):
     return out
 
 
-def make_roofline(peak, T, sites, k_ms, rle_bytes_per_site, geo, workload, counters_sites, path=None):
+def hbm_floor(pbf, T, sites, n_groups=1):
+    """Compulsory HBM bytes of one launch over `sites` rows: the run-length strings (padded to dwords, as they sit in HBM), the row
+    descriptors, one rank checkpoint of the T tracked columns and both planes per sub-block, and the counts written."""
+    sub = -(-sites // int(pbf.unit_rows))
+    parts = {"strings": float(pbf.rle_bytes) * sites / max(1, pbf.n), "row_descriptors": 16.0 * sites,
+             "checkpoints": sub * 2.0 * T * 4.0, "counts": 12.0 * sites * (1 + (n_groups if n_groups > 1 else 0))}
+    parts["total"] = sum(parts.values())
+    return parts
+
+
+def make_roofline(peak, T, sites, k_ms, rle_bytes_per_site, geo, workload, counters_sites, path=None, floor=None):
     lookups = 2.0 * T * sites                                                      # tracked columns x 2 planes x sites
     achieved = lookups / (k_ms * 1e-3) / 1e9
     alg_bytes_per_site = 16.0 * T + rle_bytes_per_site + 12.0
@@ -288,30 +309,31 @@ def make_roofline(peak, T, sites, k_ms, rle_bytes_per_site, geo, workload, count
         kname = "plane_kernel<%d" % geo["cols_per_thread"]                        # scan_plane.hip: a workgroup per (sub-block, plane)
     else:
         kname = ("walk_kernel<%d, %d" if path and path.get("directory_path") else "scan_kernel<%d, %d") % (geo["threads"], geo["cols_per_thread"])
-    r = {"bound": "valu_issue", "achieved": achieved, "peak": peak["ideal_mix_g_lookups_per_s"], "unit": "G rank-lookups/s",
-         "frac": achieved / peak["ideal_mix_g_lookups_per_s"], "traffic": None,
+    guide = guide_peak(peak)
+    r = {"bound": "valu_issue", "achieved": achieved, "peak": guide, "unit": "G rank-lookups/s",
+         "frac": achieved / guide, "traffic": None,
          "kernel": kname + (", ..., %d threads>" % geo["threads"] if kname.startswith("plane_kernel") else ", ...>"), "kernel_ms": k_ms, "lookups_per_launch": lookups,
-         "peak_source": "code-independent ceiling: 1024 SIMDs x 64 lanes x clock / (5 x four-cycle-class + 3 x two-cycle-class cycles) for the "
-                        "minimal 8-instruction lookup, class rates measured live as single-instruction streams (%.2f / %.2f cycles per "
-                        "wave-instruction at 4 waves per SIMD) -- as if the classes added up and nothing else ever issued.  They do not add "
-                        "up: profiles/r04_issue (one instruction of the slow class in 32 slows the whole stretch to 3.6 cycles, alternating "
-                        "blocks of any length issue at 4.0-4.2, a SIMD issues one VALU at a time), and three cheaper-looking row steps "
-                        "-- a ballot-free instruction-major one, a 7-instruction one with v_cmpx, SGPR operands moved to VGPRs -- all ran "
-                        "SLOWER in the kernel (profiles/r04_issue/cc_step_in_the_kernel.txt), so what the shipped statement reaches alone on "
-                        "the chip (peak_own_statement) is the ceiling this algorithm actually has"
-                        % (peak["class_cycles"]["four_cycle_class_v_bcnt_u32_b32"], peak["class_cycles"]["two_cycle_class_v_add_u32"]),
+         "peak_source": "hardware number: MI355X_MICROARCH.md's VALU issue, one wave64 instruction per %.0f cycles and SIMD, x 1024 SIMDs x 64 "
+                        "lanes x the clock measured live (%.3f GHz) / the 8 VALU instructions of the minimal lookup" % (GUIDE_VALU_CYCLES, peak["clock_ghz"]),
          "peak_clock_ghz": peak["clock_ghz"],
+         "peak_class_sum": peak["ideal_mix_g_lookups_per_s"], "frac_of_class_sum": achieved / peak["ideal_mix_g_lookups_per_s"],
+         "peak_class_sum_source": "self-calibrated, secondary: 5 x four-cycle-class + 3 x two-cycle-class cycles for the minimal 8-instruction "
+                                  "lookup, class rates measured live as single-instruction streams (%.2f / %.2f cycles per wave-instruction at 4 "
+                                  "waves per SIMD; profiles/r04_issue)"
+                                  % (peak["class_cycles"]["four_cycle_class_v_bcnt_u32_b32"], peak["class_cycles"]["two_cycle_class_v_add_u32"]),
          "peak_own_statement": peak["g_lookups_per_s"], "frac_of_own_statement": achieved / peak["g_lookups_per_s"],
          "peak_own_statement_source": peak["source"], "peak_own_statement_cycles_per_valu_instr": peak["cycles_per_valu_instr"],
-         "peak_ideal_mix": peak["ideal_mix_g_lookups_per_s"], "frac_of_ideal_mix": achieved / peak["ideal_mix_g_lookups_per_s"],
          "algorithmic_bytes_per_site": alg_bytes_per_site,
          "algorithmic_equiv_gbs": alg_bytes_per_site * sites / (k_ms * 1e-3) / 1e9,
          "hbm_peak_gbs": HBM_PEAK_GBS,
          "note": "HBM is NOT the bound and the north star's '>= 50 % of HBM read bandwidth' does not apply to this design: the "
-                 "permutation stays in registers, so HBM carries only the RLE strings, row descriptors and checkpoints (hbm_frac_measured: "
-                 "~0.5 % of 8 TB/s on C2, 1.07x the compulsory input).  algorithmic_equiv_gbs prices the REFERENCE algorithm's 16*T bytes "
+                 "permutation stays in registers, so HBM carries only the RLE strings, row descriptors and checkpoints (hbm_floor_bytes; "
+                 "traffic / hbm_floor_bytes says what is re-read).  algorithmic_equiv_gbs prices the REFERENCE algorithm's 16*T bytes "
                  "per site (SURVEY 8d) at this kernel's speed -- above the HBM peak, i.e. not moving the permutation beats moving it at full "
                  "HBM speed; it bounds nothing.  The bound is VALU issue."}
+    if floor:
+        r["hbm_floor_bytes"] = floor["total"]
+        r["hbm_floor_parts"] = floor
     rc = replayed_counters(workload, counters_sites, kname)
     if rc:
         r["counters"] = rc
@@ -462,7 +484,7 @@ def reference_cli_baseline(n_samples, ns, seed, view_args, tmp, what, all_cores=
     """The compiled reference's `bgt view` on a database of the first `ns` sites of the cohort; also this repo's CLI on
     the same command (stdout compared)."""
     __import__("bgt_amd").build_host_shell()
-    prefix = os.path.join(tmp, "db_%d_%d" % (n_samples, ns))
+    prefix = os.path.join(tmp, "full_%d_%d" % (n_samples, ns))         # (cli_end_to_end names the full database the same way)
     if not os.path.exists(prefix + ".pbf"):
         subprocess.check_call([MY_BIN, "synth", prefix, str(n_samples), str(ns), str(seed)])
     cmd = ["view"] + view_args + [prefix]
@@ -509,7 +531,8 @@ def cli_end_to_end(n_samples, sites, seed, tmp):
     __import__("bgt_amd").build_host_shell()
     prefix = os.path.join(tmp, "full_%d_%d" % (n_samples, sites))
     t0 = time.perf_counter()
-    subprocess.check_call([MY_BIN, "synth", prefix, str(n_samples), str(sites), str(seed)])
+    if not os.path.exists(prefix + ".pbf"):                            # (the CPU baseline at full length has written it already)
+        subprocess.check_call([MY_BIN, "synth", prefix, str(n_samples), str(sites), str(seed)])
     t_synth = time.perf_counter() - t0
     best, stages, lines = None, None, 0
     for _ in range(3):
@@ -840,9 +863,9 @@ def secondary_record(torch, bgt_amd, np, peak, name, what, n_samples, sites, see
            "sites_passing_filter": int(pipe.host_n_pass[last].item()), "launch": geo, "kernel_path": path,
            "rle_bytes_per_site": round(rle_bytes_per_site, 1), "hbm_resident_bytes": pbf.hbm_bytes,
            "setup": {"generate_s": round(t_gen, 1), "upload_and_checkpoints_s": round(t_load, 1)},
-           "roofline": make_roofline(peak, T, sites, k_ms, rle_bytes_per_site, geo, counters_workload, sites, path)}
+           "roofline": make_roofline(peak, T, sites, k_ms, rle_bytes_per_site, geo, counters_workload, sites, path, hbm_floor(pbf, T, sites))}
     if kept:
-        kept["roofline_frac"] = 2.0 * T * sites / (kept["kernel_ms"] * 1e-3) / 1e9 / peak["ideal_mix_g_lookups_per_s"]
+        kept["roofline_frac"] = 2.0 * T * sites / (kept["kernel_ms"] * 1e-3) / 1e9 / guide_peak(peak)
         rec["arena_kept"] = kept
     # ---- the timed step's output: (1) whole cohort: the plane-popcount identity on EVERY site; (2) a CPU-oracle window
     # across a mid-file block boundary (the oracle starts from the order the image holds 2048 rows before the boundary and
@@ -1044,7 +1067,7 @@ def sharded_run(args, ctx, workload, steps, warmup, sites_arg):
                        "filter": "AC>0 evaluated on the device (bgth_filter_apply_device); counts + flags copied "
                                  "to pinned host memory, the copy of step i overlapping the scan of step i+1",
                        "launch": geo},
-            "roofline": make_roofline(peak, T, sites, k_ms, rle_bytes_per_site, geo, workload, sites, rd.path()),
+            "roofline": make_roofline(peak, T, sites, k_ms, rle_bytes_per_site, geo, workload, sites, rd.path(), hbm_floor(pbf, T, sites)),
             "setup": {"generate_s": round(t_gen, 2), "upload_and_checkpoints_s": round(t_load, 2),
                       "hbm_resident_bytes": pbf.hbm_bytes},
         }
@@ -1088,7 +1111,9 @@ def main():
     ap.add_argument("--sites", type=int, default=0, help="sites per GPU (default 1,000,000; c4: all 10,000,000 split over the GPUs)")
     ap.add_argument("--every", type=int, default=0, help="select every N-th sample only (C3: --workload c3 --every 20)")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--cpu-sample", type=int, default=262144, help="sites for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=1000000,
+                    help="sites for the CPU baseline and the from-row-0 parity check (0 = skip; default: C2's full length -- the compiled "
+                         "reference and the CPU oracle each decode the whole database from the identity order of row 0, ~23 s each)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 100,000-sample secondary records (N = 1)")
     ap.add_argument("--secondary-steps", type=int, default=3)
     ap.add_argument("--secondary-sites", type=int, default=0, help="N > 1: total sites of the C4-sharded secondary record (default 10,000,000)")
@@ -1195,7 +1220,9 @@ def main():
                 out["parity_error"] = "GPU counts differ from the CPU oracle on the sample"
             # every site of the timed output against the strings' ones, and an oracle window across a mid-file block boundary
             par = {"popcount_identity_ok": popcount_identity(np, host.numpy()[:sites], plane_ones(np, rle, lens)[:sites], m),
-                   "sites_checked_popcount_identity": sites}
+                   "sites_checked_popcount_identity": sites,
+                   # the timed launch's own counts against ONE sequential oracle pass from the identity order of row 0
+                   "from_row_zero": {"sites": ns, "of_sites": sites, "oracle_counts_match": same}}
             mid = (sites // 2) // (1 << shift) * (1 << shift)
             if mid >= (1 << shift):
                 back, ahead = (1 << shift) if m <= 20000 else 2048, 1024 if m <= 20000 else 512
@@ -1212,6 +1239,7 @@ def main():
                                                             "the same cohort", all_cores=True)
                     base["gpu_matches_cpu_on_sample"] = same
                     base["port"] = port
+                    par["from_row_zero"]["reference_stdout_identical"] = cli_same      # the reference binary over the same ns sites
                     out["cpu_baseline"] = base
                     if not cli_same:
                         out["parity_error"] = "`bgt view` stdout differs from the reference binary"

@@ -1326,7 +1326,11 @@ static bool derive_all_checkpoints(bgth_pbf_t *p, Selection &all, const std::vec
         HIP_TRY(hipDeviceSynchronize(), break);
         hipFree(p->d_rank0);
         p->d_rank0 = rebased; rebased = nullptr;
-        if (p->d_order) { hipFree(p->d_order); p->d_order = nullptr; }      // (derived from the checkpoints: built again on demand)
+        {
+            std::lock_guard<std::mutex> guard(p->rowindex_lock);
+            if (p->d_order) { hipFree(p->d_order); p->d_order = nullptr; }  // (derived from the checkpoints: built again on demand)
+            p->order_failed = false;
+        }
         ok = true;
     } while (0);
 done:
@@ -1371,11 +1375,20 @@ extern "C" int bgth_pbf_rebase(bgth_pbf_t *p, const int32_t *start_ranks)
     if (!p->d_final) { set_err("[E::bgth_pbf_rebase] only images built by bgth_pbf_from_rle can be re-based"); return -1; }
     if (!use_device(p->device)) return -1;
     const size_t per = (size_t)2 * p->m;
-    for (int k = 0; k < 2; ++k)                                            // a start order that is no permutation would address outside the tables
-        for (int j = 0; j < p->m; ++j) {
-            const int32_t v = start_ranks[(size_t)k * p->m + j];
-            if (v < 0 || v >= p->m) { set_err("[E::bgth_pbf_rebase] rank %d out of range", v); return -1; }
+    {   // Both planes must be PERMUTATIONS of 0 .. m-1: a rank out of range would address outside the tables, and a repeated one
+        // leaves slots of the plane-1-by-plane-0 table unwritten (the rank-ordered start of whole-cohort scans scatters by rank:
+        // the default path and BGTH_FORCE_COLUMN_ORDER would then silently disagree)
+        std::vector<uint8_t> seen((size_t)p->m);
+        for (int k = 0; k < 2; ++k) {
+            std::fill(seen.begin(), seen.end(), 0);
+            for (int j = 0; j < p->m; ++j) {
+                const int32_t v = start_ranks[(size_t)k * p->m + j];
+                if (v < 0 || v >= p->m) { set_err("[E::bgth_pbf_rebase] rank %d out of range", v); return -1; }
+                if (seen[v]) { set_err("[E::bgth_pbf_rebase] plane %d: rank %d appears twice: not a permutation", k, v); return -1; }
+                seen[v] = 1;
+            }
         }
+    }
     int32_t *via = nullptr, *out = nullptr;
     const int64_t n = std::max<int64_t>(p->n_sub, 1);
     int rc = -1;
@@ -1388,9 +1401,11 @@ extern "C" int bgth_pbf_rebase(bgth_pbf_t *p, const int32_t *start_ranks)
         HIP_TRY(hipMemcpy(p->d_final, out + (size_t)n * per, per * 4, hipMemcpyDeviceToDevice), break);
         HIP_TRY(hipDeviceSynchronize(), break);
         {   // readers of the image keep no ranks of their own; an arena a reader filled holds directory rows, which do not depend on the order
+            std::lock_guard<std::mutex> guard(p->rowindex_lock);           // (d_order is built under this lock by the scans)
             hipFree(p->d_rank0);
             p->d_rank0 = out; out = nullptr;
             if (p->d_order) { hipFree(p->d_order); p->d_order = nullptr; }
+            p->order_failed = false;
         }
         rc = 0;
     } while (0);
@@ -1843,11 +1858,18 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
         a.whole_counts = 1;                              // ... and only n(code 3) is counted: the planes' ones are the rows' own (BGTH_COUNT3)
         std::lock_guard<std::mutex> guard(p->rowindex_lock);
         if (!p->d_order && !p->order_failed) {
-            if (hipMalloc((void**)&p->d_order, (size_t)std::max<int64_t>(p->n_sub, 1) * p->m * 4) != hipSuccess) { (void)hipGetLastError(); p->d_order = nullptr; p->order_failed = true; }
-            else HIP_TRY(launch_plane1_by_plane0(p->d_rank0, p->d_order, p->m, p->n_sub, s), return -1);
-            // (built on the stream of this scan; another reader's stream may use it only after this launch: both are ordered by
-            //  the lock's holder synchronising below)
-            if (p->d_order) HIP_TRY(hipStreamSynchronize(s), return -1);
+            // Built on the stream of this scan and PUBLISHED only once it is complete: another reader's stream may use it only after
+            // this launch (the lock's holder synchronises), and a launch or sync that fails leaves no half-filled table behind for
+            // later scans to start plane-1 ranks from -- they fall back to the column order.
+            int32_t *order = nullptr;
+            if (hipMalloc((void**)&order, (size_t)std::max<int64_t>(p->n_sub, 1) * p->m * 4) != hipSuccess) { (void)hipGetLastError(); p->order_failed = true; }
+            else if (launch_plane1_by_plane0(p->d_rank0, order, p->m, p->n_sub, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+                set_err("[E::bgth_reader_scan] building the plane-1-by-plane-0 rank table failed: %s", hipGetErrorString(hipGetLastError()));
+                (void)hipFree(order);
+                p->order_failed = true;
+                return -1;
+            }
+            else p->d_order = order;
         }
         if (p->d_order) { a.order0 = p->d_order; a.order_blk_stride = (int64_t)p->m; }
     }

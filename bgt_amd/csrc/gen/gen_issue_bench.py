@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates bgt_amd/csrc/issue_bench.hip: the VALU issue experiments of round 4 (profiles/r04_issue/).
+"""Generates issue_bench.hip (at build time, into the build directory: bgt_amd/csrc/Makefile): the VALU issue experiments of round 4 (profiles/r04_issue/).
 
 Question: the row step of the scan kernels issues at ~4.0 cycles per VALU wave-instruction although
 three of its eight instructions are of the class that streams at ~2.2-2.5 cycles.  Every experiment here is a kernel whose
@@ -8,12 +8,12 @@ generator lays it out (slot-major = dependent neighbours, or instruction-major =
 harness measures shader cycles per wave with s_memtime at 1 / 2 / 4 / 8 waves per SIMD.  No memory is touched: VALU timing
 does not depend on the data.
 
-Run:  python scripts/gen_issue_bench.py   (rewrites the .hip; `make -C bgt_amd/csrc` builds it into libbgt_hip_bench.so)
+Run:  python gen_issue_bench.py OUT.hip   (`make -C bgt_amd/csrc` does, and builds the result into libbgt_hip_bench.so)
 """
 import os
+import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, "bgt_amd", "csrc", "issue_bench.hip")
+OUT = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "build", "gen", "issue_bench.hip")
 
 # register slots: eight independent copies of every operand
 REG = {"A": 10, "B": 18, "C": 26, "D": 34, "E": 42, "F": 50}          # v10..v57: < 64 VGPRs, so 8 waves per SIMD fit
@@ -471,7 +471,7 @@ def emit():
     w = o.append
     clob = CLOBBER + ["v%d" % i for i in range(58, 106)] + ["s24", "s25", "s26"]
     clob = sorted(set(clob), key=lambda x: (x[0], int(x[1:]) if x[1:].isdigit() else 999))
-    w("// GENERATED by scripts/gen_issue_bench.py -- do not edit.  VALU issue experiments (profiles/r04_issue/): every kernel")
+    w("// GENERATED by bgt_amd/csrc/gen/gen_issue_bench.py -- do not edit.  VALU issue experiments (profiles/r04_issue/): every kernel")
     w("// runs one fixed list of instructions in a loop; s_memtime brackets the loop.  Measurement tool, part of")
     w("// libbgt_hip_bench.so, not of the product library.")
     w("#include <hip/hip_runtime.h>")

@@ -30,8 +30,9 @@ struct ScanArgs {
     const int32_t  *rank0;       // initial ranks by column: [blk][2][m] (blk_stride = 2*m) or one [2][m]
     int64_t         rank0_blk_stride;
     const int32_t  *slot_col;    // [n_chunks*64] column of each tracked slot, -1 = padding
-    const int32_t  *order0;      // experiment (profiling build, profiles/r05_lds): != NULL = slot s of a sub-block tracks the column of
-    int64_t         order_blk_stride;   //   plane-0 rank s at its checkpoint; order0[blk * stride + s] = that column's plane-1 rank
+    const int32_t  *order0;      // whole-cohort counts scans (the default of every such scan; measured in profiles/r05_lds): != NULL = slot s
+    int64_t         order_blk_stride;   //   of a sub-block tracks the column of plane-0 rank s at its checkpoint; order0[blk * stride + s] =
+                                 //   that column's plane-1 rank (the image's d_order table, built at the first such scan)
     const uint32_t *chunk_desc;  // [n_chunks]
     int32_t        *raw_counts;  // [(row1-row0)][G][3] += {n(code1), n(code2), n(code3)}
     uint64_t       *h0, *h1;     // optional [(row1-row0)][n_chunks] bit planes in slot order

@@ -226,8 +226,10 @@ __global__ void invert_kernel(const int32_t *perm, int32_t *inv, int m, int64_t 
     inv[base + p] = (int32_t)(i - base);
 }
 
-// Experiment of the profiling build (profiles/r05_lds): out[rec][rank0[rec][col]] = rank1[rec][col] -- the plane-1 ranks of every
-// (sub-)checkpoint in the order of its plane-0 ranks, so that slots laid out in plane-0 rank order start without a gather.
+// out[rec][rank0[rec][col]] = rank1[rec][col] -- the plane-1 ranks of every (sub-)checkpoint in the order of its plane-0 ranks, so
+// that slots laid out in plane-0 rank order start without a gather.  Product path: the table behind ScanArgs::order0, which every
+// whole-cohort counts scan uses (measured in profiles/r05_lds).  rank0[rec] must be a permutation (files: launch_invert checks the
+// 'S' records; bgth_pbf_rebase checks its input), or slots of `out` stay unwritten.
 __global__ void plane1_by_plane0_kernel(const int32_t *rank, int32_t *out, int m, int64_t total)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -100,12 +100,13 @@ __global__ __launch_bounds__(NT, LOW == 1 ? 6 : 4) void plane_kernel(const ScanA
     // loads' saddr form) -- as 64-bit per-lane arithmetic the prefetch cost every wave ~34 VALU instructions per row, 12 % of
     // the kernel's.  Rows are counted from the sub-block's first (32 bits).
     const int nrows = __builtin_amdgcn_readfirstlane((int)(blk_end - blk_beg));
-    const uint32_t str0 = (uint32_t)(2 * blk_beg) + (uint32_t)plane;     // string index of relative row 0 (< 2^31 strings)
+    const uint64_t str0 = (uint64_t)(2 * blk_beg) + (uint64_t)plane;     // string index of relative row 0: 64 bits, wave-uniform (SGPRs)
     auto vzero = []() { uint32_t z = 0; asm volatile("" : "+v"(z)); return z; };
-    auto load_desc = [&](int i) -> uint64_t {                          // relative row i
+    const char *desc0 = reinterpret_cast<const char*>(rowdesc + str0);   // (the uniform part of the address stays 64-bit on the scalar
+    auto load_desc = [&](int i) -> uint64_t {                          //  unit; only the row's delta inside the sub-block is 32-bit)
         if (i >= nrows) return 0ull;
-        const uint32_t bo = (str0 + 2u * (uint32_t)i) * 8u + vzero();
-        return *reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(rowdesc) + bo);
+        const uint32_t bo = 16u * (uint32_t)i + vzero();
+        return *reinterpret_cast<const uint64_t*>(desc0 + bo);
     };
     const char *sc0 = reinterpret_cast<const char*>(segc + (uint64_t)str0 * (uint64_t)(a.S8 + 1));
     const uint32_t sc_step = 2u * (uint32_t)(a.S8 + 1) * 4u;

@@ -44,7 +44,13 @@ def _csrc_sources():
     src = os.path.join(_HERE, "csrc")
     inc = os.path.join(os.path.dirname(_HERE), "include")
     return (glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.cpp")) + glob.glob(os.path.join(src, "*.h")) +
-            [os.path.join(src, "Makefile")] + glob.glob(os.path.join(inc, "*.h")))
+            glob.glob(os.path.join(src, "gen", "*.py")) + [os.path.join(src, "Makefile")] + glob.glob(os.path.join(inc, "*.h")))
+
+
+def _build_settings():
+    """The make variables a build depends on beside its sources: a library built for another ARCH / by another HIPCC / as the
+    profiling build is not `current` for this one."""
+    return "".join("%s=%s\n" % (k, os.environ.get(k, "")) for k in ("ARCH", "HIPCC", "ABLATE", "CXXFLAGS"))
 
 
 def build_library(force=False):
@@ -52,7 +58,8 @@ def build_library(force=False):
     built from exactly these sources (lib/.csrc.stamp)."""
     src = os.path.join(_HERE, "csrc")
     stamp = os.path.join(_HERE, "lib", ".csrc.stamp")
-    digest = _digest(_csrc_sources())
+    import hashlib
+    digest = hashlib.sha1((_digest(_csrc_sources()) + "\n" + _build_settings()).encode()).hexdigest()
     if force and os.path.exists(_LIB_PATH):
         os.remove(_LIB_PATH)
     default_lib = os.path.join(_HERE, "lib", "libbgt_hip.so")
@@ -322,6 +329,14 @@ class HipPbf:
     @property
     def rle_bytes(self):
         return lib().bgth_pbf_rle_bytes(self.h)
+
+    @property
+    def unit_rows(self):
+        """rows per sub-block = the spacing of the image's rank checkpoints = the unit of work of a launch"""
+        L = lib()
+        L.bgth_pbf_unit_rows.restype = C.c_int64
+        L.bgth_pbf_unit_rows.argtypes = [C.c_void_p]
+        return L.bgth_pbf_unit_rows(self.h)
 
     def close(self):
         if self.h:

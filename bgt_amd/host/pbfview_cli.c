@@ -1,4 +1,7 @@
-/* pbfview_cli.c -- `bgt pbfview`: the reference's codec-level tool (pbfview.c:7-101) over the device codec.
+/* pbfview_cli.c -- `bgt pbfview`: the command-line behaviour of the reference's codec-level tool (pbfview.c) over the device
+ * codec.  Same options, same bytes on stdout; the program is this repo's own: a job description filled from an option
+ * table, one of two row SOURCES (PIM text | a .pbf through bgth_reader_read) pumping into one of two row SINKS (PIM text |
+ * a .pbf through bgth_encoder_*).
  *
  *   decode   <in.pbf>             -> PIM text ("PIM1 m g", then one line of m integers per row: sum of plane k << k)
  *            -c COL (repeatable)  -> only these columns, in the order given (pbf_subset, pbwt.c:374-388)
@@ -6,9 +9,9 @@
  *   encode   -S <in.pim> -b       -> PBF on stdout, 'S' records every 1 << shift rows (-s, default 13)
  *   recode   <in.pbf> -b [-c ..]  -> the decoded rows written again
  *
- * Decoding is bgth_reader_read (rank tracking on the device), encoding bgth_encoder_* (PBWT order kept on the device);
- * the host only parses and prints integers.  The encoder takes one or two bit planes; the reader holds exactly BGT's two
- * (import.c:68) and refuses other files with a message. */
+ * Decoding is rank tracking on the device, encoding keeps the PBWT order on the device; the host only parses and prints
+ * integers.  The encoder takes one or two bit planes; the reader holds exactly BGT's two (import.c:68), or the one of a
+ * `.pb1`, and refuses other files with a message. */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -16,129 +19,199 @@
 #include <unistd.h>
 #include "../../include/bgt_hip.h"
 
-#define ROWS_PER_WRITE 4096
+#define PV_ROWS_PER_WRITE 4096                                       /* rows handed to the encoder at a time */
 
-static int flush_rows(bgth_encoder_t *enc, const uint8_t *codes, int64_t n)
+/* ---- the job ---- */
+typedef struct {
+    int         text_in, pbf_out, shift;
+    int64_t     first_row, max_rows;                                 /* max_rows < 0: all */
+    int32_t    *cols;
+    int         n_cols, cap_cols;
+    const char *input;
+} pv_job_t;
+
+typedef struct { char key; const char *arg; const char *help; } pv_opt_t;
+static const pv_opt_t PV_OPTS[] = {
+    {'S', NULL,  "input is PIM (portable integer matrix format)"},
+    {'b', NULL,  "output PBF (positional BWT format)"},
+    {'s', "INT", "write S array every 1<<INT rows (effective with -b) [13]"},
+    {'r', "INT", "start decoding from row INT (effective w/o -S) [0]"},
+    {'n', "INT", "read INT rows starting from -r (effective w/o -S) [inf]"},
+    {'c', "INT", "decode column INT (there can be multiple -c; effective w/o -S) [inf]"},
+};
+#define PV_N_OPTS ((int)(sizeof(PV_OPTS) / sizeof(PV_OPTS[0])))
+
+static int pv_usage(void)
 {
-    if (n > 0 && bgth_encoder_write(enc, codes, n) < 0) { fprintf(stderr, "[E::%s] %s\n", __func__, bgth_encoder_last_error()); return -1; }
+    int i;
+    fprintf(stderr, "Usage: pbfview [options] <in.pbf>|<in.pim>\nOptions:\n");
+    for (i = 0; i < PV_N_OPTS; ++i)
+        fprintf(stderr, "  -%c %-5s %s\n", PV_OPTS[i].key, PV_OPTS[i].arg ? PV_OPTS[i].arg : "", PV_OPTS[i].help);
+    return 1;
+}
+
+static void pv_set(pv_job_t *job, int key, const char *arg)
+{
+    switch (key) {
+    case 'S': job->text_in = 1; break;
+    case 'b': job->pbf_out = 1; break;
+    case 's': job->shift = atoi(arg); break;
+    case 'r': job->first_row = atol(arg); break;
+    case 'n': job->max_rows = atol(arg); break;
+    case 'c':
+        if (job->n_cols == job->cap_cols) {
+            job->cap_cols = job->cap_cols ? 2 * job->cap_cols : 16;
+            job->cols = (int32_t*)realloc(job->cols, (size_t)job->cap_cols * sizeof(int32_t));
+        }
+        job->cols[job->n_cols++] = (int32_t)atol(arg);
+        break;
+    default: break;                                                  /* getopt has complained */
+    }
+}
+
+static int pv_parse(pv_job_t *job, int argc, char **argv)
+{
+    char spec[2 * PV_N_OPTS + 1];
+    int i, l = 0, c;
+    for (i = 0; i < PV_N_OPTS; ++i) { spec[l++] = PV_OPTS[i].key; if (PV_OPTS[i].arg) spec[l++] = ':'; }
+    spec[l] = 0;
+    memset(job, 0, sizeof(*job));
+    job->shift = 13; job->max_rows = -1;
+    while ((c = getopt(argc, argv, spec)) >= 0) pv_set(job, c, optarg);
+    if (optind >= argc) return -1;
+    job->input = argv[optind];
     return 0;
 }
 
-static int finish_image(bgth_encoder_t *enc)
+/* ---- the sink: rows of m cells, as text or into the device encoder ---- */
+typedef struct {
+    bgth_encoder_t *enc;                                             /* NULL: PIM text on stdout */
+    uint8_t        *codes;                                           /* rows waiting for the encoder */
+    int64_t         held;
+    int             m, g, col;                                       /* col: cells of the current row so far */
+} pv_sink_t;
+
+static int sink_open(pv_sink_t *s, const pv_job_t *job, int m, int g)
 {
-    uint8_t *img = NULL;
-    const int64_t len = bgth_encoder_finish(enc, &img);
-    if (len < 0) { fprintf(stderr, "[E::%s] %s\n", __func__, bgth_encoder_last_error()); return -1; }
-    fwrite(img, 1, (size_t)len, stdout);
-    bgth_encoder_free_image(img);
+    memset(s, 0, sizeof(*s));
+    s->m = m; s->g = g;
+    if (!job->pbf_out) { printf("PIM1 %d %d\n", m, g); return 0; }
+    if (g > 2) { fprintf(stderr, "[E::%s] the device codec writes one or two bit planes, the input has %d\n", __func__, g); return -1; }
+    if ((s->enc = bgth_encoder_open(m, g, job->shift, 0)) == NULL) { fprintf(stderr, "[E::%s] %s\n", __func__, bgth_encoder_last_error()); return -1; }
+    s->codes = (uint8_t*)malloc((size_t)m * PV_ROWS_PER_WRITE);
+    return s->codes ? 0 : -1;
+}
+
+static int sink_drain(pv_sink_t *s)
+{
+    if (s->enc && s->held > 0 && bgth_encoder_write(s->enc, s->codes, s->held) < 0) {
+        fprintf(stderr, "[E::%s] %s\n", __func__, bgth_encoder_last_error());
+        return -1;
+    }
+    s->held = 0;
     return 0;
+}
+
+/* one cell of the current row: text goes out at once (an unfinished last row of a PIM echo stays visible, as in the
+ * reference), codes wait for the row to be complete */
+static void sink_cell(pv_sink_t *s, long long v)
+{
+    if (s->enc) s->codes[(size_t)s->held * s->m + s->col] = (uint8_t)(v & ((1 << s->g) - 1));
+    else printf(s->col ? " %lld" : "%lld", v);
+    ++s->col;
+}
+
+static int sink_end_row(pv_sink_t *s)
+{
+    s->col = 0;
+    if (!s->enc) { putchar('\n'); return 0; }
+    return ++s->held == PV_ROWS_PER_WRITE ? sink_drain(s) : 0;
+}
+
+static int sink_close(pv_sink_t *s, int ok)
+{
+    int rc = 0;
+    if (s->enc) {
+        if (ok && sink_drain(s) < 0) { ok = 0; rc = -1; }
+        if (ok) {
+            uint8_t *img = NULL;
+            const int64_t len = bgth_encoder_finish(s->enc, &img);
+            if (len < 0) { fprintf(stderr, "[E::%s] %s\n", __func__, bgth_encoder_last_error()); rc = -1; }
+            else { fwrite(img, 1, (size_t)len, stdout); bgth_encoder_free_image(img); }
+        }
+        bgth_encoder_close(s->enc);
+    }
+    free(s->codes);
+    fflush(stdout);
+    return rc;
+}
+
+/* ---- source 1: PIM text ---- */
+static int pump_text(const pv_job_t *job)
+{
+    FILE *fp = strcmp(job->input, "-") ? fopen(job->input, "r") : stdin;
+    char magic[256];
+    pv_sink_t sink;
+    long cell = 0;
+    int m = 0, g = 0, ok = 1;
+    if (fp == NULL) { fprintf(stderr, "[E::%s] cannot open '%s'\n", __func__, job->input); return 1; }
+    if (fscanf(fp, "%255s%d%d", magic, &m, &g) != 3 || m <= 0 || g <= 0) { fprintf(stderr, "[E::%s] not a PIM file\n", __func__); return 1; }
+    if (sink_open(&sink, job, m, g) < 0) { sink_close(&sink, 0); return 1; }
+    /* Rows are read cell by cell.  The end of the file is noticed only by the read AFTER the last number (the stream's
+     * end-of-file flag, tested before every cell as the reference tests it): that read converts nothing and leaves `cell`
+     * as it was, so after a file that ends in a newline the echo shows the last value once more, without a newline -- the
+     * reference's output, byte for byte; a row that is not complete never reaches the encoder. */
+    while (ok) {
+        while (sink.col < m && !feof(fp)) {
+            if (fscanf(fp, "%ld", &cell) == 0) { fprintf(stderr, "[E::%s] not a number in the PIM input\n", __func__); ok = 0; break; }
+            sink_cell(&sink, cell);
+        }
+        if (!ok || sink.col < m) break;
+        if (sink_end_row(&sink) < 0) ok = 0;
+    }
+    if (fp != stdin) fclose(fp);
+    return sink_close(&sink, ok) < 0 || !ok;
+}
+
+/* ---- source 2: a .pbf through the device reader ---- */
+static int pump_pbf(const pv_job_t *job)
+{
+    bgth_pbf_t *in = bgth_pbf_open(job->input, 0);
+    bgth_reader_t *rd = in ? bgth_reader_create(in) : NULL;
+    pv_sink_t sink;
+    const uint8_t **planes;
+    int64_t left = job->max_rows < 0 ? INT64_MAX : job->max_rows;
+    int m, g, j, ok = 1, opened = 0;
+    if (rd == NULL) { fprintf(stderr, "[E::%s] %s\n", __func__, bgth_last_error()); if (in) bgth_pbf_close(in); return 1; }
+    g = bgth_pbf_get_g(in);
+    if (job->n_cols > 0 && bgth_reader_select(rd, job->n_cols, job->cols, NULL, 1) < 0) { fprintf(stderr, "[E::%s] %s\n", __func__, bgth_last_error()); ok = 0; }
+    /* the width of a row: the columns named, or -- when the list names every column of the file, which pbf_subset treats as
+     * no subset at all (pbwt.c:377) -- still the number named */
+    m = job->n_cols > 0 && job->n_cols < bgth_pbf_get_m(in) ? job->n_cols : bgth_reader_width(rd);
+    if (ok) { opened = 1; if (sink_open(&sink, job, m, g) < 0) ok = 0; }
+    if (ok && job->first_row > 0) {
+        /* pbf_seek from row 0 (pbwt.c:349-372): a target inside the file is reached; one behind the end but inside the forward
+         * window of 1 << shift rows is "reached" by reading into the end -- nothing is left; one behind both makes the seek
+         * fail and leaves the reader at row 0 */
+        if (job->first_row < bgth_pbf_get_n(in)) bgth_reader_seek(rd, job->first_row);
+        else if (job->first_row <= ((int64_t)1 << bgth_pbf_get_shift(in))) left = 0;
+    }
+    for (; ok && left > 0 && (planes = bgth_reader_read(rd)) != NULL; --left) {
+        for (j = 0; j < m; ++j) sink_cell(&sink, planes[0][j] | (g > 1 ? planes[1][j] << 1 : 0));
+        if (sink_end_row(&sink) < 0) ok = 0;
+    }
+    if (opened && sink_close(&sink, ok) < 0) ok = 0;
+    bgth_reader_destroy(rd);
+    bgth_pbf_close(in);
+    return !ok;
 }
 
 int main_pbfview(int argc, char **argv)
 {
-    int c, in_txt = 0, out_pbf = 0, m_sub = 0, n_sub = 0, shift = 13, rc = 0;
-    int32_t *sub = NULL;
-    int64_t row_start = 0, n_rec = -1;
-    bgth_encoder_t *enc = NULL;
-    uint8_t *codes = NULL;
-    while ((c = getopt(argc, argv, "Sbc:r:n:s:")) >= 0) {
-        if (c == 'S') in_txt = 1;
-        else if (c == 'b') out_pbf = 1;
-        else if (c == 'r') row_start = atol(optarg);
-        else if (c == 'n') n_rec = atol(optarg);
-        else if (c == 's') shift = atoi(optarg);
-        else if (c == 'c') {
-            if (n_sub == m_sub) { m_sub = m_sub ? m_sub << 1 : 4; sub = (int32_t*)realloc(sub, (size_t)m_sub * sizeof(int32_t)); }
-            sub[n_sub++] = (int32_t)atol(optarg);
-        }
-    }
-    if (argc == optind) {
-        fprintf(stderr, "Usage: pbfview [options] <in.pbf>|<in.pim>\n");
-        fprintf(stderr, "Options:\n");
-        fprintf(stderr, "  -S       input is PIM (portable integer matrix format)\n");
-        fprintf(stderr, "  -b       output PBF (positional BWT format)\n");
-        fprintf(stderr, "  -s INT   write S array every 1<<INT rows (effective with -b) [%d]\n", shift);
-        fprintf(stderr, "  -r INT   start decoding from row INT (effective w/o -S) [0]\n");
-        fprintf(stderr, "  -n INT   read INT rows starting from -r (effective w/o -S) [inf]\n");
-        fprintf(stderr, "  -c INT   decode column INT (there can be multiple -c; effective w/o -S) [inf]\n");
-        return 1;
-    }
-    if (n_rec < 0) n_rec = INT64_MAX;
-    if (in_txt) {                                               /* PIM text in (ref pbfview.c:41-70) */
-        char magic[256];
-        FILE *fp = strcmp(argv[optind], "-") ? fopen(argv[optind], "r") : stdin;
-        int m = 0, g = 0, i;
-        int64_t n_buf = 0;
-        if (fp == NULL) { fprintf(stderr, "[E::%s] cannot open '%s'\n", __func__, argv[optind]); return 1; }
-        if (fscanf(fp, "%255s%d%d", magic, &m, &g) != 3 || m <= 0 || g <= 0) { fprintf(stderr, "[E::%s] not a PIM file\n", __func__); return 1; }
-        if (out_pbf) {
-            if (g > 2) { fprintf(stderr, "[E::%s] the device codec writes one or two bit planes, the input has %d\n", __func__, g); return 1; }
-            if ((enc = bgth_encoder_open(m, g, shift, 0)) == NULL) { fprintf(stderr, "[E::%s] %s\n", __func__, bgth_encoder_last_error()); return 1; }
-            codes = (uint8_t*)malloc((size_t)m * ROWS_PER_WRITE);
-        } else printf("PIM1 %d %d\n", m, g);
-        {
-        long x = 0;
-        while (!feof(fp)) {
-            /* the reference's loop, quirk included: end-of-file is only noticed one read late, so after a file that ends in
-             * a newline the echo prints the last value once more (no newline after it); the encoder sees no such row */
-            for (i = 0; i < m; ++i) {
-                if (feof(fp)) break;
-                if (fscanf(fp, "%ld", &x) == 0) { fprintf(stderr, "[E::%s] not a number in the PIM input\n", __func__); rc = 1; break; }
-                if (enc) codes[(size_t)n_buf * m + i] = (uint8_t)(x & ((1 << g) - 1));
-                else { if (i) putchar(' '); printf("%ld", x); }
-            }
-            if (i < m) break;                                   /* an incomplete last row is dropped, as the reference does */
-            if (enc) { if (++n_buf == ROWS_PER_WRITE) { if (flush_rows(enc, codes, n_buf) < 0) { rc = 1; break; } n_buf = 0; } }
-            else putchar('\n');
-        }
-        }
-        if (enc && rc == 0 && flush_rows(enc, codes, n_buf) < 0) rc = 1;
-        if (fp != stdin) fclose(fp);
-    } else {                                                    /* PBF in (ref pbfview.c:71-96) */
-        bgth_pbf_t *in = bgth_pbf_open(argv[optind], 0);
-        bgth_reader_t *rd;
-        const uint8_t **a;
-        int m, g, j, k;
-        int64_t i, n_buf = 0;
-        if (in == NULL) { fprintf(stderr, "[E::%s] %s\n", __func__, bgth_last_error()); return 1; }
-        if ((rd = bgth_reader_create(in)) == NULL) { fprintf(stderr, "[E::%s] %s\n", __func__, bgth_last_error()); bgth_pbf_close(in); return 1; }
-        g = bgth_pbf_get_g(in);
-        if (n_sub > 0 && bgth_reader_select(rd, n_sub, sub, NULL, 1) < 0) { fprintf(stderr, "[E::%s] %s\n", __func__, bgth_last_error()); rc = 1; }
-        m = bgth_reader_width(rd);                              /* (all the columns when the list names every one of them, pbwt.c:377) */
-        if (n_sub > 0 && n_sub < bgth_pbf_get_m(in)) m = n_sub;
-        if (rc == 0 && out_pbf) {
-            if ((enc = bgth_encoder_open(m, g, shift, 0)) == NULL) { fprintf(stderr, "[E::%s] %s\n", __func__, bgth_encoder_last_error()); rc = 1; }
-            codes = (uint8_t*)malloc((size_t)m * ROWS_PER_WRITE);
-        } else if (rc == 0) printf("PIM1 %d %d\n", m, g);
-        if (rc == 0 && row_start > 0) {                         /* pbf_seek from row 0 (pbwt.c:349-372) */
-            if (row_start < bgth_pbf_get_n(in)) bgth_reader_seek(rd, row_start);
-            else if (row_start <= ((int64_t)1 << bgth_pbf_get_shift(in))) n_rec = 0;   /* read forward into the end: nothing is left */
-            /* else: behind the end and behind the forward window: the seek fails and the reader stays at row 0 (:359) */
-        }
-        for (i = 0; rc == 0 && i < n_rec && (a = bgth_reader_read(rd)) != NULL; ++i) {
-            if (!enc) {
-                for (j = 0; j < m; ++j) {
-                    unsigned long long x = 0;
-                    for (k = 0; k < g; ++k) x |= (unsigned long long)a[k][j] << k;
-                    if (j) putchar(' ');
-                    printf("%llu", x);
-                }
-                putchar('\n');
-            } else {
-                uint8_t *dst = codes + (size_t)n_buf * m;
-                for (j = 0; j < m; ++j) dst[j] = (uint8_t)(a[0][j] | (g > 1 ? a[1][j] << 1 : 0));
-                if (++n_buf == ROWS_PER_WRITE) { if (flush_rows(enc, codes, n_buf) < 0) rc = 1; n_buf = 0; }
-            }
-        }
-        if (enc && rc == 0 && flush_rows(enc, codes, n_buf) < 0) rc = 1;
-        bgth_reader_destroy(rd);
-        bgth_pbf_close(in);
-    }
-    if (enc) {
-        if (rc == 0 && finish_image(enc) < 0) rc = 1;
-        bgth_encoder_close(enc);
-    }
-    fflush(stdout);
-    free(codes); free(sub);
+    pv_job_t job;
+    int rc;
+    if (pv_parse(&job, argc, argv) < 0) { free(job.cols); return pv_usage(); }
+    rc = job.text_in ? pump_text(&job) : pump_pbf(&job);
+    free(job.cols);
     return rc;
 }

@@ -433,17 +433,17 @@ static image_t **g_retired;
 static int g_n_retired, g_m_retired;
 static pthread_mutex_t g_cache_lock = PTHREAD_MUTEX_INITIALIZER;
 
-/* modification times of the three files of a database (prefix.pbf / .bcf / .spl); 0 on success */
-static int trio_mtimes(const char *pbf_path, struct timespec mt[3])
+/* The three files of a database are named by its PREFIX (prefix.pbf / .bcf / .spl, reference bgt.c:44-58) -- as the client
+ * spelt it, made absolute: a `prefix.pbf` that is a symlink to a differently named file still has its .bcf / .spl beside
+ * the LINK, so nothing is derived from a resolved name.  Modification times of the three; 0 on success. */
+static int trio_mtimes(const char *abs_prefix, struct timespec mt[3])
 {
     static const char *const ext[3] = {"pbf", "bcf", "spl"};
-    char fn[PATH_MAX + 8];
-    const size_t n = strlen(pbf_path) - 3;
+    char fn[2 * PATH_MAX + 8];
     int k;
-    memcpy(fn, pbf_path, n);
     for (k = 0; k < 3; ++k) {
         struct stat st;
-        strcpy(fn + n, ext[k]);
+        snprintf(fn, sizeof(fn), "%s.%s", abs_prefix, ext[k]);
         memset(&mt[k], 0, sizeof(mt[k]));
         if (stat(fn, &st) != 0) { if (k == 0) return -1; continue; }
         mt[k] = st.st_mtim;
@@ -451,30 +451,51 @@ static int trio_mtimes(const char *pbf_path, struct timespec mt[3])
     return 0;
 }
 
+/* the cache key of a database: where its three files really are (two spellings of one database share an image; two
+ * prefixes that share a .pbf but not a .spl do not) */
+static int trio_key(const char *abs_prefix, char *key, size_t cap)
+{
+    static const char *const ext[3] = {"pbf", "bcf", "spl"};
+    char fn[2 * PATH_MAX + 8], real[PATH_MAX];
+    size_t l = 0;
+    int k;
+    for (k = 0; k < 3; ++k) {
+        snprintf(fn, sizeof(fn), "%s.%s", abs_prefix, ext[k]);
+        if (realpath(fn, real) == NULL) { if (k == 0) return -1; real[0] = 0; }
+        if (l + strlen(real) + 2 > cap) return -1;
+        l += (size_t)sprintf(key + l, "%s\n", real);
+    }
+    return 0;
+}
+
 static bgt_file_t *cache_open(const char *prefix, void *ctx)
 {
-    char full[PATH_MAX], pbf[PATH_MAX + 8];
+    char full[2 * PATH_MAX], key[3 * PATH_MAX + 8];
     struct timespec mt[3];
     image_t *img = NULL;
     int i;
     (void)ctx;
-    snprintf(pbf, sizeof(pbf), "%s.pbf", prefix);
-    if (realpath(pbf, full) == NULL || trio_mtimes(full, mt) != 0) return NULL;   /* (the thread's own working directory: see unix_worker) */
+    /* (relative to the thread's own working directory: see unix_worker.  Absolute from here on: the image outlives the query
+     *  and loads its site table lazily, maybe under another query's directory.) */
+    if (prefix[0] == '/') { if (snprintf(full, sizeof(full), "%s", prefix) >= (int)sizeof(full)) return NULL; }
+    else {
+        char cwd[PATH_MAX];
+        if (getcwd(cwd, sizeof(cwd)) == NULL || snprintf(full, sizeof(full), "%s/%s", cwd, prefix) >= (int)sizeof(full)) return NULL;
+    }
+    if (trio_key(full, key, sizeof(key)) != 0 || trio_mtimes(full, mt) != 0) return NULL;
     pthread_mutex_lock(&g_cache_lock);
     for (i = 0; i < g_n_cache; ++i)
-        if (strcmp(g_cache[i].path, full) == 0) {
+        if (strcmp(g_cache[i].path, key) == 0) {
             if (memcmp(g_cache[i].mtime, mt, sizeof(mt)) == 0) img = g_cache[i].img;
             break;
         }
     if (img == NULL && (i < g_n_cache || g_n_cache < BGS_CACHE_MAX)) {
         bgt_file_t *bf;
-        full[strlen(full) - 4] = 0;                                  /* back to the prefix */
         if ((bf = bgt_open(full)) != NULL) {
             if (bgt_file_preload(bf) < 0) fprintf(stderr, "[W::%s] '%s' is not resident yet; the first query will load it\n", __func__, full);
-            strcat(full, ".pbf");
             img = (image_t*)calloc(1, sizeof(image_t));
             img->bf = bf;
-            if (i == g_n_cache) { g_cache[i].path = strdup(full); g_cache[i].img = NULL; ++g_n_cache; }
+            if (i == g_n_cache) { g_cache[i].path = strdup(key); g_cache[i].img = NULL; ++g_n_cache; }
             if (g_cache[i].img) {                                    /* the database was rewritten: the old image retires */
                 image_t *old = g_cache[i].img;
                 if (old->refs == 0) { bgt_close(old->bf); free(old); }
@@ -521,6 +542,23 @@ static int recv_all(int fd, void *buf, size_t len)
     return 0;
 }
 
+/* the bytes of a spool file (written by a query that ran under g_cwd_lock) into the client's descriptor */
+static void spool_to_fd(FILE *spool, int fd)
+{
+    char buf[1 << 16];
+    size_t n;
+    if (fd < 0 || fflush(spool) != 0) return;
+    rewind(spool);
+    while ((n = fread(buf, 1, sizeof(buf), spool)) > 0) {
+        size_t k = 0;
+        while (k < n) {
+            const ssize_t w = write(fd, buf + k, n - k);
+            if (w < 0) { if (errno == EINTR) continue; return; }      /* (EPIPE: the client left) */
+            k += (size_t)w;
+        }
+    }
+}
+
 static __thread int t_private_cwd;                                  /* this thread's chdir() moves nobody else */
 static pthread_mutex_t g_cwd_lock = PTHREAD_MUTEX_INITIALIZER;
 
@@ -541,7 +579,7 @@ static void *unix_worker(void *arg)
     union { struct cmsghdr h; char buf[CMSG_SPACE(2 * sizeof(int))]; } cm;
     struct cmsghdr *c;
     uint32_t body = 0;
-    int fds[2] = {-1, -1}, argc = 0, i, rc = 1, cwd_locked = 0;
+    int fds[2] = {-1, -1}, argc = 0, i, rc = 1, cwd_locked = 0, spooled = 0;
     char *req = NULL, *p, *end, **argv = NULL;
     unsigned char status[2] = {'S', 1};
     FILE *out = NULL, *err = NULL;
@@ -563,9 +601,14 @@ static void *unix_worker(void *arg)
     if (recv_all(fd, req, body) < 0) goto done;
     req[body] = 0; end = req + body;
     if (strcmp(req, "BGTV1") != 0) goto done;
-    out = fdopen(fds[0], "w"); err = fdopen(fds[1], "w");
+    /* Without a private working directory (below) a query holds the process-wide g_cwd_lock while it runs: its answer then
+     * goes to unlinked spool files and reaches the client AFTER the lock is released -- a client that stops reading its pipe
+     * stalls its own thread, not every other query.  With a private directory: straight into the client's
+     * descriptors. */
+    if (!t_private_cwd) { out = tmpfile(); err = tmpfile(); spooled = 1; }
+    else { out = fdopen(fds[0], "w"); err = fdopen(fds[1], "w"); }
     if (!out || !err) goto done;
-    setvbuf(err, NULL, _IONBF, 0);
+    if (!spooled) setvbuf(err, NULL, _IONBF, 0);
     p = req + 6;
     /* this thread has a working directory of its own (unshare(CLONE_FS) when it started): relative paths in the
      * arguments -- databases, -B / -d / -s / -a files -- mean what they mean to the client.  Where the kernel refuses a
@@ -588,6 +631,10 @@ static void *unix_worker(void *arg)
     status[1] = (unsigned char)rc;
 done:
     if (cwd_locked) pthread_mutex_unlock(&g_cwd_lock);
+    if (spooled) {                                                    /* deliver: stderr first (small), then the body */
+        if (err) { spool_to_fd(err, fds[1]); fclose(err); err = NULL; }
+        if (out) { spool_to_fd(out, fds[0]); fclose(out); out = NULL; }
+    }
     if (out) fclose(out); else if (fds[0] >= 0) close(fds[0]);        /* everything is written before the status leaves */
     if (err) fclose(err); else if (fds[1] >= 0) close(fds[1]);
     n = send(fd, status, 2, MSG_NOSIGNAL);
@@ -601,7 +648,7 @@ static void *unix_thread_main(void *arg)
 {
     /* a private working directory per thread: chdir() in one query must not move the others */
     static int warned;
-    t_private_cwd = unshare(CLONE_FS) == 0;
+    t_private_cwd = getenv("BGS_NO_PRIVATE_CWD") == NULL && unshare(CLONE_FS) == 0;   /* (the variable: tests of the fallback) */
     if (!t_private_cwd && !__sync_lock_test_and_set(&warned, 1))
         fprintf(stderr, "[W::%s] unshare(CLONE_FS) failed (%s): queries run one at a time, each in its client's directory\n", __func__, strerror(errno));
     return unix_worker(arg);

@@ -18,12 +18,13 @@ subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bgt_amd", "host")
 
 SYNTH = len(sys.argv) > 3 and sys.argv[3] == "synth"        # third argument: fuzz two generated multi-block databases instead
 REGIONS = ["11", "12", "11:1000-1100", "11:1050-1051", "11:1,100-1,300", "12:500-510", "11:1101", "13", "11:1-999", "12:503"]
-SAMPLES = ['pop=="X"', 'pop=="Y"', 'pop=="Z"', "idx%5==0", "idx<10", "idx>=30", ",A001,A010,A049", ",B002,B039", ":A003,B003", "idx%7==3||pop==\"X\""]
+SAMPLES = ['pop=="X"', 'pop=="Y"', 'pop=="Z"', "idx%5==0", "idx<10", "idx>=30", ",A001,A010,A049", ",B002,B039", ":A003,B003", ",A000,A001,A002,A003,A004,B000,B001", "idx%7==3||pop==\"X\""]
 FILTERS = ["AC>0", "AC==0", "AN>90", "AC/AN>0.2", "AC1>0&&AC2==0", "AC1/AN1>=0.1&&AC2<5", "AC3>0", "AC>1&&AC<10", "AC%2==1", "AN-AC>80"]
 TABLES = ["CHROM,POS,AC,AN", "POS,REF,ALT,END", "AC/AN,AC1,AN1", "POS,(AC+1)*2,AC//3", "CHROM,POS,AC2,AC3"]
 ALLELES = [",11:1010:1:A", ",11:1010:1:A,11:1010:1:C", ",11:1060:1:G,11:1040:1:G", "alleles.txt", ",11:1100:CAG:C,12:500:CAG:C",
            ",11:1060::C", ",11:1020:1:T,11:1030:1:C,11:1050:1:A", ",13:5:1:A"]
-DBS = [["synA"], ["synB"], ["synA", "synB"], ["synB", "synA"], ["ex2"], ["ex3"]]
+DBS = [["synA"], ["synB"], ["synA", "synB"], ["synB", "synA"], ["ex2"], ["ex3"],
+       ["mgsA"], ["mgsA", "mgsB"], ["mgsB", "synA"], ["mgsZ"], ["mgsZ", "mgsA"]]      # `_mgs:i:` tags: tests/golden/make_mgs_golden.py
 
 
 if SYNTH:
@@ -53,7 +54,7 @@ if SYNTH:
 def make():
     a = []
     dbs = rnd.choice(DBS)
-    syn = dbs[0].startswith("s")
+    syn = dbs[0][0] in "sm"
     if rnd.random() < 0.5:
         a += ["-G"]
     if rnd.random() < 0.4:

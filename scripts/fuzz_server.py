@@ -26,18 +26,19 @@ subprocess.check_call(["gcc", "-O1", "-DBGS_REFERENCE_LIB", "-I", os.path.join(R
                        "-o", REF, "-L", refdir, "-l:libbgt_ref.so", "-Wl,-rpath," + refdir, "-lz", "-lm", "-lpthread"])
 
 REGIONS = ["11", "12", "11:1000-1100", "11:1050-1051", "11:1,100-1,300", "12:500-510", "11:1101", "13", "11:1-999", "12:503", "zz"]
-SAMPLES = ['pop=="X"', 'pop=="Y"', 'pop=="Z"', "idx%5==0", "idx<10", "idx>=30", ",A001,A010,A049", ",B002,B039", 'idx%7==3.or.pop=="X"', "pop=="]
+SAMPLES = ['pop=="X"', 'pop=="Y"', 'pop=="Z"', "idx%5==0", "idx<10", "idx>=30", ",A001,A010,A049", ",B002,B039", ",A000,A001,A002,A003,A004,B000,B001", 'idx%7==3.or.pop=="X"', "pop=="]
 FILTERS = ["AC>0", "AC==0", "AN>90", "AC/AN>0.2", "(AC1>0.and.AC2==0)", "AC1/AN1>=0.1&&AC2<5", "AC3>0", "AC>1.AND.AC<10", "AC%2==1", "AN-AC>80", "AC>"]
 TABLES = ["CHROM,POS,AC,AN", "POS,REF,ALT,END", "AC/AN,AC1,AN1", "POS,(AC+1)*2,AC//3", "CHROM,POS,AC2,AC3"]
 ALLELES = [",11:1010:1:A", ",11:1010:1:A,11:1010:1:C", ",11:1060:1:G,11:1040:1:G", ",11:1100:CAG:C,12:500:CAG:C",
            ",11:1060::C", ",11:1020:1:T,11:1030:1:C,11:1050:1:A", ",13:5:1:A", "impact>=2", "cadd>10.5", 'gene=="ABC"', "impact>=99"]
-DBS = [["synA"], ["synB"], ["synA", "synB"], ["synB", "synA"], ["ex2"], ["ex3"]]
+DBS = [["synA"], ["synB"], ["synA", "synB"], ["synB", "synA"], ["ex2"], ["ex3"],
+       ["mgsA"], ["mgsA", "mgsB"], ["mgsB", "synA"], ["mgsZ"], ["mgsZ", "mgsA"]]      # `_mgs:i:` tags: tests/golden/make_mgs_golden.py
 enc = lambda v: urllib.parse.quote(v, safe=rnd.choice(["", "(),:=<>/*%"]) if "%" not in v else "")
 
 
 def make():
     dbs = rnd.choice(DBS)
-    syn = dbs[0].startswith("s")
+    syn = dbs[0][0] in "sm"
     opts, q = [], []
     if rnd.random() < 0.3:
         opts += ["-m", str(rnd.choice([50, 1500, 20000]))]

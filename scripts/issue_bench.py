@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Runs the VALU issue experiments of bgt_amd/csrc/issue_bench.hip (generated by scripts/gen_issue_bench.py) on the GPU
+"""Runs the VALU issue experiments of issue_bench.hip (generated at build time by bgt_amd/csrc/gen/gen_issue_bench.py) on the GPU
 box and writes gpurun_out/issue_bench.json + a text table (copy both to profiles/r04_issue/).
 Usage: python scripts/issue_bench.py [iters] [comma-separated name prefixes]"""
 import ctypes as C

@@ -229,6 +229,62 @@ def test_resident_host_parses_every_query_afresh(tmp_path):
         srv.wait(timeout=30)
 
 
+def _resident_host(sock, env=None):
+    srv = subprocess.Popen([os.path.join(ROOT, "bgt_amd", "bin", "bgt-server"), "-u", sock], stderr=subprocess.PIPE, env=env)
+    t0 = time.time()
+    while not os.path.exists(sock):
+        assert srv.poll() is None and time.time() - t0 < 60, "bgt-server -u did not come up"
+        time.sleep(0.02)
+    return srv
+
+
+@pytest.mark.parametrize("private_cwd", [True, False])
+def test_resident_host_names_the_trio_by_the_prefix_not_by_the_resolved_file(tmp_path, private_cwd):
+    """ADVICE r5.  (1) `db.pbf` is a symlink to a file with ANOTHER name elsewhere: its .bcf / .spl are the ones beside the
+    link (reference bgt.c:44-58 builds the three names from the prefix), not `<resolved name minus .pbf>.bcf`.  (2) Where the
+    kernel gives a worker thread no working directory of its own (BGS_NO_PRIVATE_CWD=1 forces that path here), queries run one
+    at a time under a lock with their answers spooled, and a client that never reads its pipe must not stall the next query.
+    `view -G` touches no genotype: no device needed."""
+    sock = str(tmp_path / "bgt.sock")
+    far, near = tmp_path / "elsewhere", tmp_path / "here"
+    far.mkdir(); near.mkdir()
+    import shutil
+    shutil.copyfile(os.path.join(GOLD, "synA.pbf"), far / "blob-0001.dat")
+    os.symlink(far / "blob-0001.dat", near / "db.pbf")
+    for ext in ("bcf", "bcf.csi", "spl"):
+        shutil.copyfile(os.path.join(GOLD, "synA." + ext), near / ("db." + ext))
+    want = open(os.path.join(GOLD, "expected", "synA_G.out"), "rb").read()
+    srv = _resident_host(sock, None if private_cwd else dict(os.environ, BGS_NO_PRIVATE_CWD="1"))
+    try:
+        env = dict(os.environ, BGT_SERVER=sock)
+        for _ in range(2):                                                        # (the second round is answered from the cache)
+            res = subprocess.run([BGT, "view", "-G", "db"], cwd=near, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120, env=env)
+            assert res.returncode == 0 and res.stdout == want, res.stderr.decode()[-300:]
+            res = subprocess.run([BGT, "view", "-G", str(near / "db")], cwd=far, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120, env=env)
+            assert res.returncode == 0 and res.stdout == want, res.stderr.decode()[-300:]
+        # a client whose stdout nobody reads (a full pipe) beside one that is read: the second must finish
+        r, w = os.pipe()
+        os.set_blocking(w, False)
+        try:
+            while True:
+                os.write(w, b"x" * 4096)                                           # fill the pipe: the very first byte of the answer blocks
+        except BlockingIOError:
+            pass
+        os.set_blocking(w, True)
+        stalled = subprocess.Popen([BGT, "view", "-G", "synA", "synB"], cwd=GOLD, stdout=w, stderr=subprocess.DEVNULL, env=env)
+        os.close(w)
+        try:
+            time.sleep(0.3)
+            res = subprocess.run([BGT, "view", "-G", "db"], cwd=near, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60, env=env)
+            assert res.returncode == 0 and res.stdout == want
+        finally:
+            os.close(r)
+            stalled.wait(timeout=60)
+    finally:
+        srv.terminate()
+        srv.wait(timeout=30)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("args,prefixes", [(["-G", "-C"], ["synA"]), (["-G", "-f", "AC>0"], ["synA", "synB"]),
                                            (["-G", "-s", 'pop=="X"', "-s", 'pop=="Y"'], ["synA"]),

@@ -66,6 +66,18 @@ DEVICE = [
     (["synA"], ["-g", "5"], qs(("s", "idx<3"), "C")),                             # 403: a group smaller than -g
     (["synA"], ["-g", "5"], qs(("s", "idx<30"), "g", "C")),                       # large enough; -g forces no genotypes
     (["ex2"], [], "g"), (["ex3", "ex2"], [], qs("g", "C")),
+    # `_mgs:i:` tags in the .spl (tests/golden/make_mgs_golden.py) against -g, the default for untagged samples
+    # (bgt-server.go:235 bgtm_set_mgs, :319 bgtm_test_mgs; bgt.c:610-653, 678-688)
+    (["mgsA"], [], qs(("s", X), "C")),                                            # tags 2 and 5 hidden, counted all the same
+    (["mgsA"], [], qs(("s", "idx<4"))),                                           # 403: a tag of 5 in a group of four
+    (["mgsA"], [], qs(("s", "idx<5"), "C")),                                      # five: allowed
+    (["mgsA"], ["-g", "3"], qs(("s", "idx<30"), "C")),                            # untagged samples take -g: only tags 0 / 1 shown
+    (["mgsA"], ["-g", "3"], qs(("s", ",A000,A001,A002,A003,A004,A005"), "C")),    # a list names only tags 0 / 1: a group of two
+    (["mgsA", "mgsB"], ["-g", "2"], qs(("s", X), ("s", Y), ("f", "AC1>0"))),
+    (["mgsA", "mgsB"], [], qs("S", ("a", ",11:1060:1:G"), ("s", X), ("s", Y))),   # SP lines skip the hidden
+    (["mgsA", "mgsB"], [], qs("H", "S", ("a", ",11:1060:1:G,11:1040:1:G"))),
+    (["mgsZ"], [], "C"), (["mgsZ", "mgsA"], ["-g", "1"], qs(("s", "idx<12"), "C")),
+    (["mgsZ"], [], qs(("s", "idx<2"))),                                           # 403: tags of 3 in a group of two
 ]
 
 
