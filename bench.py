@@ -56,6 +56,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 SAMPLES = {"c2": 10000, "c3": 100000, "c4": 100000, "small": 2504, "hrc": 32488}   # hrc: the width of the reference's published numbers (HRC r1)
+SEEDS = {"c2": 2, "c3": 3, "c4": 4, "small": 1, "hrc": 7}
 HBM_PEAK_GBS = 8000.0                      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 REF_BIN = os.path.join(ROOT, "oracle", "_ref", "bgt")
 MY_BIN = os.path.join(ROOT, "bgt_amd", "bin", "bgt")
@@ -151,6 +152,17 @@ def compact_record(out, detail_path=None):
             c[key] = {"wall_s": _num(e["wall_s"]), "sites_per_s": _num(e.get("sites_per_s")), "output_lines": e.get("output_lines")}
             if e.get("vs_cpu_baseline"):
                 c[key]["vs_cpu_baseline"] = _num(e["vs_cpu_baseline"])
+    ps = out.get("product_sharded")
+    if isinstance(ps, dict):
+        if "error" in ps:
+            c["product_sharded"] = {"error": str(ps["error"])[:200], "devices": ps.get("devices")}
+        else:
+            bv = ps.get("bgt_view") or {}
+            c["product_sharded"] = {"devices": ps.get("devices"), "ms_per_step": _num(ps.get("ms_per_step")), "sites_per_s": _num(ps.get("sites_per_s")),
+                                    "per_shard_kernel_ms": [_num(x) for x in ps.get("per_shard_kernel_ms", [])], "gather_ms": _num(ps.get("gather_ms")),
+                                    "parity_ok": ps.get("parity_ok"),
+                                    "bgt_view_wall_s": {k: _num((bv.get(k) or {}).get("wall_s")) for k in ("one_device", "sharded")},
+                                    "bgt_view_stdout_identical": bv.get("stdout_identical")}
     if out.get("n_gpus", 1) > 1:
         c["per_rank_kernel_ms"] = [_num(x) for x in out.get("per_rank_kernel_ms", [])]
         c["gather_ms"] = _num(out.get("gather_ms"))
@@ -697,6 +709,80 @@ def c5_record(tmp, n_samples=50000, sites=65536):
     return rec
 
 
+def product_sharded_record(torch, bgt_amd, np, devices, n_samples, sites, seed, steps, tmp, view_cmds=True):
+    """The PRODUCT's multi-GPU path, which `bgt view` takes under BGT_GPUS and which the torch ranks of this script do not:
+    ONE process opens one database file as block-aligned site-range shards, one per listed device (bgth_pbf_open_sharded: a
+    partial image, stream and host thread per shard), and bgth_reader_scan_device gathers the shards' counts on the first
+    device over RCCL (ncclSend / ncclRecv in one group; shards of one device: copies).  Timed: `steps` gathered whole-cohort
+    scans of all `sites` rows, wall clock around enqueue .. root-stream synchronise; per shard the kernel time by HIP events.
+    Checked: the gathered counts against a single-device image of the same file and the plane-popcount identity on every site.
+    Then the command line: `BGT_GPUS=<devices> bgt view -G -f'AC>0'` against the same command on one device."""
+    __import__("bgt_amd").build_host_shell()
+    m = 2 * n_samples
+    prefix = os.path.join(tmp, "full_%d_%d" % (n_samples, sites))
+    if not os.path.exists(prefix + ".pbf"):
+        subprocess.check_call([MY_BIN, "synth", prefix, str(n_samples), str(sites), str(seed)])
+    rec = {"devices": list(devices), "database": "%d samples x %d sites (one .pbf, %d shards)" % (n_samples, sites, len(devices)),
+           "path": "bgth_pbf_open_sharded + bgth_reader_scan_device (RCCL send/recv gather on device %d)" % devices[0]}
+    t0 = time.perf_counter()
+    pbf = bgt_amd.HipPbf.open_sharded(prefix + ".pbf", list(devices))
+    rd = bgt_amd.HipReader(pbf)
+    rec["open_s"] = round(time.perf_counter() - t0, 2)
+    with torch.cuda.device(devices[0]):
+        d = torch.empty((sites, 1, 3), dtype=torch.int32, device="cuda:%d" % devices[0])
+        wall = []
+        with bgt_amd.forced_kernels(bgt_amd.hip.FORCE_REBUILD_ROWS):          # (one-shot figures, like the ranks')
+            for k in range(steps + 1):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                rd.scan_device(0, sites, d.data_ptr())                          # stream = NULL: returns when the gathered counts are there
+                wall.append((time.perf_counter() - t0) * 1e3)
+        wall = wall[1:]                                                          # (the first one warms up)
+        shard_ms = [rd.shard_timing(i)["scan_ms"] for i in range(len(devices))]
+        got = d.cpu().numpy()
+    rec.update({"steps": steps, "ms_per_step": sum(wall) / len(wall), "best_ms": min(wall), "sites_per_s": sites / (sum(wall) / len(wall) * 1e-3),
+                "per_shard_kernel_ms": [round(x, 3) for x in shard_ms],
+                "gather_ms": max(0.0, min(wall) - max(shard_ms)),               # what the step costs beyond its slowest shard's kernel
+                "kernel_path": rd.path()})
+    rd.close()
+    pbf.close()
+    one = bgt_amd.HipPbf.open(prefix + ".pbf", device=devices[0])
+    rd1 = bgt_amd.HipReader(one)
+    want = rd1.scan(0, sites)
+    rd1.close()
+    one.close()
+    rle, lens = bgt_amd.synth_rows(m, 0, sites, seed)
+    ident = popcount_identity(np, got, plane_ones(np, rle, lens)[:sites], m)
+    del rle, lens
+    rec["parity_ok"] = bool(np.array_equal(got, want) and ident)
+    rec["parity"] = {"gathered_equals_single_image": bool(np.array_equal(got, want)), "popcount_identity_ok": ident, "sites": sites}
+    if not rec["parity_ok"]:
+        rec["parity_error"] = "product_sharded: gathered counts differ: %s" % json.dumps(rec["parity"])
+    if view_cmds:
+        cmd = [MY_BIN, "view", "-G", "-f", "AC>0", prefix]
+        runs = {}
+        # (BGT_GPUS: a list of one needs its comma -- "N" alone means devices 0..N-1)
+        for tag, env in (("one_device", {"BGT_GPUS": "%d," % devices[0]}), ("sharded", {"BGT_GPUS": ",".join(str(x) for x in devices)})):
+            best, sig = None, None
+            for _ in range(2):
+                t0 = time.perf_counter()
+                o = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+                dt = time.perf_counter() - t0
+                if o.returncode != 0:
+                    runs[tag] = {"error": o.stderr.decode()[-200:]}
+                    break
+                best = dt if best is None or dt < best else best
+                sig = (hashlib.md5(o.stdout).hexdigest(), len(o.stdout))
+            else:
+                runs[tag] = {"BGT_GPUS": env["BGT_GPUS"], "wall_s": round(best, 3), "stdout_md5": sig[0], "stdout_bytes": sig[1]}
+        same = "error" not in runs.get("one_device", {"error": 1}) and "error" not in runs.get("sharded", {"error": 1}) and \
+            runs["one_device"]["stdout_md5"] == runs["sharded"]["stdout_md5"]
+        rec["bgt_view"] = {"command": "bgt view -G -f 'AC>0' <prefix>", **runs, "stdout_identical": bool(same)}
+        if not same:
+            rec["parity_error"] = "product_sharded: `BGT_GPUS=... bgt view` differs from the one-device run: %s" % json.dumps(runs)[:300]
+    return rec
+
+
 def server_record(prefix, n_sites):
     """The resident query server (bgt_amd/bin/bgt-server, the reference's bgt-server.go restated in C) on the database
     cli_end_to_end wrote: images in HBM once, then per-query latency over HTTP next to one reference `bgt view` process per
@@ -922,7 +1008,7 @@ def sharded_run(args, ctx, workload, steps, warmup, sites_arg):
     n_samples = SAMPLES[workload]
     m = 2 * n_samples
     shift = 13
-    seed = args.seed or {"c2": 2, "c3": 3, "c4": 4, "small": 1, "hrc": 7}[workload]
+    seed = args.seed or SEEDS[workload]
     strong = workload == "c4"
     if strong:                                                # configs[3]: one database, block-aligned shards
         total = sites_arg or 10000000
@@ -1117,6 +1203,10 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the 100,000-sample secondary records (N = 1)")
     ap.add_argument("--secondary-steps", type=int, default=3)
     ap.add_argument("--secondary-sites", type=int, default=0, help="N > 1: total sites of the C4-sharded secondary record (default 10,000,000)")
+    ap.add_argument("--no-product-sharded", action="store_true",
+                    help="skip the product's own multi-GPU path (one process, bgth_pbf_open_sharded over --gpus devices, RCCL gather)")
+    ap.add_argument("--product-devices", default=None,
+                    help="device list of the product_sharded record (default: 0..gpus-1; e.g. 0,0 = two shards on one device)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo = dry run through host copies)")
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--cpt", type=int, default=0)
@@ -1314,10 +1404,33 @@ def main():
                     out["parity_error"] = "C5-cli: " + rec["parity_error"]
             except Exception as e:
                 out["secondary"].append({"name": "C5-cli", "error": repr(e)[:300]})
+    # ---- the PRODUCT's multi-GPU path: after the ranks are done -- they have released their images and left
+    # the process group -- rank 0 ALONE opens one database over all the devices through the C ABI and times its RCCL gather.
+    if world > 1:
+        try:
+            R.release()
+        except Exception:
+            pass
+        torch.cuda.empty_cache()
+        dist.barrier()
+        dist.destroy_process_group()
+    devs = [int(x) for x in args.product_devices.split(",")] if args.product_devices else (list(range(world)) if world > 1 else None)
+    if devs and os.environ.get("BENCH_ALL_RANKS_ON_DEVICE0") and not args.product_devices:
+        devs = [0] * len(devs)                                    # (the dry run of N > 1 on a one-GPU box: N shards on its one device)
+    if rank == 0 and devs and not args.no_product_sharded and headline_wl == "c2":
+        with tempfile.TemporaryDirectory() as ptmp:
+            try:
+                prec = product_sharded_record(torch, bgt_amd, np, devs, SAMPLES["c2"], (args.sites or 1000000) * max(1, world if world > 1 else 1),
+                                              SEEDS["c2"], max(3, min(args.steps, 10)), ptmp)
+                out["product_sharded"] = prec
+                if prec.get("parity_error"):
+                    out["parity_error"] = prec["parity_error"]
+            except Exception as e:                                # the torch-rank headline stands; the record says what happened
+                import traceback
+                out["product_sharded"] = {"error": repr(e)[:300], "traceback_tail": [t[:160] for t in traceback.format_exc().splitlines()[-4:]],
+                                          "devices": devs}
     if rank == 0:
         emit(out, args.detail)
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -2176,6 +2176,13 @@ extern "C" int bgth_reader_last_timing(const bgth_reader_t *rc, float out[3])
     return 0;
 }
 
+// the same for ONE shard of a sharded reader (what bench.py's product_sharded record reports per device); -1 = no such shard
+extern "C" int bgth_reader_shard_timing(const bgth_reader_t *rc, int shard, float out[3])
+{
+    if (!rc || shard < 0 || (size_t)shard >= rc->subs.size()) return -1;
+    return bgth_reader_last_timing(rc->subs[(size_t)shard], out);
+}
+
 extern "C" int bgth_reader_last_path(const bgth_reader_t *rc, float out[4])
 {
     bgth_reader_t *r = const_cast<bgth_reader_t*>(rc);

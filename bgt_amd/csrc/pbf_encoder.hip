@@ -37,7 +37,8 @@ namespace {
 
 constexpr int kThreads = 1024;                 // one word of the bit-vector per thread: m <= 32768
 constexpr int kMaxM = kThreads * 32;             // registers hold the ranks up to here
-constexpr int kMaxWideM = kThreads * 32 * 8;     // beyond: ranks in memory, up to 8 directory words per thread
+constexpr int kMaxWideM = kThreads * 32 * 8;     // beyond: ranks in memory, up to 8 directory words per thread (directory in the LDS)
+constexpr int kMaxHugeM = kThreads * 32 * 64;    // beyond kMaxWideM: the directory in memory too (encode_huge_kernel), 2,097,152 columns
 
 #ifdef BGTH_ABLATE
 #define ENC_ABLATE(a, bits) ((a).debug & (bits))
@@ -61,6 +62,7 @@ struct EncodeArgs {
     int32_t *snap;             // [g][n_snap][m]   permutation before every row with (row & mask) == 0
     const int32_t *snap_base;  // [n_units] index of the first of them in each unit
     int32_t n_snap;
+    uint2 *gdir;               // encode_huge_kernel: [n_units][g][2][1024 WPT + 1] directory entries in memory
     int32_t *status;           // != 0: output capacity exceeded
     int32_t debug;             // profiling build only (make ABLATE=1): BGTH_ENC_DEBUG ablation switches for timing (1 no byte
                                // stores, 2 no run passes, 4 no run list); the shipped encoder compiles them out (ENC_ABLATE = 0)
@@ -392,6 +394,167 @@ __global__ __launch_bounds__(kThreads) void encode_wide_kernel(EncodeArgs a)
     if (EMIT && tid == 0) a.out_len[up] = off;
 }
 
+// ---- cohorts beyond 262,144 columns: the two row directories (16 bytes per 32 columns) no longer fit the LDS either and live
+// in memory, a region per (unit, plane) workgroup (a.gdir: 0.5 MB per plane at 1,000,000 haplotypes -- L2).  encode_wide_kernel's
+// phases word for word; what changes is how the workgroup's waves see each other's directory words: the scatter is an atomic
+// OR performed in the L2, so every access to the directory is an agent-scope atomic (loads and stores that go past the CU's
+// vector cache, which an L2 atomic does not update), and the barriers also wait for memory (vmcnt), not only for the LDS.
+// The reference writer takes any int32 m (pbwt.c:199-219); this path is what lifts the encoder's limit -- speed is not its point.
+__device__ __forceinline__ uint32_t gload(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void gstore(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void mem_barrier() { __threadfence(); __syncthreads(); }
+
+template <int WPT, bool EMIT>
+__global__ __launch_bounds__(kThreads) void encode_huge_kernel(EncodeArgs a)
+{
+    __shared__ uint32_t agg[3][16];
+    constexpr int NWP = kThreads * WPT + 1;
+    const int tid = threadIdx.x, lane = tid & 63, plane = blockIdx.x, unit = blockIdx.y;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = a.m, nw = (m + 31) >> 5;
+    const size_t up = (size_t)unit * a.g + plane;
+    const int64_t r_beg = (int64_t)unit * a.unit_rows;
+    const int64_t r_end = r_beg + a.unit_rows < a.n_rows ? r_beg + a.unit_rows : a.n_rows;
+    uint8_t *out = a.out + up * a.cap;
+    uint32_t *gd = reinterpret_cast<uint32_t*>(a.gdir + up * 2 * (size_t)NWP);    // entry i of directory d: words 2 (d NWP + i) (.x bits), + 1 (.y ones before)
+    int32_t *Qg = a.rank_out + up * m;          // complemented ranks; column c belongs to thread c % 1024 throughout
+    for (int c = tid; c < m; c += kThreads) Qg[c] = ~(a.rank_in ? a.rank_in[up * m + c] : c);
+    for (int i = tid; i < 4 * NWP; i += kThreads) gstore(gd + i, 0u);
+    mem_barrier();
+    const int w0 = tid * WPT;
+    int64_t off = 0;
+    int snap_i = EMIT ? a.snap_base[unit] : 0;
+    // (entry index of rank r = NWP_base + (r >> 5); with the complement q = ~r: r >> 5 = -(q >> 5) - 1)
+    auto entry = [&](int d, int32_t q) -> uint32_t* { return gd + 2 * ((size_t)d * NWP + (size_t)(-(q >> 5) - 1)); };
+    if (r_beg < r_end) {                                    // the first row's bits; later rows are scattered by the step before them
+        const uint8_t *src = a.codes + (size_t)r_beg * a.stride;
+        for (int c = tid; c < m; c += kThreads) {
+            const int32_t q = Qg[c];
+            if ((src[c] >> plane) & 1) atomicOr(entry((int)(r_beg & 1), q), 0x80000000u >> (q & 31));
+        }
+    }
+    for (int64_t r = r_beg; r < r_end; ++r) {
+        const int cur = (int)(r & 1), oth = cur ^ 1;
+        uint32_t *dir = gd + 2 * (size_t)cur * NWP, *other = gd + 2 * (size_t)oth * NWP;
+        if (EMIT && ((a.row0 + r) & a.mask) == 0) {
+            int32_t *S = a.snap + ((size_t)plane * a.n_snap + snap_i) * m;
+            for (int c = tid; c < m; c += kThreads) S[~Qg[c]] = c;
+            ++snap_i;
+        }
+        mem_barrier();                                      // (1) the bit-vector of this row is complete
+        uint32_t pc = 0, le = 0;
+        // (the words are not kept in registers -- WPT is up to 64 --: they are read again where the runs are counted and written)
+        for (int k = 0; k < WPT; ++k) {
+            const int wi = w0 + k;
+            gstore(other + 2 * wi, 0u);
+            const uint32_t w = gload(dir + 2 * wi);
+            pc += (uint32_t)__popc(w);
+            if (EMIT) {
+                const uint32_t wn = gload(dir + 2 * (wi + 1));
+                const uint32_t valid = wi < nw ? ((wi == nw - 1 && (m & 31)) ? (1u << (m & 31)) - 1u : 0xffffffffu) : 0u;
+                const uint32_t last_bit = wi == nw - 1 ? 1u << ((m - 1) & 31) : 0u;
+                const uint32_t ends = (((w ^ (w >> 1 | wn << 31)) & valid) & ~last_bit) | last_bit;
+                if (ends) le = (uint32_t)(wi * 32 + 32 - __builtin_clz(ends));
+            }
+        }
+        const uint32_t incl = wave_incl_add(pc);
+        const uint32_t lmax = EMIT ? wave_incl_max(le) : 0u;
+        if (lane == 63) { agg[0][wave] = incl; agg[1][wave] = lmax; }
+        mem_barrier();                                      // (2)
+        uint32_t ones, start = 0;
+        {
+            const uint32_t va = lane < 16 ? agg[0][lane] : 0u;
+            const uint32_t sa = wave_incl_add(va);
+            ones = lane_value(sa, 15);
+            uint32_t base = (wave ? lane_value(sa, wave - 1) : 0u) + incl - pc;
+            for (int k = 0; k < WPT; ++k) { gstore(dir + 2 * (w0 + k) + 1, base); base += (uint32_t)__popc(gload(dir + 2 * (w0 + k))); }
+            if (EMIT) {
+                const uint32_t vm = lane < 16 ? agg[1][lane] : 0u;
+                const uint32_t sx = wave_incl_max(vm);
+                start = umax(wave ? lane_value(sx, wave - 1) : 0u, wave_shr1(lmax));
+            }
+        }
+        auto ends_of = [&](int wi, uint32_t &w) -> uint32_t {   // where runs end inside word wi (the row's last position always ends one)
+            w = gload(dir + 2 * wi);
+            const uint32_t wn = gload(dir + 2 * (wi + 1));
+            const uint32_t valid = wi < nw ? ((wi == nw - 1 && (m & 31)) ? (1u << (m & 31)) - 1u : 0xffffffffu) : 0u;
+            const uint32_t last_bit = wi == nw - 1 ? 1u << ((m - 1) & 31) : 0u;
+            return (((w ^ (w >> 1 | wn << 31)) & valid) & ~last_bit) | last_bit;
+        };
+        uint32_t nb = 0;
+        if (EMIT) {
+            uint32_t st = start;
+            for (int k = 0; k < WPT; ++k) {
+                uint32_t w;
+                for (uint32_t x = ends_of(w0 + k, w); x;) {
+                    const uint32_t e = (uint32_t)((w0 + k) * 32 + __builtin_ctz(x) + 1);
+                    x &= x - 1u;
+                    nb += run_bytes(e - st);
+                    st = e;
+                }
+            }
+        }
+        const uint32_t incl2 = EMIT ? wave_incl_add(nb) : 0u;
+        if (EMIT && lane == 63) agg[2][wave] = incl2;
+        mem_barrier();                                      // (3) (also: every .y of this row is stored before the step reads it)
+        uint32_t total = 0;
+        if (EMIT) {
+            const uint32_t vb = lane < 16 ? agg[2][lane] : 0u;
+            const uint32_t sb = wave_incl_add(vb);
+            total = lane_value(sb, 15);
+            const uint32_t bbase = wave ? lane_value(sb, wave - 1) : 0u;
+            if (off + (int64_t)total > a.cap) { if (tid == 0) *a.status = 1; break; }      // uniform
+            uint8_t *dst = out + off + bbase + incl2 - nb;
+            uint32_t st = start;
+            for (int k = 0; k < WPT; ++k) {
+                uint32_t w;
+                for (uint32_t x = ends_of(w0 + k, w); x;) {
+                    const uint32_t i = (uint32_t)__builtin_ctz(x);
+                    const uint32_t e = (uint32_t)((w0 + k) * 32) + i + 1u;
+                    x &= x - 1u;
+                    dst += put_run(dst, e - st, (w >> i) & 1u);
+                    st = e;
+                }
+            }
+            if (tid == 0) a.row_len[(size_t)plane * a.n_rows + r] = (int32_t)total;
+            off += total;
+        }
+        // the step of this row fused with the scatter of the next one, as in encode_wide_kernel
+        const int32_t neg_n0 = (int32_t)ones - m;
+        const bool more = r + 1 < r_end;
+        const uint8_t *nsrc = a.codes + (size_t)(more ? r + 1 : r) * a.stride;
+        for (int c0 = tid; c0 < m; c0 += 8 * kThreads) {
+            int32_t q[8];
+            uint32_t nb8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = c0 + j * kThreads;
+                q[j] = c < m ? Qg[c] : -1;
+                nb8[j] = (c < m && more) ? nsrc[c] : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = c0 + j * kThreads;
+                const uint32_t *e = entry(cur, q[j]);
+                const uint32_t ex = gload(e), ey = gload(e + 1);
+                const uint32_t t = ex << (q[j] & 31);
+                const int32_t oi = (int32_t)(ey + (uint32_t)__popc(t));
+                const int32_t qn = (int32_t)t < 0 ? neg_n0 - oi : q[j] + oi;
+                if (c < m) {
+                    Qg[c] = qn;
+                    if ((nb8[j] >> plane) & 1u) atomicOr(entry(oth, qn), 0x80000000u >> (qn & 31));
+                }
+            }
+        }
+    }
+    for (int c = tid; c < m; c += kThreads) {
+        const int32_t rk = ~Qg[c];
+        Qg[c] = rk;
+        if (a.perm_out) a.perm_out[up * m + rk] = c;
+    }
+    if (EMIT && tid == 0) a.out_len[up] = off;
+}
+
 // ---- phase B helpers ------------------------------------------------------------------------------------------
 // The columns of a unit as bits: colbits[(unit * wpu + j) * 2 + plane][col] = bits of the column in rows 32j..32j+31 of the
 // unit (row-block major, so that both this kernel's loads and stores are coalesced).  Planes 0 and 1 only (the parallel
@@ -644,7 +807,9 @@ struct bgth_encoder_s {
     int32_t *d_perms = nullptr;                      // [units + 1][g][m] true order before every unit as position -> column
     uint32_t *d_key[2] = {nullptr, nullptr};
     uint16_t *d_ccls = nullptr;                      // [units][g][m] class of every column in every unit's own order (narrow cohorts)
-    int32_t wpt = 0;                                 // > 0: the wide kernel with this many directory words per thread
+    int32_t wpt = 0;                                 // > 0: the wide kernel with this many directory words per thread (> 8: encode_huge_kernel)
+    uint2 *d_gdir = nullptr;                         // encode_huge_kernel's directories: [units][g][2][1024 wpt + 1]
+    size_t gdir_cap = 0;
     void *d_temp = nullptr;
     size_t temp_bytes = 0;
     int64_t *d_out_len = nullptr;
@@ -676,6 +841,7 @@ extern "C" void bgth_encoder_close(bgth_encoder_t *e)
     if (!e) return;
     hipSetDevice(e->device);
     free_batch_buffers(e);
+    hipFree(e->d_gdir);
     hipFree(e->d_state); hipFree(e->d_status); hipFree(e->d_temp); hipFree(e->d_colbits); hipFree(e->d_packed); hipFree(e->d_packed_in); hipFree(e->d_base); hipHostFree(e->h_out);
     for (int i = 0; i < 2; ++i) hipFree(e->d_key[i]);
     if (e->stream) hipStreamDestroy(e->stream);
@@ -684,7 +850,7 @@ extern "C" void bgth_encoder_close(bgth_encoder_t *e)
 
 extern "C" bgth_encoder_t *bgth_encoder_open(int32_t m, int32_t g, int32_t shift, int device)
 {
-    if (m < 1 || m > kMaxWideM) { enc_err("[E::%s] %d columns: this encoder holds 1..%d", __func__, m, kMaxWideM); return nullptr; }
+    if (m < 1 || m > kMaxHugeM) { enc_err("[E::%s] %d columns: this encoder holds 1..%d", __func__, m, kMaxHugeM); return nullptr; }
     if (g < 1 || g > 8 || shift < 0 || shift > 30) { enc_err("[E::%s] bad plane count or checkpoint shift", __func__); return nullptr; }
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) {
@@ -697,10 +863,11 @@ extern "C" bgth_encoder_t *bgth_encoder_open(int32_t m, int32_t g, int32_t shift
     e->stride = e->cpt * kThreads;
     if (m > kMaxM) {
         const int nw = (m + 31) / 32;
-        e->wpt = nw <= 2 * kThreads ? 2 : nw <= 4 * kThreads ? 4 : 8;
+        e->wpt = nw <= 2 * kThreads ? 2 : nw <= 4 * kThreads ? 4 : nw <= 8 * kThreads ? 8 : nw <= 16 * kThreads ? 16 : nw <= 32 * kThreads ? 32 : 64;
         e->stride = (m + 3) & ~3;
     }
     if (e->wpt) e->unit_rows = 1024;                 // wide rows are slow and large: smaller units, more of them at once
+    if (e->wpt > 8) e->unit_rows = 512;              // (beyond 262,144 columns: 0.5 GB of codes per unit at a million)
     if (const char *u = getenv("BGTH_ENC_UNIT_SHIFT")) {
         const int us = atoi(u);
         if (us >= 1 && us <= 20) { e->unit_rows = 1 << us; e->unit_fixed = true; }
@@ -716,7 +883,7 @@ extern "C" bgth_encoder_t *bgth_encoder_open(int32_t m, int32_t g, int32_t shift
     for (int i = 0; i < 2; ++i) {
         ENC_TRY(hipMalloc(&e->d_key[i], (size_t)g * m * 4), { bgth_encoder_close(e); return nullptr; });
     }
-    ENC_TRY(rocprim::radix_sort_pairs(nullptr, e->temp_bytes, e->d_key[0], e->d_key[1], (int32_t*)nullptr, (int32_t*)nullptr, (unsigned)(g * m), 0, 20,
+    ENC_TRY(rocprim::radix_sort_pairs(nullptr, e->temp_bytes, e->d_key[0], e->d_key[1], (int32_t*)nullptr, (int32_t*)nullptr, (unsigned)(g * m), 0, 22,
                                       e->stream), { bgth_encoder_close(e); return nullptr; });
     ENC_TRY(hipMalloc(&e->d_temp, e->temp_bytes ? e->temp_bytes : 16), { bgth_encoder_close(e); return nullptr; });
     std::vector<int32_t> ident((size_t)g * m);
@@ -761,6 +928,12 @@ template <bool EMIT>
 static void launch_encode(const bgth_encoder_t *e, const EncodeArgs &a, int n_units)
 {
     const dim3 grid((unsigned)e->g, (unsigned)n_units), block(kThreads);
+    if (e->wpt > 8) {                                   // directories in memory: any number of words per thread
+        if (e->wpt == 16)      hipLaunchKernelGGL((encode_huge_kernel<16, EMIT>), grid, block, 0, e->stream, a);
+        else if (e->wpt == 32) hipLaunchKernelGGL((encode_huge_kernel<32, EMIT>), grid, block, 0, e->stream, a);
+        else                   hipLaunchKernelGGL((encode_huge_kernel<64, EMIT>), grid, block, 0, e->stream, a);
+        return;
+    }
     if (e->wpt) {
         const size_t lds = (size_t)2 * (kThreads * e->wpt + 1) * sizeof(uint2);
         if (e->wpt == 2) {
@@ -806,6 +979,14 @@ static int encode_batch(bgth_encoder_t *e, const uint8_t *codes, int64_t rows, b
         if (((e->n + r) & mask) == 0) ++n_snap;
     }
     if (ensure_capacity(e, (int64_t)n_units * unit_rows, n_units, n_snap) < 0) return -1;
+    if (e->wpt > 8) {
+        const size_t need = (size_t)n_units * e->g * 2 * ((size_t)kThreads * e->wpt + 1);
+        if (need > e->gdir_cap) {
+            hipFree(e->d_gdir); e->d_gdir = nullptr; e->gdir_cap = 0;
+            ENC_TRY(hipMalloc(&e->d_gdir, need * sizeof(uint2)), return -1);
+            e->gdir_cap = need;
+        }
+    }
     const double t_alloc = now_ms();
     const size_t gm = (size_t)g * m;
     EncodeArgs a;
@@ -816,7 +997,7 @@ static int encode_batch(bgth_encoder_t *e, const uint8_t *codes, int64_t rows, b
     a.debug = 0;
 #endif
     a.out = e->d_out; a.cap = unit_rows * (int64_t)m; a.out_len = e->d_out_len; a.row_len = e->d_row_len;
-    a.snap = e->d_snap; a.snap_base = e->d_snap_base; a.n_snap = n_snap; a.status = e->d_status;
+    a.snap = e->d_snap; a.snap_base = e->d_snap_base; a.n_snap = n_snap; a.status = e->d_status; a.gdir = e->d_gdir;
     if (packed) {                                           // a quarter of the bytes over PCIe, spread on the device
         const size_t nb = (size_t)rows * ((m + 3) >> 2);
         if (nb > e->packed_in_cap) {
@@ -857,7 +1038,7 @@ static int encode_batch(bgth_encoder_t *e, const uint8_t *codes, int64_t rows, b
         hipEvent_t evb0 = nullptr, evb1 = nullptr;
         if (trace && hipEventCreate(&evb0) == hipSuccess && hipEventCreate(&evb1) == hipSuccess) hipEventRecord(evb0, e->stream);
         const unsigned nk = (unsigned)gm, kb = (nk + 255) / 256;
-        const int cbits = e->wpt ? 18 : 15;                 // bits of a class number
+        const int cbits = e->wpt > 8 ? 21 : e->wpt ? 18 : 15;   // bits of a class number (< m)
         hipLaunchKernelGGL(invert_kernel, dim3(kb), dim3(256), 0, e->stream, m, (int64_t)gm, e->d_state, e->d_perms);
         if (!e->wpt && !getenv("BGTH_ENC_LIBSORT")) {
             // one launch for the whole chain: a workgroup per plane, the order resident in LDS (order_chain_kernel)

@@ -488,6 +488,14 @@ class HipReader:
         lib().bgth_reader_last_timing(self.h, t)
         return {"scan_ms": t[0], "finalize_ms": t[1], "total_ms": t[2]}
 
+    def shard_timing(self, shard):
+        t = (C.c_float * 3)()
+        L = lib()
+        L.bgth_reader_shard_timing.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        if L.bgth_reader_shard_timing(self.h, shard, t) < 0:
+            raise IndexError("no shard %d" % shard)
+        return {"scan_ms": t[0], "finalize_ms": t[1], "total_ms": t[2]}
+
     def path(self):
         t = (C.c_float * 4)()
         lib().bgth_reader_last_path(self.h, t)

@@ -1758,6 +1758,23 @@ static int read_core(bgtm_t *bm, bcf1_t *b)
     return 0;
 }
 
+/* After bgtm_read the reference leaves the merged site's two byte planes in bm->a (bgt.c:829-842: a[0][j] = low bit,
+ * a[1][j] = high bit of haplotype j's 2-bit code; a database without the site contributes code 2).  The device hands this
+ * reader the finished GT vector instead (bytes 2, 4, 0, 6 for codes 0..3, bgt.c:250), which read_core merged into
+ * bm->a[0]: once the record has taken its copy, the vector is turned back into the planes IN PLACE, so a caller that
+ * reads bm->a after bgtm_read finds what bgt.h:70 promises (two compares per byte; auto-vectorised). */
+static void planes_from_gt8(bgtm_t *bm)
+{
+    uint8_t *restrict lo = bm->a[0], *restrict hi = bm->a[1];
+    const size_t n = (size_t)bm->n_out << 1;
+    size_t j;
+    for (j = 0; j < n; ++j) {
+        const uint8_t v = lo[j];
+        hi[j] = (uint8_t)((v == 0) | (v == 6));
+        lo[j] = (uint8_t)((v == 4) | (v == 6));
+    }
+}
+
 int bgtm_read(bgtm_t *bm, bcf1_t *b)                          /* ref bgt.c:880-888 */
 {
     int ret;
@@ -1765,7 +1782,10 @@ int bgtm_read(bgtm_t *bm, bcf1_t *b)                          /* ref bgt.c:880-8
     while ((ret = read_core(bm, b)) > 0) {}
     if (ret == -1 && bm->h_al && sync_folds(bm) < 0) ret = -2;  /* the end: bm->alcnt / bm->hap are complete for callers that read them */
     if (ret >= 0 && (bm->flag & BGT_F_NO_GT) == 0) {
-        if (bm->n_bgt > 0 && (((devrd_t*)bm->bgt[0]->pb)->want & BGTH_WANT_GT8)) gen_gt8(bm->h_out, b, bm->n_out, bm->a[0]);
+        if (bm->n_bgt > 0 && (((devrd_t*)bm->bgt[0]->pb)->want & BGTH_WANT_GT8)) {
+            gen_gt8(bm->h_out, b, bm->n_out, bm->a[0]);
+            planes_from_gt8(bm);                              /* bm->a as bgt.h:70 promises it to the caller */
+        }
         else gen_gt(bm->h_out, b, bm->n_out, (const uint8_t *const*)bm->a, bm->mgs);
     }
     return ret;

@@ -111,7 +111,8 @@ int64_t     bgth_pbf_rle_bytes(const bgth_pbf_t *p);   /* total RLE payload     
  * The image is byte for byte the file the reference writer produces from the same rows.  `codes` is a HOST array
  * [n_rows][m], bit k of a byte = the bit of plane k (what import.c:96-97 hands to pbf_write as g byte arrays).
  * A call is cut into units of 4096 rows (1024 above 32768 columns) that are encoded in parallel, so hand over rows in
- * bulk; m <= 262144 columns in this version.  No CPU path. */
+ * bulk; m <= 2,097,152 columns (beyond 262,144 the row directories live in memory instead of the LDS: slower, same bytes).
+ * No CPU path. */
 typedef struct bgth_encoder_s bgth_encoder_t;
 bgth_encoder_t *bgth_encoder_open(int32_t m, int32_t g, int32_t shift, int device);      /* NULL on failure       */
 int             bgth_encoder_write(bgth_encoder_t *e, const uint8_t *codes, int64_t n_rows);   /* <0 on failure   */
@@ -206,6 +207,8 @@ int bgth_reader_take_folds(bgth_reader_t *r, int32_t *carriers, uint64_t *hap);
 /* Timing of the last scan on the device (HIP events on the launch stream), milliseconds:
  * out[0] = decode kernel, out[1] = finalize kernel, out[2] = whole enqueue..done. */
 int bgth_reader_last_timing(const bgth_reader_t *r, float out[3]);
+/* ... of shard `shard` of a reader over a sharded image alone (last_timing reports the slowest shard); -1: no such shard */
+int bgth_reader_shard_timing(const bgth_reader_t *r, int shard, float out[3]);
 /* Launch geometry of the last scan: out = {threads, cols_per_thread, slices, rows_per_batch,
  * lds_bytes, workgroups}. */
 int bgth_reader_last_geometry(const bgth_reader_t *r, int out[6]);

@@ -14,8 +14,10 @@
  *   bgt_file_t::gpu    (appended member) the HBM image of prefix.pbf shared by the readers of the file
  *   bgt_t::pb          the reader's device side: a bgth_reader_t, possibly over a partial image of its own
  *   bgt_t::bcf, ::itr  cursor / region state over the site table
- *   bgtm_t::a          with genotypes on and no sample masked out: a[0] = the finished BCF GT vector of the merged
- *                      site, a[1] = its VCF text (when requested), instead of the two byte planes
+ *   bgtm_t::a          after bgtm_read(): the two byte planes of the merged site, as in the reference (bgt.c:829-842;
+ *                      tests/test_api_harness.py reads them through both libraries).  Two departures: with
+ *                      BGT_F_NO_GT no genotype is decoded at all (counts only), so bm->a is not filled; and the text
+ *                      extension bgtm_read_vcf() leaves the device's GT vector / VCF text there instead
  * Everything `bgt view` of the reference does is served; import / atomize and the server are not part of this
  * library.
  */

@@ -69,7 +69,7 @@ static int do_server(int argc, char **argv)
         ++n_files;
     }
     bm = bgtm_reader_init(n_files, files);                              /* bgt-server.go:233 */
-    bgtm_set_mgs(bm, 1);                                                /* :235 */
+    bgtm_set_mgs(bm, getenv("API_DUMP_MGS") ? atoi(getenv("API_DUMP_MGS")) : 1);   /* :235 (the server's -g; 1 when unset) */
     {   /* flags first (:237-254), then the setters in the server's order: f r i n t a s */
         int k;
         const char *order = "fritnas";
@@ -101,6 +101,11 @@ static int do_server(int argc, char **argv)
         if (n_read > max_read || bm->n_gt_read > max_gt) break;
         if ((ret = bgtm_read(bm, b)) < 0) break;
         if (vcf_out) { s.l = 0; vcf_format1(bm->h_out, b, &s); printf("%s\n", s.s); }   /* bgtm_format_bcf1, :24-29 */
+        if (!(flag & BGT_F_NO_GT) && bm->n_out > 0) {                   /* bgt.h:70: the merged site's two byte planes (bgt.c:829-842) */
+            hex("a0", (const char*)bm->a[0], (size_t)bm->n_out << 1);
+            hex("a1", (const char*)bm->a[1], (size_t)bm->n_out << 1);
+            printf("\n");
+        }
         else if (bm->n_fields > 0) printf("%s\n", bm->tbl_line.s);      /* :348 */
         ++n_read;
     }

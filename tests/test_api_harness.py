@@ -76,6 +76,14 @@ def test_bgt_read_on_a_multi_block_database(harness, tmp_path):
     ["server", "100000", "synA", "synB", "--", "-s", "pop==\"X\"", "-t", "CHROM,POS,REF,ALT,AC1,AN1"],
     ["server", "100000", "synA", "--", "-S", "-a", ",11:1000:C:G,11:1030:TAG:T"],
     ["server", "100000", "synA", "--", "-H", "-a", ",11:1000:C:G,11:1030:TAG:T", "-s", "pop==\"X\"", "-s", "pop==\"Y\""],
+    # with genotypes on the harness also prints bm->a[0] / bm->a[1] after every bgtm_read: the merged site's two byte planes
+    # (bgt.h:70, bgt.c:829-842) -- two databases with sites only one of them has (the code-2 fill), and `_mgs` tags that hide
+    # samples from the record (bgt.c:290-313) but not from the planes
+    ["server", "100000", "synA", "synB", "--", "-g"],
+    ["server", "100000", "synB", "synA", "--", "-g", "-s", "pop==\"X\"", "-s", "pop==\"Y\"", "-f", "AC1>0"],
+    ["server", "100000", "mgsA", "--", "-g", "-C"],
+    ["server", "100000", "mgsA", "mgsB", "--", "-g", "-s", "idx<12"],
+    ["server", "100000", "mgsZ", "mgsA", "--", "-g", "-C", "-r", "11:1000-1100"],
 ])
 def test_server_call_sequence_like_the_reference(harness, args):
     mine, ref = both(harness, args)

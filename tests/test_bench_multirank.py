@@ -68,3 +68,24 @@ def test_default_run_of_two_ranks_carries_the_sharded_c4_record(tmp_path):
     assert sec["scaling"] == "strong" and sec["config"]["haplotypes"] == 200000 and sec["value"] > 0
     assert sec["parity_ok"] is True and sec["parity"]["sites_checked_popcount_identity"] == sec["config"]["sites_total"]
     assert "parity_error" not in out
+    # ... and the PRODUCT's multi-GPU path, timed by rank 0 alone after the ranks have left: one process, the same database file
+    # dealt over the devices by bgth_pbf_open_sharded, counts gathered by bgth_reader_scan_device; `BGT_GPUS=... bgt view` beside it
+    ps = out["product_sharded"]
+    assert "error" not in ps, ps
+    assert ps["devices"] == [0, 0] and ps["parity_ok"] is True and ps["parity"]["sites"] == 80000 and len(ps["per_shard_kernel_ms"]) == 2
+    assert ps["ms_per_step"] > 0 and ps["gather_ms"] >= 0 and ps["bgt_view"]["stdout_identical"] is True
+    assert short["product_sharded"]["parity_ok"] is True and short["product_sharded"]["bgt_view_stdout_identical"] is True
+
+
+def test_product_sharded_record_on_one_rank(tmp_path):
+    """`--product-devices 0,0,0` on a plain N = 1 run: three shards of one database on the box's one device, gathered through RCCL
+    rank-to-itself as well (BGTH_FORCE_RCCL_TO_SELF is the library's test knob for the send / receive pairs)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--sites", "50000", "--no-secondary",
+           "--cpu-sample", "0", "--no-counters", "--product-devices", "0,0,0", "--detail", str(tmp_path / "detail.json")]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200, cwd=ROOT)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    short = json.loads(p.stdout.decode().splitlines()[-1])
+    ps = json.load(open(tmp_path / "detail.json"))["product_sharded"]
+    assert "error" not in ps, ps
+    assert ps["devices"] == [0, 0, 0] and ps["parity_ok"] is True and len(ps["per_shard_kernel_ms"]) == 3 and ps["parity"]["sites"] == 50000
+    assert short["product_sharded"]["parity_ok"] is True

@@ -67,7 +67,7 @@ def test_full_length_from_row_zero(name, n_samples, sites, seed, every, view_arg
     r = md5_stdout([ref, "view"] + view_args + [prefix], 900)
     mine = md5_stdout([BGT, "view"] + view_args + [prefix], 600)
     assert r[0] == mine[0] == 0, (r, mine)
-    assert r[2] > 40 * sites and r[1:3] == mine[1:3], (name, r, mine)
+    assert r[2] > 30 * sites and r[1:3] == mine[1:3], (name, r, mine)
 
     # (2) the counts: one sequential oracle pass over the FILE from the identity order of row 0 ...
     sel = np.arange(0, n_samples, every) if every else None
