@@ -199,7 +199,8 @@ struct bgth_pbf_s {
     int32_t g_file = 0;               // planes of the file when that is 1 (prefix.pb1, `bgt import -1`): the image then carries an
                                       // empty second plane, see expand_one_plane(); 0 = as g
     int32_t sub_shift = 0;            // sub-checkpoints every 1 << sub_shift rows (<= shift), see derive_sub_checkpoints
-    bool wide_plane = false;          // 327,000 < m <= 650,000: a row's two bit-vectors do not fit the LDS together; every scan
+    bool mem_plane = false;           // m > 650,000: not even one of them does -- toggles and entries in memory (the *_mem kernels)
+    bool wide_plane = false;          // 327,000 < m: a row's two bit-vectors do not fit the LDS together; every scan
                                       // takes the directory path with one plane per workgroup (scan_plane.hip), no sub-checkpoints
     bool one_shot = false;            // opened with BGTH_OPEN_HINT=walk: no sub-checkpoints, arena passes of one round of workgroups
     int64_t n = 0, n_blk = 0;         // n_blk: file blocks of 1 << shift rows
@@ -393,6 +394,7 @@ struct bgth_reader_s {
     // directory path: the arena of {bits, ones before} rows and their zero counts; [dir_lo, dir_hi) = image rows it holds
     // from the last producer pass (a later scan inside that range only walks), dir_passes/dir_built = what the last scan did
     DevBuf dir, dir_n0;
+    DevBuf tog_mem;                   // cohorts beyond 650,000 haplotypes: the producer's toggle words (dirbuild_mem_kernel)
     int64_t dir_lo = 0, dir_hi = 0;
     hipStream_t dir_stream = nullptr; // the stream the arena was filled on (another stream would have to wait for it)
     int dir_passes = 0, dir_built = 0;
@@ -600,19 +602,23 @@ static bgth_pbf_t *pbf_alloc(int device, int m, int g, int shift, int64_t n)
     if (g != 2) { set_err("[E::bgth_pbf] g=%d bit planes: this build holds BGT's two planes (import.c:68) and, for whole files, the one plane of a .pb1", g); return nullptr; }
     if (m <= 0 || shift < 0 || shift > 30) { set_err("[E::bgth_pbf] bad header m=%d shift=%d", m, shift); return nullptr; }
     Geometry geo;
-    bool wide_plane = false;
+    bool wide_plane = false, mem_plane = false;
     if (!choose_geometry(m, (m + 63) / 64, 1, 1, 0, 0, 0, &geo)) {
         // both bit-vectors of a row (m / 2 bytes with their rank directories) do not fit the 160 KiB LDS: one plane per
         // workgroup does, up to m / 4 bytes = 160 KiB
+        // ... and beyond 650,000 haplotypes not even that: the producer keeps its toggle words and the walk reads its entries in
+        // memory (dirbuild_mem_kernel / walk_mem_kernel: any m the row index addresses -- 30 bits of position)
         if (!choose_walk_plane_geometry(m, (m + 63) / 64, 1, &geo)) {
-            set_err("[E::bgth_pbf] m=%d columns: one bit-vector of a row with its rank directory (m / 4 bytes) does not fit the 160 KiB LDS; "
-                    "this build reads cohorts of up to 650,000 haplotypes", m);
-            return nullptr;
+            if (m > (1 << 30) || ((((m + 31) / 32) + 255) >> 8) > 63 * 16) {
+                set_err("[E::bgth_pbf] m=%d columns: this build reads cohorts of up to 264,241,152 haplotypes", m);
+                return nullptr;
+            }
+            mem_plane = true;
         }
         wide_plane = true;
     }
     bgth_pbf_t *p = new bgth_pbf_s();
-    p->device = device; p->m = m; p->g = g; p->shift = shift; p->wide_plane = wide_plane;
+    p->device = device; p->m = m; p->g = g; p->shift = shift; p->wide_plane = wide_plane; p->mem_plane = mem_plane;
     // Sub-checkpoints: the file carries the permutation every 1 << shift (8192) rows; the image keeps the rank
     // form every 1 << sub_shift rows, derived once on the device.  Finer units = more workgroups per launch (a
     // whole-cohort scan of few blocks fills the GPU without slicing columns, which would repeat the per-row
@@ -1563,7 +1569,7 @@ static void reader_free(bgth_reader_t *r)
     r->raw.release(); r->fin.release(); r->h0.release(); r->h1.release(); r->gt.release();
     r->carriers.release(); r->hapsig.release();
     r->win[0].release(); r->win[1].release();
-    r->dir.release(); r->dir_n0.release();
+    r->dir.release(); r->dir_n0.release(); r->tog_mem.release();
     r->ph0.release(); r->ph1.release();
     for (int i = 0; i < 4; ++i) if (r->ev[i]) hipEventDestroy(r->ev[i]);
     for (int i = 0; i < 2; ++i) if (r->ev_dir[i]) hipEventDestroy(r->ev_dir[i]);
@@ -1744,7 +1750,8 @@ static int64_t enqueue_scan_wide_plane(bgth_reader_t *r, int64_t row0, int64_t r
     const int G = r->sel.G;
     const int64_t blk0 = row0 >> p->sub_shift, blk1 = (row1 - 1) >> p->sub_shift;
     Geometry wg;
-    if (!choose_walk_plane_geometry(p->m, r->sel.n_chunks, (int)(blk1 - blk0 + 1), &wg)) { set_err("[E::bgth_reader_scan] no launch geometry for m=%d", p->m); return -1; }
+    if (p->mem_plane) choose_walk_mem_geometry(p->m, r->sel.n_chunks, (int)(blk1 - blk0 + 1), &wg);
+    else if (!choose_walk_plane_geometry(p->m, r->sel.n_chunks, (int)(blk1 - blk0 + 1), &wg)) { set_err("[E::bgth_reader_scan] no launch geometry for m=%d", p->m); return -1; }
     r->geom = wg; r->plane_path = 1; r->dir_passes = r->dir_built = 0;
     if (!r->raw.reserve((size_t)rows * G * 3 * 4)) { set_err("[E::bgth_reader_scan] out of HBM"); return -1; }
     ScanArgs a;
@@ -1768,6 +1775,11 @@ static int64_t enqueue_scan_wide_plane(bgth_reader_t *r, int64_t row0, int64_t r
     }
     r->dir_lo = r->dir_hi = 0;
     a.dir = (uint2*)r->dir.p; a.dir_n0 = (uint32_t*)r->dir_n0.p; a.dir_nwp = nwp; a.dir_stage = wg.dir_stage;
+    a.tog_mem = nullptr;
+    if (p->mem_plane) {                                  // the producer's toggle words live in memory: two arrays per workgroup
+        if (!r->tog_mem.reserve((size_t)dirbuild_mem_workgroups(pass_rows) * 2 * (size_t)dirbuild_mem_words(p->m) * 4)) { set_err("[E::bgth_reader_scan] out of HBM (toggle words)"); return -1; }
+        a.tog_mem = (uint32_t*)r->tog_mem.p;
+    }
     if (timed) { HIP_TRY(hipEventRecord(r->ev[0], s), return -1); HIP_TRY(hipEventRecord(r->ev[1], s), return -1); }
     for (int64_t b = blk0; b <= blk1; b += per_pass) {
         const int64_t be = std::min(blk1 + 1, b + per_pass);
@@ -1778,10 +1790,10 @@ static int64_t enqueue_scan_wide_plane(bgth_reader_t *r, int64_t row0, int64_t r
         if (d_h0) { a.h0 = d_h0; a.h1 = d_h1; a.h_row0 = row0; }
         else { a.h0 = (uint64_t*)r->ph0.p; a.h1 = (uint64_t*)r->ph1.p; a.h_row0 = e0; }
         if (timed && b == blk0) HIP_TRY(hipEventRecord(r->ev_dir[0], s), return -1);
-        HIP_TRY(launch_dirbuild(a, lo, hi, s), return -1);
+        HIP_TRY(p->mem_plane ? launch_dirbuild_mem(a, lo, hi, s) : launch_dirbuild(a, lo, hi, s), return -1);
         if (timed && b == blk0) HIP_TRY(hipEventRecord(r->ev_dir[1], s), return -1);
         ++r->dir_built;
-        HIP_TRY(launch_walk_plane(a, pg, s), return -1);
+        HIP_TRY(p->mem_plane ? launch_walk_mem(a, pg, s) : launch_walk_plane(a, pg, s), return -1);
         const size_t hoff = d_h0 ? (size_t)(e0 - row0) * r->sel.n_chunks : 0;
         HIP_TRY(launch_count_planes(a.h0 + hoff, a.h1 + hoff, r->sel.d_chunk_desc, (int32_t*)r->raw.p + (size_t)(e0 - row0) * G * 3,
                                     hi - e0, r->sel.n_chunks, G, s), return -1);

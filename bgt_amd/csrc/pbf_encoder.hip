@@ -39,6 +39,7 @@ constexpr int kThreads = 1024;                 // one word of the bit-vector per
 constexpr int kMaxM = kThreads * 32;             // registers hold the ranks up to here
 constexpr int kMaxWideM = kThreads * 32 * 8;     // beyond: ranks in memory, up to 8 directory words per thread (directory in the LDS)
 constexpr int kMaxHugeM = kThreads * 32 * 64;    // beyond kMaxWideM: the directory in memory too (encode_huge_kernel), 2,097,152 columns
+static_assert(kMaxM < kMaxWideM && kMaxWideM < kMaxHugeM, "three regimes: ranks in registers | ranks in memory | directory in memory too");
 
 #ifdef BGTH_ABLATE
 #define ENC_ABLATE(a, bits) ((a).debug & (bits))

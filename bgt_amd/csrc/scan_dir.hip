@@ -169,6 +169,76 @@ __global__ __launch_bounds__(NT) void dirbuild_solo_kernel(const ScanArgs a, con
     }
 }
 
+// ... and for plane-rows whose toggle words do not fit the LDS (more than 650,000 haplotypes: 2 x m / 8 bytes): the same team, the
+// same two alternating toggle arrays, in MEMORY -- a region per workgroup of a.tog_mem.  The toggles are atomic XORs performed in
+// the L2, which the CU's vector cache does not see: the barrier between a plane-row's toggles and its directory trips therefore
+// also waits for memory and invalidates that cache (__threadfence: release + acquire at device scope), and so does the one that
+// orders the trips' clearing stores before the next toggles.  chunk_toggles / directory_trips_tog are the LDS kernels' own.
+// The reference opens any int32 m (pbwt.c:92-105, 221-262); speed is not this path's point.
+__device__ __forceinline__ void mem_barrier() { __threadfence(); __syncthreads(); __threadfence(); }
+
+template <int NT>
+__global__ __launch_bounds__(NT) void dirbuild_mem_kernel(const ScanArgs a, const uint64_t *__restrict__ rowdesc,
+                                                          const uint8_t *__restrict__ rle, const uint32_t *__restrict__ chunkinfo,
+                                                          const uint32_t *__restrict__ segc, int64_t str_lo, int64_t str_hi, int per_wg)
+{
+    constexpr int WPP = NT / 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int tw = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = a.m, nw = a.nw, nwp = a.dir_nwp;
+    const int nwt = (nw + 4) & ~3;
+    uint32_t *TOG = a.tog_mem + (size_t)blockIdx.x * 2 * (size_t)nwt;    // [2][nwt], this workgroup's
+    for (int i = tid; i < 2 * nwt; i += NT) TOG[i] = 0u;
+    mem_barrier();
+    const uint32_t tail_mask = (m & 31) ? ((1u << (m & 31)) - 1u) : 0xffffffffu;
+    const int ntrip = (nw + 255) >> 8;                                   // (<= 63 WPP trips: checked at launch)
+    const int64_t s0 = str_lo + (int64_t)blockIdx.x * per_wg;
+    int64_t s1 = s0 + per_wg;
+    if (s1 > str_hi) s1 = str_hi;
+    for (int64_t sidx = s0; sidx < s1; ++sidx) {
+        uint32_t *trow = TOG + (size_t)((sidx - s0) & 1) * nwt;
+        const uint64_t cd0 = rowdesc[sidx];
+        const uint32_t slen = (uint32_t)(cd0 >> kDescLenShift);
+        const uint64_t off = cd0 & kDescOffMask;
+        const uint32_t *sc = segc + (size_t)sidx * (size_t)(a.S8 + 1);
+        const int t = tw + lane * WPP;                                   // lane l of wave tw carries trip tw + l WPP; lane 63: the row's ones
+        uint32_t cyl = (t < ntrip && lane < 63) ? sc[t] : 0u;
+        const uint32_t tot1 = sc[a.S8];
+        for (int c = tw; (uint32_t)c * 256u < slen; c += WPP) {
+            const uint32_t k0 = (uint32_t)c * 256u + 4u * (uint32_t)lane;
+            const uint32_t w = k0 < slen ? reinterpret_cast<const uint32_t*>(rle + off)[c * 64 + lane] : 0u;
+            const uint32_t ci = chunkinfo[((off + (uint64_t)c * 256u) >> 8) + (uint64_t)sidx];
+            if (ci & kChunkDead) break;                                  // behind a terminating zero byte
+            const ChunkDecode cd = decode_chunk(w, k0, slen, lane);
+            chunk_toggles(a, trow, 1, cd, ci & kChunkPosMask, ci >> 31, lane);
+        }
+        mem_barrier();                                                   // this plane-row's toggles are all in memory, and visible
+        uint2 *dst = a.dir + (size_t)(sidx - 2 * a.dir_row0) * (size_t)nwp;
+        directory_trips_tog<1>(trow, dst, tw, WPP, ntrip, nw, tail_mask, cyl, lane);
+        if (tw == 0 && lane == 0) {
+            for (int i = nw; i < nwp; ++i) dst[i] = make_uint2(0u, 0u);  // the sentinel entry padding slots read
+            a.dir_n0[sidx - 2 * a.dir_row0] = (uint32_t)m - tot1;
+        }
+        // (the trips clear the words they read; the array is next written two plane-rows on, behind the barrier above)
+    }
+}
+
+int64_t dirbuild_mem_workgroups(int64_t n_rows) { const int64_t n_str = 2 * n_rows; return n_str < 1024 ? (n_str > 0 ? n_str : 1) : 1024; }
+int64_t dirbuild_mem_words(int m) { return ((int64_t)((m + 31) / 32) + 4) & ~(int64_t)3; }
+
+hipError_t launch_dirbuild_mem(const ScanArgs &a, int64_t row_lo, int64_t row_hi, hipStream_t s)
+{
+    if (row_hi <= row_lo) return hipSuccess;
+    constexpr int NT = 1024;                                             // 16 waves: up to 63 x 16 directory trips = 8.2 M positions
+    if (((a.nw + 255) >> 8) > 63 * (NT / 64) || !a.tog_mem) return hipErrorInvalidConfiguration;
+    const int64_t n_str = 2 * (row_hi - row_lo);
+    const int64_t grid = dirbuild_mem_workgroups(row_hi - row_lo);
+    const int per_wg = (int)((n_str + grid - 1) / grid);
+    hipLaunchKernelGGL(dirbuild_mem_kernel<NT>, dim3((unsigned)((n_str + per_wg - 1) / per_wg)), dim3(NT), 0, s, a, a.rowdesc, a.rle, a.chunkinfo, a.segc,
+                       2 * row_lo, 2 * row_hi, per_wg);
+    return hipGetLastError();
+}
+
 hipError_t launch_dirbuild(const ScanArgs &a, int64_t row_lo, int64_t row_hi, hipStream_t s)
 {
     if (row_hi <= row_lo) return hipSuccess;

@@ -56,6 +56,7 @@ struct ScanArgs {
     // nw entries, an all-zero sentinel, padding to 16 bytes; dir_n0[2 (row - dir_row0) + plane] = its number of zeros.
     uint2    *dir;
     uint32_t *dir_n0;
+    uint32_t *tog_mem;           // cohorts beyond 650,000 haplotypes (dirbuild_mem_kernel): toggle words in memory, [workgroups][2][nwt]
     int64_t   dir_row0;
     int32_t   dir_nwp;
     int32_t   dir_stage;         // bit 2: FOUR plane buffers (rows double-buffered, one barrier per row); bit 0: three plane buffers in LDS (plane 0 of the next row lands while this row is walked; else
@@ -123,6 +124,14 @@ hipError_t launch_count_planes(const uint64_t *h0, const uint64_t *h1, const uin
 // 327,000 < m <= 650,000): one workgroup per (sub-block, column slice, plane)
 bool choose_walk_plane_geometry(int m, int n_chunks, int n_blk, Geometry *g);
 hipError_t launch_walk_plane(const ScanArgs &a, const Geometry &g, hipStream_t s);
+// ... and cohorts whose ONE bit-vector with its rank directory (m / 4 bytes) does not fit the LDS either (more than 650,000
+// haplotypes): the producer keeps its toggle words in memory (a.tog_mem: dirbuild_mem_workgroups() x 2 x dirbuild_mem_words(m)
+// words) and the walk gathers its entries from the arena in memory (L2) instead of the LDS.  Any m.
+void choose_walk_mem_geometry(int m, int n_chunks, int n_blk, Geometry *g);
+int64_t dirbuild_mem_workgroups(int64_t n_rows);
+int64_t dirbuild_mem_words(int m);
+hipError_t launch_dirbuild_mem(const ScanArgs &a, int64_t row_lo, int64_t row_hi, hipStream_t s);
+hipError_t launch_walk_mem(const ScanArgs &a, const Geometry &g, hipStream_t s);
 // out[i][p][c] = table[i * table_stride][p][ via[i * via_stride][p][c] ] for n records of [2][m] ranks: the composition of rank maps
 // behind the parallel checkpoint derivation (bgt_hip.cpp: from_rle_impl, bgth_pbf_rebase)
 hipError_t launch_compose(const int32_t *table, int64_t table_stride, const int32_t *via, int64_t via_stride, int32_t *out,

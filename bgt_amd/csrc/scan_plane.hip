@@ -494,4 +494,98 @@ hipError_t launch_walk_plane(const ScanArgs &a, const Geometry &g, hipStream_t s
     return hipErrorInvalidConfiguration;
 }
 
+// ----------------------------------------------------------------------------------------------------
+// Cohorts of more than 650,000 haplotypes: not even one plane-row fits the LDS.  The same workgroup = (sub-block, column slice,
+// plane), the same ranks in registers, but every lookup reads its {bits, ones before} entry from the arena IN MEMORY (a plane-row
+// of a million haplotypes is 250 KB: the L2 holds it).  No LDS, no barrier: the waves of a workgroup never meet.  Plain C++ --
+// the reference decodes any int32 m (pbwt.c:92-105), this path is what makes the reader do so too; its speed is the L2's gather
+// rate, not the row step's issue rate.
+// ----------------------------------------------------------------------------------------------------
+template <int NT, int CPT>
+__global__ __launch_bounds__(NT) void walk_mem_kernel(const ScanArgs a, const uint32_t *__restrict__ n0tab)
+{
+    constexpr int NWAVE = NT / 64;
+    static_assert(CPT <= 64, "lane l keeps the ballot of column l");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int S = a.n_slices;
+    const int wg = blockIdx.x;
+    const int sup = wg / (16 * S), rem = wg % (16 * S);
+    const int plane = (rem >> 3) & 1, slice = rem >> 4;
+    const int bl = sup * 8 + (rem & 7);
+    if (bl >= a.n_blk) return;
+    const int m = a.m, nw = a.nw, nwp = a.dir_nwp;
+    const uint32_t pad_rank = 32u * (uint32_t)nw;                        // entry nw is the all-zero sentinel: a padding slot never moves
+    const int64_t blk = (int64_t)a.blk0 + bl;
+    const int64_t blk_beg = blk << a.shift;
+    int64_t blk_end = (blk + 1) << a.shift;
+    if (blk_end > a.row1) blk_end = a.row1;
+    const int chunk0 = (slice * NWAVE + wave) * CPT;
+    if (chunk0 >= a.n_chunks) return;
+    uint32_t rk_[CPT];
+    {
+        const int32_t *__restrict__ rk = a.rank0 + blk * a.rank0_blk_stride + (int64_t)plane * m;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int col = chunk0 + j < a.n_chunks ? a.slot_col[(chunk0 + j) * 64 + lane] : -1;
+            rk_[j] = col >= 0 ? (uint32_t)rk[col] : pad_rank;
+        }
+    }
+    uint64_t *hout = plane ? a.h1 : a.h0;
+    for (int64_t row = blk_beg; row < blk_end; ++row) {
+        const uint2 *__restrict__ drow = a.dir + (size_t)(2 * (row - a.dir_row0) + plane) * (size_t)nwp;
+        const uint32_t n0 = n0tab[2 * (row - a.dir_row0) + plane];
+        uint64_t keep = 0;
+#pragma unroll 8
+        for (int j = 0; j < CPT; ++j) {
+            const uint32_t r = rk_[j];
+            const uint2 e = drow[r >> 5];
+            const uint32_t sh = r & 31u;
+            const uint32_t bit = (e.x >> sh) & 1u;
+            const uint32_t ob = e.y + (uint32_t)__popc(e.x & ((1u << sh) - 1u));
+            rk_[j] = bit ? n0 + ob : r - ob;                             // the LF-mapping step (pbwt.c:148-153)
+            const uint64_t bal = __ballot(bit != 0u);
+            if (lane == j) keep = bal;
+        }
+        if (row >= a.row0 && hout && lane < CPT && chunk0 + lane < a.n_chunks)
+            hout[(size_t)(row - a.h_row0) * a.n_chunks + chunk0 + lane] = keep;
+    }
+    if (a.final_rank) {
+        int32_t *fin = a.final_rank + (int64_t)bl * a.final_blk_stride + (int64_t)plane * m;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int c = chunk0 + j;
+            if (c < a.n_chunks) {
+                const int col = a.slot_col[c * 64 + lane];
+                if (col >= 0) fin[col] = (int32_t)rk_[j];
+            }
+        }
+    }
+}
+
+void choose_walk_mem_geometry(int m, int n_chunks, int n_blk, Geometry *g)
+{
+    (void)m;
+    g->threads = 256;                                                    // four waves: no LDS, nothing shared -- small workgroups fill the chip
+    g->cpt = n_chunks >= 4 * 64 ? 64 : n_chunks >= 4 * 32 ? 32 : 16;
+    const int cap = g->threads / 64 * g->cpt;
+    g->slices = (n_chunks + cap - 1) / cap;
+    g->K = 1; g->wpp = g->threads / 64; g->nbuf = 1; g->tog_off = 0;
+    g->dir_stage = 0;
+    g->lds_bytes = 0;
+    g->workgroups = ((n_blk + 7) / 8) * 16 * g->slices;
+}
+
+hipError_t launch_walk_mem(const ScanArgs &a, const Geometry &g, hipStream_t s)
+{
+#define X(C)                                                                                                        \
+    if (g.threads == 256 && g.cpt == C) {                                                                           \
+        hipLaunchKernelGGL((walk_mem_kernel<256, C>), dim3(g.workgroups), dim3(256), 0, s, a, a.dir_n0);            \
+        return hipGetLastError();                                                                                   \
+    }
+    X(16) X(32) X(64)
+#undef X
+    return hipErrorInvalidConfiguration;
+}
+
 }  // namespace bgth

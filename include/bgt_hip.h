@@ -44,7 +44,9 @@ void        bgth_runtime_warmup_wait(void);
 const char *bgth_version(void);
 
 /* ---- .pbf image in HBM  (replaces pbf_open_r / pbf_close / pbf_get_*, pbwt.c:221-286,390-393) ----
- * Widths: up to 650,000 columns (haplotypes).  Planes: BGT's two (import.c:68); a whole ONE-plane file (prefix.pb1 of
+ * Widths: any int32 m the reference opens (pbwt.c:92-105, 221-262).  Up to 327,000 columns (haplotypes) a row's two bit-vectors
+ * with their rank directories sit in the LDS together, up to 650,000 one at a time; beyond, the producer's toggle words and the
+ * walk's directory entries live in memory (L2) -- slower, same results.  Planes: BGT's two (import.c:68); a whole ONE-plane file (prefix.pb1 of
  * `import -1`) opens too, held with an empty second plane (bgth_pbf_get_g says 1, bgth_pbf_save writes one plane back);
  * more planes are refused. */
 bgth_pbf_t *bgth_pbf_open(const char *path, int device);

@@ -37,7 +37,7 @@ def test_encoder_refuses_what_it_cannot_hold():
     with pytest.raises(RuntimeError):
         bgt_amd.HipEncoder(0)
     with pytest.raises(RuntimeError):
-        bgt_amd.HipEncoder(300000)                # more than 262144 columns: not in this version, and no CPU path
+        bgt_amd.HipEncoder(3000000)               # more than 2,097,152 columns: not in this version, and no CPU path
 
 
 @pytest.mark.gpu
@@ -250,6 +250,28 @@ def test_encoder_packed_rows(m, rows):
     enc.write(mat[rows // 3:rows // 2])                       # the two forms may alternate
     enc.write_packed(packed[rows // 2:])
     assert enc.finish() == orc.encode_pbf(mat, 2, 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,rows,unit,g", [(262145, 20, 2, 2), (300000, 40, 3, 2), (524288, 16, 0, 2), (600001, 24, 3, 1), (1048577, 12, 2, 2),
+                                           (2000000, 9, 0, 2), (2097152, 6, 1, 2)])
+def test_encoder_beyond_262144_columns(monkeypatch, m, rows, unit, g):
+    """VERDICT r5 missing #2: pbf_open_w / pbf_write take any int32 m (pbwt.c:199-219, 288-311).  Beyond 262,144 columns the two
+    row directories no longer fit the LDS and live in memory (encode_huge_kernel: 16, 32 or 64 directory words per thread, up to
+    2,097,152 columns = a million samples); same bytes as the oracle writer, one unit and several, one plane and two."""
+    import bgt_amd
+    if unit:
+        monkeypatch.setenv("BGTH_ENC_UNIT_SHIFT", str(unit))
+    rng = np.random.default_rng(m + rows)
+    mat = scenarios.ld_matrix(rng, rows, m, n_founders=6, switch=0.0003)
+    if g == 1:
+        mat &= 1
+    mat[2] = 0
+    mat[3, ::3] = 1                                                   # ~m / 3 runs of one: every word has run ends
+    enc = bgt_amd.HipEncoder(m, g, 3)
+    enc.write(mat[:rows // 2])
+    enc.write(mat[rows // 2:])
+    assert enc.finish() == orc.encode_pbf(mat, g, 3)
 
 
 @pytest.mark.gpu
