@@ -215,6 +215,7 @@ struct bgth_pbf_s {
     uint8_t  *d_rle = nullptr;
     uint64_t *d_rowdesc = nullptr;
     int32_t  *d_rank0 = nullptr;      // [n_sub][2][m] ranks by column at every (sub-)checkpoint
+    int64_t   rank_epoch = 0;         // counts the times d_rank0 was replaced (rebase): readers key their compact start-rank tables on it
     // [n_sub][m]: the plane-1 ranks of every (sub-)checkpoint in the order of its plane-0 ranks -- what a whole-cohort, one-group,
     // counts-only scan starts from (slots in plane-0 rank order: profiles/r05_lds); built at the first such scan, dropped when the
     // checkpoints change (rebase); order_failed: no HBM for it, the scans use the column order
@@ -390,6 +391,9 @@ struct bgth_reader_s {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     DevBuf raw, fin, h0, h1, gt;      // scratch of every scan; results of bgth_reader_scan
     DevBuf ph0, ph1;                  // bit planes of the plane-split kernels when the caller wants counts only
+    DevBuf start_tab;                 // plane-split kernels: this selection's start ranks at every sub-checkpoint, in slot order
+    int64_t start_epoch = -1, start_n_sub = 0;   // (valid for the image's rank_epoch / n_sub; -1: to be gathered)
+    int start_slots = 0;
     int plane_path = 0;               // the last scan ran the plane-split kernels
     // directory path: the arena of {bits, ones before} rows and their zero counts; [dir_lo, dir_hi) = image rows it holds
     // from the last producer pass (a later scan inside that range only walks), dir_passes/dir_built = what the last scan did
@@ -1332,6 +1336,7 @@ static bool derive_all_checkpoints(bgth_pbf_t *p, Selection &all, const std::vec
         HIP_TRY(hipDeviceSynchronize(), break);
         hipFree(p->d_rank0);
         p->d_rank0 = rebased; rebased = nullptr;
+        ++p->rank_epoch;
         {
             std::lock_guard<std::mutex> guard(p->rowindex_lock);
             if (p->d_order) { hipFree(p->d_order); p->d_order = nullptr; }  // (derived from the checkpoints: built again on demand)
@@ -1410,6 +1415,7 @@ extern "C" int bgth_pbf_rebase(bgth_pbf_t *p, const int32_t *start_ranks)
             std::lock_guard<std::mutex> guard(p->rowindex_lock);           // (d_order is built under this lock by the scans)
             hipFree(p->d_rank0);
             p->d_rank0 = out; out = nullptr;
+            ++p->rank_epoch;
             if (p->d_order) { hipFree(p->d_order); p->d_order = nullptr; }
             p->order_failed = false;
         }
@@ -1569,7 +1575,7 @@ static void reader_free(bgth_reader_t *r)
     r->raw.release(); r->fin.release(); r->h0.release(); r->h1.release(); r->gt.release();
     r->carriers.release(); r->hapsig.release();
     r->win[0].release(); r->win[1].release();
-    r->dir.release(); r->dir_n0.release(); r->tog_mem.release();
+    r->dir.release(); r->dir_n0.release(); r->tog_mem.release(); r->start_tab.release();
     r->ph0.release(); r->ph1.release();
     for (int i = 0; i < 4; ++i) if (r->ev[i]) hipEventDestroy(r->ev[i]);
     for (int i = 0; i < 2; ++i) if (r->ev_dir[i]) hipEventDestroy(r->ev_dir[i]);
@@ -1657,6 +1663,7 @@ extern "C" int bgth_reader_select(bgth_reader_t *r, int n_sub, const int32_t *su
     if (!use_device(r->pbf->device)) return -1;
     hipStreamSynchronize(r->stream);
     if (!guarded("bgth_reader_select", false, [&] { return build_selection(r->sel, r->pbf->m, n_sub, sub, group, n_groups); })) return -1;
+    r->start_epoch = -1;              // (the compact start ranks belong to the selection before)
     r->ring0 = r->ring1 = 0;          // invalidate the pull ring (the stream is idle: nothing is pending any more)
     for (PullWindow &w : r->win) w.valid = w.pending = false;
     r->folds_live = false;
@@ -1861,6 +1868,23 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
     else if (!common_scan_args(a, p, r->sel, geo, s)) return -1;
     a.shift = p->sub_shift;                              // units = sub-blocks
     a.rank0_blk_stride = (int64_t)2 * p->m;
+    if (planepath && !r->sel.whole && !variant_flag(kVariantColumnOrder)) {
+        // A sparse selection's start ranks, gathered once per selection into slot order (gather_start_ranks_kernel): a workgroup then
+        // starts with one contiguous read instead of T gathers of 4 bytes per 64-byte line.  Up to 1/16 of the free HBM (C3: 314 MB).
+        const int n_slots = r->sel.n_chunks * 64;
+        const int64_t n_rec = std::max<int64_t>(p->n_sub, 1);
+        if (r->start_epoch != p->rank_epoch || r->start_n_sub != n_rec || r->start_slots != n_slots) {
+            size_t fr = 0, tot = 0;
+            const size_t need = (size_t)n_rec * 2 * n_slots * 4;
+            r->start_epoch = -1;
+            if ((need <= r->start_tab.cap || (hipMemGetInfo(&fr, &tot) == hipSuccess && need <= fr / 16)) && r->start_tab.reserve(need)) {
+                HIP_TRY(launch_gather_start_ranks(p->d_rank0, r->sel.d_slot_col, (int32_t*)r->start_tab.p, p->m, n_slots, n_rec, (int32_t)(32 * ((p->m + 31) / 32)), s), return -1);
+                HIP_TRY(hipStreamSynchronize(s), return -1);                 // (a later scan may come on another stream; once per selection)
+                r->start_epoch = p->rank_epoch; r->start_n_sub = n_rec; r->start_slots = n_slots;
+            } else (void)hipGetLastError();
+        }
+        if (r->start_epoch == p->rank_epoch) { a.start_slots = (const int32_t*)r->start_tab.p; a.start_blk_stride = (int64_t)2 * n_slots; }
+    }
     // Whole cohort, one group, counts only: the counts do not care which lane tracks which column, so slot s of a sub-block tracks
     // the column whose plane-0 rank at its checkpoint is s.  The 64 lanes of a wave then start on 64 consecutive ranks, PBWT order
     // keeps neighbours together for a while, and a wave's ds_read_b64 gather hits few distinct entries of the plane-0 row instead of

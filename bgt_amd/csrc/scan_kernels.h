@@ -33,6 +33,8 @@ struct ScanArgs {
     const int32_t  *order0;      // whole-cohort counts scans (the default of every such scan; measured in profiles/r05_lds): != NULL = slot s
     int64_t         order_blk_stride;   //   of a sub-block tracks the column of plane-0 rank s at its checkpoint; order0[blk * stride + s] =
                                  //   that column's plane-1 rank (the image's d_order table, built at the first such scan)
+    const int32_t  *start_slots; // plane-split kernels, != NULL: the start ranks of the reader's OWN slots, compact -- [sub-block][plane][n_chunks * 64]
+    int64_t         start_blk_stride;   //   (= 2 n_chunks 64), gathered once per selection (launch_gather_start_ranks); padding slots hold 32 nw
     const uint32_t *chunk_desc;  // [n_chunks]
     int32_t        *raw_counts;  // [(row1-row0)][G][3] += {n(code1), n(code2), n(code3)}
     uint64_t       *h0, *h1;     // optional [(row1-row0)][n_chunks] bit planes in slot order
@@ -112,6 +114,9 @@ hipError_t launch_finalize(const int32_t *raw, int32_t *out, const int32_t *grou
 // inv[perm[j]] = j for n_perm permutations of m entries each.  bad != NULL (untrusted input): entries outside
 // 0..m-1 are not stored and every record is checked to be a permutation; *bad (device int) becomes non-zero otherwise
 hipError_t launch_plane1_by_plane0(const int32_t *rank, int32_t *out, int m, int64_t n_rec, hipStream_t s);
+// out[rec][plane][slot] = rank[rec][plane][slot_col[slot]] (pad where slot_col < 0): a selection's start ranks at every (sub-)checkpoint
+hipError_t launch_gather_start_ranks(const int32_t *rank, const int32_t *slot_col, int32_t *out, int m, int n_slots, int64_t n_rec, int32_t pad,
+                                     hipStream_t s);
 hipError_t launch_invert(const int32_t *perm, int32_t *inv, int m, int64_t n_perm, hipStream_t s, int *bad = nullptr);
 // plane-split kernels (scan_plane.hip; sparse selections of wide cohorts): one workgroup per (sub-block, plane), two per CU;
 // the planes meet in count_planes (raw[row][g][3] = the three popcounts per group from the bit planes h0 / h1)

@@ -238,6 +238,28 @@ __global__ void plane1_by_plane0_kernel(const int32_t *rank, int32_t *out, int m
     const int32_t col = (int32_t)(i - rec * m);
     out[rec * m + rank[rec * 2 * m + col]] = rank[rec * 2 * m + m + col];
 }
+// A sparse selection of a wide cohort (C3: 10,000 of 200,000 columns) starts every sub-block by gathering its columns' ranks out of
+// the [2][m] checkpoint record -- 4 useful bytes per 64-byte line, for every workgroup of every launch (profiles/r05_c3: 7.25 GB
+// fetched per launch against 2.3 GB compulsory).  Gathered ONCE per selection into slot order, the start of a workgroup is a
+// contiguous read of T x 4 bytes.
+__global__ void gather_start_ranks_kernel(const int32_t *__restrict__ rank, const int32_t *__restrict__ slot_col, int32_t *__restrict__ out,
+                                          int m, int n_slots, int64_t total, int32_t pad)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int64_t rp = i / n_slots;                                     // (record, plane)
+    const int col = slot_col[(int)(i - rp * n_slots)];
+    out[i] = col >= 0 ? rank[rp * m + col] : pad;
+}
+hipError_t launch_gather_start_ranks(const int32_t *rank, const int32_t *slot_col, int32_t *out, int m, int n_slots, int64_t n_rec, int32_t pad,
+                                     hipStream_t s)
+{
+    const int64_t total = n_rec * 2 * n_slots;
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_start_ranks_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, rank, slot_col, out, m, n_slots, total, pad);
+    return hipGetLastError();
+}
+
 hipError_t launch_plane1_by_plane0(const int32_t *rank, int32_t *out, int m, int64_t n_rec, hipStream_t s)
 {
     const int64_t total = n_rec * m;

@@ -62,7 +62,11 @@ __global__ __launch_bounds__(NT, LOW == 1 ? 6 : 4) void plane_kernel(const ScanA
 
     const int chunk0 = wave * CPT;
     uint32_t rk_[CPT];
-    {
+    if (a.start_slots) {                                                 // the selection's own start ranks, compact: one coalesced read
+        const int32_t *__restrict__ st = a.start_slots + blk * a.start_blk_stride + (int64_t)plane * (a.n_chunks * 64);
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) rk_[j] = ~(chunk0 + j < a.n_chunks ? (uint32_t)st[(chunk0 + j) * 64 + lane] : pad_rank);
+    } else {
         // (unconditional loads from clamped indices, the gathers in a second loop: see load_start_ranks)
         const int32_t *__restrict__ rk = a.rank0 + blk * a.rank0_blk_stride + (int64_t)plane * m;
         const int last = a.n_chunks * 64 - 1;

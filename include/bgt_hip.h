@@ -235,7 +235,8 @@ enum {
     BGTH_FORCE_DIRECTORY_PATH           = 32,    /* always / never: rows built once into an HBM arena + walk-only workgroups */
     BGTH_FORCE_NO_DIRECTORY_PATH        = 64,
     BGTH_FORCE_COLUMN_ORDER             = 8,     /* whole-cohort counts take the general path: slots in column order (not in plane-0 rank
-                                                  * order per sub-block), all three counts per column (not n(code 3) alone) */
+                                                  * order per sub-block), all three counts per column (not n(code 3) alone); sparse
+                                                  * selections gather their start ranks per workgroup (no compact per-selection table) */
     BGTH_FORCE_REBUILD_ROWS             = 128,   /* a scan never walks the arena the previous scan of the reader left */
     BGTH_FORCE_SEQUENTIAL_CHECKPOINTS   = 512,   /* bgth_pbf_from_rle derives its checkpoints block after block */
     BGTH_FORCE_RCCL_TO_SELF             = 1024,  /* a sharded scan gathers through RCCL even between shards of ONE device */

@@ -130,6 +130,11 @@ def test_plane_split_kernels(hip, monkeypatch, seed, m, rows, shift, n_sel):
         assert np.array_equal(c, oc) and np.array_equal(g, ogt), rd.geometry()
         a, b = rows // 3, rows - 1
         assert np.array_equal(rd.scan(a, b), oc[a:b])                  # counts only: planes in the reader's own buffers
+        # (the start ranks came from the selection's compact table, gathered once; FORCE_COLUMN_ORDER makes every workgroup gather
+        #  its own from the checkpoint records: same numbers)
+        hip.force_kernels(4096 | hip.hip.FORCE_COLUMN_ORDER)
+        assert np.array_equal(rd.scan(0, rows), oc) and rd.path()["plane_split"]
+        hip.force_kernels(4096)
     hip.force_kernels(2048)
     assert np.array_equal(rd.scan(0, rows), oc) and not rd.path()["plane_split"]
     rd.close()
