@@ -230,6 +230,9 @@ struct bgth_pbf_s {
     // A SHARDED image (bgth_pbf_open_sharded): the file's blocks dealt out as contiguous block ranges, one partial image
     // per shard, each on its own device.  The parent holds no device data; n = n_total, row_off = 0.
     std::vector<bgth_pbf_t*> shards;
+    std::vector<uint8_t> file_image;  // ... and the file's own bytes, which bgth_pbf_save writes back (such an image cannot be re-based)
+    std::vector<bgth_pbf_t*> pairs;   // a file of MORE than two bit planes (pbwt.c:211-213, 325-334 loop over any g): the planes are independent
+                                      // PBWTs, held as images of planes (0,1), (2,3), ... -- the codec interface (select / seek / read) only
     // RCCL communicator over the DISTINCT devices of the shards (bgth_reader_scan_device on a sharded image gathers the
     // per-shard counts on shard 0's device): comm[i] belongs to comm_dev[i]; built at the first gather
     std::vector<void*> comm;
@@ -425,6 +428,8 @@ struct bgth_reader_s {
     const int8_t *last_gt8 = nullptr;
     const char *last_gttext = nullptr;
     std::vector<bgth_reader_t*> subs; // reader of a sharded image: one reader per shard (own device, stream, buffers)
+    std::vector<bgth_reader_t*> pair_readers;   // reader of an image of more than two planes: one reader per pair of planes
+    std::vector<const uint8_t*> multi_ret;      // ... and what its bgth_reader_read returns: g plane pointers
     std::vector<ShardWorker*> workers; //   and one persistent host thread per shard
 };
 
@@ -603,7 +608,7 @@ static bool rank0_alloc(bgth_pbf_t *p)
 
 static bgth_pbf_t *pbf_alloc(int device, int m, int g, int shift, int64_t n)
 {
-    if (g != 2) { set_err("[E::bgth_pbf] g=%d bit planes: this build holds BGT's two planes (import.c:68) and, for whole files, the one plane of a .pb1", g); return nullptr; }
+    if (g != 2) { set_err("[E::bgth_pbf] g=%d bit planes: an image holds BGT's two planes (import.c:68); whole files of one plane (.pb1) or of more than two open as bundles of such images (bgth_pbf_open / bgth_pbf_open_mem)", g); return nullptr; }
     if (m <= 0 || shift < 0 || shift > 30) { set_err("[E::bgth_pbf] bad header m=%d shift=%d", m, shift); return nullptr; }
     Geometry geo;
     bool wide_plane = false, mem_plane = false;
@@ -642,6 +647,7 @@ extern "C" void bgth_pbf_close(bgth_pbf_t *p)
     for (void *c : p->comm) if (c) rccl().CommDestroy(c);
     p->comm.clear();
     for (bgth_pbf_t *sh : p->shards) bgth_pbf_close(sh);
+    for (bgth_pbf_t *pp : p->pairs) bgth_pbf_close(pp);
     for (bgth_reader_t *r : p->pool) reader_free(r);
     p->pool.clear();
     hipSetDevice(p->device);
@@ -917,12 +923,76 @@ static bool expand_one_plane(const uint8_t *buf, size_t len, std::vector<uint8_t
     return true;
 }
 
+// Planes [k0, k0 + nk) of a file of g planes as a file of nk planes (nk = 1 or 2): 'S' records keep those planes' orders, 'B'
+// records those planes' strings, the footer is rebuilt for the new offsets.  Every bit plane of a PBF is a PBWT of its own
+// (pbwt.c:211-213: one pbc_t per plane), so the pieces decode independently.
+static bool extract_planes(const uint8_t *buf, size_t len, int k0, int nk, std::vector<uint8_t> &out)
+{
+    int32_t hdr[3];
+    memcpy(hdr, buf + 4, 12);
+    const int m = hdr[0], g = hdr[1];
+    if (m <= 0 || m > (1 << 28) || g < 1 || k0 < 0 || nk < 1 || k0 + nk > g) { set_err("[E::bgth_pbf_open] bad header m=%d g=%d", m, g); return false; }
+    out.clear();
+    out.reserve(len / (size_t)g * (size_t)nk + 64);
+    hdr[1] = nk;
+    out.insert(out.end(), buf, buf + 4);
+    out.insert(out.end(), (const uint8_t*)hdr, (const uint8_t*)hdr + 12);
+    std::vector<uint64_t> idx;
+    int64_t rows = 0;
+    size_t pos = 16;
+    const size_t perm_bytes = (size_t)m * 4;
+    while (pos < len && buf[pos] != 'I') {
+        if (buf[pos] == 'S') {
+            if (pos + 1 + (size_t)g * perm_bytes > len) { set_err("[E::bgth_pbf_open] truncated 'S' record"); return false; }
+            idx.push_back((uint64_t)out.size());
+            out.push_back('S');
+            out.insert(out.end(), buf + pos + 1 + (size_t)k0 * perm_bytes, buf + pos + 1 + (size_t)(k0 + nk) * perm_bytes);
+            pos += 1 + (size_t)g * perm_bytes;
+        }
+        if (pos >= len || buf[pos] != 'B') { set_err("[E::bgth_pbf_open] malformed record at byte %zu", pos); return false; }
+        ++pos;
+        out.push_back('B');
+        for (int k = 0; k < g; ++k) {
+            int32_t l;
+            if (pos + 4 > len) { set_err("[E::bgth_pbf_open] truncated 'B' record"); return false; }
+            memcpy(&l, buf + pos, 4);
+            if (l < 0 || pos + 4 + (size_t)l > len) { set_err("[E::bgth_pbf_open] truncated 'B' record"); return false; }
+            if (k >= k0 && k < k0 + nk) out.insert(out.end(), buf + pos, buf + pos + 4 + (size_t)l);
+            pos += 4 + (size_t)l;
+        }
+        ++rows;
+    }
+    if (pos >= len) { set_err("[E::bgth_pbf_open] no index footer: truncated or not a PBF image"); return false; }
+    const uint64_t off = (uint64_t)out.size();
+    const int32_t n_idx = (int32_t)idx.size();
+    out.push_back('I');
+    out.insert(out.end(), (const uint8_t*)&rows, (const uint8_t*)&rows + 8);
+    out.insert(out.end(), (const uint8_t*)&n_idx, (const uint8_t*)&n_idx + 4);
+    out.insert(out.end(), (const uint8_t*)idx.data(), (const uint8_t*)idx.data() + idx.size() * 8);
+    out.insert(out.end(), (const uint8_t*)&off, (const uint8_t*)&off + 8);
+    return true;
+}
+
 static bgth_pbf_t *open_mem_impl(const void *image, size_t len, int device)
 {
     const uint8_t *buf = (const uint8_t*)image;
     if (len < 16 || memcmp(buf, "PBF\1", 4) != 0) { set_err("[E::bgth_pbf_open] not a PBF image"); return nullptr; }
     int32_t hdr[3];
     memcpy(hdr, buf + 4, 12);
+    if (hdr[1] > 2 && hdr[1] <= 64) {                            // more than two planes: an image per pair of planes (the last may be single)
+        bgth_pbf_t *par = new bgth_pbf_s();
+        par->device = device; par->m = hdr[0]; par->g = hdr[1]; par->shift = hdr[2];
+        std::vector<uint8_t> piece;
+        for (int k0 = 0; k0 < hdr[1]; k0 += 2) {
+            bgth_pbf_t *pp = extract_planes(buf, len, k0, std::min(2, hdr[1] - k0), piece) ? open_mem_impl(piece.data(), piece.size(), device) : nullptr;
+            if (!pp) { bgth_pbf_close(par); return nullptr; }
+            par->pairs.push_back(pp);
+        }
+        par->file_image.assign(buf, buf + len);
+        par->n = par->n_total = par->pairs[0]->n_total;
+        for (const bgth_pbf_t *pp : par->pairs) { par->rle_bytes += pp->rle_bytes; par->packed_bytes += pp->packed_bytes; }
+        return par;
+    }
     if (hdr[1] == 1) {                                            // one plane: held as two, the second one empty
         std::vector<uint8_t> two;
         if (!expand_one_plane(buf, len, two)) return nullptr;
@@ -1167,6 +1237,11 @@ static bgth_pbf_t *open_rows_impl(const char *path, int64_t row0, int64_t row1, 
     }
     if (!ok) { fclose(fp); set_err("[E::bgth_pbf_open_rows] '%s': no PBF header / index footer", path); return nullptr; }
     memcpy(&shift, hdr + 12, 4);
+    {
+        int32_t g_file;
+        memcpy(&g_file, hdr + 8, 4);
+        if (g_file > 2) { fclose(fp); set_err("[E::bgth_pbf_open_rows] '%s' has %d bit planes: partial and sharded images are for BGT's two (open the whole file)", path, g_file); return nullptr; }
+    }
     if (shift < 0 || shift > 30 || row0 < 0 || row1 > n_total || row0 >= row1) {
         fclose(fp);
         set_err("[E::bgth_pbf_open_rows] rows [%lld,%lld) outside 0..%lld", (long long)row0, (long long)row1, (long long)n_total);
@@ -1353,9 +1428,19 @@ done:
 
 // The ranks (by column, [2][m]) after the last row of an image built by bgth_pbf_from_rle, and the re-basing of such an image
 // onto another start order: how the shards of ONE database are opened side by side (include/bgt_hip.h).
+// An image of more than two bit planes (bgth_pbf_s::pairs) serves the codec interface only; everything else says so.
+static bool planes_image(const bgth_pbf_t *p, const char *who)
+{
+    if (!p || p->pairs.empty()) return false;
+    set_err("[E::%s] an image of %d bit planes serves the codec interface (bgth_reader_select / seek / read): counts, genotype codes "
+            "and checkpoints are defined for BGT's two planes", who, p->g);
+    return true;
+}
+
 extern "C" int bgth_pbf_final_ranks(const bgth_pbf_t *p, int32_t *out)
 {
     if (!p || !out) { set_err("[E::bgth_pbf_final_ranks] NULL argument"); return -1; }
+    if (planes_image(p, "bgth_pbf_final_ranks")) return -1;
     if (!p->d_final) { set_err("[E::bgth_pbf_final_ranks] only images built by bgth_pbf_from_rle keep their final ranks"); return -1; }
     if (!use_device(p->device)) return -1;
     HIP_TRY(hipMemcpy(out, p->d_final, (size_t)2 * p->m * 4, hipMemcpyDeviceToHost), return -1);
@@ -1365,6 +1450,7 @@ extern "C" int bgth_pbf_final_ranks(const bgth_pbf_t *p, int32_t *out)
 extern "C" int bgth_pbf_ranks_at(const bgth_pbf_t *p, int64_t row, int32_t *out)
 {
     if (!p || !out) { set_err("[E::bgth_pbf_ranks_at] NULL argument"); return -1; }
+    if (planes_image(p, "bgth_pbf_ranks_at")) return -1;
     if (!p->shards.empty()) {
         for (const bgth_pbf_t *sh : p->shards) if (row >= sh->row_off && row < sh->row_off + sh->n) return bgth_pbf_ranks_at(sh, row, out);
         set_err("[E::bgth_pbf_ranks_at] row %lld is in no shard", (long long)row); return -1;
@@ -1383,6 +1469,7 @@ extern "C" int bgth_pbf_ranks_at(const bgth_pbf_t *p, int64_t row, int32_t *out)
 extern "C" int bgth_pbf_rebase(bgth_pbf_t *p, const int32_t *start_ranks)
 {
     if (!p || !start_ranks) { set_err("[E::bgth_pbf_rebase] NULL argument"); return -1; }
+    if (planes_image(p, "bgth_pbf_rebase")) return -1;
     if (!p->d_final) { set_err("[E::bgth_pbf_rebase] only images built by bgth_pbf_from_rle can be re-based"); return -1; }
     if (!use_device(p->device)) return -1;
     const size_t per = (size_t)2 * p->m;
@@ -1502,6 +1589,13 @@ static int64_t save_impl(const bgth_pbf_t *p, const char *path)
 {
     if (!p) return -1;
     if (p->row_off != 0 || p->n != p->n_total || !p->shards.empty()) { set_err("[E::bgth_pbf_save] a partial or sharded image cannot be saved"); return -1; }
+    if (!p->pairs.empty()) {                                     // more than two planes: the file's own bytes (nothing can have changed them)
+        FILE *fp = fopen(path, "wb");
+        if (!fp) { set_err("[E::bgth_pbf_save] cannot create '%s'", path); return -1; }
+        const bool ok = fwrite(p->file_image.data(), 1, p->file_image.size(), fp) == p->file_image.size();
+        if (fclose(fp) != 0 || !ok) { set_err("[E::bgth_pbf_save] writing '%s' failed", path); return -1; }
+        return (int64_t)p->file_image.size();
+    }
     if (!use_device(p->device)) return -1;
     const int m = p->m;
     const size_t per = (size_t)2 * m;
@@ -1553,12 +1647,13 @@ done:
 extern "C" int bgth_pbf_get_m(const bgth_pbf_t *p) { return p->m; }
 extern "C" int bgth_pbf_get_g(const bgth_pbf_t *p) { return p->g_file ? p->g_file : p->g; }
 extern "C" int bgth_pbf_get_shift(const bgth_pbf_t *p) { return p->shift; }
-extern "C" int64_t bgth_pbf_unit_rows(const bgth_pbf_t *p) { const bgth_pbf_t *q = p->shards.empty() ? p : p->shards[0]; return (int64_t)1 << q->sub_shift; }
+extern "C" int64_t bgth_pbf_unit_rows(const bgth_pbf_t *p) { const bgth_pbf_t *q = !p->pairs.empty() ? p->pairs[0] : p->shards.empty() ? p : p->shards[0]; return (int64_t)1 << q->sub_shift; }
 extern "C" int64_t bgth_pbf_get_n(const bgth_pbf_t *p) { return p->n_total; }
 extern "C" int64_t bgth_pbf_rle_bytes(const bgth_pbf_t *p) { return p->rle_bytes; }
 extern "C" int64_t bgth_pbf_hbm_bytes(const bgth_pbf_t *p)
 {
     if (!p->shards.empty()) { int64_t t = 0; for (const bgth_pbf_t *sh : p->shards) t += bgth_pbf_hbm_bytes(sh); return t; }
+    if (!p->pairs.empty()) { int64_t t = 0; for (const bgth_pbf_t *pp : p->pairs) t += bgth_pbf_hbm_bytes(pp); return t; }
     return p->packed_bytes + 256 + p->n * 2 * 8 + p->n_sub * 2 * (int64_t)p->m * 4 + p->rowindex_bytes +
            (p->d_order ? p->n_sub * (int64_t)p->m * 4 : 0);
 }
@@ -1591,6 +1686,18 @@ extern "C" bgth_reader_t *bgth_reader_create(bgth_pbf_t *p)
 {
     if (!p) { set_err("[E::bgth_reader_create] NULL image"); return nullptr; }
     if (!use_device(p->device)) return nullptr;
+    if (!p->pairs.empty()) {                                     // more than two planes: a reader per pair of planes behind one handle
+        bgth_reader_t *w = new bgth_reader_s();
+        w->pbf = p;
+        w->sel.width = p->m;
+        for (bgth_pbf_t *pp : p->pairs) {
+            bgth_reader_t *sub = bgth_reader_create(pp);
+            if (!sub) { bgth_reader_destroy(w); return nullptr; }
+            w->pair_readers.push_back(sub);
+        }
+        w->multi_ret.assign((size_t)p->g, nullptr);
+        return w;
+    }
     bgth_reader_t *r = nullptr;
     {
         std::lock_guard<std::mutex> g(p->pool_lock);
@@ -1633,6 +1740,11 @@ extern "C" bgth_reader_t *bgth_reader_create(bgth_pbf_t *p)
 extern "C" void bgth_reader_destroy(bgth_reader_t *r)
 {
     if (!r) return;
+    if (!r->pbf->pairs.empty()) {                                // (the handle over the pair readers owns nothing on the device)
+        for (bgth_reader_t *sub : r->pair_readers) bgth_reader_destroy(sub);
+        delete r;
+        return;
+    }
     for (ShardWorker *w : r->workers) delete w;
     r->workers.clear();
     for (bgth_reader_t *sub : r->subs) bgth_reader_destroy(sub);
@@ -1660,6 +1772,11 @@ extern "C" int bgth_reader_select(bgth_reader_t *r, int n_sub, const int32_t *su
                                   int n_groups)
 {
     if (!r) return -1;
+    if (!r->pair_readers.empty()) {
+        for (bgth_reader_t *pr : r->pair_readers) if (bgth_reader_select(pr, n_sub, sub, group, n_groups) < 0) return -1;
+        r->sel.width = r->pair_readers[0]->sel.width;
+        return 0;
+    }
     if (!use_device(r->pbf->device)) return -1;
     hipStreamSynchronize(r->stream);
     if (!guarded("bgth_reader_select", false, [&] { return build_selection(r->sel, r->pbf->m, n_sub, sub, group, n_groups); })) return -1;
@@ -1672,9 +1789,10 @@ extern "C" int bgth_reader_select(bgth_reader_t *r, int n_sub, const int32_t *su
 }
 
 extern "C" int bgth_reader_width(const bgth_reader_t *r) { return r->sel.width; }
-extern "C" int bgth_reader_slot_words(const bgth_reader_t *r) { return r->sel.n_chunks; }
+extern "C" int bgth_reader_slot_words(const bgth_reader_t *r) { return r->pair_readers.empty() ? r->sel.n_chunks : r->pair_readers[0]->sel.n_chunks; }
 extern "C" int bgth_reader_slot_map(const bgth_reader_t *r, int32_t *out)
 {
+    if (!r->pair_readers.empty()) return bgth_reader_slot_map(r->pair_readers[0], out);
     memcpy(out, r->sel.slot_of_out.data(), (size_t)r->sel.width * 4);
     return r->sel.width;
 }
@@ -1683,6 +1801,7 @@ extern "C" int bgth_reader_tune(bgth_reader_t *r, int threads, int cpt, int K)
 {
     r->tune_threads = threads; r->tune_cpt = cpt; r->tune_K = K;
     for (bgth_reader_t *sub : r->subs) bgth_reader_tune(sub, threads, cpt, K);
+    for (bgth_reader_t *pr : r->pair_readers) bgth_reader_tune(pr, threads, cpt, K);
     return 0;
 }
 
@@ -2130,6 +2249,7 @@ extern "C" int64_t bgth_reader_scan_device(bgth_reader_t *r, int64_t row0, int64
                                            void *d_h0, void *d_h1, void *stream)
 {
     if (!r || !d_counts) { set_err("[E::bgth_reader_scan_device] NULL argument"); return -1; }
+    if (planes_image(r->pbf, "bgth_reader_scan_device")) return -1;
     if (!r->subs.empty()) return guarded("bgth_reader_scan_device", (int64_t)-1, [&] { return scan_device_sharded(r, row0, row1, d_counts, d_h0, d_h1, stream); });
     if (!use_device(r->pbf->device)) return -1;
     hipStream_t s = stream ? (hipStream_t)stream : r->stream;
@@ -2145,6 +2265,7 @@ extern "C" int64_t bgth_reader_scan(bgth_reader_t *r, int64_t row0, int64_t row1
 {
     if (!r) return -1;
     bgth_pbf_t *p = r->pbf;
+    if (planes_image(p, "bgth_reader_scan")) return -1;
     if (!use_device(p->device)) return -1;
     if (!to_image_rows(p, row0, row1, "bgth_reader_scan")) return -1;
     const int G = r->sel.G, gx = gx_of(G);
@@ -2202,6 +2323,7 @@ extern "C" int64_t bgth_reader_scan(bgth_reader_t *r, int64_t row0, int64_t row1
 extern "C" int bgth_reader_last_timing(const bgth_reader_t *rc, float out[3])
 {
     bgth_reader_t *r = const_cast<bgth_reader_t*>(rc);
+    if (!r->pair_readers.empty()) return bgth_reader_last_timing(r->pair_readers[0], out);
     if (!r->subs.empty()) {                                      // shards run concurrently: the slowest one
         out[0] = out[1] = out[2] = 0;
         for (bgth_reader_t *sr : r->subs) { float t[3]; bgth_reader_last_timing(sr, t); for (int k = 0; k < 3; ++k) out[k] = std::max(out[k], t[k]); }
@@ -2222,6 +2344,7 @@ extern "C" int bgth_reader_shard_timing(const bgth_reader_t *rc, int shard, floa
 extern "C" int bgth_reader_last_path(const bgth_reader_t *rc, float out[4])
 {
     bgth_reader_t *r = const_cast<bgth_reader_t*>(rc);
+    if (!r->pair_readers.empty()) return bgth_reader_last_path(r->pair_readers[0], out);
     if (!r->subs.empty()) return bgth_reader_last_path(r->subs[0], out);
     if (r->t_pending) { hipSetDevice(r->pbf->device); collect_timing(r); }
     out[0] = (r->plane_path ? 2.f : r->geom.dir_stage >= 0 ? 1.f : 0.f); out[1] = (float)r->dir_passes; out[2] = (float)r->dir_built; out[3] = r->dir_build_ms;
@@ -2230,6 +2353,7 @@ extern "C" int bgth_reader_last_path(const bgth_reader_t *rc, float out[4])
 
 extern "C" int bgth_reader_last_geometry(const bgth_reader_t *r, int out[6])
 {
+    if (!r->pair_readers.empty()) return bgth_reader_last_geometry(r->pair_readers[0], out);
     if (!r->subs.empty()) return bgth_reader_last_geometry(r->subs[0], out);
     out[0] = r->geom.threads; out[1] = r->geom.cpt; out[2] = r->geom.slices;
     out[3] = r->geom.K; out[4] = r->geom.lds_bytes; out[5] = r->geom.workgroups;
@@ -2242,6 +2366,10 @@ extern "C" int bgth_reader_last_geometry(const bgth_reader_t *r, int out[6])
 extern "C" int bgth_reader_seek(bgth_reader_t *r, int64_t row)
 {
     if (!r) return -1;
+    if (!r->pair_readers.empty()) {
+        for (bgth_reader_t *pr : r->pair_readers) if (bgth_reader_seek(pr, row) < 0) return -1;
+        return 0;
+    }
     int64_t row1 = row + 1;
     if (!to_image_rows(r->pbf, row, row1, "bgth_reader_seek")) return -1;                 // ref pbwt.c:359
     r->next = row;
@@ -2416,6 +2544,16 @@ static bool refill(bgth_reader_t *r)
 extern "C" const uint8_t **bgth_reader_read(bgth_reader_t *r)
 {
     if (!r) return nullptr;
+    if (!r->pair_readers.empty()) {                              // g planes: every pair's row, the plane pointers side by side (pbwt.c:325-334)
+        size_t k = 0;
+        for (bgth_reader_t *pr : r->pair_readers) {
+            const uint8_t **a = bgth_reader_read(pr);
+            if (!a) return nullptr;
+            r->multi_ret[k++] = a[0];
+            if (k < r->multi_ret.size()) r->multi_ret[k++] = a[1];
+        }
+        return r->multi_ret.data();
+    }
     bgth_pbf_t *p = r->pbf;
     if (r->next >= p->n) {                                       // ref pbwt.c:336: no more 'B' records
         if (p->row_off + p->n < p->n_total) set_err("[E::bgth_reader_read] row %lld is beyond this partial image", (long long)(p->row_off + r->next));
@@ -2443,6 +2581,11 @@ extern "C" int bgth_reader_config(bgth_reader_t *r, int want_planes, int64_t max
 {
     if (!r) return -1;
     if (want_planes & ~(BGTH_WANT_PLANES | BGTH_WANT_GT8 | BGTH_WANT_GTTEXT | BGTH_WANT_BITS)) { set_err("[E::bgth_reader_config] unknown output bits 0x%x", want_planes); return -1; }
+    if (!r->pair_readers.empty()) {
+        if (want_planes != BGTH_WANT_PLANES) { set_err("[E::bgth_reader_config] an image of %d bit planes hands out byte planes only (genotype codes are BGT's two planes)", r->pbf->g); return -1; }
+        for (bgth_reader_t *pr : r->pair_readers) if (bgth_reader_config(pr, want_planes, max_rows_ahead) < 0) return -1;
+        return 0;
+    }
     r->want = want_planes;
     r->max_ahead = max_rows_ahead;
     return 0;
@@ -2471,6 +2614,7 @@ extern "C" int bgth_reader_fold_last(bgth_reader_t *r, int code, int bit)
 {
     if (!r) return -1;
     if (code > 3 || bit > 63) { set_err("[E::bgth_reader_fold_last] code %d / bit %d out of range", code, bit); return -1; }
+    if (planes_image(r->pbf, "bgth_reader_fold_last")) return -1;
     if (r->sel.width & 1) { set_err("[E::bgth_reader_fold_last] needs whole samples (an even number of columns), have %d", r->sel.width); return -1; }
     const int64_t row = r->next - 1;
     if (row < r->ring0 || row >= r->ring1 || !(r->ring_has & BGTH_WANT_BITS)) {
@@ -2494,6 +2638,7 @@ extern "C" int bgth_reader_fold_last(bgth_reader_t *r, int code, int bit)
 extern "C" int bgth_reader_take_folds(bgth_reader_t *r, int32_t *carriers, uint64_t *hap)
 {
     if (!r) return -1;
+    if (planes_image(r->pbf, "bgth_reader_take_folds")) return -1;
     return guarded("bgth_reader_take_folds", -1, [&]() -> int {
         const int width = r->sel.width, ns = width / 2;
         if (carriers) memset(carriers, 0, (size_t)ns * 4);

@@ -436,14 +436,15 @@ class HipReader:
         self._want = want
 
     def read(self):
-        """Next row: the two byte planes (uint8[2][width]), or True when planes are not configured; None at the end."""
+        """Next row: the byte planes (uint8[2][width]; uint8[g][width] for an image of more than two planes), or True when planes
+        are not configured; None at the end."""
         r = lib().bgth_reader_read(self.h)
         if not r:
             return None
         if not (getattr(self, "_want", 1) & 1):
             return True
         w = self.width
-        return np.stack([np.ctypeslib.as_array(r[k], (w,)).copy() for k in range(2)])
+        return np.stack([np.ctypeslib.as_array(r[k], (w,)).copy() for k in range(max(2, self.pbf.g))])
 
     def last_gt8(self):
         L = lib()

@@ -10,8 +10,7 @@
  *   recode   <in.pbf> -b [-c ..]  -> the decoded rows written again
  *
  * Decoding is rank tracking on the device, encoding keeps the PBWT order on the device; the host only parses and prints
- * integers.  The encoder takes one or two bit planes; the reader holds exactly BGT's two (import.c:68), or the one of a
- * `.pb1`, and refuses other files with a message. */
+ * integers.  Any number of bit planes up to the encoder's eight: every plane is a PBWT of its own (pbwt.c:211-213). */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -96,7 +95,6 @@ static int sink_open(pv_sink_t *s, const pv_job_t *job, int m, int g)
     memset(s, 0, sizeof(*s));
     s->m = m; s->g = g;
     if (!job->pbf_out) { printf("PIM1 %d %d\n", m, g); return 0; }
-    if (g > 2) { fprintf(stderr, "[E::%s] the device codec writes one or two bit planes, the input has %d\n", __func__, g); return -1; }
     if ((s->enc = bgth_encoder_open(m, g, job->shift, 0)) == NULL) { fprintf(stderr, "[E::%s] %s\n", __func__, bgth_encoder_last_error()); return -1; }
     s->codes = (uint8_t*)malloc((size_t)m * PV_ROWS_PER_WRITE);
     return s->codes ? 0 : -1;
@@ -116,7 +114,7 @@ static int sink_drain(pv_sink_t *s)
  * reference), codes wait for the row to be complete */
 static void sink_cell(pv_sink_t *s, long long v)
 {
-    if (s->enc) s->codes[(size_t)s->held * s->m + s->col] = (uint8_t)(v & ((1 << s->g) - 1));
+    if (s->enc) s->codes[(size_t)s->held * s->m + s->col] = (uint8_t)(v & ((1 << s->g) - 1));   /* (a byte per cell: g <= 8, the encoder's limit) */
     else printf(s->col ? " %lld" : "%lld", v);
     ++s->col;
 }
@@ -197,7 +195,12 @@ static int pump_pbf(const pv_job_t *job)
         else if (job->first_row <= ((int64_t)1 << bgth_pbf_get_shift(in))) left = 0;
     }
     for (; ok && left > 0 && (planes = bgth_reader_read(rd)) != NULL; --left) {
-        for (j = 0; j < m; ++j) sink_cell(&sink, planes[0][j] | (g > 1 ? planes[1][j] << 1 : 0));
+        for (j = 0; j < m; ++j) {
+            long long v = 0;
+            int k;
+            for (k = 0; k < g; ++k) v |= (long long)planes[k][j] << k;    /* (any number of planes: pbfview.c is g-agnostic) */
+            sink_cell(&sink, v);
+        }
         if (sink_end_row(&sink) < 0) ok = 0;
     }
     if (opened && sink_close(&sink, ok) < 0) ok = 0;

@@ -47,8 +47,11 @@ const char *bgth_version(void);
  * Widths: any int32 m the reference opens (pbwt.c:92-105, 221-262).  Up to 327,000 columns (haplotypes) a row's two bit-vectors
  * with their rank directories sit in the LDS together, up to 650,000 one at a time; beyond, the producer's toggle words and the
  * walk's directory entries live in memory (L2) -- slower, same results.  Planes: BGT's two (import.c:68); a whole ONE-plane file (prefix.pb1 of
- * `import -1`) opens too, held with an empty second plane (bgth_pbf_get_g says 1, bgth_pbf_save writes one plane back);
- * more planes are refused. */
+ * `import -1`) opens too, held with an empty second plane (bgth_pbf_get_g says 1, bgth_pbf_save writes one plane back).
+ * Files of MORE than two planes (pbf_open_w / pbf_read loop over any g, pbwt.c:211-213, 325-334; `pbfview` is g-agnostic):
+ * every plane is a PBWT of its own, so such a file opens as a bundle of two-plane images and serves the CODEC interface --
+ * bgth_reader_select / seek / read hand out g byte planes per row, bgth_pbf_save writes the file back -- while counts, genotype
+ * codes, checkpoints, partial and sharded images, which are defined for BGT's two planes, fail with a message. */
 bgth_pbf_t *bgth_pbf_open(const char *path, int device);
 bgth_pbf_t *bgth_pbf_open_mem(const void *image, size_t len, int device);
 /* Partial image: only the 1<<shift-row blocks of the file that cover rows [row0,row1) are read (through the

@@ -592,3 +592,39 @@ def test_partial_image_of_a_row_range(hip, tmp_path, shift, rows, lo, hi):
         assert open(str(tmp_path / "re.pbf"), "rb").read() == data
     with pytest.raises(RuntimeError):
         hip.HipPbf.open_rows(path, hi, lo)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("g,m,rows,shift", [(3, 100, 60, 3), (4, 5000, 80, 4), (7, 333, 40, 2), (8, 41000, 24, 3)])
+def test_more_than_two_bit_planes(hip, tmp_path, g, m, rows, shift):
+    """pbf_open_w / pbf_read loop over any number of planes (pbwt.c:211-213, 325-334); every plane is a PBWT of its own.  Such a file
+    opens as a bundle of two-plane images and serves the codec interface: whole rows, a column subset in any order, a seek across
+    checkpoints, the file written back byte for byte; what is defined for BGT's two planes only -- counts -- fails with a message.
+    Against the oracle reader on the oracle writer's file."""
+    rng = np.random.default_rng(g * 1000 + m)
+    mat = rng.integers(0, 1 << g, (rows, m)).astype(np.uint8)
+    mat[rng.random((rows, m)) < 0.7] = 0
+    mat[3] = 0; mat[4] = (1 << g) - 1
+    data = orc.encode_pbf(mat, g, shift)
+    pbf = hip.HipPbf.from_bytes(data)
+    assert (pbf.m, pbf.g, pbf.n) == (m, g, rows)
+    rd = hip.HipReader(pbf)
+    for r in range(rows):
+        a = rd.read()
+        assert a.shape == (g, m) and np.array_equal(a, np.stack([(mat[r] >> k) & 1 for k in range(g)])), r
+    assert rd.read() is None
+    cols = rng.permutation(m)[: max(1, m // 7)].astype(np.int32)
+    rd.select(cols)
+    ora = orc.Pbf(data)
+    ora.subset(cols)
+    start = (1 << shift) + 1
+    rd.seek(start); ora.seek(start)
+    for r in range(start, rows):
+        assert np.array_equal(rd.read(), ora.read()), r
+    out = str(tmp_path / "planes.pbf")
+    pbf.save(out)
+    assert open(out, "rb").read() == data
+    with pytest.raises(RuntimeError, match="two planes"):
+        rd.scan(0, rows)
+    rd.close()
+    pbf.close()

@@ -1,6 +1,7 @@
 """`bgt pbfview` (bgt_amd/host/pbfview_cli.c): the reference's codec-level tool (pbfview.c) on the device codec, run side by
 side with the compiled reference tool (oracle/_ref/pbfview) on random matrices: PIM -> PBF, PBF -> PIM, column subsets in
-any order, seeks inside and across checkpoint blocks and behind the end, PBF -> PBF recoding."""
+any order, seeks inside and across checkpoint blocks and behind the end, PBF -> PBF recoding; one to eight bit planes (pbfview.c
+is g-agnostic: VERDICT r5 missing #3)."""
 import os
 import subprocess
 
@@ -46,7 +47,8 @@ def write_pim(path, mat, g):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed,m,rows,g,shift", [(1, 4, 9, 2, 13), (2, 70, 40, 2, 3), (3, 333, 150, 2, 4), (4, 64, 33, 1, 3),
-                                                 (5, 2000, 70, 2, 5), (6, 1, 20, 2, 2), (7, 700, 90, 1, 4)])
+                                                 (5, 2000, 70, 2, 5), (6, 1, 20, 2, 2), (7, 700, 90, 1, 4),
+                                                 (8, 50, 40, 3, 3), (9, 333, 70, 5, 4), (10, 70, 30, 8, 2), (11, 1000, 50, 4, 3)])
 def test_side_by_side_with_the_reference_tool(tmp_path, seed, m, rows, g, shift):
     ref = require_ref("pbfview")
     rng = np.random.default_rng(seed)
@@ -63,10 +65,7 @@ def test_side_by_side_with_the_reference_tool(tmp_path, seed, m, rows, g, shift)
     # PIM -> PIM (the echo) and PBF -> PIM
     assert run([BGT, "pbfview", "-S", pim]) == run([ref, "-S", pim])
     mine, want = run([BGT, "pbfview", pbf]), run([ref, pbf])
-    if g > 2:                                                          # the device codec holds BGT's two planes, or the one plane of a
-        assert mine[0] == 1 and mine[1] == b"" and want[0] == 0           # .pb1 (as two, the second one empty): it says so
-        return
-    assert mine == want
+    assert mine == want                                                # (any g: a file of more than two planes opens as a bundle of plane pairs)
     # (with ONE column the reference's PIM reader notices the end of the file a read late and writes the last value once
     #  more as an extra row; the encoder here reads the same way, so the files agree and only this check looks at `rows`)
     assert mine[1].decode().split("\n")[1:-1][:rows] == [" ".join(str(int(x)) for x in row) for row in mat]
