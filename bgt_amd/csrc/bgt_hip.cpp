@@ -254,7 +254,7 @@ enum { kVariantNoTog = BGTH_FORCE_NO_TOGGLE_ARRAY, kVariantNeverZP = BGTH_FORCE_
        kVariantSeqCheckpoints = BGTH_FORCE_SEQUENTIAL_CHECKPOINTS, kVariantRcclSelf = BGTH_FORCE_RCCL_TO_SELF,
        kVariantPlaneNever = BGTH_FORCE_NO_PLANE_SPLIT, kVariantPlaneAlways = BGTH_FORCE_PLANE_SPLIT,
        kVariantColumnOrder = BGTH_FORCE_COLUMN_ORDER,
-       kVariantThreeBuffers = BGTH_FORCE_THREE_PLANE_BUFFERS,
+       kVariantThreeBuffers = BGTH_FORCE_THREE_PLANE_BUFFERS, kVariantPackedRanks = BGTH_FORCE_PACKED_RANKS,
        // profiling build only: no window prefetch in the pull interface | no L2 warming of the next row's plane 1 | no
        // progress-based wave priorities in the walk
        kVariantNoPrefetch = 16, kVariantDirNoWarm = 256, kVariantNoWalkPrio = 16384 };
@@ -2011,6 +2011,7 @@ static int64_t enqueue_scan(bgth_reader_t *r, int64_t row0, int64_t row1, int32_
     // (2048 rows); kernel time -5.2 % / -2.3 % / -0.8 % (profiles/r05_lds).  BGTH_FORCE_COLUMN_ORDER keeps the slots in column order.
     if (r->sel.whole && G == 1 && !d_h0 && !planepath && !variant_flag(kVariantColumnOrder)) {
         a.whole_counts = 1;                              // ... and only n(code 3) is counted: the planes' ones are the rows' own (BGTH_COUNT3)
+        a.pk16 = variant_flag(kVariantPackedRanks) && p->m <= 65504 ? 1 : 0;
         std::lock_guard<std::mutex> guard(p->rowindex_lock);
         if (!p->d_order && !p->order_failed) {
             // Built on the stream of this scan and PUBLISHED only once it is complete: another reader's stream may use it only after

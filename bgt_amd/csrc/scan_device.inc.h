@@ -319,6 +319,65 @@ __device__ __forceinline__ void step4(uint32_t (&r0)[4], uint32_t (&r1)[4], uint
     }
 }
 
+// ---- round 6 A/B: TWO RANKS PER REGISTER where m <= 65,535.  A column's plane-0 rank sits in the low half of
+// its register, its plane-1 rank in the high half, both complemented as above (16-bit complements).  What can be shared by the two
+// lookups of a column is the rank update: one v_lshl_or packs the two "ones up to r", one v_pk_sub_u16 / v_pk_add_u16 make both
+// candidates of both planes, and the select is done per half by v_cndmask_b32_sdwa (dst_unused:UNUSED_PRESERVE) straight from
+// vcc -- 5 instructions where the plain form has 6; the address (v_bfe_u32 / v_lshrrev + v_mad), the shift (the high half's shift
+// amount through SDWA src0_sel:WORD_1), v_bcnt and v_cmp stay per lookup: 15 VALU instructions per column against 16.
+//   BASE operands here = (LDS address of the plane-row) + 8 * 2047: the unsigned 11-bit field (q >> 5) = 2047 - (r >> 5).
+//   N0PK = (-n0 of plane 1) << 16 | (-n0 of plane 0) & 0xffff.     Whole-cohort counting only (n(code 3): BGTH_COUNT3's sums).
+#define BGTH_PK_COL(Q, E0L, E0H, E0P, E1L, E1H, E1P, MSAVE)                                             \
+    "v_lshlrev_b32 " E0L ", " Q ", " E0L "\n\t"                                                          \
+    "v_lshlrev_b32_sdwa " E1L ", " Q ", " E1L " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t" \
+    "v_bcnt_u32_b32 " E0H ", " E0L ", " E0H "\n\t"                                                       \
+    "v_bcnt_u32_b32 " E1H ", " E1L ", " E1H "\n\t"                                                       \
+    "v_lshl_or_b32 " E0H ", " E1H ", 16, " E0H "\n\t"                                                    \
+    "v_pk_sub_u16 " E1H ", %8, " E0H "\n\t"                                                             \
+    "v_pk_add_u16 " E0H ", " Q ", " E0H "\n\t"                                                           \
+    "v_cmp_gt_i32 vcc, 0, " E0L "\n\t"                                                                   \
+    "v_cndmask_b32_sdwa " Q ", " E0H ", " E1H ", vcc dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0\n\t" \
+    "s_mov_b64 " MSAVE ", vcc\n\t"                                                                       \
+    "v_cmp_gt_i32 vcc, 0, " E1L "\n\t"                                                                   \
+    "v_cndmask_b32_sdwa " Q ", " E0H ", " E1H ", vcc dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1\n\t" \
+    "s_and_b64 vcc, " MSAVE ", vcc\n\t"                                                                  \
+    "s_bcnt1_i32_b64 vcc_lo, vcc\n\t"                                                                    \
+    "s_add_u32 %5, %5, vcc_lo\n\t"
+#define BGTH_PK_ADDR(Q, T0, T1)                                                                        \
+    "v_bfe_u32 " T0 ", " Q ", 5, 11\n\t"                                                                 \
+    "v_lshrrev_b32 " T1 ", 21, " Q "\n\t"                                                                \
+    "v_mad_i32_i24 " T0 ", " T0 ", -8, %6\n\t"                                                          \
+    "v_mad_i32_i24 " T1 ", " T1 ", -8, %7\n\t"
+// four columns x two planes in four registers (operands: %0-%3 the packed ranks, %4 a scratch SGPR pair -- the plane-0 ballot while a
+// column's plane 1 is selected --, %5 the n(code 3) sum, %6 / %7 the plane rows' bases, %8 N0PK)
+__device__ __forceinline__ void step4pk(uint32_t (&rp)[4], uint32_t &cc, uint32_t base0, uint32_t base1, uint32_t n0pk)
+{
+    uint64_t ms;
+    asm volatile(
+        "s_waitcnt lgkmcnt(0)\n\t"
+        BGTH_PK_ADDR("%0", "v64", "v66") BGTH_PK_ADDR("%1", "v68", "v70") BGTH_PK_ADDR("%2", "v72", "v74") BGTH_PK_ADDR("%3", "v76", "v78")
+        "ds_read_b64 v[64:65], v64\n\t"
+        "ds_read_b64 v[66:67], v66\n\t"
+        "ds_read_b64 v[68:69], v68\n\t"
+        "ds_read_b64 v[70:71], v70\n\t"
+        "ds_read_b64 v[72:73], v72\n\t"
+        "ds_read_b64 v[74:75], v74\n\t"
+        "ds_read_b64 v[76:77], v76\n\t"
+        "ds_read_b64 v[78:79], v78\n\t"
+        "s_waitcnt lgkmcnt(6)\n\t"
+        BGTH_PK_COL("%0", "v64", "v65", "v[64:65]", "v66", "v67", "v[66:67]", "%4")
+        "s_waitcnt lgkmcnt(4)\n\t"
+        BGTH_PK_COL("%1", "v68", "v69", "v[68:69]", "v70", "v71", "v[70:71]", "%4")
+        "s_waitcnt lgkmcnt(2)\n\t"
+        BGTH_PK_COL("%2", "v72", "v73", "v[72:73]", "v74", "v75", "v[74:75]", "%4")
+        "s_waitcnt lgkmcnt(0)\n\t"
+        BGTH_PK_COL("%3", "v76", "v77", "v[76:77]", "v78", "v79", "v[78:79]", "%4")
+        : "+v"(rp[0]), "+v"(rp[1]), "+v"(rp[2]), "+v"(rp[3]), "=&s"(ms), "+s"(cc)
+        : "s"(base0), "s"(base1), "s"(n0pk)
+        : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75",
+          "v76", "v77", "v78", "v79", "vcc", "scc", "memory");
+}
+
 // (No counts: its only user, the plane-split kernel, takes them from the bit planes -- until round 5 every column still paid an
 // s_bcnt1 + s_add into a sum nobody read.)
 // One plane only, eight scratch registers just below the VGPR budget: the statement of the plane-split kernels at six waves
@@ -751,7 +810,8 @@ __device__ __forceinline__ void load_start_ranks(const ScanArgs &a, int64_t blk,
 
 // WC: whole cohort, one group, counts only (ScanArgs::whole_counts; narrow pipelined kernels without the empty-plane shortcut): the
 // per-plane ones come from the rows' strings, only n(code 3) is counted (BGTH_COUNT3).
-template <int NT, int CPT, bool MULTI, bool GT, bool TEAM, bool ZP, bool SNAP = false, bool WC = false>
+// PK (round 6 A/B, with WC, m <= 65,504): a column's two ranks packed in one register (step4pk)
+template <int NT, int CPT, bool MULTI, bool GT, bool TEAM, bool ZP, bool SNAP = false, bool WC = false, bool PK = false>
 __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64_t *__restrict__ rowdesc,
                                                   const uint8_t *__restrict__ rle,
                                                   const uint32_t *__restrict__ chunkinfo,
@@ -764,6 +824,7 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
     static_assert(CPT % 2 == 0, "columns per thread are stepped in pairs");
     static_assert(CPT * 64 < 65536, "per-wave counts of a row are kept in 16 bits");
     static_assert(!WC || (!MULTI && !GT && !TEAM && !ZP), "whole-cohort counting serves the plain narrow kernel");
+    static_assert(!PK || (WC && !SNAP && CPT % 4 == 0), "packed ranks: whole-cohort counting, four columns per statement");
     const int tid  = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -803,6 +864,11 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
     {
         const int32_t *rk = a.rank0 + blk * a.rank0_blk_stride;
         load_start_ranks<CPT>(a, blk, rk, chunk0, lane, BGTH_SKIP(a, 8) != 0, pad_rank, r0, r1);
+    }
+    uint32_t rp[PK ? CPT : 1];                                           // PK: {plane-1 rank : plane-0 rank}, 16-bit complements
+    if constexpr (PK) {
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) rp[j] = (r1[j] << 16) | (r0[j] & 0xffffu);
     }
     if (MULTI) for (int i = tid; i < (TEAM ? 1 : 2) * K * G * 3; i += NT) lcnt[i] = 0;
     // MULTI: the group of every row-step statement of this wave (four chunks, the tail two): slots are laid out group by group,
@@ -1106,7 +1172,13 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
                     else if (j / 4 == NS * 13 / 16) __builtin_amdgcn_s_setprio(1);
                     else if (j / 4 == NS * 15 / 16) __builtin_amdgcn_s_setprio(0);
                 }
-                if (NC == 4) {
+                if constexpr (PK) {
+                    uint32_t qp[4] = {rp[j], rp[j + 1], rp[j + 2], rp[j + 3]};
+                    // (bases: + 8 for the "- 8" of the plain form, + 8 x 2047 for the unsigned word index; N0PK: both planes' -n0)
+                    step4pk(qp, cc, base0 + 16384u, base1 + 16384u, (n01 << 16) | (n00 & 0xffffu));
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) rp[j + u] = qp[u];
+                } else if (NC == 4) {
                     uint32_t q0[4] = {r0[j], r0[j + 1], r0[j + 2], r0[j + 3]};
                     uint32_t q1[4] = {r1[j], r1[j + 1], r1[j + 2], r1[j + 3]};
                     step4<ZP, WC>(q0, q1, m0, m1, ca, cb, cc, base0, base1, n00, n01);
@@ -1240,6 +1312,10 @@ __global__ __launch_bounds__(NT) void scan_kernel(const ScanArgs a, const uint64
 #endif
     if (a.final_rank) {
         int32_t *fin = a.final_rank + (int64_t)bl * a.final_blk_stride;
+        if constexpr (PK) {                                              // (back to one 32-bit complement per plane)
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) { r0[j] = 0xffff0000u | (rp[j] & 0xffffu); r1[j] = 0xffff0000u | (rp[j] >> 16); }
+        }
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
             const int c = chunk0 + j;

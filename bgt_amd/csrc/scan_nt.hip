@@ -8,10 +8,10 @@ namespace bgth {
 
 static const int kLdsBytesLocal = 160 * 1024;
 
-template <int NT, int CPT, bool MULTI, bool GT, bool TEAM, bool ZP, bool SNAP = false, bool WC = false>
+template <int NT, int CPT, bool MULTI, bool GT, bool TEAM, bool ZP, bool SNAP = false, bool WC = false, bool PK = false>
 static hipError_t launch_one(const ScanArgs &a, const Geometry &g, hipStream_t s)
 {
-    auto fn = scan_kernel<NT, CPT, MULTI, GT, TEAM, ZP, SNAP, WC>;
+    auto fn = scan_kernel<NT, CPT, MULTI, GT, TEAM, ZP, SNAP, WC, PK>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes);
     if (e != hipSuccess) return e;
@@ -30,6 +30,7 @@ static hipError_t launch_variant(const ScanArgs &a, const Geometry &g, hipStream
         return hipErrorInvalidConfiguration;
     }
     // whole cohort, one group, counts only, pipelined narrow mode, no empty-plane shortcut: n(code 3) alone is counted (WC)
+    if constexpr (!ZP && CPT % 4 == 0) if (v == 0 && a.whole_counts && a.pk16) return launch_one<NT, CPT, false, false, false, false, false, true, true>(a, g, s);
     if constexpr (!ZP) if (v == 0 && a.whole_counts) return launch_one<NT, CPT, false, false, false, false, false, true>(a, g, s);
     switch (v) {
     case 0: return launch_one<NT, CPT, false, false, false, ZP>(a, g, s);
