@@ -254,10 +254,11 @@ enum { kVariantNoTog = BGTH_FORCE_NO_TOGGLE_ARRAY, kVariantNeverZP = BGTH_FORCE_
        kVariantSeqCheckpoints = BGTH_FORCE_SEQUENTIAL_CHECKPOINTS, kVariantRcclSelf = BGTH_FORCE_RCCL_TO_SELF,
        kVariantPlaneNever = BGTH_FORCE_NO_PLANE_SPLIT, kVariantPlaneAlways = BGTH_FORCE_PLANE_SPLIT,
        kVariantColumnOrder = BGTH_FORCE_COLUMN_ORDER,
-       kVariantThreeBuffers = BGTH_FORCE_THREE_PLANE_BUFFERS, kVariantPackedRanks = BGTH_FORCE_PACKED_RANKS,
+       kVariantThreeBuffers = BGTH_FORCE_THREE_PLANE_BUFFERS,
        // profiling build only: no window prefetch in the pull interface | no L2 warming of the next row's plane 1 | no
-       // progress-based wave priorities in the walk
-       kVariantNoPrefetch = 16, kVariantDirNoWarm = 256, kVariantNoWalkPrio = 16384 };
+       // progress-based wave priorities in the walk | whole-cohort counts with a column's two ranks packed in one register (the
+       // round-6 A/B that lost: profiles/r06_pk16)
+       kVariantNoPrefetch = 16, kVariantDirNoWarm = 256, kVariantNoWalkPrio = 16384, kVariantPackedRanks = 32768 };
 static std::atomic<unsigned> g_forced{0};
 extern "C" void bgth_force_kernels(unsigned flags) { g_forced.store(flags, std::memory_order_relaxed); }
 static bool variant_flag(int bit)
@@ -266,7 +267,7 @@ static bool variant_flag(int bit)
 #ifdef BGTH_ABLATE
     if (const char *d = getenv("BGTH_VARIANT")) f |= (unsigned)atoi(d);
 #else
-    if (bit == kVariantNoPrefetch || bit == kVariantDirNoWarm || bit == kVariantNoWalkPrio) return false;
+    if (bit == kVariantNoPrefetch || bit == kVariantDirNoWarm || bit == kVariantNoWalkPrio || bit == kVariantPackedRanks) return false;
 #endif
     return (f & (unsigned)bit) != 0;
 }

@@ -33,7 +33,7 @@ struct ScanArgs {
     const int32_t  *order0;      // whole-cohort counts scans (the default of every such scan; measured in profiles/r05_lds): != NULL = slot s
     int64_t         order_blk_stride;   //   of a sub-block tracks the column of plane-0 rank s at its checkpoint; order0[blk * stride + s] =
                                  //   that column's plane-1 rank (the image's d_order table, built at the first such scan)
-    int32_t         pk16;        // with whole_counts, m <= 65,504: a column's two ranks packed in one register (step4pk; round 6 A/B)
+    int32_t         pk16;        // profiling build only (round-6 A/B, profiles/r06_pk16): with whole_counts, m <= 65,504, a column's two ranks in one register
     const int32_t  *start_slots; // plane-split kernels, != NULL: the start ranks of the reader's OWN slots, compact -- [sub-block][plane][n_chunks * 64]
     int64_t         start_blk_stride;   //   (= 2 n_chunks 64), gathered once per selection (launch_gather_start_ranks); padding slots hold 32 nw
     const uint32_t *chunk_desc;  // [n_chunks]

@@ -30,7 +30,9 @@ static hipError_t launch_variant(const ScanArgs &a, const Geometry &g, hipStream
         return hipErrorInvalidConfiguration;
     }
     // whole cohort, one group, counts only, pipelined narrow mode, no empty-plane shortcut: n(code 3) alone is counted (WC)
+#ifdef BGTH_ABLATE      // (profiling build: the packed-rank statement of the round-6 A/B, profiles/r06_pk16 -- slower, not in the product)
     if constexpr (!ZP && CPT % 4 == 0) if (v == 0 && a.whole_counts && a.pk16) return launch_one<NT, CPT, false, false, false, false, false, true, true>(a, g, s);
+#endif
     if constexpr (!ZP) if (v == 0 && a.whole_counts) return launch_one<NT, CPT, false, false, false, false, false, true>(a, g, s);
     switch (v) {
     case 0: return launch_one<NT, CPT, false, false, false, ZP>(a, g, s);

@@ -209,7 +209,7 @@ def last_error():
 FORCE_NO_TOGGLE_ARRAY, FORCE_NO_EMPTY_PLANE_SHORTCUT, FORCE_EMPTY_PLANE_SHORTCUT, FORCE_COLUMN_ORDER = 1, 2, 4, 8
 FORCE_DIRECTORY_PATH, FORCE_NO_DIRECTORY_PATH, FORCE_REBUILD_ROWS = 32, 64, 128
 FORCE_SEQUENTIAL_CHECKPOINTS, FORCE_RCCL_TO_SELF, FORCE_NO_PLANE_SPLIT, FORCE_PLANE_SPLIT = 512, 1024, 2048, 4096
-FORCE_THREE_PLANE_BUFFERS, FORCE_PACKED_RANKS = 8192, 32768
+FORCE_THREE_PLANE_BUFFERS = 8192
 _forced = 0
 
 

@@ -245,10 +245,8 @@ enum {
     BGTH_FORCE_RCCL_TO_SELF             = 1024,  /* a sharded scan gathers through RCCL even between shards of ONE device */
     BGTH_FORCE_NO_PLANE_SPLIT           = 2048,  /* never / always one workgroup per bit plane (sparse selections of wide cohorts) */
     BGTH_FORCE_PLANE_SPLIT              = 4096,
-    BGTH_FORCE_THREE_PLANE_BUFFERS      = 8192,  /* directory path: the walk-only kernels of cohorts too wide for four plane-row buffers in
+    BGTH_FORCE_THREE_PLANE_BUFFERS      = 8192   /* directory path: the walk-only kernels of cohorts too wide for four plane-row buffers in
                                                   * LDS (m > 160,000: a row's planes walked one after the other) on narrower ones */
-    BGTH_FORCE_PACKED_RANKS             = 32768  /* whole-cohort counts of cohorts of up to 65,504 haplotypes: a column's two ranks packed in one
-                                                  * register, 15 instead of 16 VALU instructions per column (measured in round 6: profiles/r06_pk16) */
 };
 void bgth_force_kernels(unsigned flags);
 

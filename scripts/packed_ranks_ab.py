@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Round 6 A/B: whole-cohort counts with a column's two ranks packed in one register (BGTH_FORCE_PACKED_RANKS:
-step4pk, 15 VALU instructions per column) against the shipped statement (16), IN THE KERNEL, same run, alternating.
-usage: python scripts/packed_ranks_ab.py [samples:sites,...]   (kernel time by HIP events, best of 7; counts compared)"""
+"""Round 6 A/B: whole-cohort counts with a column's two ranks packed in one register (step4pk, 15 VALU
+instructions per column) against the shipped statement (16), IN THE KERNEL, same run, alternating.  The packed statement lost
+(profiles/r06_pk16) and is compiled into the PROFILING build only:
+    make -C bgt_amd/csrc ABLATE=1 && BGT_AMD_LIB=bgt_amd/lib/libbgt_hip_ablate.so python scripts/packed_ranks_ab.py [samples:sites,...]
+(kernel time by HIP events, best of 7; counts compared)"""
 import os
 import sys
 
@@ -19,8 +21,9 @@ for sh in shapes.split(","):
     del rle
     rd = bgt_amd.HipReader(pbf)
     res = []
-    for label, var in (("two registers", 0), ("packed", bgt_amd.hip.FORCE_PACKED_RANKS), ("two registers", 0), ("packed", bgt_amd.hip.FORCE_PACKED_RANKS)):
-        bgt_amd.force_kernels(var | bgt_amd.hip.FORCE_REBUILD_ROWS)
+    for label, var in (("two registers", 0), ("packed", 32768), ("two registers", 0), ("packed", 32768)):
+        os.environ["BGTH_VARIANT"] = str(var)                     # (read by the profiling build at every scan)
+        bgt_amd.force_kernels(bgt_amd.hip.FORCE_REBUILD_ROWS)
         rd.scan(0, min(sites, 8192))
         best, times = 1e9, []
         for _ in range(7):

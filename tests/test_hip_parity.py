@@ -629,26 +629,3 @@ def test_more_than_two_bit_planes(hip, tmp_path, g, m, rows, shift):
     rd.close()
     pbf.close()
 
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("m,rows,shift", [(5008, 300, 6), (20000, 200, 5), (40000, 90, 4), (64, 50, 3), (2000, 130, 5)])
-def test_packed_ranks_count_what_two_registers_count(hip, m, rows, shift):
-    """BGTH_FORCE_PACKED_RANKS (round 6 A/B): whole-cohort counts with a column's plane-0 and plane-1 rank in the two halves of one
-    register (16-bit complements, v_pk_add / v_pk_sub, per-half select through SDWA) -- the same counts as the oracle, scans that
-    start inside a block included; noisy rows, all-zero / all-one rows (n0 = m and 0: the 16-bit -n0), ranks on both sides of 32768."""
-    rng = np.random.default_rng(m + rows)
-    mat = scenarios.ld_matrix(rng, rows, m, n_founders=7, switch=0.02)
-    mat[2] = 0; mat[3] = 1; mat[4] = 3; mat[5] = 2
-    mat[6] = rng.integers(0, 4, m)
-    data = orc.encode_pbf(mat, 2, shift)
-    pbf = hip.HipPbf.from_bytes(data)
-    rd = hip.HipReader(pbf)
-    oc = oracle_scan(data, 0, rows)[0]
-    hip.force_kernels(hip.hip.FORCE_PACKED_RANKS)
-    assert np.array_equal(rd.scan(0, rows), oc), rd.geometry()
-    a = (1 << shift) + 5
-    assert np.array_equal(rd.scan(a, rows - 3), oc[a:rows - 3])
-    hip.force_kernels(0)
-    assert np.array_equal(rd.scan(0, rows), oc)
-    rd.close()
-    pbf.close()
