@@ -783,6 +783,36 @@ def product_sharded_record(torch, bgt_amd, np, devices, n_samples, sites, seed, 
     return rec
 
 
+def product_child(spec):
+    """Child mode of the product_sharded record: a process of its own -- a first run on eight real devices that hangs (RCCL
+    initialisation beside torch's, a device that does not answer) is killed by its parent after a deadline and costs the bench
+    line one record, not the line.  Prints one JSON object."""
+    import numpy as np
+    import torch
+    import bgt_amd
+    devs, n_samples, sites, seed, steps, tmp = spec.split(":")
+    try:
+        rec = product_sharded_record(torch, bgt_amd, np, [int(x) for x in devs.split(",")], int(n_samples), int(sites), int(seed), int(steps), tmp)
+    except Exception as e:
+        import traceback
+        rec = {"error": repr(e)[:300], "traceback_tail": [t[:160] for t in traceback.format_exc().splitlines()[-4:]], "devices": devs}
+    sys.stdout.flush()
+    print("PRODUCT_SHARDED_JSON " + json.dumps(rec, default=str), flush=True)
+
+
+def product_sharded_in_a_child(devs, n_samples, sites, seed, steps, tmp, deadline_s=420):
+    spec = ":".join([",".join(str(x) for x in devs), str(n_samples), str(sites), str(seed), str(steps), tmp])
+    try:
+        pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--product-child", spec], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                            timeout=deadline_s, env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")})
+    except subprocess.TimeoutExpired:
+        return {"error": "no answer within %d s: the child was killed (the ranks' headline above is unaffected)" % deadline_s, "devices": list(devs)}
+    for ln in reversed(pr.stdout.decode(errors="replace").splitlines()):
+        if ln.startswith("PRODUCT_SHARDED_JSON "):
+            return json.loads(ln[len("PRODUCT_SHARDED_JSON "):])
+    return {"error": "the child left with status %d and no record: %s" % (pr.returncode, pr.stderr.decode(errors="replace")[-300:]), "devices": list(devs)}
+
+
 def server_record(prefix, n_sites):
     """The resident query server (bgt_amd/bin/bgt-server, the reference's bgt-server.go restated in C) on the database
     cli_end_to_end wrote: images in HBM once, then per-query latency over HTTP next to one reference `bgt view` process per
@@ -1215,9 +1245,13 @@ def main():
     ap.add_argument("--detail", default=None, help="where the full record goes (default: bench_detail.json beside bench.py); stdout carries "
                                                    "one compact line")
     ap.add_argument("--counters-child", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--product-child", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.counters_child:
         counters_child(args.counters_child)
+        return
+    if args.product_child:
+        product_child(args.product_child)
         return
 
     rank = int(os.environ.get("RANK", "0"))
@@ -1419,16 +1453,12 @@ def main():
         devs = [0] * len(devs)                                    # (the dry run of N > 1 on a one-GPU box: N shards on its one device)
     if rank == 0 and devs and not args.no_product_sharded and headline_wl == "c2":
         with tempfile.TemporaryDirectory() as ptmp:
-            try:
-                prec = product_sharded_record(torch, bgt_amd, np, devs, SAMPLES["c2"], (args.sites or 1000000) * max(1, world if world > 1 else 1),
-                                              SEEDS["c2"], max(3, min(args.steps, 10)), ptmp)
-                out["product_sharded"] = prec
-                if prec.get("parity_error"):
-                    out["parity_error"] = prec["parity_error"]
-            except Exception as e:                                # the torch-rank headline stands; the record says what happened
-                import traceback
-                out["product_sharded"] = {"error": repr(e)[:300], "traceback_tail": [t[:160] for t in traceback.format_exc().splitlines()[-4:]],
-                                          "devices": devs}
+            # (in a process of its own, with a deadline: whatever happens there, the ranks' headline line is printed)
+            prec = product_sharded_in_a_child(devs, SAMPLES["c2"], (args.sites or 1000000) * max(1, world if world > 1 else 1), SEEDS["c2"],
+                                              max(3, min(args.steps, 10)), ptmp)
+            out["product_sharded"] = prec
+            if prec.get("parity_error"):
+                out["parity_error"] = prec["parity_error"]
     if rank == 0:
         emit(out, args.detail)
 
