@@ -1461,6 +1461,11 @@ def main():
                 out["parity_error"] = prec["parity_error"]
     if rank == 0:
         emit(out, args.detail)
+    try:                                                              # (readers before their images, explicitly: not left to the
+        pipe = rd = pbf = None                                        #  order the garbage collector finalises a cycle in at exit)
+        R.release()
+    except Exception:
+        pass
 
 
 if __name__ == "__main__":

@@ -806,17 +806,18 @@ static bool parse_blocks_parallel(const uint8_t *buf, size_t end, size_t len, in
     std::atomic<int> hip_err((int)hipSuccess), no_mem(0);
     run([&](int b, int t) {
         if (hip_err.load() != (int)hipSuccess || no_mem.load()) return;
-        if (!mine[t]) {                                          // (pinned: the copies below are DMA straight out of it)
+        if (!mine[t]) {
+            mine[t] = (uint8_t*)malloc(widest + sbytes);
+            if (!mine[t]) { no_mem = 1; return; }
             hipError_t e = hipSetDevice(up->device);
             if (e != hipSuccess) { hip_err = (int)e; return; }
-            if (hipHostMalloc((void**)&mine[t], widest + sbytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); mine[t] = nullptr; no_mem = 1; return; }
         }
         empty1 += scan_block(buf, idx[b], idx[b + 1], m, g, mine[t], out.desc + (size_t)row0[b] * g, off[b], (int32_t*)(mine[t] + widest)).empty1;
         hipError_t e = info[b].packed ? hipMemcpy(up->d_rle + off[b], mine[t], info[b].packed, hipMemcpyHostToDevice) : hipSuccess;
         if (e == hipSuccess) e = hipMemcpy(up->d_perm + (size_t)b * g * m, mine[t] + widest, sbytes, hipMemcpyHostToDevice);
         if (e != hipSuccess) hip_err = (int)e;
     });
-    for (uint8_t *q : mine) if (q) (void)hipHostFree(q);
+    for (uint8_t *q : mine) free(q);
     tr.lap("  blocks packed + copied");
     if (no_mem.load()) throw std::bad_alloc();
     if (hip_err.load() != (int)hipSuccess) { set_err("[E::bgth_pbf_open] copying the strings to the device: %s", hipGetErrorString((hipError_t)hip_err.load())); return false; }
@@ -866,42 +867,6 @@ static bool parse_sequential(const uint8_t *buf, size_t end, int m, int g, int s
     }
     ps.take(rle, desc, perms, payload, n_empty1, row);
     return true;
-}
-
-// A large PAGEABLE host buffer to the device.  hipMemcpy stages such a copy through its own pinned bounce buffers on one thread:
-// 35-50 ms for the 331 MB of a C2 database's strings (6.6-9 GB/s), the largest single stage of a cold `bgt view` once the runtime
-// is up; eight threads each calling hipMemcpy on a slice were slower still (round 4).  Here a few threads each own a PINNED chunk
-// and a stream: copy a chunk of the source into it (plain memcpy, ~8 GB/s per thread), send it on (hipMemcpyAsync from pinned
-// memory: DMA at the link's rate), take the next -- the host copies of some overlap the DMA of the others.  BGTH_PLAIN_UPLOAD=1: the
-// single hipMemcpy as before.  Small buffers go the plain way.
-static hipError_t upload_pageable(void *dst, const void *src, size_t n, int device)
-{
-    constexpr size_t kChunk = (size_t)8 << 20;
-    if (n < 4 * kChunk || getenv("BGTH_PLAIN_UPLOAD")) return hipMemcpy(dst, src, n, hipMemcpyHostToDevice);
-    const size_t n_chunks = (n + kChunk - 1) / kChunk;
-    const int nt = (int)std::min<size_t>(std::min<size_t>(6, std::max(1u, std::thread::hardware_concurrency())), n_chunks);
-    std::atomic<size_t> next(0);
-    std::atomic<int> err((int)hipSuccess);
-    std::vector<std::thread> th;
-    for (int t = 0; t < nt; ++t)
-        th.emplace_back([&] {
-            void *pin = nullptr;
-            hipStream_t st = nullptr;
-            hipError_t e = hipSetDevice(device);
-            if (e == hipSuccess) e = hipHostMalloc(&pin, kChunk, hipHostMallocDefault);
-            if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-            for (size_t c; e == hipSuccess && err.load() == (int)hipSuccess && (c = next.fetch_add(1)) < n_chunks;) {
-                const size_t off = c * kChunk, len = std::min(kChunk, n - off);
-                memcpy(pin, (const char*)src + off, len);
-                e = hipMemcpyAsync((char*)dst + off, pin, len, hipMemcpyHostToDevice, st);
-                if (e == hipSuccess) e = hipStreamSynchronize(st);        // (the chunk is this thread's only one: the others overlap)
-            }
-            if (e != hipSuccess) err = (int)e;
-            if (st) (void)hipStreamDestroy(st);
-            if (pin) (void)hipHostFree(pin);
-        });
-    for (std::thread &t : th) t.join();
-    return (hipError_t)err.load();
 }
 
 static bgth_pbf_t *open_mem_impl(const void *image, size_t len, int device);
@@ -1110,10 +1075,13 @@ static bgth_pbf_t *open_mem_impl(const void *image, size_t len, int device)
         else {
             HIP_TRY(hipMalloc((void**)&p->d_rle, rle.size() + pad), goto fail);
             HIP_TRY(hipMemset(p->d_rle + rle.size(), 0, pad), goto fail);
-            if (!rle.empty()) HIP_TRY(upload_pageable(p->d_rle, rle.data(), rle.size(), device), goto fail);
+            // (ONE copy.  Measured and dropped: eight threads copying slices -- 48-97 against 35-40 ms for 331 MB, round 4 --, and a few
+            //  threads each staging 8 MB chunks through a pinned buffer of their own + hipMemcpyAsync -- a cold C2 `bgt view` 261-356 ms
+            //  against 225-305, this stage 100 ms against 70, round 6: profiles/r06_cold)
+            if (!rle.empty()) HIP_TRY(hipMemcpy(p->d_rle, rle.data(), rle.size(), hipMemcpyHostToDevice), goto fail);
         }
         HIP_TRY(hipMalloc((void**)&p->d_rowdesc, std::max<size_t>(desc.size(), 1) * 8), goto fail);
-        if (!desc.empty()) HIP_TRY(upload_pageable(p->d_rowdesc, desc.data(), desc.size() * 8, device), goto fail);
+        if (!desc.empty()) HIP_TRY(hipMemcpy(p->d_rowdesc, desc.data(), desc.size() * 8, hipMemcpyHostToDevice), goto fail);
         tr.lap("upload strings");
         // checkpoints: permutation (rank -> column) to rank form (column -> rank), on the device, each at the
         // sub-block index of its row; then one decode pass fills the sub-checkpoints in between
@@ -1127,7 +1095,7 @@ static bgth_pbf_t *open_mem_impl(const void *image, size_t len, int device)
             HIP_TRY(hipMemset(d_bad, 0, 4), { hipFree(d_perm); hipFree(d_bad); goto fail; });
             if (!rank0_alloc(p)) { hipFree(d_perm); hipFree(d_bad); goto fail; }
             const int d = p->shift - p->sub_shift;                // (after the allocation: it may fall back to the default spacing)
-            if (perms.data()) HIP_TRY(upload_pageable(d_perm, perms.data(), np * 4, device), { hipFree(d_perm); hipFree(d_bad); goto fail; });
+            if (perms.data()) HIP_TRY(hipMemcpy(d_perm, perms.data(), np * 4, hipMemcpyHostToDevice), { hipFree(d_perm); hipFree(d_bad); goto fail; });
             for (size_t b = 0; b < np / per; ++b)                 // validated: the records come from a file
                 HIP_TRY(launch_invert(d_perm + b * per, p->d_rank0 + ((size_t)b << d) * per, m, 2, nullptr, d_bad), { hipFree(d_perm); hipFree(d_bad); goto fail; });
             HIP_TRY(hipDeviceSynchronize(), { hipFree(d_perm); hipFree(d_bad); goto fail; });
@@ -1169,11 +1137,9 @@ extern "C" bgth_pbf_t *bgth_pbf_open(const char *path, int device)
     madvise(map, (size_t)st.st_size, MADV_SEQUENTIAL);       // (advice values are enumerators, not flags: one call each)
     madvise(map, (size_t)st.st_size, MADV_WILLNEED);
     bgth_pbf_t *p = bgth_pbf_open_mem(map, (size_t)st.st_size, device);
-    // (7 ms for a C2 database, and nobody waits for it: on a thread of its own, beside the reader's set-up and the first scan;
-    //  a process that exits first loses nothing -- the mapping goes with it)
-    const size_t map_len = (size_t)st.st_size;
-    try { std::thread([map, map_len] { munmap(map, map_len); }).detach(); }
-    catch (...) { munmap(map, map_len); }
+    Trace tr;
+    munmap(map, (size_t)st.st_size);                          // (leaving it to the process's exit costs the same there: measured)
+    tr.lap("unmap the file");
     return p;
 }
 

@@ -1,5 +1,6 @@
 """ctypes mirror of include/bgt_hip.h.  No fallback: a missing library or device raises."""
 import ctypes as C
+import weakref
 import os
 import subprocess
 
@@ -247,7 +248,8 @@ class HipPbf:
         if not handle:
             raise RuntimeError(last_error() or "bgth_pbf_open failed")
         self.h = handle
-        L = lib()
+        self._readers = weakref.WeakSet()       # readers (and encoders of nothing): destroyed BEFORE their image, whatever order the
+        L = lib()                               # garbage collector finalises a cycle in (bgth_reader_destroy reads its image)
         self.m = L.bgth_pbf_get_m(handle)
         self.g = L.bgth_pbf_get_g(handle)
         self.shift = L.bgth_pbf_get_shift(handle)
@@ -340,6 +342,8 @@ class HipPbf:
 
     def close(self):
         if self.h:
+            for r in list(self._readers):
+                r.close()
             lib().bgth_pbf_close(self.h)
             self.h = None
 
@@ -359,10 +363,12 @@ class HipReader:
         if not self.h:
             raise RuntimeError(last_error())
         self.n_groups = 1
+        pbf._readers.add(self)
 
     def close(self):
         if self.h:
-            lib().bgth_reader_destroy(self.h)
+            if self.pbf.h:                       # (an image closed first has taken its readers with it)
+                lib().bgth_reader_destroy(self.h)
             self.h = None
 
     def __del__(self):
