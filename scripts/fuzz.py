@@ -21,8 +21,10 @@ GEOMS = [(0, 0, 0), (256, 2, 1), (256, 8, 3), (256, 20, 2), (512, 4, 1), (512, 1
 t_end = time.time() + budget
 n_case = n_check = 0
 while time.time() < t_end:
-    m = int(rng.choice([1, 2, 3, 63, 64, 65, 127, 500, 1000, 2049, 5008, 9000, 33000, 70002, 120001]))
-    rows = int(rng.integers(1, 400 if m < 10000 else 60 if m < 50000 else 12))
+    # (round 6: 400,000 = one plane per workgroup in the LDS; 700,001 / 1,100,000 = toggles and directory entries in memory)
+    m = int(rng.choice([1, 2, 3, 63, 64, 65, 127, 500, 1000, 2049, 5008, 9000, 33000, 70002, 120001, 400000, 700001, 1100000],
+                       p=[1 / 16] * 15 + [1 / 48] * 3))
+    rows = int(rng.integers(1, 400 if m < 10000 else 60 if m < 50000 else 12 if m < 300000 else 6))
     shift = int(rng.integers(2, 9))
     mat = scenarios.ld_matrix(rng, rows, m, n_founders=int(rng.integers(2, 30)), switch=float(rng.choice([0.0, 0.01, 0.1, 0.5])))
     style = rng.integers(0, 4)

@@ -20,8 +20,9 @@ t_end = time.time() + budget
 n_case = 0
 while time.time() < t_end:
     m = int(rng.choice([1, 2, 3, 31, 32, 33, 63, 64, 65, 500, 1023, 1024, 1025, 4095, 4096, 4097, 5008, 8191, 8192, 8193, 12345,
-                        20000, 20479, 20480, 20481, 30000, 32767, 32768, 32769, 50001, 65536, 65537, 100000, 131072, 131073, 200000]))
-    rows = int(rng.integers(1, 500 if m < 6000 else 120 if m < 40000 else 30))
+                        20000, 20479, 20480, 20481, 30000, 32767, 32768, 32769, 50001, 65536, 65537, 100000, 131072, 131073, 200000,
+                        262145, 400000, 524289, 700001, 1100000]))          # (round 6, beyond 262,144: the directories in memory)
+    rows = int(rng.integers(1, 500 if m < 6000 else 120 if m < 40000 else 30 if m < 250000 else 10))
     shift = int(rng.integers(0, 9))
     g = int(rng.choice([1, 2, 2, 2]))
     os.environ["BGTH_ENC_UNIT_SHIFT"] = str(int(rng.integers(1, 8)))
