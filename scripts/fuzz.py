@@ -50,7 +50,9 @@ while time.time() < t_end:
         if flag & (32 | 4096):
             th = cpt = K = 0                                  # (a tuned geometry names a classic kernel)
             if rng.random() < 0.3:
-                os.environ["BGTH_DIR_ARENA_MB"] = "1"         # several passes over the arena
+                # several passes over the arena (a cohort of one plane per workgroup needs room for ONE file block of its rows:
+                # 2^shift <= 256 rows x up to 0.8 MB here)
+                os.environ["BGTH_DIR_ARENA_MB"] = "1" if m < 300000 else "300"
             else:
                 os.environ.pop("BGTH_DIR_ARENA_MB", None)
         rd.tune(th, cpt, K)
