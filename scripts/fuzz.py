@@ -42,6 +42,7 @@ while time.time() < t_end:
     if flag:
         bgt_amd.force_kernels(int(str(flag)))
     os.environ["BGTH_SUB_SHIFT"] = str(int(rng.integers(1, 12)))
+    os.environ.pop("BGTH_DIR_ARENA_MB", None)                 # (a cap of the case before must not meet this one's width)
     pbf = bgt_amd.HipPbf.from_bytes(data)
     for _ in range(3):
         ora = orc.Pbf(data)
