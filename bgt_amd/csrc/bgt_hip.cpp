@@ -1756,9 +1756,10 @@ extern "C" void bgth_reader_destroy(bgth_reader_t *r)
     {   // a reader that served a big streaming query does not keep its windows (up to 2 x 256 MiB pinned + as much HBM)
         size_t held = 0;
         for (const PullWindow &w : r->win) held += w.h_counts.cap + w.h_planes.cap + w.h_gt8.cap + w.h_gttext.cap;
-        if (held > ((size_t)64 << 20) || r->dir.cap > ((size_t)256 << 20) || r->ph0.cap > ((size_t)256 << 20)) {
+        if (held > ((size_t)64 << 20) || r->dir.cap > ((size_t)256 << 20) || r->ph0.cap > ((size_t)256 << 20) || r->start_tab.cap > ((size_t)64 << 20)) {
             hipSetDevice(r->pbf->device);
             if (r->stream) hipStreamSynchronize(r->stream);
+            if (r->start_tab.cap > ((size_t)64 << 20)) { r->start_tab.release(); r->start_epoch = -1; }   // (a selection's compact start ranks: C3 314 MB)
             if (held > ((size_t)64 << 20)) { r->win[0].release(); r->win[1].release(); }
             if (r->dir.cap > ((size_t)256 << 20)) { r->dir.release(); r->dir_n0.release(); r->dir_lo = r->dir_hi = 0; }
             if (r->ph0.cap > ((size_t)256 << 20)) { r->ph0.release(); r->ph1.release(); }
