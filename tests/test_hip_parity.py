@@ -628,4 +628,9 @@ def test_more_than_two_bit_planes(hip, tmp_path, g, m, rows, shift):
         rd.scan(0, rows)
     rd.close()
     pbf.close()
+    # partial and sharded images are for BGT's two planes: a clean refusal, nothing half-opened
+    with pytest.raises(RuntimeError, match="bit planes"):
+        hip.HipPbf.open_rows(out, 0, min(rows, 8))
+    with pytest.raises(RuntimeError, match="bit planes"):
+        hip.HipPbf.open_sharded(out, [0, 0])
 
