@@ -292,8 +292,11 @@ bool choose_plane_geometry(int m, int n_chunks, int n_blk, Geometry *g)
     // (round 5, measured and dropped: two workgroups of 896 threads at 72 VGPRs = seven waves per SIMD, 12 columns per wave, no wave
     // with two directory units: C3 19.6 ms against 13.9 -- profiles/r05_c3)
     else if (low_knob && 12 * 20 >= n_chunks) { threads = 768; low = 1; }
+#ifdef BGTH_ABLATE      // (profiling build, round 6: ten waves instead of twelve where they hold the selection -- C3: 160 chunk slots for 157 chunks)
+    if (threads == 768 && plane_knob("BGTH_PLANE_THREADS", 768) == 640 && 10 * 20 >= n_chunks && n_chunks > 10 * 12) threads = 640;
+#endif
     const int waves = threads / 64;
-    if (threads == 768) {
+    if (threads == 768 || threads == 640) {
 #define X(C) if (!cpt && waves * C >= n_chunks) cpt = C;
         BGTH_PLANE_CPTS_768(X)
 #undef X
@@ -328,6 +331,10 @@ hipError_t launch_plane_scan(const ScanArgs &a, const Geometry &g, hipStream_t s
 #define X(C) if (g.cpt == C && g.threads == 768 && g.low == 1) LAUNCH((plane_kernel<C, 1, 768>))
     BGTH_PLANE_CPTS_768(X)
 #undef X
+#ifdef BGTH_ABLATE
+    if (g.cpt == 16 && g.threads == 640 && g.low == 1) LAUNCH((plane_kernel<16, 1, 640>))
+    if (g.cpt == 20 && g.threads == 640 && g.low == 1) LAUNCH((plane_kernel<20, 1, 640>))
+#endif
 #define X(C) if (g.cpt == C && g.threads == 512 && g.low == 0) LAUNCH((plane_kernel<C, 0, 512>))
     BGTH_PLANE_CPTS(X)
 #undef X
