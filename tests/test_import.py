@@ -139,3 +139,47 @@ def test_bcf_input_imports_like_the_reference_binary(tmp_path):
     a = subprocess.run([BGT, "view", "-C", mine], stdout=subprocess.PIPE, check=True).stdout
     b = subprocess.run([ref, "view", "-C", want], stdout=subprocess.PIPE, check=True).stdout
     assert a == b and a.count(b"\n") > 500
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(2400)
+def test_biobank_width_through_both_command_lines(tmp_path):
+    """400,000 samples = 800,000 haplotypes (round 6: beyond every LDS width -- the writer's directories and the reader's rows live
+    in memory) through the COMMAND LINES: one VCF of 60 records (multi-allelic sites, an indel, missing calls) imported by this
+    repo's `bgt import` (device encoder) and by the compiled reference's; the .pbf / .bcf must be the same bytes.  Then `bgt view`
+    of both on this repo's database: counts of the whole cohort, a filter, two sample groups, a sparse subset WITH genotype
+    columns, a region -- every stdout byte for byte (reference pbwt.c:92-105 / 199-219 take any width; bgt.c as it is)."""
+    ref = require_ref("bgt")
+    n, n_rec = 400000, 60
+    rng = np.random.default_rng(400000)
+    vcf = str(tmp_path / "wide.vcf")
+    gts = np.array([b"0|0", b"0|1", b"1|0", b"1|1", b"./.", b"0|2", b"2|1", b".|1"], dtype=object)
+    founder = rng.integers(0, 16, n)                                   # columns that share a founder share most calls: runs for the PBWT
+    with open(vcf, "wb") as f:
+        f.write(b"##fileformat=VCFv4.1\n##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n##contig=<ID=11,length=135006516>\n")
+        f.write(b"#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + b"\t".join(b"S%06d" % i for i in range(n)) + b"\n")
+        for r in range(n_rec):
+            multi = r % 5 == 2 and r % 7 != 3
+            per_founder = rng.integers(0, 4, 16) if rng.random() < 0.7 else np.zeros(16, np.int64)
+            call = per_founder[founder]
+            noise = rng.random(n)
+            call = np.where(noise < 0.002, 4, call)                    # missing
+            if multi:
+                call = np.where((noise > 0.002) & (noise < 0.01), rng.integers(5, 8, n), call)
+            ref_al, alt = (b"CAG", b"C") if r % 7 == 3 else (b"A", b"G,T" if multi else b"G")
+            f.write(b"11\t%d\t.\t%s\t%s\t50\tPASS\t.\tGT\t" % (1000 + 10 * r, ref_al, alt) + b"\t".join(gts[call]) + b"\n")
+    mine, want = str(tmp_path / "mine"), str(tmp_path / "want")
+    for exe, out in ((BGT, mine), (ref, want)):
+        p = subprocess.run([exe, "import", "-S", out, vcf], timeout=1200, stderr=subprocess.PIPE)
+        assert p.returncode == 0, (exe, p.stderr.decode()[-600:])
+    for ext in ("pbf", "bcf", "spl"):
+        assert open(mine + "." + ext, "rb").read() == open(want + "." + ext, "rb").read(), ext
+    with open(mine + ".spl", "w") as f:                                # metadata for the expressions below
+        for i in range(n):
+            f.write("S%06d\tpop:Z:%s\tidx:i:%d\n" % (i, "XYZ"[i % 3], i))
+    import hashlib
+    for args in (["-C", "-G"], ["-G", "-f", "AC>100"], ["-G", "-s", 'pop=="X"', "-s", 'pop=="Y"', "-f", "AC1>0&&AC2>0"],
+                 ["-C", "-s", "idx%40000==7"], ["-s", ",S000001,S399999,S123456", "-r", "11:1000-1200"]):
+        out = [subprocess.run([exe, "view"] + args + [mine], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200) for exe in (BGT, ref)]
+        assert out[0].returncode == out[1].returncode == 0, (args, out[0].stderr.decode()[-300:], out[1].stderr.decode()[-300:])
+        assert len(out[0].stdout) > 500 and hashlib.md5(out[0].stdout).hexdigest() == hashlib.md5(out[1].stdout).hexdigest(), args
