@@ -968,7 +968,9 @@ static int encode_batch(bgth_encoder_t *e, const uint8_t *codes, int64_t rows, b
     // fill the chip with full-size units gets smaller ones: about one workgroup per CU.
     int64_t want = e->unit_rows;
     // (the chain of phase B grows with the number of units: below ~sqrt(9 rows) narrow / sqrt(1.4 rows) wide it costs more than it saves)
-    const int64_t least = e->wpt ? 256 : 512;
+    // (beyond 262,144 columns a workgroup needs ~0.4 ms per row -- every directory access goes to the L2 --: the parallelism of many
+    //  short units is worth more than the longer chain: 1,000,000 columns, 1,024 rows per call: 2 units of 512 -> 16 of 64)
+    const int64_t least = e->wpt > 8 ? 64 : e->wpt ? 256 : 512;
     if (!e->unit_fixed) while (want > least && (rows + want - 1) / want * g < 256) want >>= 1;
     const bool parallel = rows > want && g <= 2;
     const int64_t unit_rows = parallel ? want : rows;
