@@ -29,7 +29,7 @@ with open(path, "wb") as f:
     for r0 in range(0, sites, per_call):
         n = min(per_call, sites - r0)
         freq = np.where(rng.random(n) < 0.5, 1.0 / rng.integers(2, 202, n), rng.random(n) * 0.5)
-        chunk = np.ascontiguousarray((rng.random((n, K)) < freq[:, None]).astype(np.uint8)[:, founder_of])   # (fancy indexing hands back a transposed layout)
+        chunk = np.take((rng.random((n, K)) < freq[:, None]).astype(np.uint8), founder_of, axis=1)   # (C-contiguous; F[:, idx] comes back transposed)
         rr, cc = rng.integers(0, n, 4000), rng.integers(0, m, 4000)
         chunk[rr[:3000], cc[:3000]] = 2
         chunk[rr[3000:], cc[3000:]] = 3

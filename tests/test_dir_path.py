@@ -255,7 +255,7 @@ def test_half_a_million_samples_round_trip(hip, tmp_path):
         for r0 in range(0, sites, per_call):
             freq = np.where(rng.random(per_call) < 0.5, 1.0 / rng.integers(2, 202, per_call), rng.random(per_call) * 0.5)
             F = (rng.random((per_call, K)) < freq[:, None]).astype(np.uint8)
-            chunk = F[:, founder_of]                                  # [per_call][m] of 0 / 1
+            chunk = np.take(F, founder_of, axis=1)                    # [per_call][m] of 0 / 1 (C-contiguous: F[:, idx] comes back transposed)
             rr, cc = rng.integers(0, per_call, 4000), rng.integers(0, m, 4000)
             chunk[rr[:3000], cc[:3000]] = 2                           # missing calls
             chunk[rr[3000:], cc[3000:]] = 3                           # <M>
